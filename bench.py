@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s of the SVO ray-march on BASELINE.json's headline config.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one frame: 1920x1080, 8x8x8-chunk procedural SVO world, 1 primary ray per pixel + 1 shadow ray
+per solid hit (config C2; inputs resident in HBM before the timed region).  With N > 1 the frame is
+sharded by interleaved 8x8 screen tiles over N processes (one per GPU) and gathered to rank 0 with one RCCL
+gather per frame plus a de-interleave kernel — total work fixed, so scaling is "strong".
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes(st, width, height):
+    """SURVEY.md §8d / DESIGN.md §Algorithmic bytes, per kernel, from exact step / node-visit counts.
+
+    march step: 4 B chunk_roots entry + 2 B x L node words + 4 B material is_liquid  = 8 + 2L
+    primary kernel: + 16 B output per pixel (f32x3 + id word) + 16 B hit record per secondary ray launched
+    shadow kernel:  + 16 B hit record read per ray (+ 32 B rgb/id read-modify-write per occluded ray, not
+                    counted: occlusion count is not part of vrt_stats)"""
+    p_steps, p_vis = st.primary_steps, st.primary_node_visits
+    s_steps, s_vis = st.steps - p_steps, st.node_visits - p_vis
+    primary = 8 * p_steps + 2 * p_vis + 16 * width * height + 16 * st.secondary_rays
+    shadow = 8 * s_steps + 2 * s_vis + 16 * st.secondary_rays
+    return primary, shadow
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--chunks", type=int, default=8, help="world size in chunks (8 = config C2)")
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from voxelraytracing_amd import Gpu, MODE_PRIMARY_SHADOW, scenes
+    from voxelraytracing_amd.shard import FrameGather
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # ---- scene (deterministic, built by every rank) and upload: off the clock ----
+    sc = scenes.procedural(args.chunks, (args.width, args.height), MODE_PRIMARY_SHADOW)
+    gpu = Gpu(sc.world.max_nodes(), sc.world.size_in_chunks(), sc.size, device=local_rank, shard_rank=rank, shard_count=world)
+    gpu.upload_world(sc.world, sc.materials)
+    gpu.write_cam_data(sc.cam)
+    gpu.write_settings(sc.settings)
+    fg = None
+    if world > 1:
+        gpu.set_stream(torch.cuda.current_stream().cuda_stream)
+        fg = FrameGather(torch, dist, rank, world, args.width, args.height, torch.device("cuda", local_rank))
+        fg.bind(gpu)
+
+    def frame():
+        gpu.render(MODE_PRIMARY_SHADOW, variant=args.variant)
+        if fg is not None:
+            fg.gather()
+            if rank == 0:
+                fg.assemble(gpu)
+
+    # exact ray / step / node-visit counts of this frame (deterministic; a stats frame is never timed)
+    gpu.render(MODE_PRIMARY_SHADOW, variant=args.variant, stats=True)
+    st = gpu.stats()
+    counts = torch.tensor([st.primary_rays, st.secondary_rays], dtype=torch.int64, device="cuda")
+    if world > 1:
+        dist.all_reduce(counts)
+    rays_per_frame = int(counts[0] + counts[1])
+
+    for _ in range(args.warmup):
+        frame()
+    gpu.stats()  # drop the warm-up frames' kernel timings
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        frame()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax[0])
+
+    # per-kernel durations over exactly the timed frames: HIP events on the stream the kernels ran on
+    kst = gpu.stats()
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    b_primary, b_shadow = algorithmic_bytes(st, args.width, args.height) if world == 1 else (0, 0)
+    ms_p = kst.sum_ms_primary / max(kst.frames, 1)
+    ms_s = kst.sum_ms_secondary / max(kst.frames, 1)
+    dom_name, dom_bytes, dom_ms = ("primary_march", b_primary, ms_p) if ms_p >= ms_s else ("shadow_march", b_shadow, ms_s)
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(dom_name)
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "Mrays/s at 1920x1080, 1 primary + 1 shadow ray",
+        "value": rays_per_frame * args.steps / dt / 1e6,
+        "unit": "Mrays/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"C2: {args.width}x{args.height} frame, {args.chunks}x{args.chunks}x{args.chunks}-chunk procedural SVO "
+                               f"world (seed 1), 1 primary + 1 shadow ray per solid hit",
+                   "rays_per_frame_actual": rays_per_frame, "rays_per_frame_nominal": 2 * args.width * args.height,
+                   "sharding": "whole frame" if world == 1 else f"8x8 tiles interleaved over {world} ranks + RCCL gather to rank 0",
+                   "kernel_variant": args.variant},
+        "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
+                     "kernels_ms": {"primary_march": ms_p, "shadow_march": ms_s}, "frames_timed": kst.frames},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(sc, args, rays_per_frame)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(sc, args, rays_per_frame):
+    """The oracle (a port, not the reference: the reference is WGSL on wgpu and has no CPU tracer) timed on
+    this box's host cores over a bounded sample of the same frame."""
+    from oracle import orc
+    o = orc.from_package_scene(sc)
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    # sample: every 4th 8-row band of the frame would bias towards sky/terrain; trace the whole frame once
+    t0 = time.perf_counter()
+    _, _, _, cst = o.render(orc.MODE_PRIMARY_SHADOW, args.width, args.height, threads=cores)
+    dt = time.perf_counter() - t0
+    rays = cst.primary_rays + cst.secondary_rays
+    assert rays == rays_per_frame, "oracle and GPU disagree on the number of rays launched"
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"1 full {args.width}x{args.height} frame of the same scene, OpenMP over 8-row bands, {dt:.2f} s"}
+
+
+if __name__ == "__main__":
+    main()

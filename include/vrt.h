@@ -1,0 +1,218 @@
+/*
+ * vrt.h — C ABI of the MI355X (gfx950) SVO ray-march backend (libvrt.so).
+ *
+ * This is the drop-in boundary for the reference's GPU seam: everything the winit frame loop does to
+ * `GpuResources` / `Buffers` / `PixelShader` (MasonFeurer/VoxelRayTracing,
+ * clientdesktop/src/graphics/{mod.rs,shader.rs}, callers in clientdesktop/src/main.rs) maps to one
+ * call below.  Plain pointers and sizes only; the four uniform structs are byte-identical to the
+ * reference's #[repr(C)] structs, so a Rust host passes its own values unchanged (INTEGRATION.md shows
+ * the `extern "C"` block a maintainer would add).
+ *
+ * Semantics shared by every write: the host owns the source memory, the call copies at call time
+ * (wgpu `queue.write_buffer`, shader.rs:105,113,141) and the data is visible to the next vrt_render.
+ * One thread per context (the reference drives this seam from the winit thread only,
+ * main.rs:681-722); calls are ordered on one HIP stream.
+ *
+ * Every function returns VRT_OK (0) or a negative vrt_status; vrt_last_error() gives the text.
+ * Nothing aborts: the reference's unwrap()/panic sites (mod.rs:223-274, client/src/world.rs:251)
+ * become status codes.
+ */
+#ifndef VRT_H
+#define VRT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vrt_ctx vrt_ctx;
+
+typedef enum {
+    VRT_OK = 0,
+    VRT_ERR_INVALID_ARG = -1,
+    VRT_ERR_OUT_OF_RANGE = -2,
+    VRT_ERR_DEVICE = -3,
+    VRT_ERR_OOM = -4,
+    VRT_ERR_STATE = -5
+} vrt_status;
+
+/* Material — clientdesktop/src/graphics/mod.rs:20-28 (32 B). */
+typedef struct {
+    float color[3];
+    uint32_t is_empty;
+    uint32_t is_liquid;
+    float scatter;
+    uint32_t _padding[2];
+} vrt_material;
+
+/* CamData — mod.rs:82-91 (160 B). Column-major 4x4 (glam Mat4). */
+typedef struct {
+    float pos[3];
+    uint32_t _padding0;
+    float inv_view_mat[16];
+    float inv_proj_mat[16];
+    float proj_size[2];
+    uint32_t _padding1[2];
+} vrt_cam_data;
+
+/* WorldData — mod.rs:113-120 (32 B). */
+typedef struct {
+    int32_t min[3];
+    uint32_t size;
+    uint32_t size_in_chunks;
+    uint32_t _padding[3];
+} vrt_world_data;
+
+/* Settings — mod.rs:132-143 (48 B). */
+typedef struct {
+    uint32_t max_ray_bounces;
+    float sun_intensity;
+    uint32_t show_step_count;
+    uint32_t _padding0;
+    float sky_color[3];
+    uint32_t _padding1;
+    float sun_pos[3];
+    uint32_t _padding2;
+} vrt_settings;
+
+/* Replaces the arguments of GpuResources::new(gpu, fmt, result_size, max_nodes, world_size)
+ * (mod.rs:155-195).  shard_rank/shard_count: this context traces only the 8x8 screen tiles t with
+ * t % shard_count == shard_rank (tile-interleaved multi-GPU sharding; 0/1 = whole frame). */
+typedef struct {
+    uint32_t max_nodes;          /* NodeBuffer capacity in nodes (shader.rs:9-16; forced even) */
+    uint32_t world_size_chunks;  /* S: chunk_roots holds S^3 entries (shader.rs:59,67) */
+    uint32_t width, height;      /* result texture size; multiples of 8 (main.rs:452) */
+    int32_t device;              /* HIP device ordinal; -1 = current */
+    uint32_t shard_rank, shard_count;
+    uint32_t flags;              /* reserved, 0 */
+} vrt_config;
+
+typedef enum {
+    VRT_MODE_PRIMARY = 0,        /* the reference's live shader (ray_tracer.wgsl) */
+    VRT_MODE_PRIMARY_SHADOW = 1, /* + 1 shadow ray per solid hit, from a compacted hit buffer */
+    VRT_MODE_PATH = 2            /* multi-bounce path trace after path_tracer.wgsl (build-defined) */
+} vrt_mode;
+
+typedef struct {
+    uint32_t mode;     /* vrt_mode */
+    uint32_t variant;  /* kernel variant, 0 = default */
+    uint32_t stats;    /* 1: also count steps / node visits this frame (slower; not for timing) */
+    uint32_t spp;      /* VRT_MODE_PATH only */
+    uint32_t seed;     /* VRT_MODE_PATH only */
+    uint32_t _reserved[3];
+} vrt_render_opts;
+
+/* New relative to the reference (it presents to a swapchain and never reads back). */
+typedef struct {
+    uint64_t primary_rays;
+    uint64_t secondary_rays;      /* shadow / bounce rays actually launched */
+    uint64_t hits;
+    uint64_t steps;               /* valid when the frame was rendered with opts.stats = 1 */
+    uint64_t node_visits;
+    uint64_t primary_steps;
+    uint64_t primary_node_visits;
+    float ms_total;               /* hipEvent time of the last frame's kernels, same stream */
+    float ms_primary;             /* the march kernel over primary rays */
+    float ms_secondary;           /* shadow / bounce kernels */
+    uint32_t frames;              /* frames rendered since the previous vrt_get_stats, and their summed */
+    double sum_ms_primary;        /* kernel times (one hipEvent triple per frame, recorded on the stream */
+    double sum_ms_secondary;      /* the kernels run on) */
+    double sum_ms_total;
+} vrt_stats;
+
+/* Per-pixel id word written next to the f32 radiance (build-defined; bit-exact parity target):
+ * bits 0..14 voxel id; 16 hit; 17..19 norm.x/y/z != 0; 20 water overlay; 21 shadow ray launched;
+ * 22 shadow ray occluded. */
+#define VRT_ID_VOXEL_MASK 0x7FFFu
+#define VRT_ID_HIT (1u << 16)
+#define VRT_ID_NX (1u << 17)
+#define VRT_ID_NY (1u << 18)
+#define VRT_ID_NZ (1u << 19)
+#define VRT_ID_WATER (1u << 20)
+#define VRT_ID_SHADOW_RAY (1u << 21)
+#define VRT_ID_SHADOWED (1u << 22)
+
+/* GpuResources::new + Buffers::new + PixelShader::new (mod.rs:155-195, shader.rs:55-72,301-344). */
+int vrt_create(const vrt_config *cfg, vrt_ctx **out);
+void vrt_destroy(vrt_ctx *ctx);
+
+/* Text of the last error on this context (ctx may be NULL: last creation error). */
+const char *vrt_last_error(const vrt_ctx *ctx);
+
+/* NodeBuffer::write(gpu, src_nodes (the whole pool), start..end) — shader.rs:22-40.
+ * `pool` points at node 0 of the host pool; [start,end) is widened to even bounds exactly as the
+ * reference does, so pool must be readable on [start&~1, end+(end&1)). */
+int vrt_write_nodes(vrt_ctx *ctx, const uint16_t *pool, uint32_t start, uint32_t end);
+
+/* ArrayBuffer<NodeAddr>::write(gpu, offset, items) — shader.rs:133-142; silently truncates to the
+ * buffer's capacity like the reference. */
+int vrt_write_chunk_roots(vrt_ctx *ctx, uint32_t offset, const uint32_t *roots, uint32_t n);
+
+/* Buffers::resize_chunk_buffer(world_size) + recreate_bind_group — shader.rs:74-80, main.rs:441-445.
+ * Contents are undefined afterwards (a fresh buffer in the reference). */
+int vrt_resize_world(vrt_ctx *ctx, uint32_t world_size_chunks);
+
+/* SimpleBuffer<[Material;256]>::write_slice(first, mats) — shader.rs:108-115, main.rs:219-223. */
+int vrt_write_materials(vrt_ctx *ctx, uint32_t first, const vrt_material *mats, uint32_t n);
+
+/* SimpleBuffer<T>::write — shader.rs:101-106; callers main.rs:428,439,447-449. */
+int vrt_set_camera(vrt_ctx *ctx, const vrt_cam_data *cam);
+int vrt_set_settings(vrt_ctx *ctx, const vrt_settings *settings);
+int vrt_set_world(vrt_ctx *ctx, const vrt_world_data *world);
+
+/* GpuResources::resize_result_texture — mod.rs:201-211. */
+int vrt_resize_output(vrt_ctx *ctx, uint32_t width, uint32_t height);
+
+/* PixelShader::encode_pass(encoder, tex_size/8) + queue.submit — shader.rs:371-379, main.rs:452-453,565.
+ * Asynchronous: enqueues the frame's kernels on the context's stream. opts NULL = primary, default. */
+int vrt_render(vrt_ctx *ctx, const vrt_render_opts *opts);
+
+/* Block until everything enqueued on the context's stream has finished. */
+int vrt_synchronize(vrt_ctx *ctx);
+
+/* Copy the last frame to host memory (synchronises). Any pointer may be NULL.
+ * rgb: width*height*3 f32 row-major; ids: width*height id words; rgba8: what textureStore would have
+ * put in the reference's rgba8unorm texture (ray_tracer.wgsl:179).
+ * With shard_count > 1 only this context's tiles are defined; the rest reads as zero. */
+int vrt_read_output(vrt_ctx *ctx, float *rgb, uint32_t *ids, uint8_t *rgba8);
+
+int vrt_get_stats(vrt_ctx *ctx, vrt_stats *out);
+
+/* Per-pixel march-loop iteration counts of the last frame (primary | shadow << 16); the frame must
+ * have been rendered with opts.stats = 1.  Numeric twin of the reference's F2 step-count heat-map
+ * (main.rs:368-370, ray_tracer.wgsl:311-314). */
+int vrt_read_steps(vrt_ctx *ctx, uint32_t *steps);
+
+/* ---- device-side plumbing for a host that owns streams / device memory (torch, RCCL) ---- */
+
+/* Use the caller's hipStream_t for all subsequent work (NULL = the context's own stream). */
+int vrt_set_stream(vrt_ctx *ctx, void *hip_stream);
+
+/* Render into caller-owned device memory (e.g. torch tensors handed to an RCCL gather) instead of the
+ * context's own buffers: rgb must hold rgb_bytes, ids ids_bytes as vrt_device_output reports them.
+ * NULL, NULL restores the context's buffers; vrt_resize_output drops the binding. */
+int vrt_bind_output(vrt_ctx *ctx, void *rgb, void *ids);
+
+/* Device pointers of the context's output.  Unsharded: rgb = f32[height][width][3],
+ * ids = u32[height][width].  Sharded: the compact tile-major shard buffers
+ * rgb = f32[tiles_local][64][3], ids = u32[tiles_local][64] (tile t_local <-> screen tile
+ * shard_rank + t_local*shard_count; pixel p of a tile = (p&7, p>>3)). */
+int vrt_device_output(vrt_ctx *ctx, void **rgb, void **ids, uint64_t *rgb_bytes, uint64_t *ids_bytes);
+
+/* Number of 8x8 tiles this context traces, and the padded per-rank count used for equal-sized
+ * gathers (ceil(total_tiles / shard_count)). */
+int vrt_shard_info(vrt_ctx *ctx, uint32_t *tiles_local, uint32_t *tiles_padded, uint32_t *tiles_total);
+
+/* On the gather root: scatter shard_count gathered tile-major buffers
+ * (gathered_rgb = f32[shard_count][tiles_padded][64][3], gathered_ids likewise) into row-major
+ * device frames dst_rgb = f32[height][width][3], dst_ids = u32[height][width]. Asynchronous.
+ * rank_stride_bytes: distance between consecutive ranks' buffers in BOTH gathered arrays (for a gather
+ * of one packed {rgb, ids} message per rank); 0 = densely packed as described above. */
+int vrt_assemble(vrt_ctx *ctx, const void *gathered_rgb, const void *gathered_ids, uint64_t rank_stride_bytes,
+                 void *dst_rgb, void *dst_ids);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,98 @@
+/*
+ * vrt_host.h — C ABI of the host-side mirror (libvrt_host.so): the reference's world / camera API
+ * surface that feeds the GPU seam, flattened for FFI (cgo, ctypes, or a Rust extern "C" block).
+ * The C++ types behind it keep the reference's names (the .hpp files under voxelraytracing_amd/csrc/host):
+ *   ClientWorld, ChunkGrid, ChunkAlloc, Chunk   client/src/world.rs:6-367
+ *   Node, Voxel, NodeAlloc, Svo                 common/src/world/mod.rs:137-471
+ *   CamData::create, WorldData::from            clientdesktop/src/graphics/mod.rs:92-130
+ *   axis_rot_to_ray                             common/src/math.rs:131-146
+ * plus the build's deterministic world generator (no reference counterpart can be
+ * reproduced: server/src/world/gen.rs uses an unseeded global RNG).
+ * No GPU is needed for anything here.  Error codes are SetVoxelErr (common/src/world/mod.rs:129-135):
+ * 0 ok, 1 PosOutOfBounds, 2 OutOfMemory, 3 NoChunk, 4 NoChange.
+ */
+#ifndef VRT_HOST_H
+#define VRT_HOST_H
+
+#include <stdint.h>
+
+#include "vrt.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vrth_world vrth_world; /* ClientWorld */
+
+/* ClientWorld::new(center, max_nodes, size) — client/src/world.rs:272-280 */
+vrth_world *vrth_world_new(const int32_t center_chunk[3], uint32_t max_nodes, uint32_t size_in_chunks);
+void vrth_world_free(vrth_world *w);
+
+/* ClientWorld::create_chunk(pos, &nodes) -> root — :310-335. Pool exhaustion is OutOfMemory here
+ * (the reference panics, :251). */
+int vrth_world_create_chunk(vrth_world *w, const int32_t chunk_pos[3], const uint16_t *nodes, uint32_t n, uint32_t *root_out);
+
+/* GameState::set_voxel / ClientWorld::set_voxel — client/src/lib.rs:67-76, world.rs:344-350.
+ * On success range_start/len is the edited chunk's whole pool range, which the caller re-uploads
+ * (main.rs:352,356-362). NoChange when the voxel already has that value. */
+int vrth_world_set_voxel(vrth_world *w, const int32_t voxel_pos[3], uint16_t voxel, uint32_t *range_start, uint32_t *range_len);
+int vrth_world_get_voxel(const vrth_world *w, const int32_t voxel_pos[3], uint16_t *voxel_out);
+
+/* GameState::center_chunks — client/src/lib.rs:55-65: recentre the grid on `anchor`, free the chunks
+ * that fell out. Returns how many were removed. */
+uint32_t vrth_world_center_chunks(vrth_world *w, const int32_t anchor_chunk[3]);
+
+/* ChunkGrid::resize — world.rs:58-88 */
+void vrth_world_resize(vrth_world *w, uint32_t size_in_chunks);
+
+/* ClientWorld::nodes — the whole flat pool (max_nodes u16 words) */
+const uint16_t *vrth_world_nodes(const vrth_world *w);
+uint32_t vrth_world_max_nodes(const vrth_world *w);
+
+/* ChunkGrid::chunk_roots — world.rs:154-159. Writes min(cap, S^3) entries, returns S^3. */
+uint32_t vrth_world_chunk_roots(const vrth_world *w, uint32_t *out, uint32_t cap);
+
+/* min_voxel, size_in_voxels, size_in_chunks, populated_count */
+void vrth_world_info(const vrth_world *w, int32_t min_voxel[3], uint32_t *size_in_voxels, uint32_t *size_in_chunks, uint32_t *populated);
+/* chunk_alloc_status -> (free, max) — world.rs:288-290 */
+void vrth_world_alloc_status(const vrth_world *w, uint32_t *free_nodes, uint32_t *max_nodes);
+/* One chunk's pool range and NodeAlloc state: spans[2*i], spans[2*i+1] = free span i (chunk-relative).
+ * Returns the number of free spans (writes at most cap_spans), or -1 if there is no chunk. */
+int vrth_world_chunk_state(const vrth_world *w, const int32_t chunk_pos[3], uint32_t *range_start, uint32_t *range_end,
+                           uint32_t *last_used_addr, uint32_t *spans, uint32_t cap_spans);
+/* highest_vox_at — world.rs:359-366; returns 1 and *y_out when a non-empty voxel exists */
+int vrth_world_highest_vox_at(const vrth_world *w, int32_t x, int32_t z, int32_t *y_out);
+
+/* WorldData::from(&world) — graphics/mod.rs:121-130 */
+void vrth_world_data_from(const vrth_world *w, vrt_world_data *out);
+/* CamData::create(rot_deg, eye, fov_deg, proj_size) — graphics/mod.rs:92-111 */
+void vrth_cam_data_create(const float rot_deg[3], const float eye[3], float fov_deg, const float proj_size[2], vrt_cam_data *out);
+/* axis_rot_to_ray(rot in radians) — common/src/math.rs:131-146 */
+void vrth_axis_rot_to_ray(const float rot_rad[3], float out[3]);
+/* Material::construct_arr for the standard data pack — graphics/mod.rs:38-60; out[256] */
+void vrth_std_materials(vrt_material *out256);
+/* Name of standard voxel id, or NULL */
+const char *vrth_std_voxel_name(uint32_t id);
+
+/* ---- SVO construction ---- */
+/* Svo::set_node driven the way server/src/world/gen.rs:171-286 drives it (x, z, y ascending, air
+ * skipped) from dense[x + 32*(y + 32*z)]. Returns nodes in use (last_used_addr + 1), 0 on OOM. */
+uint32_t vrth_svo_build_by_set_node(const uint16_t *dense, uint16_t *nodes, uint32_t cap);
+/* Minimal octree, breadth-first layout. Returns node count, 0 if > 32767 nodes or cap too small. */
+uint32_t vrth_svo_build_bottom_up(const uint16_t *dense, uint16_t *nodes, uint32_t cap);
+/* Expand a chunk's SVO back to dense[32^3] through Svo::find_node. */
+void vrth_svo_to_dense(const uint16_t *nodes, uint16_t *dense);
+
+/* ---- deterministic world generator (build-defined) ---- */
+int32_t vrth_gen_height(uint32_t seed, int32_t x, int32_t z);
+/* dense[32^3] of chunk (cx,cy,cz); returns 1 if uniform */
+int vrth_gen_dense(uint32_t seed, const int32_t chunk_pos[3], uint16_t *dense);
+void vrth_gen_dense_superflat(const int32_t chunk_pos[3], uint16_t *dense);
+/* Generate every chunk of the world's grid and create_chunk it. kind 0 = procedural (seed),
+ * 1 = superflat built by set_node (config C1). threads <= 0: all cores. Returns 0 or a SetVoxelErr. */
+int vrth_world_generate(vrth_world *w, uint32_t kind, uint32_t seed, int threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

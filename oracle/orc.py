@@ -1,0 +1,218 @@
+"""ctypes wrapper of the CPU oracle (oracle/vrt_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg — never by the package.
+``build()`` compiles the C file with gcc (strict IEEE flags, see oracle/Makefile).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libvrt_oracle.so")
+
+MODE_PRIMARY, MODE_PRIMARY_SHADOW, MODE_PATH = 0, 1, 2
+ID_VOXEL_MASK = 0x7FFF
+ID_HIT, ID_NX, ID_NY, ID_NZ = 1 << 16, 1 << 17, 1 << 18, 1 << 19
+ID_WATER, ID_SHADOW_RAY, ID_SHADOWED = 1 << 20, 1 << 21, 1 << 22
+SHADOW_FACTOR = 0.35
+
+
+class Material(C.Structure):
+    _fields_ = [("color", C.c_float * 3), ("is_empty", C.c_uint32), ("is_liquid", C.c_uint32),
+                ("scatter", C.c_float), ("_padding", C.c_uint32 * 2)]
+
+
+class CamData(C.Structure):
+    _fields_ = [("pos", C.c_float * 3), ("_padding0", C.c_uint32), ("inv_view_mat", C.c_float * 16),
+                ("inv_proj_mat", C.c_float * 16), ("proj_size", C.c_float * 2), ("_padding1", C.c_uint32 * 2)]
+
+
+class WorldData(C.Structure):
+    _fields_ = [("min", C.c_int32 * 3), ("size", C.c_uint32), ("size_in_chunks", C.c_uint32), ("_padding", C.c_uint32 * 3)]
+
+
+class Settings(C.Structure):
+    _fields_ = [("max_ray_bounces", C.c_uint32), ("sun_intensity", C.c_float), ("show_step_count", C.c_uint32),
+                ("_padding0", C.c_uint32), ("sky_color", C.c_float * 3), ("_padding1", C.c_uint32),
+                ("sun_pos", C.c_float * 3), ("_padding2", C.c_uint32)]
+
+
+class Scene(C.Structure):
+    _fields_ = [("nodes", C.c_void_p), ("n_nodes", C.c_uint32), ("chunk_roots", C.c_void_p), ("n_chunk_roots", C.c_uint32),
+                ("materials", C.c_void_p), ("cam", CamData), ("settings", Settings), ("world", WorldData)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("primary_rays", C.c_uint64), ("secondary_rays", C.c_uint64), ("hits", C.c_uint64), ("steps", C.c_uint64),
+                ("node_visits", C.c_uint64), ("primary_steps", C.c_uint64), ("primary_node_visits", C.c_uint64)]
+
+
+class NodeAlloc(C.Structure):
+    _fields_ = [("range_start", C.c_uint32), ("range_end", C.c_uint32), ("free_start", C.POINTER(C.c_uint32)),
+                ("free_end", C.POINTER(C.c_uint32)), ("n_free", C.c_uint32), ("cap_free", C.c_uint32), ("last_used_addr", C.c_uint32)]
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "vrt_oracle.c")
+    hdr = os.path.join(_HERE, "vrt_oracle.h")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libvrt_oracle.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        vp, u32, f32p = C.c_void_p, C.c_uint32, C.POINTER(C.c_float)
+        L.orc_render.argtypes = [C.POINTER(Scene), C.c_int, u32, u32, u32, u32, u32, u32, vp, vp, vp, C.POINTER(Stats), C.c_int, u32, u32]
+        L.orc_render.restype = None
+        L.orc_trace_pixel.argtypes = [C.POINTER(Scene), C.c_int, u32, u32, f32p, f32p, f32p]
+        L.orc_trace_pixel.restype = u32
+        L.orc_ray_world.argtypes = [C.POINTER(Scene), f32p, f32p, f32p, f32p]
+        L.orc_ray_world.restype = u32
+        L.orc_get_node.argtypes = [vp, u32]
+        L.orc_get_node.restype = u32
+        L.orc_find_node.argtypes = [C.POINTER(Scene), f32p, u32, vp]
+        L.orc_find_node.restype = None
+        L.orc_ray_sky.argtypes = [C.POINTER(Scene), f32p, f32p, f32p]
+        L.orc_ray_sky.restype = None
+        L.orc_cam_data_create.argtypes = [f32p, f32p, C.c_float, f32p, C.POINTER(CamData)]
+        L.orc_cam_data_create.restype = None
+        L.orc_axis_rot_to_ray.argtypes = [f32p, f32p]
+        L.orc_axis_rot_to_ray.restype = None
+        L.orc_rng_next.argtypes = [C.POINTER(u32)]
+        L.orc_rng_next.restype = C.c_float
+        L.orc_node_alloc_init.argtypes = [C.POINTER(NodeAlloc), u32, u32, u32, u32]
+        L.orc_node_alloc_destroy.argtypes = [C.POINTER(NodeAlloc)]
+        L.orc_node_alloc_next.argtypes = [C.POINTER(NodeAlloc), C.POINTER(u32)]
+        L.orc_node_alloc_next.restype = C.c_int
+        L.orc_node_alloc_free.argtypes = [C.POINTER(NodeAlloc), u32]
+        L.orc_svo_find_node.argtypes = [vp, u32, u32, C.POINTER(u32), u32, C.POINTER(u32), f32p]
+        L.orc_svo_set_node.argtypes = [vp, u32, u32, C.POINTER(u32), C.c_uint16, u32, C.POINTER(NodeAlloc)]
+        L.orc_svo_set_node.restype = C.c_int
+        L.orc_build_chunk_by_set_node.argtypes = [vp, vp, u32]
+        L.orc_build_chunk_by_set_node.restype = u32
+        _lib = L
+    return _lib
+
+
+def _f(vals, n):
+    return (C.c_float * n)(*[float(v) for v in vals])
+
+
+def _copy_struct(dst, src):
+    """Byte copy between layout-identical ctypes structs (the package's and the oracle's)."""
+    assert C.sizeof(dst) == C.sizeof(src)
+    C.memmove(C.byref(dst), C.byref(src), C.sizeof(dst))
+
+
+class OracleScene:
+    """Holds numpy copies of a scene's buffers and the C struct pointing at them."""
+
+    def __init__(self, nodes: np.ndarray, chunk_roots: np.ndarray, materials, cam, settings, world):
+        self.nodes = np.ascontiguousarray(nodes, dtype=np.uint16)
+        self.roots = np.ascontiguousarray(chunk_roots, dtype=np.uint32)
+        self.mats = (Material * 256)()
+        C.memmove(self.mats, materials, C.sizeof(self.mats))
+        s = Scene()
+        s.nodes, s.n_nodes = self.nodes.ctypes.data, self.nodes.size
+        s.chunk_roots, s.n_chunk_roots = self.roots.ctypes.data, self.roots.size
+        s.materials = C.addressof(self.mats)
+        _copy_struct(s.cam, cam)
+        _copy_struct(s.settings, settings)
+        _copy_struct(s.world, world)
+        self.c = s
+
+    def set_cam(self, cam):
+        _copy_struct(self.c.cam, cam)
+
+    def set_settings(self, st):
+        _copy_struct(self.c.settings, st)
+
+    def render(self, mode: int, w: int, h: int, rect=None, threads: int = 0, want_steps=False):
+        x0, y0, x1, y1 = rect if rect else (0, 0, w, h)
+        rgb = np.zeros((h, w, 3), dtype=np.float32)
+        ids = np.zeros((h, w), dtype=np.uint32)
+        steps = np.zeros((h, w), dtype=np.uint32) if want_steps else None
+        st = Stats()
+        lib().orc_render(C.byref(self.c), mode, w, h, x0, y0, x1, y1, rgb.ctypes.data, ids.ctypes.data,
+                         steps.ctypes.data if want_steps else None, C.byref(st), threads, 1, 0)
+        return rgb, ids, steps, st
+
+    def trace_pixel(self, mode: int, px: int, py: int):
+        rgb, d, out = (C.c_float * 3)(), (C.c_float * 3)(), (C.c_float * 8)()
+        idw = lib().orc_trace_pixel(C.byref(self.c), mode, px, py, rgb, d, out)
+        return idw, tuple(rgb), tuple(d), tuple(out)
+
+    def ray_world(self, origin, direction):
+        col, out = (C.c_float * 3)(), (C.c_float * 8)()
+        idw = lib().orc_ray_world(C.byref(self.c), _f(origin, 3), _f(direction, 3), col, out)
+        return idw, tuple(col), tuple(out)
+
+    def find_node(self, pos, max_depth=5):
+        out = (C.c_uint32 * 10)()
+        lib().orc_find_node(C.byref(self.c), _f(pos, 3), max_depth, out)
+        fl = np.frombuffer(bytes(out), dtype=np.float32)
+        return dict(idx=out[0], root=out[1], depth=out[2], min=tuple(fl[3:6]), max=tuple(fl[6:9]), size=float(fl[9]))
+
+    def ray_sky(self, origin, direction):
+        rgb = (C.c_float * 3)()
+        lib().orc_ray_sky(C.byref(self.c), _f(origin, 3), _f(direction, 3), rgb)
+        return tuple(rgb)
+
+
+def from_package_scene(scene) -> OracleScene:
+    """OracleScene over a voxelraytracing_amd.scenes.Scene (same bytes the GPU gets)."""
+    w = scene.world
+    return OracleScene(w.nodes(), w.chunk_roots(), scene.materials, scene.cam, scene.settings, w.world_data())
+
+
+def cam_data_create(rot_deg, eye, fov_deg, proj_size) -> CamData:
+    out = CamData()
+    lib().orc_cam_data_create(_f(rot_deg, 3), _f(eye, 3), float(fov_deg), _f(proj_size, 2), C.byref(out))
+    return out
+
+
+def axis_rot_to_ray(rot_rad):
+    out = (C.c_float * 3)()
+    lib().orc_axis_rot_to_ray(_f(rot_rad, 3), out)
+    return tuple(out)
+
+
+def build_chunk_by_set_node(dense: np.ndarray, cap: int = 37449 + 64) -> np.ndarray:
+    dense = np.ascontiguousarray(dense, dtype=np.uint16).reshape(-1)
+    nodes = np.zeros(cap, dtype=np.uint16)
+    used = lib().orc_build_chunk_by_set_node(dense.ctypes.data, nodes.ctypes.data, cap)
+    assert used, "oracle set_node ran out of memory"
+    return nodes[:used].copy()
+
+
+class SvoSession:
+    """One chunk edited through the oracle's Svo::set_node + NodeAlloc (server/src/world/mod.rs:82-136 style)."""
+
+    def __init__(self, cap: int, used: int = 1, nodes: np.ndarray | None = None):
+        self.nodes = np.zeros(cap, dtype=np.uint16)
+        if nodes is not None:
+            self.nodes[:nodes.size] = nodes
+        self.alloc = NodeAlloc()
+        lib().orc_node_alloc_init(C.byref(self.alloc), 0, used, used, cap)
+
+    def set_voxel(self, x, y, z, v) -> int:
+        pos = (C.c_uint32 * 3)(x, y, z)
+        return lib().orc_svo_set_node(self.nodes.ctypes.data, 0, 32, pos, v, 5, C.byref(self.alloc))
+
+    def free_spans(self):
+        return [(self.alloc.free_start[i], self.alloc.free_end[i]) for i in range(self.alloc.n_free)]
+
+    def __del__(self):
+        lib().orc_node_alloc_destroy(C.byref(self.alloc))

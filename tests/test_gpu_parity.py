@@ -1,0 +1,170 @@
+"""GPU parity proper: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+
+Bar (BASELINE.json north_star): id words bit-exact, f32 radiance within 1e-4.
+"""
+import numpy as np
+import pytest
+
+from voxelraytracing_amd import MODE_PRIMARY, MODE_PRIMARY_SHADOW, scenes
+from voxelraytracing_amd import graphics as g
+
+from util import assert_frame_parity, gpu_for_scene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def c1():
+    return scenes.c1_flat()
+
+
+@pytest.fixture(scope="module")
+def c2_small():
+    return scenes.c2((640, 360))
+
+
+@pytest.mark.parametrize("mode", [MODE_PRIMARY, MODE_PRIMARY_SHADOW])
+def test_c1_flat_matches_oracle(c1, orc, mode):
+    gpu = gpu_for_scene(c1)
+    gpu.render(mode, stats=True)
+    rgb, ids, _ = gpu.read_output()
+    o = orc.from_package_scene(c1)
+    r_rgb, r_ids, r_steps, st = o.render(mode, *c1.size, want_steps=True)
+    assert_frame_parity(rgb, ids, r_rgb, r_ids, f"C1 mode {mode}")
+    assert np.array_equal(gpu.read_steps(), r_steps)
+    s = gpu.stats()
+    assert (s.primary_rays, s.secondary_rays, s.hits, s.steps, s.node_visits) == \
+           (st.primary_rays, st.secondary_rays, st.hits, st.steps, st.node_visits)
+    assert (s.primary_steps, s.primary_node_visits) == (st.primary_steps, st.primary_node_visits)
+
+
+@pytest.mark.parametrize("mode", [MODE_PRIMARY, MODE_PRIMARY_SHADOW])
+def test_c2_procedural_matches_oracle(c2_small, orc, mode):
+    gpu = gpu_for_scene(c2_small)
+    gpu.render(mode, stats=True)
+    rgb, ids, _ = gpu.read_output()
+    o = orc.from_package_scene(c2_small)
+    r_rgb, r_ids, r_steps, st = o.render(mode, *c2_small.size, want_steps=True)
+    assert_frame_parity(rgb, ids, r_rgb, r_ids, f"C2 mode {mode}")
+    assert np.array_equal(gpu.read_steps(), r_steps)
+    s = gpu.stats()
+    assert (s.steps, s.node_visits, s.secondary_rays) == (st.steps, st.node_visits, st.secondary_rays)
+    # the timed (stats-free) kernels must give the same frame
+    gpu.render(mode, stats=False)
+    rgb2, ids2, _ = gpu.read_output()
+    assert np.array_equal(ids2, ids) and np.array_equal(rgb2, rgb)
+
+
+@pytest.mark.parametrize("rot,eye_dy", [((0.0, 0.0, 0.0), 30.0), ((89.0, 10.0, 0.0), 60.0), ((-60.0, 200.0, 0.0), 10.0),
+                                        ((35.0, 135.0, 20.0), 3.0)])
+def test_c2_other_cameras(c2_small, orc, rot, eye_dy):
+    """Axis-parallel centre ray (NaN unit steps at rot 0), straight-down, sky-only and rolled views."""
+    w, h = 320, 200
+    eye = (c2_small.eye[0], c2_small.eye[1] - 24.0 + eye_dy, c2_small.eye[2])
+    cam = g.cam_data_create(rot, eye, 70.0, (float(w), float(h)))
+    gpu = gpu_for_scene(c2_small, (w, h))
+    gpu.write_cam_data(cam)
+    gpu.render(MODE_PRIMARY_SHADOW, stats=True)
+    rgb, ids, _ = gpu.read_output()
+    o = orc.from_package_scene(c2_small)
+    o.set_cam(cam)
+    r_rgb, r_ids, r_steps, _ = o.render(MODE_PRIMARY_SHADOW, w, h, want_steps=True)
+    assert_frame_parity(rgb, ids, r_rgb, r_ids, f"rot {rot}")
+    assert np.array_equal(gpu.read_steps(), r_steps)
+
+
+def test_camera_outside_world_sees_only_sky(c1, orc):
+    cam = g.cam_data_create((10.0, 30.0, 0.0), (-5.0, 20.0, 10.0), 70.0, (64.0, 64.0))
+    gpu = gpu_for_scene(c1, (64, 64))
+    gpu.write_cam_data(cam)
+    gpu.render(MODE_PRIMARY_SHADOW)
+    rgb, ids, _ = gpu.read_output()
+    assert not ids.any()
+    o = orc.from_package_scene(c1)
+    o.set_cam(cam)
+    r_rgb, r_ids, _, _ = o.render(MODE_PRIMARY_SHADOW, 64, 64)
+    assert_frame_parity(rgb, ids, r_rgb, r_ids, "outside")
+
+
+def test_show_step_count_debug_view(c2_small, orc):
+    st = g.make_settings(sun_pos=scenes.SUN_POS, show_step_count=1)
+    gpu = gpu_for_scene(c2_small, (320, 200))
+    cam = g.cam_data_create(c2_small.rot, c2_small.eye, 70.0, (320.0, 200.0))
+    gpu.write_cam_data(cam)
+    gpu.write_settings(st)
+    gpu.render(MODE_PRIMARY)
+    rgb, ids, _ = gpu.read_output()
+    o = orc.from_package_scene(c2_small)
+    o.set_cam(cam)
+    o.set_settings(st)
+    r_rgb, r_ids, _, _ = o.render(MODE_PRIMARY, 320, 200)
+    assert_frame_parity(rgb, ids, r_rgb, r_ids, "step-count view")
+
+
+def test_edit_then_reupload_range(orc):
+    """Voxel edit -> re-upload of the chunk's range (main.rs:352-362) changes exactly what the oracle says."""
+    sc = scenes.c1_flat((128, 128))
+    gpu = gpu_for_scene(sc)
+    # dig a hole and build a pillar with water on top, in front of the camera
+    edits = [((32, 12, 40), 0), ((32, 11, 40), 0), ((30, 13, 44), 4), ((30, 14, 44), 4), ((34, 13, 44), 3), ((34, 14, 44), 3)]
+    for pos, v in edits:
+        start, n = sc.world.set_voxel(pos, v)
+        gpu.write_nodes(sc.world.nodes_ptr(), start, start + n)
+    gpu.write_chunk_roots(sc.world.chunk_roots())
+    gpu.render(MODE_PRIMARY_SHADOW)
+    rgb, ids, _ = gpu.read_output()
+    o = orc.from_package_scene(sc)
+    r_rgb, r_ids, _, _ = o.render(MODE_PRIMARY_SHADOW, 128, 128)
+    assert_frame_parity(rgb, ids, r_rgb, r_ids, "after edits")
+    assert (ids & 0x7FFF == 4).any() and (ids & g._ffi.ID_WATER).any()
+
+
+def test_sharded_contexts_assemble_to_the_unsharded_frame(c2_small):
+    """N tile-interleaved shard contexts on one GPU: their tiles together are the whole frame."""
+    full = gpu_for_scene(c2_small)
+    full.render(MODE_PRIMARY_SHADOW)
+    rgb, ids, _ = full.read_output()
+    for n in (2, 3, 8):
+        acc_rgb = np.zeros_like(rgb)
+        acc_ids = np.zeros_like(ids)
+        owned = np.zeros(ids.shape, dtype=np.int32)
+        for r in range(n):
+            sh = gpu_for_scene(c2_small, shard_rank=r, shard_count=n)
+            sh.render(MODE_PRIMARY_SHADOW)
+            s_rgb, s_ids, _ = sh.read_output()
+            tl, tp, tt = sh.shard_info()
+            assert tp == -(-tt // n) and tl == len(range(r, tt, n))
+            acc_rgb += s_rgb
+            acc_ids |= s_ids
+            ty, tx = np.divmod(np.arange(tt), c2_small.size[0] // 8)
+            mine = np.zeros((c2_small.size[1] // 8, c2_small.size[0] // 8), dtype=np.int32)
+            mine[ty[r::n], tx[r::n]] = 1
+            owned += np.kron(mine, np.ones((8, 8), dtype=np.int32))
+            sh.close()
+        assert (owned == 1).all()
+        assert np.array_equal(acc_ids, ids) and np.array_equal(acc_rgb, rgb)
+
+
+def test_full_size_properties():
+    """At BASELINE's full size (1920x1080, 8^3 world) check size-independent properties instead of the oracle:
+    determinism, shadow pass only darkens launched pixels by exactly the factor, stats add up."""
+    sc = scenes.c2()
+    gpu = gpu_for_scene(sc)
+    gpu.render(MODE_PRIMARY)
+    p_rgb, p_ids, _ = gpu.read_output()
+    gpu.render(MODE_PRIMARY_SHADOW, stats=True)
+    s_rgb, s_ids, _ = gpu.read_output()
+    st = gpu.stats()
+    launched = (s_ids & g._ffi.ID_SHADOW_RAY) != 0
+    shadowed = (s_ids & g._ffi.ID_SHADOWED) != 0
+    assert st.primary_rays == 1920 * 1080 and st.secondary_rays == int(launched.sum())
+    assert not (shadowed & ~launched).any()
+    assert np.array_equal(s_ids & ~np.uint32(g._ffi.ID_SHADOW_RAY | g._ffi.ID_SHADOWED), p_ids)
+    assert np.array_equal(s_rgb[~shadowed], p_rgb[~shadowed])
+    assert np.array_equal(s_rgb[shadowed], p_rgb[shadowed] * np.float32(0.35))
+    solid = ((p_ids & g._ffi.ID_HIT) != 0) & ((p_ids & 0x7FFF) != 0) & ((p_ids & 0x7FFF) != 3)
+    assert np.array_equal(launched, solid)
+    assert st.hits == int(((p_ids & g._ffi.ID_HIT) != 0).sum())
+    gpu.render(MODE_PRIMARY_SHADOW)
+    r2, i2, _ = gpu.read_output()
+    assert np.array_equal(i2, s_ids) and np.array_equal(r2, s_rgb)

@@ -1,0 +1,223 @@
+// host_capi.cpp — include/vrt_host.h over the C++ host mirror (world.hpp, graphics.hpp, worldgen.hpp).
+#include <algorithm>
+#include <atomic>
+#include <thread>
+
+#include "../../../include/vrt_host.h"
+#include "graphics.hpp"
+#include "materials.hpp"
+#include "worldgen.hpp"
+
+using namespace vrt;
+
+struct vrth_world {
+    ClientWorld w;
+    vrth_world(ChunkPos c, uint32_t max_nodes, uint32_t size) : w(c, max_nodes, size) {}
+};
+
+static ChunkPos cp3(const int32_t p[3]) { return {p[0], p[1], p[2]}; }
+
+extern "C" {
+
+vrth_world *vrth_world_new(const int32_t center_chunk[3], uint32_t max_nodes, uint32_t size_in_chunks) {
+    if (!center_chunk || max_nodes < 2 || size_in_chunks == 0) return nullptr;
+    try {
+        return new vrth_world(cp3(center_chunk), max_nodes, size_in_chunks);
+    } catch (...) {
+        return nullptr;
+    }
+}
+
+void vrth_world_free(vrth_world *w) { delete w; }
+
+int vrth_world_create_chunk(vrth_world *w, const int32_t chunk_pos[3], const uint16_t *nodes, uint32_t n, uint32_t *root_out) {
+    SetVoxelErr err;
+    const NodeAddr root = w->w.create_chunk(cp3(chunk_pos), reinterpret_cast<const Node *>(nodes), n, err);
+    if (root_out) *root_out = root;
+    return (int)err;
+}
+
+int vrth_world_set_voxel(vrth_world *w, const int32_t p[3], uint16_t voxel, uint32_t *range_start, uint32_t *range_len) {
+    // GameState::set_voxel (client/src/lib.rs:67-76): NoChange short-circuit, then ClientWorld::set_voxel
+    Voxel cur;
+    if (auto e = w->w.get_voxel(cp3(p), cur); e != SetVoxelErr::Ok) return (int)e;
+    if (cur == Voxel(voxel)) return (int)SetVoxelErr::NoChange;
+    const Chunk *c = nullptr;
+    const SetVoxelErr e = w->w.set_voxel(cp3(p), Voxel(voxel), &c);
+    if (e == SetVoxelErr::Ok && c) {
+        if (range_start) *range_start = c->range.start;
+        if (range_len) *range_len = c->range.len();
+    }
+    return (int)e;
+}
+
+int vrth_world_get_voxel(const vrth_world *w, const int32_t p[3], uint16_t *voxel_out) {
+    Voxel v;
+    const SetVoxelErr e = w->w.get_voxel(cp3(p), v);
+    if (e == SetVoxelErr::Ok && voxel_out) *voxel_out = v.as_data();
+    return (int)e;
+}
+
+uint32_t vrth_world_center_chunks(vrth_world *w, const int32_t anchor_chunk[3]) {
+    std::vector<std::pair<ChunkPos, Chunk>> removed;
+    w->w.center_chunks(cp3(anchor_chunk), removed);
+    for (auto &rc : removed) w->w.free_chunk(rc.second);
+    return (uint32_t)removed.size();
+}
+
+void vrth_world_resize(vrth_world *w, uint32_t size_in_chunks) { w->w.resize(size_in_chunks); }
+
+const uint16_t *vrth_world_nodes(const vrth_world *w) { return reinterpret_cast<const uint16_t *>(w->w.nodes()); }
+uint32_t vrth_world_max_nodes(const vrth_world *w) { return w->w.max_nodes(); }
+
+uint32_t vrth_world_chunk_roots(const vrth_world *w, uint32_t *out, uint32_t cap) {
+    const std::vector<NodeAddr> r = w->w.chunk_roots();
+    if (out) std::copy_n(r.begin(), std::min<size_t>(cap, r.size()), out);
+    return (uint32_t)r.size();
+}
+
+void vrth_world_info(const vrth_world *w, int32_t min_voxel[3], uint32_t *size_in_voxels, uint32_t *size_in_chunks, uint32_t *populated) {
+    const VoxelPos m = w->w.min_voxel();
+    if (min_voxel) { min_voxel[0] = m.x; min_voxel[1] = m.y; min_voxel[2] = m.z; }
+    if (size_in_voxels) *size_in_voxels = w->w.size_in_voxels();
+    if (size_in_chunks) *size_in_chunks = w->w.size_in_chunks();
+    if (populated) *populated = (uint32_t)w->w.populated_count();
+}
+
+void vrth_world_alloc_status(const vrth_world *w, uint32_t *free_nodes, uint32_t *max_nodes) {
+    const auto s = w->w.chunk_alloc_status();
+    if (free_nodes) *free_nodes = s.first;
+    if (max_nodes) *max_nodes = s.second;
+}
+
+int vrth_world_chunk_state(const vrth_world *w, const int32_t chunk_pos[3], uint32_t *range_start, uint32_t *range_end,
+                           uint32_t *last_used_addr, uint32_t *spans, uint32_t cap_spans) {
+    const Chunk *c = w->w.get_chunk(cp3(chunk_pos));
+    if (!c) return -1;
+    if (range_start) *range_start = c->range.start;
+    if (range_end) *range_end = c->range.end;
+    if (last_used_addr) *last_used_addr = c->alloc.last_used_addr;
+    const auto &fm = c->alloc.free_mem;
+    for (size_t i = 0; i < fm.size() && i < cap_spans; i++) {
+        spans[2 * i] = fm[i].start;
+        spans[2 * i + 1] = fm[i].end;
+    }
+    return (int)fm.size();
+}
+
+int vrth_world_highest_vox_at(const vrth_world *w, int32_t x, int32_t z, int32_t *y_out) {
+    const auto y = w->w.highest_vox_at({x, 0, z});
+    if (!y) return 0;
+    if (y_out) *y_out = *y;
+    return 1;
+}
+
+void vrth_world_data_from(const vrth_world *w, vrt_world_data *out) { *out = WorldData::from(w->w); }
+
+void vrth_cam_data_create(const float rot_deg[3], const float eye[3], float fov_deg, const float proj_size[2], vrt_cam_data *out) {
+    *out = CamData::create({rot_deg[0], rot_deg[1], rot_deg[2]}, {eye[0], eye[1], eye[2]}, fov_deg, {proj_size[0], proj_size[1]});
+}
+
+void vrth_axis_rot_to_ray(const float rot_rad[3], float out[3]) {
+    const float r = std::cos(rot_rad[0]);
+    out[0] = r * -std::sin(rot_rad[1]);
+    out[2] = r * -std::cos(rot_rad[1]);
+    out[1] = -std::sin(rot_rad[0]);
+}
+
+void vrth_std_materials(vrt_material *out256) {
+    std::memset(out256, 0, 256 * sizeof(vrt_material));  // Material::ZERO for unnamed slots
+    for (int i = 0; i < kStdVoxelCount; i++) {
+        out256[i].color[0] = kStdVoxels[i].r;
+        out256[i].color[1] = kStdVoxels[i].g;
+        out256[i].color[2] = kStdVoxels[i].b;
+        out256[i].is_empty = kStdVoxels[i].is_empty;
+        out256[i].is_liquid = kStdVoxels[i].is_liquid;
+        out256[i].scatter = 0.0f;
+    }
+}
+
+const char *vrth_std_voxel_name(uint32_t id) { return id < (uint32_t)kStdVoxelCount ? kStdVoxels[id].name : nullptr; }
+
+uint32_t vrth_svo_build_by_set_node(const uint16_t *dense, uint16_t *nodes, uint32_t cap) {
+    return build_svo_by_set_node(dense, reinterpret_cast<Node *>(nodes), cap);
+}
+
+uint32_t vrth_svo_build_bottom_up(const uint16_t *dense, uint16_t *nodes, uint32_t cap) {
+    std::vector<Node> out;
+    if (!build_svo_bottom_up(dense, out) || out.size() > cap) return 0;
+    std::memcpy(nodes, out.data(), out.size() * sizeof(Node));
+    return (uint32_t)out.size();
+}
+
+void vrth_svo_to_dense(const uint16_t *nodes, uint16_t *dense) {
+    const Node *n = reinterpret_cast<const Node *>(nodes);
+    const Svo svo{0, CHUNK_SIZE};
+    for (uint32_t z = 0; z < 32; z++)
+        for (uint32_t y = 0; y < 32; y++)
+            for (uint32_t x = 0; x < 32; x++) dense[x + 32 * (y + 32 * z)] = n[svo.find_node(n, {x, y, z}, CHUNK_DEPTH).idx].voxel().as_data();
+}
+
+int32_t vrth_gen_height(uint32_t seed, int32_t x, int32_t z) {
+    WorldGen g;
+    g.seed = seed;
+    return g.height(x, z);
+}
+
+int vrth_gen_dense(uint32_t seed, const int32_t chunk_pos[3], uint16_t *dense) {
+    WorldGen g;
+    g.seed = seed;
+    return g.fill_dense(cp3(chunk_pos), dense) ? 1 : 0;
+}
+
+void vrth_gen_dense_superflat(const int32_t chunk_pos[3], uint16_t *dense) { fill_dense_superflat(cp3(chunk_pos), dense); }
+
+int vrth_world_generate(vrth_world *w, uint32_t kind, uint32_t seed, int threads) {
+    const uint32_t S = w->w.size_in_chunks();
+    const size_t total = (size_t)S * S * S;
+    std::vector<std::vector<Node>> built(total);
+    std::atomic<size_t> next{0};
+    std::atomic<int> failed{0};
+    unsigned nt = threads > 0 ? (unsigned)threads : std::max(1u, std::thread::hardware_concurrency());
+    nt = (unsigned)std::min<size_t>(nt, total);
+    WorldGen g;
+    g.seed = seed;
+    const ChunkPos mn = w->w.min_chunk();
+    auto work = [&]() {
+        std::vector<uint16_t> dense(32768);
+        std::vector<Node> scratch(NODES_PER_CHUNK + 64);
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= total) return;
+            const ChunkPos cp{mn.x + (int32_t)(i % S), mn.y + (int32_t)((i / S) % S), mn.z + (int32_t)(i / ((size_t)S * S))};
+            if (kind == 1) {
+                fill_dense_superflat(cp, dense.data());
+                // C1 is built the reference's way (set_node, x -> z -> y), holes and all
+                const uint32_t used = build_svo_by_set_node(dense.data(), scratch.data(), (uint32_t)scratch.size());
+                if (!used) { failed = (int)SetVoxelErr::OutOfMemory; return; }
+                built[i].assign(scratch.begin(), scratch.begin() + used);
+            } else {
+                const bool uniform = g.fill_dense(cp, dense.data());
+                if (uniform) built[i].assign(1, Node::make(Voxel(dense[0])));
+                else if (!build_svo_bottom_up(dense.data(), built[i])) { failed = (int)SetVoxelErr::OutOfMemory; return; }
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nt; t++) pool.emplace_back(work);
+    work();
+    for (auto &t : pool) t.join();
+    if (failed) return failed;
+    // create_chunk in grid order (x fastest), so pool layout is deterministic regardless of threads
+    for (size_t i = 0; i < total; i++) {
+        const ChunkPos cp{mn.x + (int32_t)(i % S), mn.y + (int32_t)((i / S) % S), mn.z + (int32_t)(i / ((size_t)S * S))};
+        // an all-air chunk needs no storage: leaving the cell empty resolves to pool[0] (world.rs:154-159)
+        if (built[i].size() == 1 && built[i][0].w == 0) continue;
+        SetVoxelErr err;
+        w->w.create_chunk(cp, built[i].data(), (uint32_t)built[i].size(), err);
+        if (err != SetVoxelErr::Ok) return (int)err;
+    }
+    return 0;
+}
+
+}  // extern "C"

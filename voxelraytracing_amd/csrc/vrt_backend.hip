@@ -1,0 +1,534 @@
+// vrt_backend.hip — the C ABI of include/vrt.h over the gfx950 kernels in vrt_kernels.hip.
+//
+// Replaces the reference's wgpu seam: GpuResources / Buffers / NodeBuffer / SimpleBuffer /
+// ArrayBuffer / PixelShader (clientdesktop/src/graphics/{mod.rs,shader.rs}).  Device memory layout
+// (DESIGN.md §HBM layout): the node pool is kept byte-identical to the host pool (little-endian u16 =
+// the reference's packed u32 pairs), chunk_roots is a dense u32[S^3], materials 256 x 32 B, output
+// f32x3 + u32 id per pixel slot, hit buffer 16 B per local pixel.
+#include <hip/hip_runtime.h>
+
+#include <array>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "vrt_device.h"
+
+namespace vrt {
+void launch_primary(const FrameParams &P, uint32_t variant, bool stats, bool shadow, hipStream_t st);
+void launch_shadow(const FrameParams &P, uint32_t variant, bool stats, hipStream_t st);
+void launch_quantize(const float *rgb, uint8_t *rgba8, uint32_t n, hipStream_t st);
+void launch_assemble(const float *g_rgb, const uint32_t *g_ids, float *dst_rgb, uint32_t *dst_ids, uint32_t width,
+                     uint32_t tiles_x, uint32_t tiles_total, uint32_t shard_count, uint64_t stride_rgb,
+                     uint64_t stride_ids, hipStream_t st);
+}  // namespace vrt
+
+static_assert(sizeof(vrt_material) == 32, "Material layout (mod.rs:20-28)");
+static_assert(sizeof(vrt_cam_data) == 160, "CamData layout (mod.rs:82-91)");
+static_assert(sizeof(vrt_world_data) == 32, "WorldData layout (mod.rs:113-120)");
+static_assert(sizeof(vrt_settings) == 48, "Settings layout (mod.rs:132-143)");
+
+struct vrt_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    // one hipEvent triple {start, after primary, end} per frame rendered since the last vrt_get_stats
+    std::vector<std::array<hipEvent_t, 3>> ev_pool;
+    size_t ev_used = 0;
+    double acc_ms[3] = {0, 0, 0};  // frames folded early because the pool was full
+    uint32_t acc_frames = 0;
+
+    uint32_t max_nodes = 0;  // even
+    uint32_t world_size = 0;
+    uint32_t n_roots = 0;
+    uint32_t width = 0, height = 0;
+    uint32_t shard_rank = 0, shard_count = 1;
+    uint32_t tiles_x = 0, tiles_total = 0, tiles_local = 0, tiles_padded = 0;
+    uint32_t slots = 0;  // pixel slots in the output buffers
+
+    uint16_t *d_nodes = nullptr;
+    uint32_t *d_roots = nullptr;
+    vrt_material *d_mats = nullptr;
+    float *d_rgb = nullptr;      // where frames are written: own_rgb or caller-bound memory
+    uint32_t *d_ids = nullptr;
+    float *own_rgb = nullptr;
+    uint32_t *own_ids = nullptr;
+    uint4 *d_hits = nullptr;
+    unsigned long long *d_counters = nullptr;
+    uint32_t *d_steps = nullptr;
+    uint8_t *d_rgba8 = nullptr;
+
+    vrt_material h_mats[256];
+    vrt_cam_data cam;
+    vrt_settings settings;
+    vrt_world_data world;
+
+    bool rendered = false;
+    bool last_stats = false;
+    uint32_t last_mode = 0;
+    bool timing_pending = false;
+    vrt_stats stats;
+
+    std::string err;
+};
+
+static thread_local std::string g_create_err;
+
+static int fail(vrt_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    else g_create_err = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                          \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? VRT_ERR_OOM : VRT_ERR_DEVICE, "%s: %s", #expr, \
+                        hipGetErrorString(e_));                                                     \
+    } while (0)
+
+static void layout_tiles(vrt_ctx *c) {
+    c->tiles_x = c->width / 8u;
+    c->tiles_total = c->tiles_x * (c->height / 8u);
+    c->tiles_padded = (c->tiles_total + c->shard_count - 1u) / c->shard_count;
+    c->tiles_local = c->shard_rank < c->tiles_total ? (c->tiles_total - c->shard_rank + c->shard_count - 1u) / c->shard_count : 0u;
+    c->slots = c->shard_count > 1u ? c->tiles_padded * 64u : c->width * c->height;
+}
+
+static int alloc_output(vrt_ctx *c) {
+    (void)hipFree(c->own_rgb); (void)hipFree(c->own_ids); (void)hipFree(c->d_hits); (void)hipFree(c->d_steps); (void)hipFree(c->d_rgba8);
+    c->own_rgb = nullptr; c->own_ids = nullptr; c->d_hits = nullptr; c->d_steps = nullptr; c->d_rgba8 = nullptr;
+    layout_tiles(c);
+    const size_t n = c->slots ? c->slots : 1;
+    HIP_TRY(c, hipMalloc(&c->own_rgb, n * 3 * sizeof(float)));
+    HIP_TRY(c, hipMalloc(&c->own_ids, n * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc(&c->d_hits, n * sizeof(uint4)));
+    c->d_rgb = c->own_rgb;  // a resize drops any caller-bound output (its size no longer matches)
+    c->d_ids = c->own_ids;
+    HIP_TRY(c, hipMemsetAsync(c->d_rgb, 0, n * 3 * sizeof(float), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_ids, 0, n * sizeof(uint32_t), c->stream));
+    c->rendered = false;
+    return VRT_OK;
+}
+
+static int alloc_roots(vrt_ctx *c, uint32_t world_size) {
+    const uint64_t n = (uint64_t)world_size * world_size * world_size;
+    if (world_size == 0 || n > (1ull << 28)) return fail(c, VRT_ERR_INVALID_ARG, "world_size_chunks %u out of range", world_size);
+    (void)hipFree(c->d_roots);
+    c->d_roots = nullptr;
+    HIP_TRY(c, hipMalloc(&c->d_roots, n * sizeof(uint32_t)));
+    // A fresh wgpu buffer is zero-initialised: every chunk resolves to pool[0], the air leaf.
+    HIP_TRY(c, hipMemsetAsync(c->d_roots, 0, n * sizeof(uint32_t), c->stream));
+    c->world_size = world_size;
+    c->n_roots = (uint32_t)n;
+    return VRT_OK;
+}
+
+extern "C" {
+
+int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
+    if (!cfg || !out) return fail(nullptr, VRT_ERR_INVALID_ARG, "vrt_create: null argument");
+    *out = nullptr;
+    if (cfg->max_nodes < 2) return fail(nullptr, VRT_ERR_INVALID_ARG, "max_nodes must be >= 2");
+    if (cfg->width == 0 || cfg->height == 0 || (cfg->width % 8u) || (cfg->height % 8u))
+        return fail(nullptr, VRT_ERR_INVALID_ARG,
+                    "output %ux%u: dimensions must be non-zero multiples of 8 (the reference dispatches "
+                    "tex_size/8 workgroups with no bounds check, main.rs:452)", cfg->width, cfg->height);
+    if ((uint64_t)cfg->width * cfg->height > (1ull << 28))
+        return fail(nullptr, VRT_ERR_INVALID_ARG, "output too large");
+    const uint32_t sc = cfg->shard_count ? cfg->shard_count : 1u;
+    if (cfg->shard_rank >= sc) return fail(nullptr, VRT_ERR_INVALID_ARG, "shard_rank %u >= shard_count %u", cfg->shard_rank, sc);
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(nullptr, VRT_ERR_DEVICE, "no HIP device available (%s)", hipGetErrorString(e));
+    int dev = cfg->device;
+    if (dev < 0) {
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    }
+    if (dev >= ndev) return fail(nullptr, VRT_ERR_INVALID_ARG, "device %d out of range (%d devices)", dev, ndev);
+
+    vrt_ctx *c = new (std::nothrow) vrt_ctx();
+    if (!c) return fail(nullptr, VRT_ERR_OOM, "host allocation failed");
+    c->device = dev;
+    c->shard_rank = cfg->shard_rank;
+    c->shard_count = sc;
+    c->width = cfg->width;
+    c->height = cfg->height;
+    c->max_nodes = cfg->max_nodes & ~1u;  // NodeBuffer::new forces an even size (shader.rs:10-12)
+    memset(c->h_mats, 0, sizeof c->h_mats);
+    memset(&c->cam, 0, sizeof c->cam);
+    memset(&c->settings, 0, sizeof c->settings);
+    memset(&c->world, 0, sizeof c->world);
+    memset(&c->stats, 0, sizeof c->stats);
+
+    int rc = VRT_OK;
+    auto body = [&]() -> int {
+        HIP_TRY(c, hipSetDevice(dev));
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+        c->stream = c->own_stream;
+        HIP_TRY(c, hipMalloc(&c->d_nodes, (size_t)c->max_nodes * sizeof(uint16_t)));
+        // fresh buffer = zeros = every node an air leaf (client/src/world.rs:273-274)
+        HIP_TRY(c, hipMemsetAsync(c->d_nodes, 0, (size_t)c->max_nodes * sizeof(uint16_t), c->stream));
+        HIP_TRY(c, hipMalloc(&c->d_mats, sizeof c->h_mats));
+        HIP_TRY(c, hipMemsetAsync(c->d_mats, 0, sizeof c->h_mats, c->stream));
+        HIP_TRY(c, hipMalloc(&c->d_counters, vrt::kCtrCount * sizeof(unsigned long long)));
+        HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, vrt::kCtrCount * sizeof(unsigned long long), c->stream));
+        int r = alloc_roots(c, cfg->world_size_chunks);
+        if (r) return r;
+        r = alloc_output(c);
+        if (r) return r;
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return VRT_OK;
+    };
+    rc = body();
+    if (rc != VRT_OK) {
+        g_create_err = c->err;
+        vrt_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return VRT_OK;
+}
+
+void vrt_destroy(vrt_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipSetDevice(c->device);
+    (void)hipFree(c->d_nodes); (void)hipFree(c->d_roots); (void)hipFree(c->d_mats); (void)hipFree(c->own_rgb); (void)hipFree(c->own_ids);
+    (void)hipFree(c->d_hits); (void)hipFree(c->d_counters); (void)hipFree(c->d_steps); (void)hipFree(c->d_rgba8);
+    for (auto &t : c->ev_pool)
+        for (auto &ev : t)
+            if (ev) (void)hipEventDestroy(ev);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+const char *vrt_last_error(const vrt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int vrt_write_nodes(vrt_ctx *c, const uint16_t *pool, uint32_t start, uint32_t end) {
+    if (!c || !pool) return fail(c, VRT_ERR_INVALID_ARG, "vrt_write_nodes: null argument");
+    if (end < start) return fail(c, VRT_ERR_INVALID_ARG, "vrt_write_nodes: end %u < start %u", end, start);
+    // NodeBuffer::write, shader.rs:24-33: widen to even bounds
+    uint32_t root = start, count = end - start;
+    if (root % 2 == 1) { root -= 1; count += 1; }
+    if (count % 2 == 1) count += 1;
+    if (count == 0) return VRT_OK;
+    if ((uint64_t)root + count > c->max_nodes)
+        return fail(c, VRT_ERR_OUT_OF_RANGE, "vrt_write_nodes: [%u,%u) exceeds the %u-node buffer", start, end, c->max_nodes);
+    HIP_TRY(c, hipSetDevice(c->device));
+    // stream-ordered after earlier renders; the sync makes it copy-at-call-time (write_buffer
+    // semantics: the caller may reuse `pool` as soon as this returns)
+    HIP_TRY(c, hipMemcpyAsync(c->d_nodes + root, pool + root, (size_t)count * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VRT_OK;
+}
+
+int vrt_write_chunk_roots(vrt_ctx *c, uint32_t offset, const uint32_t *roots, uint32_t n) {
+    if (!c || (!roots && n)) return fail(c, VRT_ERR_INVALID_ARG, "vrt_write_chunk_roots: null argument");
+    if (offset > c->n_roots) return fail(c, VRT_ERR_OUT_OF_RANGE, "vrt_write_chunk_roots: offset %u > %u", offset, c->n_roots);
+    // ArrayBuffer::write truncates to capacity (shader.rs:134-135)
+    const uint32_t cut = n < c->n_roots - offset ? n : c->n_roots - offset;
+    if (cut == 0) return VRT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(c->d_roots + offset, roots, (size_t)cut * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VRT_OK;
+}
+
+int vrt_resize_world(vrt_ctx *c, uint32_t world_size_chunks) {
+    if (!c) return VRT_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return alloc_roots(c, world_size_chunks);
+}
+
+int vrt_write_materials(vrt_ctx *c, uint32_t first, const vrt_material *mats, uint32_t n) {
+    if (!c || (!mats && n)) return fail(c, VRT_ERR_INVALID_ARG, "vrt_write_materials: null argument");
+    if ((uint64_t)first + n > 256) return fail(c, VRT_ERR_OUT_OF_RANGE, "vrt_write_materials: %u+%u > 256", first, n);
+    if (n == 0) return VRT_OK;
+    memcpy(c->h_mats + first, mats, (size_t)n * sizeof(vrt_material));
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(c->d_mats + first, mats, (size_t)n * sizeof(vrt_material), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VRT_OK;
+}
+
+int vrt_set_camera(vrt_ctx *c, const vrt_cam_data *cam) {
+    if (!c || !cam) return fail(c, VRT_ERR_INVALID_ARG, "vrt_set_camera: null argument");
+    c->cam = *cam;
+    return VRT_OK;
+}
+
+int vrt_set_settings(vrt_ctx *c, const vrt_settings *s) {
+    if (!c || !s) return fail(c, VRT_ERR_INVALID_ARG, "vrt_set_settings: null argument");
+    c->settings = *s;
+    return VRT_OK;
+}
+
+int vrt_set_world(vrt_ctx *c, const vrt_world_data *w) {
+    if (!c || !w) return fail(c, VRT_ERR_INVALID_ARG, "vrt_set_world: null argument");
+    c->world = *w;
+    return VRT_OK;
+}
+
+int vrt_resize_output(vrt_ctx *c, uint32_t width, uint32_t height) {
+    if (!c) return VRT_ERR_INVALID_ARG;
+    if (width == 0 || height == 0 || (width % 8u) || (height % 8u) || (uint64_t)width * height > (1ull << 28))
+        return fail(c, VRT_ERR_INVALID_ARG, "output %ux%u: dimensions must be non-zero multiples of 8", width, height);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->width = width;
+    c->height = height;
+    return alloc_output(c);
+}
+
+static int validate_frame(vrt_ctx *c) {
+    const uint32_t S = c->world.size_in_chunks;
+    if (S == 0 || (uint64_t)S * S * S > c->n_roots)
+        return fail(c, VRT_ERR_STATE, "world.size_in_chunks %u does not fit the %u-entry chunk_roots buffer "
+                    "(call vrt_resize_world first, main.rs:441-445)", S, c->n_roots);
+    if (c->world.size != S * 32u)
+        return fail(c, VRT_ERR_STATE, "world.size %u != size_in_chunks*32 (%u)", c->world.size, S * 32u);
+    return VRT_OK;
+}
+
+// Fold the event triples of all frames rendered since the last call into acc_ms (synchronises).
+static int fold_events(vrt_ctx *c, float last[3]) {
+    if (c->ev_used == 0) return VRT_OK;
+    HIP_TRY(c, hipEventSynchronize(c->ev_pool[c->ev_used - 1][2]));
+    for (size_t i = 0; i < c->ev_used; i++) {
+        auto &t = c->ev_pool[i];
+        float a = 0, b = 0, tot = 0;
+        HIP_TRY(c, hipEventElapsedTime(&a, t[0], t[1]));
+        HIP_TRY(c, hipEventElapsedTime(&b, t[1], t[2]));
+        HIP_TRY(c, hipEventElapsedTime(&tot, t[0], t[2]));
+        c->acc_ms[0] += a; c->acc_ms[1] += b; c->acc_ms[2] += tot;
+        c->acc_frames += 1;
+        if (last) { last[0] = a; last[1] = b; last[2] = tot; }
+    }
+    c->ev_used = 0;
+    return VRT_OK;
+}
+
+int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
+    if (!c) return VRT_ERR_INVALID_ARG;
+    vrt_render_opts o;
+    memset(&o, 0, sizeof o);
+    if (opts) o = *opts;
+    if (o.mode > VRT_MODE_PRIMARY_SHADOW) return fail(c, VRT_ERR_INVALID_ARG, "vrt_render: mode %u not supported", o.mode);
+    int rc = validate_frame(c);
+    if (rc) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+
+    if (o.stats && !c->d_steps) HIP_TRY(c, hipMalloc(&c->d_steps, (size_t)(c->slots ? c->slots : 1) * sizeof(uint32_t)));
+
+    vrt::FrameParams P;
+    memset(&P, 0, sizeof P);
+    P.nodes = c->d_nodes;
+    P.roots = c->d_roots;
+    P.mats = c->d_mats;
+    P.rgb = c->d_rgb;
+    P.ids = c->d_ids;
+    P.hits = c->d_hits;
+    P.counters = c->d_counters;
+    P.steps = o.stats ? c->d_steps : nullptr;
+    P.n_nodes = c->max_nodes;
+    // only the S^3 entries the frame's WorldData describes are addressable (find_node :120-123)
+    P.n_roots = c->world.size_in_chunks * c->world.size_in_chunks * c->world.size_in_chunks;
+    P.width = c->width;
+    P.height = c->height;
+    P.tiles_x = c->tiles_x;
+    P.tiles_total = c->tiles_total;
+    P.shard_rank = c->shard_rank;
+    P.shard_count = c->shard_count;
+    P.tiles_local = c->tiles_local;
+    P.cam = c->cam;
+    P.settings = c->settings;
+    P.world = c->world;
+    for (int v = 0; v < 256; v++)
+        if (c->h_mats[v].is_liquid == 1u) P.liquid[v >> 5] |= 1u << (v & 31);
+
+    const bool shadow = o.mode == VRT_MODE_PRIMARY_SHADOW;
+    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, vrt::kCtrCount * sizeof(unsigned long long), c->stream));
+    if (c->ev_used == c->ev_pool.size()) {
+        if (c->ev_pool.size() >= 1024) {
+            rc = fold_events(c, nullptr);
+            if (rc) return rc;
+        } else {
+            std::array<hipEvent_t, 3> t{nullptr, nullptr, nullptr};
+            for (auto &ev : t) HIP_TRY(c, hipEventCreate(&ev));
+            c->ev_pool.push_back(t);
+        }
+    }
+    auto &ev = c->ev_pool[c->ev_used++];
+    HIP_TRY(c, hipEventRecord(ev[0], c->stream));
+    vrt::launch_primary(P, o.variant, o.stats != 0, shadow, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(ev[1], c->stream));
+    if (shadow) {
+        vrt::launch_shadow(P, o.variant, o.stats != 0, c->stream);
+        HIP_TRY(c, hipGetLastError());
+    }
+    HIP_TRY(c, hipEventRecord(ev[2], c->stream));
+    c->rendered = true;
+    c->last_stats = o.stats != 0;
+    c->last_mode = o.mode;
+    c->timing_pending = true;
+    return VRT_OK;
+}
+
+int vrt_synchronize(vrt_ctx *c) {
+    if (!c) return VRT_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VRT_OK;
+}
+
+int vrt_read_output(vrt_ctx *c, float *rgb, uint32_t *ids, uint8_t *rgba8) {
+    if (!c) return VRT_ERR_INVALID_ARG;
+    if (!c->rendered) return fail(c, VRT_ERR_STATE, "vrt_read_output: nothing rendered yet");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t npix = (size_t)c->width * c->height;
+    if (c->shard_count == 1u) {
+        if (rgba8) {
+            if (!c->d_rgba8) HIP_TRY(c, hipMalloc(&c->d_rgba8, npix * 4));
+            vrt::launch_quantize(c->d_rgb, c->d_rgba8, (uint32_t)npix, c->stream);
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipMemcpyAsync(rgba8, c->d_rgba8, npix * 4, hipMemcpyDeviceToHost, c->stream));
+        }
+        if (rgb) HIP_TRY(c, hipMemcpyAsync(rgb, c->d_rgb, npix * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        if (ids) HIP_TRY(c, hipMemcpyAsync(ids, c->d_ids, npix * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return VRT_OK;
+    }
+    // sharded: de-interleave this context's tiles on the host; foreign tiles read as zero
+    if (rgba8) return fail(c, VRT_ERR_STATE, "vrt_read_output: rgba8 readback is only available unsharded");
+    std::vector<float> t_rgb(rgb ? (size_t)c->slots * 3 : 0);
+    std::vector<uint32_t> t_ids(ids ? (size_t)c->slots : 0);
+    if (rgb) HIP_TRY(c, hipMemcpyAsync(t_rgb.data(), c->d_rgb, t_rgb.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (ids) HIP_TRY(c, hipMemcpyAsync(t_ids.data(), c->d_ids, t_ids.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (rgb) memset(rgb, 0, npix * 3 * sizeof(float));
+    if (ids) memset(ids, 0, npix * sizeof(uint32_t));
+    for (uint32_t tl = 0; tl < c->tiles_local; tl++) {
+        const uint32_t tile = c->shard_rank + tl * c->shard_count;
+        const uint32_t tx = (tile % c->tiles_x) * 8u, ty = (tile / c->tiles_x) * 8u;
+        for (uint32_t p = 0; p < 64; p++) {
+            const size_t dst = (size_t)(ty + (p >> 3)) * c->width + tx + (p & 7u);
+            const size_t src = (size_t)tl * 64 + p;
+            if (rgb) { rgb[dst * 3] = t_rgb[src * 3]; rgb[dst * 3 + 1] = t_rgb[src * 3 + 1]; rgb[dst * 3 + 2] = t_rgb[src * 3 + 2]; }
+            if (ids) ids[dst] = t_ids[src];
+        }
+    }
+    return VRT_OK;
+}
+
+int vrt_read_steps(vrt_ctx *c, uint32_t *steps) {
+    if (!c || !steps) return fail(c, VRT_ERR_INVALID_ARG, "vrt_read_steps: null argument");
+    if (!c->rendered || !c->last_stats || !c->d_steps)
+        return fail(c, VRT_ERR_STATE, "vrt_read_steps: the last frame was not rendered with opts.stats = 1");
+    if (c->shard_count != 1u) return fail(c, VRT_ERR_STATE, "vrt_read_steps: only available unsharded");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(steps, c->d_steps, (size_t)c->width * c->height * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VRT_OK;
+}
+
+int vrt_get_stats(vrt_ctx *c, vrt_stats *out) {
+    if (!c || !out) return fail(c, VRT_ERR_INVALID_ARG, "vrt_get_stats: null argument");
+    if (!c->rendered) return fail(c, VRT_ERR_STATE, "vrt_get_stats: nothing rendered yet");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->timing_pending) {
+        float last[3] = {0, 0, 0};
+        int rc = fold_events(c, last);
+        if (rc) return rc;
+        unsigned long long h[vrt::kCtrCount];
+        HIP_TRY(c, hipMemcpyAsync(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        vrt_stats s;
+        memset(&s, 0, sizeof s);
+        s.primary_rays = (uint64_t)c->tiles_local * 64u;
+        s.secondary_rays = c->last_mode == VRT_MODE_PRIMARY_SHADOW ? h[vrt::kCtrHitCount] : 0;
+        if (c->last_stats) {
+            s.hits = h[vrt::kCtrHits];
+            s.steps = h[vrt::kCtrSteps];
+            s.node_visits = h[vrt::kCtrVisits];
+            s.primary_steps = h[vrt::kCtrPrimarySteps];
+            s.primary_node_visits = h[vrt::kCtrPrimaryVisits];
+        }
+        s.ms_primary = last[0]; s.ms_secondary = last[1]; s.ms_total = last[2];
+        s.frames = c->acc_frames;
+        s.sum_ms_primary = c->acc_ms[0]; s.sum_ms_secondary = c->acc_ms[1]; s.sum_ms_total = c->acc_ms[2];
+        c->acc_frames = 0;
+        c->acc_ms[0] = c->acc_ms[1] = c->acc_ms[2] = 0;
+        c->stats = s;
+        c->timing_pending = false;
+    }
+    *out = c->stats;
+    return VRT_OK;
+}
+
+int vrt_set_stream(vrt_ctx *c, void *hip_stream) {
+    if (!c) return VRT_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return VRT_OK;
+}
+
+int vrt_bind_output(vrt_ctx *c, void *rgb, void *ids) {
+    if (!c) return VRT_ERR_INVALID_ARG;
+    if ((rgb == nullptr) != (ids == nullptr)) return fail(c, VRT_ERR_INVALID_ARG, "vrt_bind_output: bind both buffers or neither");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->d_rgb = rgb ? (float *)rgb : c->own_rgb;
+    c->d_ids = ids ? (uint32_t *)ids : c->own_ids;
+    c->rendered = false;
+    return VRT_OK;
+}
+
+int vrt_device_output(vrt_ctx *c, void **rgb, void **ids, uint64_t *rgb_bytes, uint64_t *ids_bytes) {
+    if (!c) return VRT_ERR_INVALID_ARG;
+    if (rgb) *rgb = c->d_rgb;
+    if (ids) *ids = c->d_ids;
+    if (rgb_bytes) *rgb_bytes = (uint64_t)c->slots * 3 * sizeof(float);
+    if (ids_bytes) *ids_bytes = (uint64_t)c->slots * sizeof(uint32_t);
+    return VRT_OK;
+}
+
+int vrt_shard_info(vrt_ctx *c, uint32_t *tiles_local, uint32_t *tiles_padded, uint32_t *tiles_total) {
+    if (!c) return VRT_ERR_INVALID_ARG;
+    if (tiles_local) *tiles_local = c->tiles_local;
+    if (tiles_padded) *tiles_padded = c->tiles_padded;
+    if (tiles_total) *tiles_total = c->tiles_total;
+    return VRT_OK;
+}
+
+int vrt_assemble(vrt_ctx *c, const void *gathered_rgb, const void *gathered_ids, uint64_t rank_stride_bytes, void *dst_rgb, void *dst_ids) {
+    if (!c) return VRT_ERR_INVALID_ARG;
+    if ((dst_rgb && !gathered_rgb) || (dst_ids && !gathered_ids))
+        return fail(c, VRT_ERR_INVALID_ARG, "vrt_assemble: destination without a gathered source");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (rank_stride_bytes % 4) return fail(c, VRT_ERR_INVALID_ARG, "vrt_assemble: rank stride must be a multiple of 4 bytes");
+    const uint32_t per_rank = c->tiles_padded * 64u;
+    const uint64_t stride_rgb = rank_stride_bytes ? rank_stride_bytes / 4 : (uint64_t)per_rank * 3u;
+    const uint64_t stride_ids = rank_stride_bytes ? rank_stride_bytes / 4 : (uint64_t)per_rank;
+    vrt::launch_assemble((const float *)gathered_rgb, (const uint32_t *)gathered_ids, (float *)dst_rgb, (uint32_t *)dst_ids,
+                         c->width, c->tiles_x, c->tiles_total, c->shard_count, stride_rgb, stride_ids, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    return VRT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,84 @@
+// vrt_device.h — shared device-side definitions for the gfx950 SVO ray-march kernels.
+//
+// Float contract: every expression that feeds control flow is strict IEEE
+// binary32 in the evaluation order the reference shader text gives
+// (clientdesktop/src/graphics/ray_tracer.wgsl).  The translation unit is built with
+// -ffp-contract=off and hipcc's default correctly-rounded f32 divide/sqrt; no fast-math.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vrt.h"
+
+namespace vrt {
+
+constexpr float kShadowBias = 0.002f;   // DESIGN.md §Shadow rays (build-defined)
+constexpr float kShadowFactor = 0.35f;
+constexpr uint32_t kMaxSteps = 500u;    // ray_tracer.wgsl:220
+
+// Everything a frame's kernels read, passed by value (kernarg -> SGPRs).
+struct FrameParams {
+    const uint16_t *nodes;   // flat node pool, little-endian u16 == the reference's packed u32 pairs
+    const uint32_t *roots;   // chunk_roots, S^3
+    const vrt_material *mats;  // 256 x 32 B
+    float *rgb;              // f32 x3 per pixel slot
+    uint32_t *ids;           // id word per pixel slot
+    uint4 *hits;             // compacted hit buffer: {slot, origin.xyz as bits}
+    unsigned long long *counters;  // see Counter
+    uint32_t *steps;         // optional per-slot step counts (stats frames only), may be null
+    uint32_t n_nodes, n_roots;
+    uint32_t width, height;
+    uint32_t tiles_x, tiles_total;
+    uint32_t shard_rank, shard_count, tiles_local;
+    uint32_t pad0;
+    vrt_cam_data cam;
+    vrt_settings settings;
+    vrt_world_data world;
+    uint32_t liquid[8];      // bit v set <=> materials[v].is_liquid == 1, v < 256
+};
+
+enum Counter : int {
+    kCtrHitCount = 0,       // number of records in the compacted hit buffer (low 32 bits used)
+    kCtrSteps = 1,
+    kCtrVisits = 2,
+    kCtrPrimarySteps = 3,
+    kCtrPrimaryVisits = 4,
+    kCtrHits = 5,
+    kCtrTileQueue = 6,      // persistent-kernel work queue head
+    kCtrCount = 8
+};
+
+struct V3 { float x, y, z; };
+
+// WGSL min() with a NaN operand is implementation-defined; choice: a NaN operand is ignored, ties
+// return b (same text as oracle/vrt_oracle.c:orc_min — restated, not shared).
+__device__ __forceinline__ float vmin(float a, float b) { return (a < b || b != b) ? a : b; }
+__device__ __forceinline__ float vclamp(float e, float lo, float hi) {
+    float m = (e > lo) ? e : lo;
+    return vmin(m, hi);
+}
+__device__ __forceinline__ float vsign(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : x); }
+__device__ __forceinline__ float vsmoothstep(float e0, float e1, float x) {
+    float t = vclamp((x - e0) / (e1 - e0), 0.0f, 1.0f);
+    return t * t * (3.0f - 2.0f * t);
+}
+__device__ __forceinline__ float vmix(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+__device__ __forceinline__ float vdot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 vnormalize(V3 v) {
+    float len = sqrtf(vdot(v, v));
+    return V3{v.x / len, v.y / len, v.z / len};
+}
+// WGSL i32(f32): NaN -> 0 (the only out-of-range case reachable: positions are range-checked).
+__device__ __forceinline__ int f2i(float x) { return (x != x) ? 0 : (int)x; }
+
+struct MarchResult {
+    bool hit;
+    V3 pos, norm;
+    float water_dist;
+    uint32_t voxel;
+    uint32_t iters;
+    uint32_t visits;
+};
+
+}  // namespace vrt

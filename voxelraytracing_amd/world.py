@@ -1,0 +1,225 @@
+"""Host world — thin Python handles on the C++ mirror of the reference's ``ClientWorld``.
+
+Names and argument meaning follow client/src/world.rs:259-367 and common/src/world/mod.rs; all logic
+lives in libvrt_host.so (voxelraytracing_amd/csrc/host/world.hpp).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _ffi
+
+CHUNK_SIZE = 32               # common/src/world/mod.rs:10
+CHUNK_DEPTH = 5               # :14
+NODES_PER_CHUNK = 37449       # :18
+CHUNK_INIT_FREE_MEM = 2048    # :23
+
+
+class SetVoxelErr(Exception):
+    """common/src/world/mod.rs:129-135"""
+    NAMES = {1: "PosOutOfBounds", 2: "OutOfMemory", 3: "NoChunk", 4: "NoChange"}
+
+    def __init__(self, code: int):
+        super().__init__(self.NAMES.get(code, str(code)))
+        self.code = code
+        self.kind = self.NAMES.get(code, str(code))
+
+
+def _i3(v):
+    return (C.c_int32 * 3)(int(v[0]), int(v[1]), int(v[2]))
+
+
+def _u16p(a: np.ndarray):
+    assert a.dtype == np.uint16 and a.flags.c_contiguous
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Node:
+    """Node word helpers, common/src/world/mod.rs:150-194."""
+    SPLIT_MASK, DATA_MASK = 0x8000, 0x7FFF
+
+    @staticmethod
+    def new(voxel: int) -> int:
+        return voxel & Node.DATA_MASK
+
+    @staticmethod
+    def new_split(child_idx: int) -> int:
+        return child_idx | Node.SPLIT_MASK
+
+    @staticmethod
+    def is_split(w: int) -> bool:
+        return (w & Node.SPLIT_MASK) != 0
+
+    @staticmethod
+    def voxel(w: int) -> int:
+        return w & Node.DATA_MASK
+
+    child_idx = voxel
+
+
+@dataclass
+class ChunkState:
+    range_start: int
+    range_end: int
+    last_used_addr: int
+    free_mem: list
+
+
+class ClientWorld:
+    """client/src/world.rs:259-367."""
+
+    def __init__(self, center, max_nodes: int, size: int):
+        self._lib = _ffi.host()
+        self._h = self._lib.vrth_world_new(_i3(center), max_nodes, size)
+        if not self._h:
+            raise MemoryError("vrth_world_new failed")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.vrth_world_free(self._h)
+            self._h = None
+
+    # --- chunk ingest / edits ---
+    def create_chunk(self, pos, nodes: np.ndarray) -> int:
+        nodes = np.ascontiguousarray(nodes, dtype=np.uint16)
+        root = C.c_uint32()
+        rc = self._lib.vrth_world_create_chunk(self._h, _i3(pos), _u16p(nodes), nodes.size, C.byref(root))
+        if rc:
+            raise SetVoxelErr(rc)
+        return root.value
+
+    def set_voxel(self, pos, voxel: int):
+        """-> (range_start, range_len) of the chunk to re-upload (main.rs:352-362)."""
+        s, n = C.c_uint32(), C.c_uint32()
+        rc = self._lib.vrth_world_set_voxel(self._h, _i3(pos), voxel, C.byref(s), C.byref(n))
+        if rc:
+            raise SetVoxelErr(rc)
+        return s.value, n.value
+
+    def get_voxel(self, pos) -> int:
+        v = C.c_uint16()
+        rc = self._lib.vrth_world_get_voxel(self._h, _i3(pos), C.byref(v))
+        if rc:
+            raise SetVoxelErr(rc)
+        return v.value
+
+    def center_chunks(self, anchor) -> int:
+        return self._lib.vrth_world_center_chunks(self._h, _i3(anchor))
+
+    def resize(self, size: int) -> None:
+        self._lib.vrth_world_resize(self._h, size)
+
+    def generate(self, kind: int = 0, seed: int = 1, threads: int = 0) -> None:
+        rc = self._lib.vrth_world_generate(self._h, kind, seed, threads)
+        if rc:
+            raise SetVoxelErr(rc)
+
+    # --- views ---
+    def nodes(self) -> np.ndarray:
+        """The whole flat pool as a zero-copy u16 view (client/src/world.rs:292-294)."""
+        n = self._lib.vrth_world_max_nodes(self._h)
+        buf = (C.c_uint16 * n).from_address(self._lib.vrth_world_nodes(self._h))
+        a = np.frombuffer(buf, dtype=np.uint16)
+        a.flags.writeable = False
+        return a
+
+    def nodes_ptr(self) -> int:
+        return self._lib.vrth_world_nodes(self._h)
+
+    def max_nodes(self) -> int:
+        return self._lib.vrth_world_max_nodes(self._h)
+
+    def chunk_roots(self) -> np.ndarray:
+        n = self._lib.vrth_world_chunk_roots(self._h, None, 0)
+        out = np.zeros(n, dtype=np.uint32)
+        self._lib.vrth_world_chunk_roots(self._h, out.ctypes.data_as(C.c_void_p), n)
+        return out
+
+    def _info(self):
+        mn = (C.c_int32 * 3)()
+        sv, sc, pop = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._lib.vrth_world_info(self._h, mn, C.byref(sv), C.byref(sc), C.byref(pop))
+        return tuple(mn), sv.value, sc.value, pop.value
+
+    def min_voxel(self):
+        return self._info()[0]
+
+    def size_in_voxels(self) -> int:
+        return self._info()[1]
+
+    def size_in_chunks(self) -> int:
+        return self._info()[2]
+
+    def populated_count(self) -> int:
+        return self._info()[3]
+
+    def chunk_alloc_status(self):
+        f, m = C.c_uint32(), C.c_uint32()
+        self._lib.vrth_world_alloc_status(self._h, C.byref(f), C.byref(m))
+        return f.value, m.value
+
+    def chunk_state(self, pos):
+        rs, re, lu = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        spans = (C.c_uint32 * 4096)()
+        n = self._lib.vrth_world_chunk_state(self._h, _i3(pos), C.byref(rs), C.byref(re), C.byref(lu), spans, 2048)
+        if n < 0:
+            return None
+        return ChunkState(rs.value, re.value, lu.value, [(spans[2 * i], spans[2 * i + 1]) for i in range(min(n, 2048))])
+
+    def highest_vox_at(self, x: int, z: int):
+        y = C.c_int32()
+        return y.value if self._lib.vrth_world_highest_vox_at(self._h, x, z, C.byref(y)) else None
+
+    def world_data(self) -> _ffi.WorldData:
+        """WorldData::from(&world), clientdesktop/src/graphics/mod.rs:121-130."""
+        wd = _ffi.WorldData()
+        self._lib.vrth_world_data_from(self._h, C.byref(wd))
+        return wd
+
+
+# ---- SVO construction helpers (server/src/world/gen.rs:171-286 and the build's bottom-up builder) ----
+
+def svo_build_by_set_node(dense: np.ndarray, cap: int = NODES_PER_CHUNK + 64) -> np.ndarray:
+    dense = np.ascontiguousarray(dense, dtype=np.uint16).reshape(-1)
+    assert dense.size == 32768
+    nodes = np.zeros(cap, dtype=np.uint16)
+    used = _ffi.host().vrth_svo_build_by_set_node(_u16p(dense), _u16p(nodes), cap)
+    if not used:
+        raise SetVoxelErr(2)
+    return nodes[:used].copy()
+
+
+def svo_build_bottom_up(dense: np.ndarray) -> np.ndarray:
+    dense = np.ascontiguousarray(dense, dtype=np.uint16).reshape(-1)
+    assert dense.size == 32768
+    nodes = np.zeros(32768, dtype=np.uint16)
+    n = _ffi.host().vrth_svo_build_bottom_up(_u16p(dense), _u16p(nodes), nodes.size)
+    if not n:
+        raise SetVoxelErr(2)
+    return nodes[:n].copy()
+
+
+def svo_to_dense(nodes: np.ndarray) -> np.ndarray:
+    nodes = np.ascontiguousarray(nodes, dtype=np.uint16)
+    dense = np.zeros(32768, dtype=np.uint16)
+    _ffi.host().vrth_svo_to_dense(_u16p(nodes), _u16p(dense))
+    return dense
+
+
+def gen_dense(seed: int, chunk_pos) -> np.ndarray:
+    dense = np.zeros(32768, dtype=np.uint16)
+    _ffi.host().vrth_gen_dense(seed, _i3(chunk_pos), _u16p(dense))
+    return dense
+
+
+def gen_dense_superflat(chunk_pos) -> np.ndarray:
+    dense = np.zeros(32768, dtype=np.uint16)
+    _ffi.host().vrth_gen_dense_superflat(_i3(chunk_pos), _u16p(dense))
+    return dense
+
+
+def gen_height(seed: int, x: int, z: int) -> int:
+    return _ffi.host().vrth_gen_height(seed, x, z)
