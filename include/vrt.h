@@ -189,28 +189,27 @@ int vrt_read_steps(vrt_ctx *ctx, uint32_t *steps);
 /* Use the caller's hipStream_t for all subsequent work (NULL = the context's own stream). */
 int vrt_set_stream(vrt_ctx *ctx, void *hip_stream);
 
-/* Render into caller-owned device memory (e.g. torch tensors handed to an RCCL gather) instead of the
- * context's own buffers: rgb must hold rgb_bytes, ids ids_bytes as vrt_device_output reports them.
- * NULL, NULL restores the context's buffers; vrt_resize_output drops the binding. */
-int vrt_bind_output(vrt_ctx *ctx, void *rgb, void *ids);
+/* The device output is one 16-byte texel per pixel slot: {r, g, b as f32, id word as u32}.
+ * Unsharded: texel[height][width] row-major.  Sharded: the compact tile-major shard buffer
+ * texel[tiles_padded][64] (tile t_local <-> screen tile shard_rank + t_local*shard_count; pixel p of a tile =
+ * (p&7, p>>3)); tiles_padded = ceil(total_tiles / shard_count), so every rank's buffer has the same size. */
 
-/* Device pointers of the context's output.  Unsharded: rgb = f32[height][width][3],
- * ids = u32[height][width].  Sharded: the compact tile-major shard buffers
- * rgb = f32[tiles_local][64][3], ids = u32[tiles_local][64] (tile t_local <-> screen tile
- * shard_rank + t_local*shard_count; pixel p of a tile = (p&7, p>>3)). */
-int vrt_device_output(vrt_ctx *ctx, void **rgb, void **ids, uint64_t *rgb_bytes, uint64_t *ids_bytes);
+/* Render into caller-owned device memory (e.g. a torch tensor handed to an RCCL gather) instead of the
+ * context's own buffer: `texels` must hold the byte count vrt_device_output reports and be 16-byte
+ * aligned.  NULL restores the context's buffer; vrt_resize_output drops the binding. */
+int vrt_bind_output(vrt_ctx *ctx, void *texels);
 
-/* Number of 8x8 tiles this context traces, and the padded per-rank count used for equal-sized
- * gathers (ceil(total_tiles / shard_count)). */
+/* Device pointer and size in bytes of the buffer frames are currently written to. */
+int vrt_device_output(vrt_ctx *ctx, void **texels, uint64_t *bytes);
+
+/* Number of 8x8 tiles this context traces, the padded per-rank count used for equal-sized gathers
+ * (ceil(total_tiles / shard_count)) and the total. */
 int vrt_shard_info(vrt_ctx *ctx, uint32_t *tiles_local, uint32_t *tiles_padded, uint32_t *tiles_total);
 
-/* On the gather root: scatter shard_count gathered tile-major buffers
- * (gathered_rgb = f32[shard_count][tiles_padded][64][3], gathered_ids likewise) into row-major
- * device frames dst_rgb = f32[height][width][3], dst_ids = u32[height][width]. Asynchronous.
- * rank_stride_bytes: distance between consecutive ranks' buffers in BOTH gathered arrays (for a gather
- * of one packed {rgb, ids} message per rank); 0 = densely packed as described above. */
-int vrt_assemble(vrt_ctx *ctx, const void *gathered_rgb, const void *gathered_ids, uint64_t rank_stride_bytes,
-                 void *dst_rgb, void *dst_ids);
+/* On the gather root: scatter the shard_count gathered tile-major buffers (rank r's texels start at
+ * gathered + r*rank_stride_bytes; 0 = densely packed, tiles_padded*64*16 bytes apart) into the
+ * row-major device frame dst = texel[height][width].  Asynchronous on the context's stream. */
+int vrt_assemble(vrt_ctx *ctx, const void *gathered, uint64_t rank_stride_bytes, void *dst);
 
 #ifdef __cplusplus
 }

@@ -88,10 +88,10 @@ VRT_SYMBOLS = {
     "vrt_get_stats": (C.c_int, [_P, C.POINTER(Stats)]),
     "vrt_read_steps": (C.c_int, [_P, _P]),
     "vrt_set_stream": (C.c_int, [_P, _P]),
-    "vrt_bind_output": (C.c_int, [_P, _P, _P]),
-    "vrt_device_output": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "vrt_bind_output": (C.c_int, [_P, _P]),
+    "vrt_device_output": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     "vrt_shard_info": (C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
-    "vrt_assemble": (C.c_int, [_P, _P, _P, C.c_uint64, _P, _P]),
+    "vrt_assemble": (C.c_int, [_P, _P, C.c_uint64, _P]),
 }
 
 
@@ -116,6 +116,14 @@ def vrt() -> C.CDLL:
     """The HIP backend. Loading needs libamdhip64 but no GPU; every compute call needs a GPU."""
     global _vrt
     if _vrt is None:
+        # One HIP runtime per process: the torch wheel bundles its own libamdhip64.so.7 / libhsa-runtime64 and
+        # fails to initialise ("No HIP GPUs are available") if the system copy was mapped first.  Loading torch's
+        # first lets libvrt.so bind to it by SONAME, so torch streams / tensors and vrt_* calls share one runtime
+        # (needed by vrt_set_stream and vrt_bind_output).  A C or Rust host simply links /opt/rocm's.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _vrt = _load("libvrt.so", VRT_SYMBOLS)
     return _vrt
 

@@ -3,11 +3,12 @@
 // Replaces the reference's wgpu seam: GpuResources / Buffers / NodeBuffer / SimpleBuffer /
 // ArrayBuffer / PixelShader (clientdesktop/src/graphics/{mod.rs,shader.rs}).  Device memory layout
 // (DESIGN.md §HBM layout): the node pool is kept byte-identical to the host pool (little-endian u16 =
-// the reference's packed u32 pairs), chunk_roots is a dense u32[S^3], materials 256 x 32 B, output
-// f32x3 + u32 id per pixel slot, hit buffer 16 B per local pixel.
+// the reference's packed u32 pairs), chunk_roots is a dense u32[S^3], materials 256 x 32 B, output one
+// 16-byte texel {r,g,b f32, id u32} per pixel slot, hit buffer 16 B per local pixel.
 #include <hip/hip_runtime.h>
 
 #include <array>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -18,18 +19,19 @@
 #include "vrt_device.h"
 
 namespace vrt {
+bool variant_supported(uint32_t variant);
 void launch_primary(const FrameParams &P, uint32_t variant, bool stats, bool shadow, hipStream_t st);
 void launch_shadow(const FrameParams &P, uint32_t variant, bool stats, hipStream_t st);
-void launch_quantize(const float *rgb, uint8_t *rgba8, uint32_t n, hipStream_t st);
-void launch_assemble(const float *g_rgb, const uint32_t *g_ids, float *dst_rgb, uint32_t *dst_ids, uint32_t width,
-                     uint32_t tiles_x, uint32_t tiles_total, uint32_t shard_count, uint64_t stride_rgb,
-                     uint64_t stride_ids, hipStream_t st);
+void launch_quantize(const Texel *out, uint8_t *rgba8, uint32_t n, hipStream_t st);
+void launch_assemble(const Texel *gathered, Texel *dst, uint32_t width, uint32_t tiles_x, uint32_t tiles_total,
+                     uint32_t shard_count, uint64_t rank_stride, hipStream_t st);
 }  // namespace vrt
 
 static_assert(sizeof(vrt_material) == 32, "Material layout (mod.rs:20-28)");
 static_assert(sizeof(vrt_cam_data) == 160, "CamData layout (mod.rs:82-91)");
 static_assert(sizeof(vrt_world_data) == 32, "WorldData layout (mod.rs:113-120)");
 static_assert(sizeof(vrt_settings) == 48, "Settings layout (mod.rs:132-143)");
+static_assert(sizeof(vrt::Texel) == 16, "texel");
 
 struct vrt_ctx {
     int device = 0;
@@ -38,7 +40,7 @@ struct vrt_ctx {
     // one hipEvent triple {start, after primary, end} per frame rendered since the last vrt_get_stats
     std::vector<std::array<hipEvent_t, 3>> ev_pool;
     size_t ev_used = 0;
-    double acc_ms[3] = {0, 0, 0};  // frames folded early because the pool was full
+    double acc_ms[3] = {0, 0, 0};
     uint32_t acc_frames = 0;
 
     uint32_t max_nodes = 0;  // even
@@ -47,17 +49,16 @@ struct vrt_ctx {
     uint32_t width = 0, height = 0;
     uint32_t shard_rank = 0, shard_count = 1;
     uint32_t tiles_x = 0, tiles_total = 0, tiles_local = 0, tiles_padded = 0;
-    uint32_t slots = 0;  // pixel slots in the output buffers
+    uint32_t slots = 0;  // pixel slots in the output buffer
 
     uint16_t *d_nodes = nullptr;
     uint32_t *d_roots = nullptr;
     vrt_material *d_mats = nullptr;
-    float *d_rgb = nullptr;      // where frames are written: own_rgb or caller-bound memory
-    uint32_t *d_ids = nullptr;
-    float *own_rgb = nullptr;
-    uint32_t *own_ids = nullptr;
+    vrt::Texel *d_out = nullptr;    // where frames are written: own_out or caller-bound memory
+    vrt::Texel *own_out = nullptr;
     uint4 *d_hits = nullptr;
-    unsigned long long *d_counters = nullptr;
+    unsigned long long *d_counters = nullptr;  // [kCtrCount] stats, then the hit-segment counters
+    uint32_t hit_seg_cap = 0;
     uint32_t *d_steps = nullptr;
     uint8_t *d_rgba8 = nullptr;
 
@@ -74,6 +75,9 @@ struct vrt_ctx {
 
     std::string err;
 };
+
+static constexpr size_t kSegBytes = (size_t)vrt::kHitSegments * vrt::kSegStride * sizeof(uint32_t);
+static constexpr size_t kCounterBytes = vrt::kCtrCount * sizeof(unsigned long long) + kSegBytes;
 
 static thread_local std::string g_create_err;
 
@@ -105,17 +109,18 @@ static void layout_tiles(vrt_ctx *c) {
 }
 
 static int alloc_output(vrt_ctx *c) {
-    (void)hipFree(c->own_rgb); (void)hipFree(c->own_ids); (void)hipFree(c->d_hits); (void)hipFree(c->d_steps); (void)hipFree(c->d_rgba8);
-    c->own_rgb = nullptr; c->own_ids = nullptr; c->d_hits = nullptr; c->d_steps = nullptr; c->d_rgba8 = nullptr;
+    (void)hipFree(c->own_out); (void)hipFree(c->d_hits); (void)hipFree(c->d_steps); (void)hipFree(c->d_rgba8);
+    c->own_out = nullptr; c->d_hits = nullptr; c->d_steps = nullptr; c->d_rgba8 = nullptr;
     layout_tiles(c);
     const size_t n = c->slots ? c->slots : 1;
-    HIP_TRY(c, hipMalloc(&c->own_rgb, n * 3 * sizeof(float)));
-    HIP_TRY(c, hipMalloc(&c->own_ids, n * sizeof(uint32_t)));
-    HIP_TRY(c, hipMalloc(&c->d_hits, n * sizeof(uint4)));
-    c->d_rgb = c->own_rgb;  // a resize drops any caller-bound output (its size no longer matches)
-    c->d_ids = c->own_ids;
-    HIP_TRY(c, hipMemsetAsync(c->d_rgb, 0, n * 3 * sizeof(float), c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->d_ids, 0, n * sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipMalloc(&c->own_out, n * sizeof(vrt::Texel)));
+    // hit buffer: kHitSegments segments, each able to hold every record its workgroups can produce
+    const uint32_t nblocks = (c->tiles_local + 3u) / 4u;
+    c->hit_seg_cap = ((nblocks + vrt::kHitSegments - 1u) / vrt::kHitSegments) * 256u;
+    if (c->hit_seg_cap == 0) c->hit_seg_cap = 256u;
+    HIP_TRY(c, hipMalloc(&c->d_hits, (size_t)vrt::kHitSegments * c->hit_seg_cap * sizeof(uint4)));
+    HIP_TRY(c, hipMemsetAsync(c->own_out, 0, n * sizeof(vrt::Texel), c->stream));
+    c->d_out = c->own_out;  // a resize drops any caller-bound output (its size no longer matches)
     c->rendered = false;
     return VRT_OK;
 }
@@ -172,7 +177,6 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     memset(&c->world, 0, sizeof c->world);
     memset(&c->stats, 0, sizeof c->stats);
 
-    int rc = VRT_OK;
     auto body = [&]() -> int {
         HIP_TRY(c, hipSetDevice(dev));
         HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
@@ -182,8 +186,8 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         HIP_TRY(c, hipMemsetAsync(c->d_nodes, 0, (size_t)c->max_nodes * sizeof(uint16_t), c->stream));
         HIP_TRY(c, hipMalloc(&c->d_mats, sizeof c->h_mats));
         HIP_TRY(c, hipMemsetAsync(c->d_mats, 0, sizeof c->h_mats, c->stream));
-        HIP_TRY(c, hipMalloc(&c->d_counters, vrt::kCtrCount * sizeof(unsigned long long)));
-        HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, vrt::kCtrCount * sizeof(unsigned long long), c->stream));
+        HIP_TRY(c, hipMalloc(&c->d_counters, kCounterBytes));
+        HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, kCounterBytes, c->stream));
         int r = alloc_roots(c, cfg->world_size_chunks);
         if (r) return r;
         r = alloc_output(c);
@@ -191,7 +195,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         return VRT_OK;
     };
-    rc = body();
+    const int rc = body();
     if (rc != VRT_OK) {
         g_create_err = c->err;
         vrt_destroy(c);
@@ -205,8 +209,7 @@ void vrt_destroy(vrt_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    (void)hipSetDevice(c->device);
-    (void)hipFree(c->d_nodes); (void)hipFree(c->d_roots); (void)hipFree(c->d_mats); (void)hipFree(c->own_rgb); (void)hipFree(c->own_ids);
+    (void)hipFree(c->d_nodes); (void)hipFree(c->d_roots); (void)hipFree(c->d_mats); (void)hipFree(c->own_out);
     (void)hipFree(c->d_hits); (void)hipFree(c->d_counters); (void)hipFree(c->d_steps); (void)hipFree(c->d_rgba8);
     for (auto &t : c->ev_pool)
         for (auto &ev : t)
@@ -328,6 +331,7 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     memset(&o, 0, sizeof o);
     if (opts) o = *opts;
     if (o.mode > VRT_MODE_PRIMARY_SHADOW) return fail(c, VRT_ERR_INVALID_ARG, "vrt_render: mode %u not supported", o.mode);
+    if (!vrt::variant_supported(o.variant)) return fail(c, VRT_ERR_INVALID_ARG, "vrt_render: unknown kernel variant %u", o.variant);
     int rc = validate_frame(c);
     if (rc) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -339,10 +343,11 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     P.nodes = c->d_nodes;
     P.roots = c->d_roots;
     P.mats = c->d_mats;
-    P.rgb = c->d_rgb;
-    P.ids = c->d_ids;
+    P.out = c->d_out;
     P.hits = c->d_hits;
     P.counters = c->d_counters;
+    P.seg_counts = reinterpret_cast<uint32_t *>(c->d_counters + vrt::kCtrCount);
+    P.hit_seg_cap = c->hit_seg_cap;
     P.steps = o.stats ? c->d_steps : nullptr;
     P.n_nodes = c->max_nodes;
     // only the S^3 entries the frame's WorldData describes are addressable (find_node :120-123)
@@ -357,11 +362,14 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     P.cam = c->cam;
     P.settings = c->settings;
     P.world = c->world;
+    const vrt_settings &s = c->settings;
+    P.finite_settings = std::isfinite(s.sun_intensity) && std::isfinite(s.sky_color[0]) && std::isfinite(s.sky_color[1]) &&
+                        std::isfinite(s.sky_color[2]) && std::isfinite(s.sun_pos[0]) && std::isfinite(s.sun_pos[1]) &&
+                        std::isfinite(s.sun_pos[2]);
     for (int v = 0; v < 256; v++)
         if (c->h_mats[v].is_liquid == 1u) P.liquid[v >> 5] |= 1u << (v & 31);
 
     const bool shadow = o.mode == VRT_MODE_PRIMARY_SHADOW;
-    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, vrt::kCtrCount * sizeof(unsigned long long), c->stream));
     if (c->ev_used == c->ev_pool.size()) {
         if (c->ev_pool.size() >= 1024) {
             rc = fold_events(c, nullptr);
@@ -373,6 +381,7 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
         }
     }
     auto &ev = c->ev_pool[c->ev_used++];
+    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, kCounterBytes, c->stream));
     HIP_TRY(c, hipEventRecord(ev[0], c->stream));
     vrt::launch_primary(P, o.variant, o.stats != 0, shadow, c->stream);
     HIP_TRY(c, hipGetLastError());
@@ -401,36 +410,35 @@ int vrt_read_output(vrt_ctx *c, float *rgb, uint32_t *ids, uint8_t *rgba8) {
     if (!c->rendered) return fail(c, VRT_ERR_STATE, "vrt_read_output: nothing rendered yet");
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t npix = (size_t)c->width * c->height;
+    if (rgba8) {
+        if (c->shard_count != 1u) return fail(c, VRT_ERR_STATE, "vrt_read_output: rgba8 readback is only available unsharded");
+        if (!c->d_rgba8) HIP_TRY(c, hipMalloc(&c->d_rgba8, npix * 4));
+        vrt::launch_quantize(c->d_out, c->d_rgba8, (uint32_t)npix, c->stream);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipMemcpyAsync(rgba8, c->d_rgba8, npix * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    std::vector<vrt::Texel> t;
+    if (rgb || ids) {
+        t.resize(c->slots);
+        HIP_TRY(c, hipMemcpyAsync(t.data(), c->d_out, t.size() * sizeof(vrt::Texel), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (!rgb && !ids) return VRT_OK;
+    auto put = [&](size_t dst, const vrt::Texel &x) {
+        if (rgb) { memcpy(rgb + dst * 3, &x, 12); }
+        if (ids) ids[dst] = x.w;
+    };
     if (c->shard_count == 1u) {
-        if (rgba8) {
-            if (!c->d_rgba8) HIP_TRY(c, hipMalloc(&c->d_rgba8, npix * 4));
-            vrt::launch_quantize(c->d_rgb, c->d_rgba8, (uint32_t)npix, c->stream);
-            HIP_TRY(c, hipGetLastError());
-            HIP_TRY(c, hipMemcpyAsync(rgba8, c->d_rgba8, npix * 4, hipMemcpyDeviceToHost, c->stream));
-        }
-        if (rgb) HIP_TRY(c, hipMemcpyAsync(rgb, c->d_rgb, npix * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-        if (ids) HIP_TRY(c, hipMemcpyAsync(ids, c->d_ids, npix * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        for (size_t i = 0; i < npix; i++) put(i, t[i]);
         return VRT_OK;
     }
-    // sharded: de-interleave this context's tiles on the host; foreign tiles read as zero
-    if (rgba8) return fail(c, VRT_ERR_STATE, "vrt_read_output: rgba8 readback is only available unsharded");
-    std::vector<float> t_rgb(rgb ? (size_t)c->slots * 3 : 0);
-    std::vector<uint32_t> t_ids(ids ? (size_t)c->slots : 0);
-    if (rgb) HIP_TRY(c, hipMemcpyAsync(t_rgb.data(), c->d_rgb, t_rgb.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    if (ids) HIP_TRY(c, hipMemcpyAsync(t_ids.data(), c->d_ids, t_ids.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // sharded: de-interleave this context's tiles; foreign tiles read as zero
     if (rgb) memset(rgb, 0, npix * 3 * sizeof(float));
     if (ids) memset(ids, 0, npix * sizeof(uint32_t));
     for (uint32_t tl = 0; tl < c->tiles_local; tl++) {
         const uint32_t tile = c->shard_rank + tl * c->shard_count;
         const uint32_t tx = (tile % c->tiles_x) * 8u, ty = (tile / c->tiles_x) * 8u;
-        for (uint32_t p = 0; p < 64; p++) {
-            const size_t dst = (size_t)(ty + (p >> 3)) * c->width + tx + (p & 7u);
-            const size_t src = (size_t)tl * 64 + p;
-            if (rgb) { rgb[dst * 3] = t_rgb[src * 3]; rgb[dst * 3 + 1] = t_rgb[src * 3 + 1]; rgb[dst * 3 + 2] = t_rgb[src * 3 + 2]; }
-            if (ids) ids[dst] = t_ids[src];
-        }
+        for (uint32_t p = 0; p < 64; p++) put((size_t)(ty + (p >> 3)) * c->width + tx + (p & 7u), t[(size_t)tl * 64 + p]);
     }
     return VRT_OK;
 }
@@ -454,13 +462,17 @@ int vrt_get_stats(vrt_ctx *c, vrt_stats *out) {
         float last[3] = {0, 0, 0};
         int rc = fold_events(c, last);
         if (rc) return rc;
-        unsigned long long h[vrt::kCtrCount];
-        HIP_TRY(c, hipMemcpyAsync(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
+        std::vector<unsigned long long> hbuf(kCounterBytes / sizeof(unsigned long long));
+        HIP_TRY(c, hipMemcpyAsync(hbuf.data(), c->d_counters, kCounterBytes, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
+        unsigned long long *h = hbuf.data();
+        const uint32_t *seg = reinterpret_cast<const uint32_t *>(h + vrt::kCtrCount);
+        unsigned long long launched = 0;
+        for (uint32_t i = 0; i < vrt::kHitSegments; i++) launched += seg[i * vrt::kSegStride];
         vrt_stats s;
         memset(&s, 0, sizeof s);
         s.primary_rays = (uint64_t)c->tiles_local * 64u;
-        s.secondary_rays = c->last_mode == VRT_MODE_PRIMARY_SHADOW ? h[vrt::kCtrHitCount] : 0;
+        s.secondary_rays = c->last_mode == VRT_MODE_PRIMARY_SHADOW ? launched : 0;
         if (c->last_stats) {
             s.hits = h[vrt::kCtrHits];
             s.steps = h[vrt::kCtrSteps];
@@ -488,23 +500,20 @@ int vrt_set_stream(vrt_ctx *c, void *hip_stream) {
     return VRT_OK;
 }
 
-int vrt_bind_output(vrt_ctx *c, void *rgb, void *ids) {
+int vrt_bind_output(vrt_ctx *c, void *texels) {
     if (!c) return VRT_ERR_INVALID_ARG;
-    if ((rgb == nullptr) != (ids == nullptr)) return fail(c, VRT_ERR_INVALID_ARG, "vrt_bind_output: bind both buffers or neither");
+    if (texels && ((uintptr_t)texels % 16u)) return fail(c, VRT_ERR_INVALID_ARG, "vrt_bind_output: texels must be 16-byte aligned");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->d_rgb = rgb ? (float *)rgb : c->own_rgb;
-    c->d_ids = ids ? (uint32_t *)ids : c->own_ids;
+    c->d_out = texels ? (vrt::Texel *)texels : c->own_out;
     c->rendered = false;
     return VRT_OK;
 }
 
-int vrt_device_output(vrt_ctx *c, void **rgb, void **ids, uint64_t *rgb_bytes, uint64_t *ids_bytes) {
+int vrt_device_output(vrt_ctx *c, void **texels, uint64_t *bytes) {
     if (!c) return VRT_ERR_INVALID_ARG;
-    if (rgb) *rgb = c->d_rgb;
-    if (ids) *ids = c->d_ids;
-    if (rgb_bytes) *rgb_bytes = (uint64_t)c->slots * 3 * sizeof(float);
-    if (ids_bytes) *ids_bytes = (uint64_t)c->slots * sizeof(uint32_t);
+    if (texels) *texels = c->d_out;
+    if (bytes) *bytes = (uint64_t)c->slots * sizeof(vrt::Texel);
     return VRT_OK;
 }
 
@@ -516,17 +525,14 @@ int vrt_shard_info(vrt_ctx *c, uint32_t *tiles_local, uint32_t *tiles_padded, ui
     return VRT_OK;
 }
 
-int vrt_assemble(vrt_ctx *c, const void *gathered_rgb, const void *gathered_ids, uint64_t rank_stride_bytes, void *dst_rgb, void *dst_ids) {
+int vrt_assemble(vrt_ctx *c, const void *gathered, uint64_t rank_stride_bytes, void *dst) {
     if (!c) return VRT_ERR_INVALID_ARG;
-    if ((dst_rgb && !gathered_rgb) || (dst_ids && !gathered_ids))
-        return fail(c, VRT_ERR_INVALID_ARG, "vrt_assemble: destination without a gathered source");
+    if (!gathered || !dst) return fail(c, VRT_ERR_INVALID_ARG, "vrt_assemble: null argument");
+    if (rank_stride_bytes % 16u) return fail(c, VRT_ERR_INVALID_ARG, "vrt_assemble: rank stride must be a multiple of 16 bytes");
     HIP_TRY(c, hipSetDevice(c->device));
-    if (rank_stride_bytes % 4) return fail(c, VRT_ERR_INVALID_ARG, "vrt_assemble: rank stride must be a multiple of 4 bytes");
-    const uint32_t per_rank = c->tiles_padded * 64u;
-    const uint64_t stride_rgb = rank_stride_bytes ? rank_stride_bytes / 4 : (uint64_t)per_rank * 3u;
-    const uint64_t stride_ids = rank_stride_bytes ? rank_stride_bytes / 4 : (uint64_t)per_rank;
-    vrt::launch_assemble((const float *)gathered_rgb, (const uint32_t *)gathered_ids, (float *)dst_rgb, (uint32_t *)dst_ids,
-                         c->width, c->tiles_x, c->tiles_total, c->shard_count, stride_rgb, stride_ids, c->stream);
+    const uint64_t stride = rank_stride_bytes ? rank_stride_bytes / 16u : (uint64_t)c->tiles_padded * 64u;
+    vrt::launch_assemble((const vrt::Texel *)gathered, (vrt::Texel *)dst, c->width, c->tiles_x, c->tiles_total, c->shard_count,
+                         stride, c->stream);
     HIP_TRY(c, hipGetLastError());
     return VRT_OK;
 }

@@ -17,29 +17,40 @@ constexpr float kShadowBias = 0.002f;   // DESIGN.md §Shadow rays (build-define
 constexpr float kShadowFactor = 0.35f;
 constexpr uint32_t kMaxSteps = 500u;    // ray_tracer.wgsl:220
 
+// One output texel: {r, g, b as f32 bits, id word}. 16 B so that a wave stores 1 KiB contiguously.
+using Texel = uint4;
+
 // Everything a frame's kernels read, passed by value (kernarg -> SGPRs).
 struct FrameParams {
     const uint16_t *nodes;   // flat node pool, little-endian u16 == the reference's packed u32 pairs
     const uint32_t *roots;   // chunk_roots, S^3
     const vrt_material *mats;  // 256 x 32 B
-    float *rgb;              // f32 x3 per pixel slot
-    uint32_t *ids;           // id word per pixel slot
-    uint4 *hits;             // compacted hit buffer: {slot, origin.xyz as bits}
+    Texel *out;              // one texel per pixel slot
+    uint4 *hits;             // compacted hit buffer, kHitSegments segments of hit_seg_cap records: {slot, origin.xyz bits}
+    uint32_t *seg_counts;    // records in segment s at seg_counts[s * kSegStride]
     unsigned long long *counters;  // see Counter
     uint32_t *steps;         // optional per-slot step counts (stats frames only), may be null
     uint32_t n_nodes, n_roots;
     uint32_t width, height;
     uint32_t tiles_x, tiles_total;
     uint32_t shard_rank, shard_count, tiles_local;
-    uint32_t pad0;
+    uint32_t hit_seg_cap;    // capacity of one hit-buffer segment, a multiple of 256
+    uint32_t finite_settings;  // 1: every Settings float is finite (lets hits skip the sky term exactly)
     vrt_cam_data cam;
     vrt_settings settings;
     vrt_world_data world;
     uint32_t liquid[8];      // bit v set <=> materials[v].is_liquid == 1, v < 256
 };
 
+// The hit buffer is compacted per segment, not globally: one device-scope counter saturates at ~88
+// returning atomics per microsecond (MI355X_MICROARCH.md "dequeue"), which made 32 400 per-wave atomics the
+// whole 0.37 ms of the first primary kernel.  Workgroup b appends to segment b % kHitSegments; each counter
+// sits on its own 64-byte line so the adds spread over the L2 channels.
+constexpr uint32_t kHitSegments = 256;
+constexpr uint32_t kSegStride = 16;  // u32 words between counters (64 B)
+
 enum Counter : int {
-    kCtrHitCount = 0,       // number of records in the compacted hit buffer (low 32 bits used)
+    kCtrHitCount = 0,       // unused by the kernels (the host sums the segment counters)
     kCtrSteps = 1,
     kCtrVisits = 2,
     kCtrPrimarySteps = 3,

@@ -3,27 +3,37 @@
 // What the kernels compute is fixed by the reference shader
 // (clientdesktop/src/graphics/ray_tracer.wgsl: update :173-180, create_ray_from_screen :159-171,
 // ray_world :182-316, find_node/find_chunk_node :76-125, ray_color :131-142, ray_sky :144-157).
-// How they compute it is not: one wave64 per 8x8 tile, the in-chunk descent done on the integer
-// voxel coordinate (exactly equivalent to the shader's f32 `pos >= center` compares because every
-// centre compared against is an integer), chunk roots and the liquid mask staged in LDS, secondary
-// rays launched from a wave-compacted hit buffer.  See DESIGN.md §Kernels.
+// How they compute it is not — see DESIGN.md §Kernels.  In short:
+//   * one wave64 per 8x8 screen tile (the reference's @workgroup_size(8,8,1) is exactly one CDNA wave);
+//   * the in-chunk descent runs on the integer voxel coordinate (every centre the shader compares against
+//     is an integer, so `pos >= center` is one bit of floor(pos)) — no float centres, no min/max vectors;
+//   * the descent is not restarted from the chunk root every step: each lane keeps the child-block base of
+//     every split ancestor of its current leaf in registers and resumes below the deepest ancestor the new
+//     position shares with the old one (the found leaf is the same, the node loads are not);
+//   * the step arithmetic is branch-free and algebraically reduced where the reduction is bit-exact;
+//   * chunk roots and the 256-bit liquid mask are staged in LDS; secondary rays are launched from a
+//     wave-compacted hit buffer; one 16-byte texel {r,g,b,id} per pixel so a wave stores 1 KiB contiguously.
 #include "vrt_device.h"
 
 namespace vrt {
 
-// ------------------------------------------------------------------------------------------------
-// Node lookup
-// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool is_liquid(const uint32_t *s_liquid, uint32_t voxel) {
+    // voxel_mats[voxel].is_liquid == 1 (ray_tracer.wgsl:226); ids >= 256 clamp to material 255.
+    const uint32_t v = min(voxel, 255u);
+    return (s_liquid[v >> 5] >> (v & 31u)) & 1u;
+}
 
+// ------------------------------------------------------------------------------------------------
+// MARCH = 1: literal restatement of ray_world (ray_tracer.wgsl:182-316) with the descent restarted from
+// the chunk root every step.  Kept as the A/B baseline for DESIGN.md's evidence table and as an
+// in-backend cross-check of the fast march.
+// ------------------------------------------------------------------------------------------------
 struct Leaf {
     uint32_t node;   // the leaf's 16-bit word
     uint32_t depth;  // 0..5
     int bx, by, bz;  // world-local integer min corner of the leaf
 };
 
-// find_node (ray_tracer.wgsl:116-125) + find_chunk_node (:76-114), restated on integers.
-// vx = floor(pos) per axis (f2i: NaN -> 0).  chunk = v >> 5, local = v & 31; at depth d the shader's
-// `pos >= center` is bit (4-d) of the local coordinate.
 template <bool LDS_ROOTS>
 __device__ __forceinline__ Leaf find_leaf(const FrameParams &P, const uint32_t *s_roots, int vx, int vy, int vz) {
     const uint32_t S = P.world.size_in_chunks;
@@ -51,18 +61,9 @@ __device__ __forceinline__ Leaf find_leaf(const FrameParams &P, const uint32_t *
     return L;
 }
 
-__device__ __forceinline__ bool is_liquid(const uint32_t *s_liquid, uint32_t voxel) {
-    // voxel_mats[voxel].is_liquid == 1 (ray_tracer.wgsl:226); ids >= 256 clamp to material 255.
-    const uint32_t v = min(voxel, 255u);
-    return (s_liquid[v >> 5] >> (v & 31u)) & 1u;
-}
-
-// ------------------------------------------------------------------------------------------------
-// ray_world, ray_tracer.wgsl:182-316
-// ------------------------------------------------------------------------------------------------
 template <bool LDS_ROOTS>
-__device__ __forceinline__ MarchResult march(const FrameParams &P, const uint32_t *s_roots,
-                                             const uint32_t *s_liquid, V3 origin, V3 dir) {
+__device__ __forceinline__ MarchResult march_literal(const FrameParams &P, const uint32_t *s_roots,
+                                                     const uint32_t *s_liquid, V3 origin, V3 dir) {
     MarchResult R;
     R.hit = false;
     R.pos = V3{0.f, 0.f, 0.f};
@@ -167,6 +168,162 @@ __device__ __forceinline__ MarchResult march(const FrameParams &P, const uint32_
     return R;
 }
 
+// ------------------------------------------------------------------------------------------------
+// MARCH = 0: the fast march.  Same positions, same leaves, same results, bit for bit; the reductions
+// used (each argued in DESIGN.md §Exact reductions):
+//   (a) `pos >= center` at depth d  ==  bit (4-d) of floor(pos) & 31            (centres are integers)
+//   (b) (pos-min)*imask + (max-pos)*mask  ==  mask ? max-pos : -(min-pos)         (x*0 adds a signed zero)
+//   (c) the :247-270 branch tree  ==  minNum over the non-zero axis distances, ad.z if all are zero
+//   (d) dir*(step+.001)*e + dir*step*(1-e)  ==  dir * (e ? step+.001 : step)       (the dropped term is a
+//       zero with dir's sign)
+//   (e) pos<0 || pos>=size  ==  (unsigned)floor(pos) >= size                      (size is an integer)
+//   (f) the leaf of the new position is found by resuming the descent below the deepest split ancestor
+//       it shares with the previous position instead of from the chunk root.
+// ------------------------------------------------------------------------------------------------
+template <bool LDS_ROOTS>
+__device__ __forceinline__ MarchResult march_fast(const FrameParams &P, const uint32_t *s_roots,
+                                                  const uint32_t *s_liquid, V3 origin, V3 dir) {
+    MarchResult R;
+    R.hit = false;
+    R.pos = V3{0.f, 0.f, 0.f};
+    R.norm = V3{0.f, 0.f, 0.f};
+    R.water_dist = 0.0f;
+    R.voxel = 0u;
+    R.iters = 0u;
+    R.visits = 0u;
+
+    const bool mx = dir.x >= 0.0f, my = dir.y >= 0.0f, mz = dir.z >= 0.0f;
+
+    V3 pos = origin;
+    if (pos.x - floorf(pos.x) < 0.001f || pos.y - floorf(pos.y) < 0.001f || pos.z - floorf(pos.z) < 0.001f) {
+        pos.x += 0.001f * dir.x;
+        pos.y += 0.001f * dir.y;
+        pos.z += 0.001f * dir.z;
+    }
+    const float world_max = 0.0f + (float)P.world.size;
+    if ((pos.x <= 0.0f || pos.y <= 0.0f || pos.z <= 0.0f) || (pos.x >= world_max || pos.y >= world_max || pos.z >= world_max))
+        return R;
+
+    const V3 unit{
+        sqrtf(1.0f + (dir.y / dir.x) * (dir.y / dir.x) + (dir.z / dir.x) * (dir.z / dir.x)),
+        sqrtf(1.0f + (dir.x / dir.y) * (dir.x / dir.y) + (dir.z / dir.y) * (dir.z / dir.y)),
+        sqrtf(1.0f + (dir.x / dir.z) * (dir.x / dir.z) + (dir.y / dir.z) * (dir.y / dir.z))};
+
+    const uint32_t S = P.world.size_in_chunks;
+    const uint32_t wsize = P.world.size;
+    const uint32_t last = P.n_nodes - 1u;
+    const float qnan = __builtin_nanf("");
+
+    int vx = f2i(floorf(pos.x)), vy = f2i(floorf(pos.y)), vz = f2i(floorf(pos.z));
+    int pvx = vx, pvy = vy, pvz = vz;
+    uint32_t root = 0u, node = 0u, depth = 0u;
+    uint32_t b0 = 0u, b1 = 0u, b2 = 0u, b3 = 0u, b4 = 0u;  // child-block base of the split ancestor at depth 0..4
+    bool fresh = true;
+
+    uint32_t voxel = 0u;
+    bool ex = false, ey = false, ez = false;
+    float dew = -1.0f;  // dist_entered_water
+    float total_len = 0.0f;
+    uint32_t iter = 0u;
+    bool left_world = false;
+
+    for (;;) {
+        iter += 1u;
+        // ---- find_node ----
+        const uint32_t diff = fresh ? 0xFFFFFFFFu : (uint32_t)((vx ^ pvx) | (vy ^ pvy) | (vz ^ pvz));
+        pvx = vx; pvy = vy; pvz = vz;
+        bool resume = false;
+        if (diff >= 32u) {  // another chunk (or the first lookup): start at that chunk's root
+            uint32_t cidx = (uint32_t)(vx >> 5) + (uint32_t)(vy >> 5) * S + (uint32_t)(vz >> 5) * S * S;
+            cidx = min(cidx, P.n_roots - 1u);
+            root = LDS_ROOTS ? s_roots[cidx] : P.roots[cidx];
+            node = P.nodes[min(root, last)];
+            depth = 0u;
+            fresh = false;
+        } else {
+            // k = number of leading local-coordinate bits shared with the previous position (5 if none differ)
+            const uint32_t k = (uint32_t)__clz((int)diff) - 27u;
+            if (k < depth) { depth = k; resume = true; }
+        }
+#define VRT_LEVEL(D, BD)                                                                               \
+        if (depth == D && (resume || (node & 0x8000u))) {                                              \
+            if (!resume) BD = node & 0x7FFFu;                                                          \
+            resume = false;                                                                            \
+            const uint32_t sel = (((uint32_t)vx >> (4 - D)) & 1u) | ((((uint32_t)vy >> (4 - D)) & 1u) << 1) | \
+                                 ((((uint32_t)vz >> (4 - D)) & 1u) << 2);                               \
+            node = P.nodes[min(root + BD + sel, last)];                                                \
+            depth = D + 1u;                                                                            \
+        }
+        VRT_LEVEL(0, b0)
+        VRT_LEVEL(1, b1)
+        VRT_LEVEL(2, b2)
+        VRT_LEVEL(3, b3)
+        VRT_LEVEL(4, b4)
+#undef VRT_LEVEL
+        voxel = node & 0x7FFFu;
+        R.visits += depth + 1u;
+
+        bool liquid = false;
+        if (voxel != 0u) {
+            liquid = is_liquid(s_liquid, voxel);
+            if (!liquid) break;  // solid: the hit
+        }
+        if (liquid) {
+            if (dew == -1.0f) dew = total_len;
+        } else if (dew != -1.0f) {
+            R.water_dist += total_len - dew;
+            dew = -1.0f;
+        }
+
+        // ---- step to the leaf's exit face ----
+        const int sz = 32 >> depth;
+        const int m = ~(sz - 1);
+        const float tx = (float)((vx & m) + (mx ? sz : 0)) - pos.x;
+        const float ty = (float)((vy & m) + (my ? sz : 0)) - pos.y;
+        const float tz = (float)((vz & m) + (mz ? sz : 0)) - pos.z;
+        const float adx = (mx ? tx : -tx) * unit.x;
+        const float ady = (my ? ty : -ty) * unit.y;
+        const float adz = (mz ? tz : -tz) * unit.z;
+        const bool zx = adx == 0.0f, zy = ady == 0.0f, zz = adz == 0.0f;
+        float step = __builtin_fminf(__builtin_fminf(zx ? qnan : adx, zy ? qnan : ady), zz ? qnan : adz);
+        if (zx && zy && zz) step = adz;
+        total_len += step;
+        ex = step == adx;
+        ey = step == ady;
+        ez = step == adz;
+        const float sp = step + 0.001f;
+        pos.x += dir.x * (ex ? sp : step);
+        pos.y += dir.y * (ey ? sp : step);
+        pos.z += dir.z * (ez ? sp : step);
+
+        vx = f2i(floorf(pos.x));
+        vy = f2i(floorf(pos.y));
+        vz = f2i(floorf(pos.z));
+        if (max(max((uint32_t)vx, (uint32_t)vy), (uint32_t)vz) >= wsize) {
+            if (dew != -1.0f) R.water_dist += total_len - dew;
+            left_world = true;
+            break;
+        }
+        if (iter >= kMaxSteps) break;
+    }
+    R.iters = iter;
+    if (left_world) return R;
+
+    R.hit = true;
+    R.pos = pos;
+    R.norm = V3{(ex ? 1.0f : 0.0f) * -vsign(dir.x), (ey ? 1.0f : 0.0f) * -vsign(dir.y), (ez ? 1.0f : 0.0f) * -vsign(dir.z)};
+    R.voxel = voxel;
+    if (dew != -1.0f) R.water_dist += total_len - dew;
+    return R;
+}
+
+template <int MARCH, bool LDS_ROOTS>
+__device__ __forceinline__ MarchResult march(const FrameParams &P, const uint32_t *s_roots, const uint32_t *s_liquid,
+                                             V3 origin, V3 dir) {
+    if (MARCH == 1) return march_literal<LDS_ROOTS>(P, s_roots, s_liquid, origin, dir);
+    return march_fast<LDS_ROOTS>(P, s_roots, s_liquid, origin, dir);
+}
+
 // ray_sky, ray_tracer.wgsl:144-157
 __device__ __forceinline__ V3 ray_sky(const FrameParams &P, V3 origin, V3 dir) {
     const float ground_to_sky_t = vsmoothstep(-0.01f, 0.0f, dir.y);
@@ -200,6 +357,9 @@ __device__ __forceinline__ void create_ray(const FrameParams &P, int sx, int sy,
 }
 
 // Face shading + ray_color + overlay, ray_tracer.wgsl:127-142, 296-314. Returns the id word.
+// `color = vox*f32(hit) + sky*f32(!hit)` (:135): with finite settings the sky term of a hit is a zero and
+// the material term of a miss is a zero, so only one side is evaluated (exact up to the sign of a zero).
+template <bool EXACT_SKY>
 __device__ __forceinline__ uint32_t shade(const FrameParams &P, const MarchResult &R, V3 origin, V3 dir, V3 &color) {
     V3 mc{0.f, 0.f, 0.f};
     if (R.hit) {
@@ -213,9 +373,15 @@ __device__ __forceinline__ uint32_t shade(const FrameParams &P, const MarchResul
             mc = V3{f, f, f};
         }
     }
-    const V3 sky = ray_sky(P, origin, dir);
-    const float fh = R.hit ? 1.0f : 0.0f, fm = R.hit ? 0.0f : 1.0f;
-    color = V3{mc.x * fh + sky.x * fm, mc.y * fh + sky.y * fm, mc.z * fh + sky.z * fm};
+    if (EXACT_SKY || !P.finite_settings) {
+        const V3 sky = ray_sky(P, origin, dir);
+        const float fh = R.hit ? 1.0f : 0.0f, fm = R.hit ? 0.0f : 1.0f;
+        color = V3{mc.x * fh + sky.x * fm, mc.y * fh + sky.y * fm, mc.z * fh + sky.z * fm};
+    } else if (R.hit) {
+        color = mc;
+    } else {
+        color = ray_sky(P, origin, dir);
+    }
     if (R.water_dist != 0.0f) {
         const float factor = vclamp(R.water_dist / 14.0f, 0.8f, 1.0f);
         color.x = color.x * (1.0f - factor) + 0.2f * factor;
@@ -244,81 +410,102 @@ __device__ __forceinline__ void stage_lds(const FrameParams &P, uint32_t *s_root
     __syncthreads();
 }
 
-// ------------------------------------------------------------------------------------------------
-// Variant 0: one wave per 8x8 tile (the reference's @workgroup_size(8,8,1) = one CDNA wave),
-// 4 tiles per 256-thread workgroup.
-// ------------------------------------------------------------------------------------------------
+// stats frames: per-block reduction in LDS, then one atomic per counter per block
+__device__ __forceinline__ void block_add(unsigned long long *s_acc, int slot, unsigned long long v) {
+    const unsigned long long s = wave_sum(v);
+    if ((threadIdx.x & 63u) == 0 && s) atomicAdd(&s_acc[slot], s);
+}
+
 constexpr uint32_t kLdsRootsMax = 8192;  // entries (32 KiB): S <= 20
 
-template <bool LDS_ROOTS, bool STATS, bool SHADOW>
+// ------------------------------------------------------------------------------------------------
+// Primary rays: one wave per 8x8 tile, 4 tiles per 256-thread workgroup.
+// ------------------------------------------------------------------------------------------------
+template <int MARCH, bool LDS_ROOTS, bool STATS, bool SHADOW>
 __global__ void __launch_bounds__(256) primary_tile_kernel(FrameParams P) {
-    extern __shared__ uint32_t smem[];  // [0,8) liquid mask, [8, 8+n_roots) chunk roots
-    uint32_t *s_liquid = smem, *s_roots = smem + 8;
+    extern __shared__ uint32_t smem[];  // [0,8) liquid mask, [8,24) stats scratch, [24, 24+n_roots) chunk roots
+    uint32_t *s_liquid = smem, *s_roots = smem + 24;
+    unsigned long long *s_acc = reinterpret_cast<unsigned long long *>(smem + 8);
+    if (STATS && threadIdx.x < 8) s_acc[threadIdx.x] = 0ull;
     stage_lds(P, s_roots, s_liquid, LDS_ROOTS);
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t t_local = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (t_local >= P.tiles_local) return;
-    const uint32_t tile = P.shard_rank + t_local * P.shard_count;
-    const uint32_t px = (tile % P.tiles_x) * 8u + (lane & 7u);
-    const uint32_t py = (tile / P.tiles_x) * 8u + (lane >> 3);
-    const uint32_t slot = P.shard_count > 1u ? t_local * 64u + lane : py * P.width + px;
+    const bool live = t_local < P.tiles_local;
+    if (!STATS && !live) return;
+    MarchResult R;
+    R.iters = 0; R.visits = 0; R.hit = false;
+    uint32_t slot = 0;
+    if (live) {
+        const uint32_t tile = P.shard_rank + t_local * P.shard_count;
+        const uint32_t px = (tile % P.tiles_x) * 8u + (lane & 7u);
+        const uint32_t py = (tile / P.tiles_x) * 8u + (lane >> 3);
+        slot = P.shard_count > 1u ? t_local * 64u + lane : py * P.width + px;
 
-    V3 origin, dir;
-    create_ray(P, (int)px, (int)py, origin, dir);
-    const MarchResult R = march<LDS_ROOTS>(P, s_roots, s_liquid, origin, dir);
-    V3 color;
-    uint32_t id = shade(P, R, origin, dir, color);
+        V3 origin, dir;
+        create_ray(P, (int)px, (int)py, origin, dir);
+        R = march<MARCH, LDS_ROOTS>(P, s_roots, s_liquid, origin, dir);
+        V3 color;
+        uint32_t id = shade<MARCH == 1>(P, R, origin, dir, color);
 
-    bool launch = false;
-    if (SHADOW) {
-        launch = R.hit && R.voxel != 0u && !is_liquid(s_liquid, R.voxel);
-        if (launch) id |= VRT_ID_SHADOW_RAY;
-    }
-    P.rgb[slot * 3u + 0u] = color.x;
-    P.rgb[slot * 3u + 1u] = color.y;
-    P.rgb[slot * 3u + 2u] = color.z;
-    P.ids[slot] = id;
-
-    if (SHADOW) {
-        // wave-aggregated compaction into the hit buffer: one atomic per wave
-        const unsigned long long ballot = __ballot(launch);
-        const uint32_t n = (uint32_t)__popcll(ballot);
-        uint32_t base = 0;
-        if (n) {
-            if (lane == (uint32_t)__ffsll((long long)ballot) - 1u)
-                base = (uint32_t)atomicAdd(&P.counters[kCtrHitCount], (unsigned long long)n);
-            base = __shfl(base, __ffsll((long long)ballot) - 1, 64);
+        bool launch = false;
+        if (SHADOW) {
+            launch = R.hit && R.voxel != 0u && !is_liquid(s_liquid, R.voxel);
+            if (launch) id |= VRT_ID_SHADOW_RAY;
         }
-        if (launch) {
-            const uint32_t rank = (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
-            const V3 so{R.pos.x + R.norm.x * kShadowBias, R.pos.y + R.norm.y * kShadowBias, R.pos.z + R.norm.z * kShadowBias};
-            P.hits[base + rank] = make_uint4(slot, __float_as_uint(so.x), __float_as_uint(so.y), __float_as_uint(so.z));
+        P.out[slot] = make_uint4(__float_as_uint(color.x), __float_as_uint(color.y), __float_as_uint(color.z), id);
+
+        if (SHADOW) {
+            // wave-aggregated compaction into the hit buffer: one atomic per wave
+            const unsigned long long ballot = __ballot(launch);
+            const uint32_t n = (uint32_t)__popcll(ballot);
+            if (n) {
+                const int leader = __ffsll((long long)ballot) - 1;
+                const uint32_t seg = blockIdx.x % kHitSegments;
+                uint32_t base = 0;
+                if ((int)lane == leader) base = atomicAdd(&P.seg_counts[seg * kSegStride], n);
+                base = __shfl(base, leader, 64) + seg * P.hit_seg_cap;
+                if (launch) {
+                    const uint32_t rank = (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
+                    const V3 so{R.pos.x + R.norm.x * kShadowBias, R.pos.y + R.norm.y * kShadowBias,
+                                R.pos.z + R.norm.z * kShadowBias};
+                    P.hits[base + rank] = make_uint4(slot, __float_as_uint(so.x), __float_as_uint(so.y), __float_as_uint(so.z));
+                }
+            }
         }
+        if (STATS && P.steps) P.steps[slot] = R.iters;
     }
     if (STATS) {
-        if (P.steps) P.steps[slot] = R.iters;
-        const unsigned long long s = wave_sum(R.iters), v = wave_sum(R.visits), h = wave_sum(R.hit ? 1ull : 0ull);
-        if (lane == 0) {
-            atomicAdd(&P.counters[kCtrSteps], s);
-            atomicAdd(&P.counters[kCtrVisits], v);
-            atomicAdd(&P.counters[kCtrPrimarySteps], s);
-            atomicAdd(&P.counters[kCtrPrimaryVisits], v);
-            atomicAdd(&P.counters[kCtrHits], h);
+        block_add(s_acc, 0, R.iters);
+        block_add(s_acc, 1, R.visits);
+        block_add(s_acc, 2, R.hit ? 1ull : 0ull);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            atomicAdd(&P.counters[kCtrSteps], s_acc[0]);
+            atomicAdd(&P.counters[kCtrVisits], s_acc[1]);
+            atomicAdd(&P.counters[kCtrPrimarySteps], s_acc[0]);
+            atomicAdd(&P.counters[kCtrPrimaryVisits], s_acc[1]);
+            atomicAdd(&P.counters[kCtrHits], s_acc[2]);
         }
     }
 }
 
 // Shadow rays from the compacted hit buffer: lane i of the grid takes record i.
-template <bool LDS_ROOTS, bool STATS>
+template <int MARCH, bool LDS_ROOTS, bool STATS>
 __global__ void __launch_bounds__(256) shadow_kernel(FrameParams P) {
-    extern __shared__ uint32_t smem[];  // [0,8) liquid mask, [8, 8+n_roots) chunk roots
-    uint32_t *s_liquid = smem, *s_roots = smem + 8;
+    extern __shared__ uint32_t smem[];
+    uint32_t *s_liquid = smem, *s_roots = smem + 24;
+    unsigned long long *s_acc = reinterpret_cast<unsigned long long *>(smem + 8);
+    if (STATS && threadIdx.x < 8) s_acc[threadIdx.x] = 0ull;
     stage_lds(P, s_roots, s_liquid, LDS_ROOTS);
 
-    const uint32_t count = (uint32_t)P.counters[kCtrHitCount];
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = i < count;
+    // workgroup -> (segment, 256-record part of it): consecutive workgroups read different segments
+    const uint32_t seg = blockIdx.x % kHitSegments, part = blockIdx.x / kHitSegments;
+    const uint32_t count = P.seg_counts[seg * kSegStride];
+    const uint32_t j = part * blockDim.x + threadIdx.x;
+    const bool active = j < count;
+    const uint32_t i = seg * P.hit_seg_cap + j;
+    if (!STATS && part * blockDim.x >= count) return;
     MarchResult R;
     R.iters = 0; R.visits = 0; R.hit = false;
     uint32_t slot = 0;
@@ -329,20 +516,24 @@ __global__ void __launch_bounds__(256) shadow_kernel(FrameParams P) {
         const V3 sd = vnormalize(V3{P.settings.sun_pos[0] - (float)P.world.min[0] - so.x,
                                     P.settings.sun_pos[1] - (float)P.world.min[1] - so.y,
                                     P.settings.sun_pos[2] - (float)P.world.min[2] - so.z});
-        R = march<LDS_ROOTS>(P, s_roots, s_liquid, so, sd);
+        R = march<MARCH, LDS_ROOTS>(P, s_roots, s_liquid, so, sd);
         if (R.hit) {
-            P.rgb[slot * 3u + 0u] *= kShadowFactor;
-            P.rgb[slot * 3u + 1u] *= kShadowFactor;
-            P.rgb[slot * 3u + 2u] *= kShadowFactor;
-            P.ids[slot] |= VRT_ID_SHADOWED;
+            uint4 t = P.out[slot];
+            t.x = __float_as_uint(__uint_as_float(t.x) * kShadowFactor);
+            t.y = __float_as_uint(__uint_as_float(t.y) * kShadowFactor);
+            t.z = __float_as_uint(__uint_as_float(t.z) * kShadowFactor);
+            t.w |= VRT_ID_SHADOWED;
+            P.out[slot] = t;
         }
+        if (STATS && P.steps) P.steps[slot] |= R.iters << 16;
     }
     if (STATS) {
-        if (active && P.steps) P.steps[slot] |= R.iters << 16;
-        const unsigned long long s = wave_sum(active ? R.iters : 0u), v = wave_sum(active ? R.visits : 0u);
-        if ((threadIdx.x & 63u) == 0 && s) {
-            atomicAdd(&P.counters[kCtrSteps], s);
-            atomicAdd(&P.counters[kCtrVisits], v);
+        block_add(s_acc, 0, active ? R.iters : 0u);
+        block_add(s_acc, 1, active ? R.visits : 0u);
+        __syncthreads();
+        if (threadIdx.x == 0 && s_acc[0]) {
+            atomicAdd(&P.counters[kCtrSteps], s_acc[0]);
+            atomicAdd(&P.counters[kCtrVisits], s_acc[1]);
         }
     }
 }
@@ -352,88 +543,91 @@ __global__ void __launch_bounds__(256) shadow_kernel(FrameParams P) {
 // ------------------------------------------------------------------------------------------------
 
 // textureStore to rgba8unorm (ray_tracer.wgsl:179): clamp to [0,1], scale by 255, round to nearest.
-__global__ void quantize_rgba8_kernel(const float *rgb, uint8_t *rgba8, uint32_t n) {
+__global__ void quantize_rgba8_kernel(const Texel *out, uint8_t *rgba8, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint32_t out = 0xFF000000u;
+    const Texel t = out[i];
+    const float c[3] = {__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z)};
+    uint32_t q = 0xFF000000u;
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-        const float v = vclamp(rgb[i * 3u + c], 0.0f, 1.0f);
-        out |= ((uint32_t)rintf(v * 255.0f) & 0xFFu) << (8 * c);
-    }
-    reinterpret_cast<uint32_t *>(rgba8)[i] = out;
+    for (int k = 0; k < 3; k++) q |= ((uint32_t)rintf(vclamp(c[k], 0.0f, 1.0f) * 255.0f) & 0xFFu) << (8 * k);
+    reinterpret_cast<uint32_t *>(rgba8)[i] = q;
 }
 
-// Gather root: tile-major [rank][tiles_padded][64] -> row-major frame.
-__global__ void assemble_kernel(const float *g_rgb, const uint32_t *g_ids, float *dst_rgb, uint32_t *dst_ids,
-                                uint32_t width, uint32_t tiles_x, uint32_t tiles_total, uint32_t shard_count,
-                                uint64_t stride_rgb, uint64_t stride_ids) {
+// Gather root: tile-major [rank][slots_per_rank] texels -> row-major frame of texels.
+__global__ void assemble_kernel(const Texel *gathered, Texel *dst, uint32_t width, uint32_t tiles_x, uint32_t tiles_total,
+                                uint32_t shard_count, uint64_t rank_stride) {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t tile = gid >> 6, p = gid & 63u;
     if (tile >= tiles_total) return;
     const uint32_t rank = tile % shard_count, t_local = tile / shard_count;
-    const uint64_t local = (uint64_t)t_local * 64u + p;  // slot inside rank's buffer
-    const float *s_rgb = g_rgb + rank * stride_rgb + local * 3u;
     const uint32_t px = (tile % tiles_x) * 8u + (p & 7u), py = (tile / tiles_x) * 8u + (p >> 3);
-    const uint32_t dst = py * width + px;
-    if (dst_rgb) {
-        dst_rgb[dst * 3u + 0u] = s_rgb[0];
-        dst_rgb[dst * 3u + 1u] = s_rgb[1];
-        dst_rgb[dst * 3u + 2u] = s_rgb[2];
-    }
-    if (dst_ids) dst_ids[dst] = g_ids[rank * stride_ids + local];
+    dst[py * width + px] = gathered[rank * rank_stride + (uint64_t)t_local * 64u + p];
 }
 
 // ------------------------------------------------------------------------------------------------
 // Launchers (called from vrt_backend.hip)
 // ------------------------------------------------------------------------------------------------
 
-static size_t lds_bytes(const FrameParams &P, bool lds_roots) { return (8u + (lds_roots ? P.n_roots : 0u)) * 4u; }
+static size_t lds_bytes(const FrameParams &P, bool lds_roots) { return (24u + (lds_roots ? P.n_roots : 0u)) * 4u; }
 
-template <bool LDS_ROOTS>
-static void launch_primary_v0(const FrameParams &P, bool stats, bool shadow, hipStream_t st) {
+template <int MARCH, bool LDS_ROOTS>
+static void launch_primary_t(const FrameParams &P, bool stats, bool shadow, hipStream_t st) {
     const dim3 grid((P.tiles_local + 3u) / 4u), block(256);
     const size_t lds = lds_bytes(P, LDS_ROOTS);
     if (stats) {
-        if (shadow) hipLaunchKernelGGL((primary_tile_kernel<LDS_ROOTS, true, true>), grid, block, lds, st, P);
-        else hipLaunchKernelGGL((primary_tile_kernel<LDS_ROOTS, true, false>), grid, block, lds, st, P);
+        if (shadow) hipLaunchKernelGGL((primary_tile_kernel<MARCH, LDS_ROOTS, true, true>), grid, block, lds, st, P);
+        else hipLaunchKernelGGL((primary_tile_kernel<MARCH, LDS_ROOTS, true, false>), grid, block, lds, st, P);
     } else {
-        if (shadow) hipLaunchKernelGGL((primary_tile_kernel<LDS_ROOTS, false, true>), grid, block, lds, st, P);
-        else hipLaunchKernelGGL((primary_tile_kernel<LDS_ROOTS, false, false>), grid, block, lds, st, P);
+        if (shadow) hipLaunchKernelGGL((primary_tile_kernel<MARCH, LDS_ROOTS, false, true>), grid, block, lds, st, P);
+        else hipLaunchKernelGGL((primary_tile_kernel<MARCH, LDS_ROOTS, false, false>), grid, block, lds, st, P);
     }
 }
 
+template <int MARCH, bool LDS_ROOTS>
+static void launch_shadow_t(const FrameParams &P, bool stats, hipStream_t st) {
+    const dim3 grid(kHitSegments * (P.hit_seg_cap / 256u)), block(256);
+    const size_t lds = lds_bytes(P, LDS_ROOTS);
+    if (stats) hipLaunchKernelGGL((shadow_kernel<MARCH, LDS_ROOTS, true>), grid, block, lds, st, P);
+    else hipLaunchKernelGGL((shadow_kernel<MARCH, LDS_ROOTS, false>), grid, block, lds, st, P);
+}
+
+bool variant_supported(uint32_t variant) { return variant <= 1u; }
+
 void launch_primary(const FrameParams &P, uint32_t variant, bool stats, bool shadow, hipStream_t st) {
-    (void)variant;
     if (P.tiles_local == 0) return;
-    if (P.n_roots <= kLdsRootsMax) launch_primary_v0<true>(P, stats, shadow, st);
-    else launch_primary_v0<false>(P, stats, shadow, st);
+    const bool lds = P.n_roots <= kLdsRootsMax;
+    if (variant == 1u) {
+        if (lds) launch_primary_t<1, true>(P, stats, shadow, st);
+        else launch_primary_t<1, false>(P, stats, shadow, st);
+    } else {
+        if (lds) launch_primary_t<0, true>(P, stats, shadow, st);
+        else launch_primary_t<0, false>(P, stats, shadow, st);
+    }
 }
 
 void launch_shadow(const FrameParams &P, uint32_t variant, bool stats, hipStream_t st) {
-    (void)variant;
     if (P.tiles_local == 0) return;
-    const dim3 grid((P.tiles_local * 64u + 255u) / 256u), block(256);
-    if (P.n_roots <= kLdsRootsMax) {
-        if (stats) hipLaunchKernelGGL((shadow_kernel<true, true>), grid, block, lds_bytes(P, true), st, P);
-        else hipLaunchKernelGGL((shadow_kernel<true, false>), grid, block, lds_bytes(P, true), st, P);
+    const bool lds = P.n_roots <= kLdsRootsMax;
+    if (variant == 1u) {
+        if (lds) launch_shadow_t<1, true>(P, stats, st);
+        else launch_shadow_t<1, false>(P, stats, st);
     } else {
-        if (stats) hipLaunchKernelGGL((shadow_kernel<false, true>), grid, block, lds_bytes(P, false), st, P);
-        else hipLaunchKernelGGL((shadow_kernel<false, false>), grid, block, lds_bytes(P, false), st, P);
+        if (lds) launch_shadow_t<0, true>(P, stats, st);
+        else launch_shadow_t<0, false>(P, stats, st);
     }
 }
 
-void launch_quantize(const float *rgb, uint8_t *rgba8, uint32_t n, hipStream_t st) {
+void launch_quantize(const Texel *out, uint8_t *rgba8, uint32_t n, hipStream_t st) {
     if (!n) return;
-    hipLaunchKernelGGL(quantize_rgba8_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, rgb, rgba8, n);
+    hipLaunchKernelGGL(quantize_rgba8_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, out, rgba8, n);
 }
 
-void launch_assemble(const float *g_rgb, const uint32_t *g_ids, float *dst_rgb, uint32_t *dst_ids, uint32_t width,
-                     uint32_t tiles_x, uint32_t tiles_total, uint32_t shard_count, uint64_t stride_rgb,
-                     uint64_t stride_ids, hipStream_t st) {
+void launch_assemble(const Texel *gathered, Texel *dst, uint32_t width, uint32_t tiles_x, uint32_t tiles_total,
+                     uint32_t shard_count, uint64_t rank_stride, hipStream_t st) {
     if (!tiles_total) return;
-    hipLaunchKernelGGL(assemble_kernel, dim3((tiles_total * 64u + 255u) / 256u), dim3(256), 0, st, g_rgb, g_ids,
-                       dst_rgb, dst_ids, width, tiles_x, tiles_total, shard_count, stride_rgb, stride_ids);
+    hipLaunchKernelGGL(assemble_kernel, dim3((tiles_total * 64u + 255u) / 256u), dim3(256), 0, st, gathered, dst, width,
+                       tiles_x, tiles_total, shard_count, rank_stride);
 }
 
 }  // namespace vrt

@@ -153,25 +153,23 @@ class Gpu:
     def set_stream(self, hip_stream: int):
         self._ck(self._lib.vrt_set_stream(self._h, C.c_void_p(hip_stream)))
 
-    def bind_output(self, rgb_ptr: int, ids_ptr: int):
-        """Render into caller-owned device memory (torch tensors); 0, 0 restores the context's own."""
-        self._ck(self._lib.vrt_bind_output(self._h, C.c_void_p(rgb_ptr or None), C.c_void_p(ids_ptr or None)))
+    def bind_output(self, texels_ptr: int):
+        """Render into caller-owned device memory (a torch tensor); 0 restores the context's own buffer."""
+        self._ck(self._lib.vrt_bind_output(self._h, C.c_void_p(texels_ptr or None)))
 
     def device_output(self):
-        """(rgb_ptr, ids_ptr, rgb_bytes, ids_bytes) of the context's device output buffers."""
-        r, i = C.c_void_p(), C.c_void_p()
-        rb, ib = C.c_uint64(), C.c_uint64()
-        self._ck(self._lib.vrt_device_output(self._h, C.byref(r), C.byref(i), C.byref(rb), C.byref(ib)))
-        return r.value, i.value, rb.value, ib.value
+        """(device pointer, bytes) of the 16-byte-texel buffer frames are written to."""
+        t, nb = C.c_void_p(), C.c_uint64()
+        self._ck(self._lib.vrt_device_output(self._h, C.byref(t), C.byref(nb)))
+        return t.value, nb.value
 
     def shard_info(self):
         a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
         self._ck(self._lib.vrt_shard_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
-    def assemble(self, gathered_rgb: int, gathered_ids: int, dst_rgb: int, dst_ids: int, rank_stride_bytes: int = 0):
-        self._ck(self._lib.vrt_assemble(self._h, C.c_void_p(gathered_rgb), C.c_void_p(gathered_ids), rank_stride_bytes,
-                                        C.c_void_p(dst_rgb), C.c_void_p(dst_ids)))
+    def assemble(self, gathered_ptr: int, dst_ptr: int, rank_stride_bytes: int = 0):
+        self._ck(self._lib.vrt_assemble(self._h, C.c_void_p(gathered_ptr), rank_stride_bytes, C.c_void_p(dst_ptr)))
 
     # --- convenience: what join_game does (main.rs:211-223) ---
     def upload_world(self, world, materials=None):
