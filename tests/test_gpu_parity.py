@@ -92,6 +92,31 @@ def test_camera_outside_world_sees_only_sky(c1, orc):
     assert_frame_parity(rgb, ids, r_rgb, r_ids, "outside")
 
 
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_nan_and_degenerate_cameras(c1, orc, variant):
+    """NaN eye components march 500 steps through chunk 0 (i32(NaN) = 0); exactly axis-parallel rays have
+    NaN / inf unit steps; an eye on an integer lattice point triggers the start nudge and zero axis distances."""
+    w, h = 64, 64
+    gpu = gpu_for_scene(c1, (w, h))
+    o = orc.from_package_scene(c1)
+    cases = [((0.0, 0.0, 0.0), (32.0, 20.0, 60.0)), ((90.0, 0.0, 0.0), (32.5, 20.0, 32.5)),
+             ((0.0, 90.0, 0.0), (40.0, 13.0, 40.0)), ((15.0, 0.0, 0.0), (float("nan"), 20.5, 60.5)),
+             ((15.0, 30.0, 0.0), (32.5, float("nan"), float("nan")))]
+    for rot, eye in cases:
+        cam = g.cam_data_create(rot, eye, 70.0, (float(w), float(h)))
+        gpu.write_cam_data(cam)
+        gpu.render(MODE_PRIMARY_SHADOW, variant=variant, stats=True)
+        rgb, ids, _ = gpu.read_output()
+        o.set_cam(cam)
+        r_rgb, r_ids, r_steps, _ = o.render(MODE_PRIMARY_SHADOW, w, h, want_steps=True)
+        bad = ids != r_ids
+        assert not bad.any(), f"rot {rot} eye {eye}: {int(bad.sum())} id words differ"
+        assert np.array_equal(gpu.read_steps(), r_steps)
+        both = np.isfinite(rgb) & np.isfinite(r_rgb)
+        assert np.array_equal(np.isnan(rgb), np.isnan(r_rgb))
+        assert float(np.abs(rgb[both] - r_rgb[both]).max(initial=0.0)) <= 1e-4
+
+
 def test_show_step_count_debug_view(c2_small, orc):
     st = g.make_settings(sun_pos=scenes.SUN_POS, show_step_count=1)
     gpu = gpu_for_scene(c2_small, (320, 200))

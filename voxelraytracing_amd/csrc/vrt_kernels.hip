@@ -17,6 +17,15 @@
 
 namespace vrt {
 
+// f32 -> i32 with the hardware's own NaN -> 0 (v_cvt_i32_f32; what WGSL's i32(f32) specifies), truncating.
+// For x >= 0 this is floor(x); the march never uses it for a negative coordinate (it has left the world).
+// Measured on MI355X: NaN -> 0, +-inf and |x| >= 2^31 saturate.  (v_cvt_flr_i32_f32 maps NaN to INT_MAX.)
+__device__ __forceinline__ int trunc2i(float x) {
+    int r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 __device__ __forceinline__ bool is_liquid(const uint32_t *s_liquid, uint32_t voxel) {
     // voxel_mats[voxel].is_liquid == 1 (ray_tracer.wgsl:226); ids >= 256 clamp to material 255.
     const uint32_t v = min(voxel, 255u);
@@ -159,10 +168,13 @@ __device__ __forceinline__ MarchResult march_literal(const FrameParams &P, const
     }
     R.iters = iter;
     if (left_world) return R;  // hit = false, voxel = 0
+    const bool stepped = iter > 1u || voxel == 0u || is_liquid(s_liquid, voxel);  // a step ran before the exit
 
     R.hit = true;
     R.pos = pos;
-    R.norm = V3{ex * -vsign(dir.x), ey * -vsign(dir.y), ez * -vsign(dir.z)};
+    // `norm` is only assigned inside the loop (:272): a hit on the very first lookup leaves it zero, which
+    // differs from 0 * -sign(dir) when dir is NaN
+    if (stepped) R.norm = V3{ex * -vsign(dir.x), ey * -vsign(dir.y), ez * -vsign(dir.z)};
     R.voxel = voxel;
     if (dist_entered_water != -1.0f) R.water_dist += total_len - dist_entered_water;
     return R;
@@ -214,11 +226,11 @@ __device__ __forceinline__ MarchResult march_fast(const FrameParams &P, const ui
     const uint32_t last = P.n_nodes - 1u;
     const float qnan = __builtin_nanf("");
 
-    int vx = f2i(floorf(pos.x)), vy = f2i(floorf(pos.y)), vz = f2i(floorf(pos.z));
-    int pvx = vx, pvy = vy, pvz = vz;
+    int vx = trunc2i(pos.x), vy = trunc2i(pos.y), vz = trunc2i(pos.z);  // pos > 0 here (or NaN -> 0)
+    int pvx = ~vx, pvy = vy, pvz = vz;  // ~vx: the first lookup sees "another chunk"
     uint32_t root = 0u, node = 0u, depth = 0u;
     uint32_t b0 = 0u, b1 = 0u, b2 = 0u, b3 = 0u, b4 = 0u;  // child-block base of the split ancestor at depth 0..4
-    bool fresh = true;
+    const int mxm = mx ? -1 : 0, mym = my ? -1 : 0, mzm = mz ? -1 : 0;
 
     uint32_t voxel = 0u;
     bool ex = false, ey = false, ez = false;
@@ -230,16 +242,15 @@ __device__ __forceinline__ MarchResult march_fast(const FrameParams &P, const ui
     for (;;) {
         iter += 1u;
         // ---- find_node ----
-        const uint32_t diff = fresh ? 0xFFFFFFFFu : (uint32_t)((vx ^ pvx) | (vy ^ pvy) | (vz ^ pvz));
+        const uint32_t diff = (uint32_t)((vx ^ pvx) | (vy ^ pvy) | (vz ^ pvz));
         pvx = vx; pvy = vy; pvz = vz;
         bool resume = false;
         if (diff >= 32u) {  // another chunk (or the first lookup): start at that chunk's root
-            uint32_t cidx = (uint32_t)(vx >> 5) + (uint32_t)(vy >> 5) * S + (uint32_t)(vz >> 5) * S * S;
+            uint32_t cidx = __umul24(__umul24((uint32_t)(vz >> 5), S) + (uint32_t)(vy >> 5), S) + (uint32_t)(vx >> 5);
             cidx = min(cidx, P.n_roots - 1u);
             root = LDS_ROOTS ? s_roots[cidx] : P.roots[cidx];
             node = P.nodes[min(root, last)];
             depth = 0u;
-            fresh = false;
         } else {
             // k = number of leading local-coordinate bits shared with the previous position (5 if none differ)
             const uint32_t k = (uint32_t)__clz((int)diff) - 27u;
@@ -278,9 +289,9 @@ __device__ __forceinline__ MarchResult march_fast(const FrameParams &P, const ui
         // ---- step to the leaf's exit face ----
         const int sz = 32 >> depth;
         const int m = ~(sz - 1);
-        const float tx = (float)((vx & m) + (mx ? sz : 0)) - pos.x;
-        const float ty = (float)((vy & m) + (my ? sz : 0)) - pos.y;
-        const float tz = (float)((vz & m) + (mz ? sz : 0)) - pos.z;
+        const float tx = (float)((vx & m) + (sz & mxm)) - pos.x;
+        const float ty = (float)((vy & m) + (sz & mym)) - pos.y;
+        const float tz = (float)((vz & m) + (sz & mzm)) - pos.z;
         const float adx = (mx ? tx : -tx) * unit.x;
         const float ady = (my ? ty : -ty) * unit.y;
         const float adz = (mz ? tz : -tz) * unit.z;
@@ -296,10 +307,13 @@ __device__ __forceinline__ MarchResult march_fast(const FrameParams &P, const ui
         pos.y += dir.y * (ey ? sp : step);
         pos.z += dir.z * (ez ? sp : step);
 
-        vx = f2i(floorf(pos.x));
-        vy = f2i(floorf(pos.y));
-        vz = f2i(floorf(pos.z));
-        if (max(max((uint32_t)vx, (uint32_t)vy), (uint32_t)vz) >= wsize) {
+        // (e): pos < 0 on some axis (NaN-ignoring min: a NaN is not < 0), or floor(pos) >= size.  trunc == floor
+        // for the non-negative coordinates that survive the first test.
+        vx = trunc2i(pos.x);
+        vy = trunc2i(pos.y);
+        vz = trunc2i(pos.z);
+        if (__builtin_fminf(__builtin_fminf(pos.x, pos.y), pos.z) < 0.0f ||
+            max(max((uint32_t)vx, (uint32_t)vy), (uint32_t)vz) >= wsize) {
             if (dew != -1.0f) R.water_dist += total_len - dew;
             left_world = true;
             break;
@@ -308,10 +322,12 @@ __device__ __forceinline__ MarchResult march_fast(const FrameParams &P, const ui
     }
     R.iters = iter;
     if (left_world) return R;
+    const bool stepped = iter > 1u || voxel == 0u || is_liquid(s_liquid, voxel);  // a step ran before the exit
 
     R.hit = true;
     R.pos = pos;
-    R.norm = V3{(ex ? 1.0f : 0.0f) * -vsign(dir.x), (ey ? 1.0f : 0.0f) * -vsign(dir.y), (ez ? 1.0f : 0.0f) * -vsign(dir.z)};
+    if (stepped)  // see march_literal: norm stays zero when no step was taken
+        R.norm = V3{(ex ? 1.0f : 0.0f) * -vsign(dir.x), (ey ? 1.0f : 0.0f) * -vsign(dir.y), (ez ? 1.0f : 0.0f) * -vsign(dir.z)};
     R.voxel = voxel;
     if (dew != -1.0f) R.water_dist += total_len - dew;
     return R;
