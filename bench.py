@@ -158,24 +158,41 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(sc, args, rays_per_frame):
-    """The oracle (a port, not the reference: the reference is WGSL on wgpu and has no CPU tracer) timed on
-    this box's host cores over a bounded sample of the same frame."""
-    from oracle import orc
-    o = orc.from_package_scene(sc)
-    cores = os.cpu_count() or 1
+def usable_cores():
+    """CPU share of this process: the affinity mask, capped by the cgroup CPU quota when there is one."""
+    n = os.cpu_count() or 1
     try:
-        cores = len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    # sample: every 4th 8-row band of the frame would bias towards sky/terrain; trace the whole frame once
-    t0 = time.perf_counter()
-    _, _, _, cst = o.render(orc.MODE_PRIMARY_SHADOW, args.width, args.height, threads=cores)
-    dt = time.perf_counter() - t0
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return min(n, int(os.environ.get("VRT_CPU_BASELINE_THREADS", "64")))
+
+
+def cpu_baseline(sc, args, rays_per_frame):
+    """The oracle (a port, not the reference: the reference is WGSL on wgpu and has no CPU tracer) timed on
+    this box's host cores over a bounded sample of the same workload: whole frames of the same scene and
+    camera, repeated for about 3 s of wall time (>= 2 frames)."""
+    from oracle import orc
+    o = orc.from_package_scene(sc)
+    cores = usable_cores()
+    times = []
+    t_all = time.perf_counter()
+    while len(times) < 2 or (time.perf_counter() - t_all < 3.0 and len(times) < 50):
+        t0 = time.perf_counter()
+        _, _, _, cst = o.render(orc.MODE_PRIMARY_SHADOW, args.width, args.height, threads=cores)
+        times.append(time.perf_counter() - t0)
     rays = cst.primary_rays + cst.secondary_rays
     assert rays == rays_per_frame, "oracle and GPU disagree on the number of rays launched"
+    dt = sorted(times)[len(times) // 2]
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"1 full {args.width}x{args.height} frame of the same scene, OpenMP over 8-row bands, {dt:.2f} s"}
+            "sample": f"{len(times)} full {args.width}x{args.height} frames of the same scene (median {dt:.3f} s/frame, "
+                      f"{sum(times):.1f} s total), OpenMP dynamic over 8-row bands"}
 
 
 if __name__ == "__main__":

@@ -738,7 +738,7 @@ int orc_svo_set_node(uint16_t *nodes, uint32_t root, uint32_t svo_size, const ui
         uint32_t first_child;
         if (!orc_node_alloc_next(alloc, &first_child)) return 1;
         /* assert!(first_child < Voxel::MAX_VALUE) :416 — a chunk can address <= 32766 */
-        if (first_child >= 32767u) abort();
+        if (first_child >= 32767u) return 2; /* the reference panics here */
         for (int i = 0; i < 8; i++) nodes[first_child + i] = parent_voxel;
         nodes[node.idx] = (uint16_t)(first_child | 0x8000u);
         node.size /= 2;

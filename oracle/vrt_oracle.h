@@ -176,7 +176,7 @@ void orc_svo_find_node(const uint16_t *nodes, uint32_t root, uint32_t svo_size,
                        const uint32_t pos[3], uint32_t max_depth, uint32_t *out3, float *c);
 
 /* Svo::set_node, common/src/world/mod.rs:397-459.
- * Returns 0 ok, 1 out of memory (SetVoxelErr::OutOfMemory). */
+ * Returns 0 ok, 1 out of memory (SetVoxelErr::OutOfMemory), 2 where the assert at :416 would fire. */
 int orc_svo_set_node(uint16_t *nodes, uint32_t root, uint32_t svo_size, const uint32_t pos[3],
                      uint16_t voxel, uint32_t target_depth, orc_node_alloc *alloc);
 

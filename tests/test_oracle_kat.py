@@ -1,0 +1,275 @@
+"""Known-answer tests that pin the CPU oracle to the reference shader's text.
+
+The reference has no tests or golden vectors, so these are hand-derived from
+clientdesktop/src/graphics/ray_tracer.wgsl and the host data model; each test names the lines it checks.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from voxelraytracing_amd import graphics as g
+from voxelraytracing_amd import scenes, world as W
+
+AIR, WATER, LIMESTONE, DIRT, GRASS, SAND = 0, 3, 4, 39, 40, 47
+
+
+def _scene(orc, nodes, roots, S, eye, rot=(0.0, 0.0, 0.0), size=(64, 64), settings=None, mats=None):
+    cam = orc.cam_data_create(rot, eye, 70.0, (float(size[0]), float(size[1])))
+    st = settings or g.make_settings(sun_pos=scenes.SUN_POS)
+    wd = g.WorldData()
+    wd.size, wd.size_in_chunks = S * 32, S
+    return orc.OracleScene(np.asarray(nodes, dtype=np.uint16), np.asarray(roots, dtype=np.uint32),
+                           mats if mats is not None else g.std_materials(), cam, st, wd)
+
+
+def _nine_node_pool():
+    """pool[0] = permanent air leaf; chunk root at 1: split -> children at chunk-relative 1..8 (abs 2..9),
+    child k holds voxel 10+k."""
+    pool = np.zeros(16, dtype=np.uint16)
+    pool[1] = 0x8000 | 1
+    pool[2:10] = 10 + np.arange(8)
+    return pool
+
+
+def test_get_node_unpacks_u16_pairs(orc):
+    # ray_tracer.wgsl:38-42: even index in the low half of the u32
+    pool = np.arange(100, 132, dtype=np.uint16)
+    pairs = pool.view(np.uint32)
+    for i in range(32):
+        assert orc.lib().orc_get_node(pairs.ctypes.data, i) == pool[i]
+
+
+def test_node_word_helpers():
+    # common/src/world/mod.rs:150-194
+    assert W.Node.new(40) == 40 and not W.Node.is_split(W.Node.new(40))
+    n = W.Node.new_split(123)
+    assert n == 0x8000 | 123 and W.Node.is_split(n) and W.Node.child_idx(n) == 123
+    assert W.Node.new(0xFFFF) == 0x7FFF  # Voxel::MAX_VALUE mask
+
+
+def test_find_chunk_node_octants(orc):
+    # ray_tracer.wgsl:76-114 on a 9-node tree: child order x | y<<1 | z<<2, min/max/size per octant
+    s = _scene(orc, _nine_node_pool(), [1], 1, (8.0, 8.0, 8.0))
+    for k in range(8):
+        p = [8.0 + 16.0 * ((k >> a) & 1) for a in range(3)]
+        f = s.find_node(p)
+        assert (f["idx"], f["root"], f["depth"], f["size"]) == (1 + k, 1, 1, 16.0)
+        assert f["min"] == tuple(16.0 * ((k >> a) & 1) for a in range(3))
+        assert f["max"] == tuple(16.0 * ((k >> a) & 1) + 16.0 for a in range(3))
+        assert s.nodes[1 + f["idx"]] == 10 + k
+    # the boundary belongs to the upper child (pos >= center, :102-104)
+    assert s.find_node((16.0, 0.5, 0.5))["idx"] == 1 + 1
+    assert s.find_node((15.999, 0.5, 0.5))["idx"] == 1 + 0
+    # max_depth = 0 stops at the root even though it is split (:89)
+    assert s.find_node((3.0, 3.0, 3.0), max_depth=0)["depth"] == 0
+
+
+def test_missing_chunk_is_32_cubed_air(orc):
+    # client/src/world.rs:154-159 + ray_tracer.wgsl:116-125: root 0 -> pool[0], a depth-0 air leaf
+    s = _scene(orc, _nine_node_pool(), [0, 1, 0, 0, 0, 0, 0, 0], 2, (8.0, 8.0, 8.0))
+    f = s.find_node((5.0, 40.0, 33.0))
+    assert (f["idx"], f["root"], f["depth"], f["size"]) == (0, 0, 0, 32.0)
+    assert f["min"] == (0.0, 32.0, 32.0) and f["max"] == (32.0, 64.0, 64.0)
+    f = s.find_node((40.0, 5.0, 5.0))  # chunk index 1 = x + y*S + z*S*S
+    assert f["root"] == 1 and f["depth"] == 1
+
+
+def _flat(orc, eye, rot, size=(64, 64), **kw):
+    sc = scenes.c1_flat()
+    cam = orc.cam_data_create(rot, eye, 70.0, (float(size[0]), float(size[1])))
+    st = g.make_settings(sun_pos=scenes.SUN_POS, **kw)
+    return orc.OracleScene(sc.world.nodes(), sc.world.chunk_roots(), sc.materials, cam, st, sc.world.world_data()), sc
+
+
+def test_vertical_ray_hits_grass_top_face_unshaded(orc):
+    # ray straight down onto the flat ground: id = grass(40), norm = (0,1,0), colour unscaled (:298-306)
+    s, _ = _flat(orc, (20.5, 30.5, 20.5), (90.0, 0.0, 0.0))
+    idw, col, out = s.ray_world((20.5, 30.5, 20.5), (0.0, -1.0, 0.0))
+    assert idw & orc.ID_VOXEL_MASK == GRASS and idw & orc.ID_HIT
+    assert out[3:6] == (-0.0, 1.0, -0.0) or out[3:6] == (0.0, 1.0, 0.0)
+    assert (idw & (orc.ID_NX | orc.ID_NY | orc.ID_NZ)) == orc.ID_NY
+    assert col == pytest.approx((0.18, 0.45, 0.09), abs=1e-7)
+    # the hit position is 0.001*|dir.y| inside the voxel below y = 13 (:274-283)
+    assert out[1] == pytest.approx(13.0 - 0.001, abs=1e-4)
+
+
+def test_face_shading_factors(orc):
+    # +-x face x0.5, +-z face x0.7, -y face x0.2 (:298-306), on a limestone block floating in air
+    pool = np.zeros(64, dtype=np.uint16)
+    dense = np.zeros(32768, dtype=np.uint16)
+    for x in range(8, 16):
+        for y in range(8, 16):
+            for z in range(8, 16):
+                dense[x + 32 * (y + 32 * z)] = LIMESTONE
+    nodes = orc.build_chunk_by_set_node(dense)
+    pool = np.zeros(1 + nodes.size, dtype=np.uint16)
+    pool[1:] = nodes
+    s = _scene(orc, pool, [1], 1, (4.0, 4.0, 4.0))
+    base = np.float32(0.4)
+    for origin, d, factor, bit in [((2.5, 12.5, 12.5), (1, 0, 0), 0.5, orc.ID_NX), ((20.5, 12.5, 12.5), (-1, 0, 0), 0.5, orc.ID_NX),
+                                   ((12.5, 12.5, 2.5), (0, 0, 1), 0.7, orc.ID_NZ), ((12.5, 12.5, 20.5), (0, 0, -1), 0.7, orc.ID_NZ),
+                                   ((12.5, 2.5, 12.5), (0, 1, 0), 0.2, orc.ID_NY), ((12.5, 20.5, 12.5), (0, -1, 0), 1.0, orc.ID_NY)]:
+        idw, col, out = s.ray_world(origin, [float(c) for c in d])
+        assert idw & orc.ID_VOXEL_MASK == LIMESTONE
+        assert idw & (orc.ID_NX | orc.ID_NY | orc.ID_NZ) == bit
+        assert col[0] == np.float32(base * np.float32(factor))
+        # norm = -sign(dir) on the entry axis (:272)
+        assert [out[3 + a] for a in range(3) if d[a]] == [-float(c) for c in d if c]
+
+
+def test_first_node_solid_has_zero_normal(orc):
+    # camera inside a solid: break on the first lookup, norm stays zero, colour unshaded
+    s, _ = _flat(orc, (20.5, 5.5, 20.5), (0.0, 0.0, 0.0))
+    idw, col, out = s.ray_world((20.5, 5.5, 20.5), (0.6, 0.0, 0.8))
+    assert idw & orc.ID_VOXEL_MASK == LIMESTONE and out[3:6] == (0.0, 0.0, 0.0) and out[7] == 1.0
+    assert not idw & (orc.ID_NX | orc.ID_NY | orc.ID_NZ)
+
+
+def test_camera_outside_world_is_pure_sky(orc):
+    # :197-200
+    s, _ = _flat(orc, (-3.0, 20.0, 20.0), (0.0, 0.0, 0.0), size=(32, 32))
+    rgb, ids, _, st = s.render(orc.MODE_PRIMARY_SHADOW, 32, 32)
+    assert not ids.any() and st.hits == 0 and st.steps == 0 and st.secondary_rays == 0
+    for py in (0, 31):
+        idw, col, d, _ = s.trace_pixel(orc.MODE_PRIMARY, 5, py)
+        assert col == pytest.approx(s.ray_sky((-3.0, 20.0, 20.0), d), abs=0)
+
+
+def test_sky_known_values(orc):
+    # :144-157: dir.y >= 0.4 -> sky_color exactly (no sun in view); dir.y <= -0.01 -> void 0.03
+    s, _ = _flat(orc, (20.5, 30.5, 20.5), (0.0, 0.0, 0.0))
+    up = s.ray_sky((20.5, 30.5, 20.5), (0.0, 0.6, -0.8))
+    assert up == pytest.approx((0.81, 0.93, 1.0), abs=1e-6)
+    assert s.ray_sky((20.5, 30.5, 20.5), (0.0, -0.5, -0.8660254)) == pytest.approx((0.03,) * 3, abs=1e-7)
+    # horizon: dir.y = 0 -> smoothstep(-.01,0,0) = 1, gradient t = 0 -> horizon colour (1, .3, 0)
+    assert s.ray_sky((20.5, 30.5, 20.5), (1.0, 0.0, 0.0)) == pytest.approx((1.0, 0.3, 0.0), abs=1e-6)
+    # looking at the sun adds sun_intensity (:154-156)
+    sd = np.array(scenes.SUN_POS) - np.array((20.5, 30.5, 20.5))
+    sd /= np.linalg.norm(sd)
+    assert s.ray_sky((20.5, 30.5, 20.5), sd)[0] == pytest.approx(0.81 + 4.0, abs=1e-5)
+
+
+def test_centre_ray_equals_axis_rot_to_ray(orc):
+    # create_ray_from_screen (:159-171) vs common/src/math.rs:131-146
+    # (roll = 0 as in the game, player.rs never sets rot.z; with roll the shader's row-vector product
+    # applies R^T and the centre ray does depend on it, unlike axis_rot_to_ray)
+    for rot in [(0.0, 0.0, 0.0), (15.0, 0.0, 0.0), (20.0, 35.0, 0.0), (-40.0, 200.0, 0.0), (89.0, -75.0, 0.0)]:
+        s, _ = _flat(orc, (20.5, 30.5, 20.5), rot, size=(64, 64))
+        _, _, d, _ = s.trace_pixel(orc.MODE_PRIMARY, 32, 32)
+        want = orc.axis_rot_to_ray([math.radians(a) for a in rot])
+        assert d == pytest.approx(want, abs=2e-6)
+    # closed form of A5: pixel (px,py) -> e.x = x*aspect*tan(fov/2), e.y = -y*tan(fov/2) at rot 0
+    s, _ = _flat(orc, (20.5, 30.5, 20.5), (0.0, 0.0, 0.0), size=(64, 32))
+    _, _, d, _ = s.trace_pixel(orc.MODE_PRIMARY, 48, 8)
+    t = math.tan(math.radians(35.0))
+    v = np.array([(2 * 48 / 64 - 1) * 2.0 * t, -(2 * 8 / 32 - 1) * t, -1.0])
+    assert d == pytest.approx(v / np.linalg.norm(v), abs=2e-6)
+
+
+def test_water_distance_and_overlay(orc):
+    # k voxels of water above sand, vertical ray: water_dist = k (ray-length units), >= 80 % blue mix (:131-142,231-242)
+    k = 5
+    dense = np.zeros(32768, dtype=np.uint16)
+    for x in range(32):
+        for z in range(32):
+            for y in range(0, 4):
+                dense[x + 32 * (y + 32 * z)] = SAND
+            for y in range(4, 4 + k):
+                dense[x + 32 * (y + 32 * z)] = WATER
+    nodes = orc.build_chunk_by_set_node(dense)
+    pool = np.zeros(1 + nodes.size, dtype=np.uint16)
+    pool[1:] = nodes
+    s = _scene(orc, pool, [1], 1, (16.5, 20.5, 16.5), rot=(90.0, 0.0, 0.0))
+    idw, col, out = s.ray_world((16.5, 20.5, 16.5), (0.0, -1.0, 0.0))
+    assert idw & orc.ID_VOXEL_MASK == SAND and idw & orc.ID_WATER
+    assert out[6] == pytest.approx(float(k), abs=0.02)
+    idw, rgb, _, _ = s.trace_pixel(orc.MODE_PRIMARY, 32, 32)
+    f = min(max(out[6] / 14.0, 0.8), 1.0)
+    sand = np.array((1.0, 0.9, 0.3))
+    assert rgb == pytest.approx(sand * (1 - f) + np.array((0.2, 0.5, 1.0)) * f, abs=1e-5)
+    # a ray that leaves the world through water still reports the water it crossed (:285-288)
+    idw, _, out = s.ray_world((16.5, 6.5, 16.5), (1.0, 0.0, 0.0))
+    assert not idw & orc.ID_HIT and idw & orc.ID_WATER and out[6] == pytest.approx(15.5, abs=0.05)
+
+
+def test_step_exhaustion_reports_a_hit(orc):
+    # 500 steps in air/water -> hit = true with the last voxel's material (:220,293)
+    # a 3-D checkerboard of single water voxels in the lower half of the chunk keeps every leaf there at
+    # size 1 (a full 32^3 checkerboard needs 37 449 nodes, more than the 15-bit child index can address,
+    # common/src/world/mod.rs:416); the same chunk tiles a 16^3 world so a shallow ray takes > 500 steps
+    x, y, z = np.meshgrid(np.arange(32), np.arange(32), np.arange(32), indexing="ij")
+    dense = np.zeros(32768, dtype=np.uint16)
+    dense[(x + 32 * (y + 32 * z))[((x + y + z) % 2 == 0) & (y < 16)]] = WATER
+    nodes = orc.build_chunk_by_set_node(dense)
+    S = 16
+    pool = np.zeros(1 + nodes.size, dtype=np.uint16)
+    pool[1:] = nodes
+    s = _scene(orc, pool, [1] * (S ** 3), S, (1.5, 1.5, 1.5))
+    d = np.array([1.0, 0.002, 0.8])
+    d /= np.linalg.norm(d)
+    idw, col, out = s.ray_world((1.5, 1.5, 1.5), d.astype(np.float32))
+    assert out[7] == 500.0 and idw & orc.ID_HIT
+    assert idw & orc.ID_VOXEL_MASK in (AIR, WATER)
+    assert idw & orc.ID_WATER
+
+
+def test_superflat_chunk_minimal_tree_is_5289_nodes(orc):
+    # limestone y<=8, dirt 9..11, grass 12 -> 1+8+32+128+1024+4096 live nodes
+    dense = W.gen_dense_superflat((0, 0, 0))
+    tree = W.svo_build_bottom_up(dense)
+    assert tree.size == 5289
+    by_set_node = orc.build_chunk_by_set_node(dense)
+    assert by_set_node.size >= 5289  # incremental set_node leaves holes below last_used_addr
+    assert np.array_equal(W.svo_to_dense(by_set_node), dense)
+
+
+def test_rng_matches_pcg_reference_values(orc):
+    # path_tracer.wgsl:56-61, first outputs for seed 0 computed by hand from the text
+    state = C.c_uint32(0)
+    vals = [orc.lib().orc_rng_next(C.byref(state)) for _ in range(3)]
+
+    def pcg(s):
+        s = (s * 747796405 + 2891336453) & 0xFFFFFFFF
+        r = (((s >> ((s >> 28) + 4)) ^ s) * 277803737) & 0xFFFFFFFF
+        r = (r >> 22) ^ r
+        return s, np.float32(r) / np.float32(4294967295.0)
+
+    st, want = 0, []
+    for _ in range(3):
+        st, v = pcg(st)
+        want.append(float(v))
+    assert vals == pytest.approx(want, abs=0)
+
+
+def test_shadow_ray_definition(orc):
+    # build-defined (DESIGN.md §Shadow rays): a pillar shadows the ground behind it w.r.t. the sun
+    sc = scenes.c1_flat((64, 64))
+    for y in range(13, 30):
+        sc.world.set_voxel((20, y, 30), LIMESTONE)
+    s = orc.from_package_scene(sc)
+    sun = np.array(scenes.SUN_POS, dtype=np.float64)
+    # ground point in the pillar's shadow: walk from the pillar away from the sun
+    top = np.array((20.5, 25.0, 30.5))
+    dirn = (top - sun) / np.linalg.norm(top - sun)
+    t = (13.0 - top[1]) / dirn[1]
+    gx, gz = top[0] + dirn[0] * t, top[2] + dirn[2] * t
+    idw, col, out = s.ray_world((gx, 20.0, gz), (0.0, -1.0, 0.0))
+    assert idw & orc.ID_VOXEL_MASK == GRASS
+    cam = orc.cam_data_create((90.0, 0.0, 0.0), (gx, 20.0, gz), 70.0, (64.0, 64.0))
+    s.set_cam(cam)
+    idw, rgb, _, _ = s.trace_pixel(orc.MODE_PRIMARY_SHADOW, 32, 32)
+    assert idw & orc.ID_SHADOW_RAY and idw & orc.ID_SHADOWED
+    assert rgb == pytest.approx(np.array((0.18, 0.45, 0.09)) * 0.35, abs=1e-6)
+    # a lit point far from the pillar
+    cam = orc.cam_data_create((90.0, 0.0, 0.0), (50.5, 20.0, 10.5), 70.0, (64.0, 64.0))
+    s.set_cam(cam)
+    idw, rgb, _, _ = s.trace_pixel(orc.MODE_PRIMARY_SHADOW, 32, 32)
+    assert idw & orc.ID_SHADOW_RAY and not idw & orc.ID_SHADOWED
+    assert rgb == pytest.approx((0.18, 0.45, 0.09), abs=1e-6)
+    # sky pixels launch nothing
+    cam = orc.cam_data_create((-80.0, 0.0, 0.0), (50.5, 20.0, 10.5), 70.0, (64.0, 64.0))
+    s.set_cam(cam)
+    idw, _, _, _ = s.trace_pixel(orc.MODE_PRIMARY_SHADOW, 32, 32)
+    assert idw == 0
