@@ -32,7 +32,7 @@ def algorithmic_bytes(st, width, height):
                     counted: occlusion count is not part of vrt_stats)"""
     p_steps, p_vis = st.primary_steps, st.primary_node_visits
     s_steps, s_vis = st.steps - p_steps, st.node_visits - p_vis
-    primary = 8 * p_steps + 2 * p_vis + 16 * width * height + 16 * st.secondary_rays
+    primary = 8 * p_steps + 2 * p_vis + 16 * st.primary_rays + 16 * st.secondary_rays
     shadow = 8 * s_steps + 2 * s_vis + 16 * st.secondary_rays
     return primary, shadow
 
@@ -47,6 +47,9 @@ def main():
     ap.add_argument("--chunks", type=int, default=8, help="world size in chunks (8 = config C2)")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="development only: run the N > 1 code path with every rank on cuda:0 and a gloo gather staged "
+                         "through host memory (RCCL refuses two ranks on one device); never used for reported numbers")
     args = ap.parse_args()
 
     import torch
@@ -60,11 +63,28 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU path")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def all_reduce(t, op=None):
+        """all_reduce of a small cuda tensor (through the host when rehearsing over gloo)."""
+        if world == 1:
+            return t
+        kw = {} if op is None else {"op": op}
+        if args.rehearse_on_one_gpu:
+            c = t.cpu()
+            dist.all_reduce(c, **kw)
+            return c.to(t.device)
+        dist.all_reduce(t, **kw)
+        return t
 
     # ---- scene (deterministic, built by every rank) and upload: off the clock ----
     sc = scenes.procedural(args.chunks, (args.width, args.height), MODE_PRIMARY_SHADOW)
@@ -77,6 +97,14 @@ def main():
         gpu.set_stream(torch.cuda.current_stream().cuda_stream)
         fg = FrameGather(torch, dist, rank, world, args.width, args.height, torch.device("cuda", local_rank))
         fg.bind(gpu)
+        if args.rehearse_on_one_gpu:
+            def staged_gather():
+                torch.cuda.synchronize()
+                parts = [torch.empty(fg.msg.numel(), dtype=torch.int32) for _ in range(world)] if rank == 0 else None
+                dist.gather(fg.msg.cpu(), parts, dst=0)
+                if rank == 0:
+                    fg.gathered.copy_(torch.stack(parts))
+            fg.gather = staged_gather
 
     def frame():
         gpu.render(MODE_PRIMARY_SHADOW, variant=args.variant)
@@ -88,9 +116,7 @@ def main():
     # exact ray / step / node-visit counts of this frame (deterministic; a stats frame is never timed)
     gpu.render(MODE_PRIMARY_SHADOW, variant=args.variant, stats=True)
     st = gpu.stats()
-    counts = torch.tensor([st.primary_rays, st.secondary_rays], dtype=torch.int64, device="cuda")
-    if world > 1:
-        dist.all_reduce(counts)
+    counts = all_reduce(torch.tensor([st.primary_rays, st.secondary_rays], dtype=torch.int64, device="cuda"))
     rays_per_frame = int(counts[0] + counts[1])
 
     for _ in range(args.warmup):
@@ -106,18 +132,29 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax[0])
+    dt = float(all_reduce(torch.tensor([dt], dtype=torch.float64, device="cuda"), dist.ReduceOp.MAX if world > 1 else None)[0])
 
     # per-kernel durations over exactly the timed frames: HIP events on the stream the kernels ran on
     kst = gpu.stats()
+    if world > 1 and rank == 0 and os.environ.get("VRT_BENCH_VERIFY", "1") == "1":
+        # off the clock: the assembled frame must equal an unsharded render of the same frame on this GPU
+        ref = Gpu(sc.world.max_nodes(), sc.world.size_in_chunks(), sc.size, device=local_rank)
+        ref.upload_world(sc.world, sc.materials)
+        ref.write_cam_data(sc.cam)
+        ref.write_settings(sc.settings)
+        ref.render(MODE_PRIMARY_SHADOW, variant=args.variant)
+        r_rgb, r_ids, _ = ref.read_output()
+        from voxelraytracing_amd.shard import texels_to_frame
+        import numpy as np
+        a_rgb, a_ids = texels_to_frame(fg.frame.cpu().numpy().view(np.uint32))
+        if not (np.array_equal(a_ids, r_ids) and np.array_equal(a_rgb, r_rgb)):
+            raise SystemExit("gathered frame differs from the unsharded render")
+        ref.close()
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
-    b_primary, b_shadow = algorithmic_bytes(st, args.width, args.height) if world == 1 else (0, 0)
+    b_primary, b_shadow = algorithmic_bytes(st, args.width, args.height)  # rank 0's own launches (its shard when N > 1)
     ms_p = kst.sum_ms_primary / max(kst.frames, 1)
     ms_s = kst.sum_ms_secondary / max(kst.frames, 1)
     dom_name, dom_bytes, dom_ms = ("primary_march", b_primary, ms_p) if ms_p >= ms_s else ("shadow_march", b_shadow, ms_s)
