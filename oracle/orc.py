@@ -92,6 +92,11 @@ def lib() -> C.CDLL:
         L.orc_axis_rot_to_ray.restype = None
         L.orc_rng_next.argtypes = [C.POINTER(u32)]
         L.orc_rng_next.restype = C.c_float
+        L.orc_test_log.argtypes = [C.c_float]
+        L.orc_test_log.restype = C.c_float
+        L.orc_test_cos2pi.argtypes = [C.c_float]
+        L.orc_test_cos2pi.restype = C.c_float
+        L.orc_test_rng_dir.argtypes = [C.POINTER(u32), f32p]
         L.orc_node_alloc_init.argtypes = [C.POINTER(NodeAlloc), u32, u32, u32, u32]
         L.orc_node_alloc_destroy.argtypes = [C.POINTER(NodeAlloc)]
         L.orc_node_alloc_next.argtypes = [C.POINTER(NodeAlloc), C.POINTER(u32)]
@@ -139,14 +144,14 @@ class OracleScene:
     def set_settings(self, st):
         _copy_struct(self.c.settings, st)
 
-    def render(self, mode: int, w: int, h: int, rect=None, threads: int = 0, want_steps=False):
+    def render(self, mode: int, w: int, h: int, rect=None, threads: int = 0, want_steps=False, spp: int = 1, seed: int = 0):
         x0, y0, x1, y1 = rect if rect else (0, 0, w, h)
         rgb = np.zeros((h, w, 3), dtype=np.float32)
         ids = np.zeros((h, w), dtype=np.uint32)
         steps = np.zeros((h, w), dtype=np.uint32) if want_steps else None
         st = Stats()
         lib().orc_render(C.byref(self.c), mode, w, h, x0, y0, x1, y1, rgb.ctypes.data, ids.ctypes.data,
-                         steps.ctypes.data if want_steps else None, C.byref(st), threads, 1, 0)
+                         steps.ctypes.data if want_steps else None, C.byref(st), threads, spp, seed)
         return rgb, ids, steps, st
 
     def trace_pixel(self, mode: int, px: int, py: int):

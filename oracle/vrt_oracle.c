@@ -429,6 +429,125 @@ static pixel_result trace_pixel(const orc_scene *s, int mode, uint32_t px, uint3
     return pr;
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* Build-defined path trace (ORC_MODE_PATH), after the stale path_tracer.wgsl:56-76,149-194        */
+/* ------------------------------------------------------------------------------------------ */
+/* The reference's path tracer is compiled but never dispatched and no longer matches the host's node /
+ * Material layouts; this mode keeps its structure — PCG state seeded per pixel, Box-Muller
+ * direction, dir = normalize(mix(reflect, normalize(norm + rand_dir), scatter)), throughput *= colour,
+ * light += sky * throughput on a miss, at most settings.max_ray_bounces segments — on top of the LIVE
+ * ray_world (ray_tracer.wgsl:182-316), with two fixes: the bounce starts at hit.pos + norm * ORC_SHADOW_BIAS
+ * (the stale shader starts inside the voxel it just hit and self-intersects), and log(0) is avoided by
+ * clamping the uniform sample to 1e-10.  log and cos are spelled out in +,-,*,/ so that gcc and hipcc
+ * produce the same bits (libm and ocml do not agree to the last ulp, and a one-ulp different bounce
+ * direction eventually hits a different voxel).  The live Material has no emission, so light enters only
+ * through the sky; water is transparent to path segments and does not tint them. */
+
+static inline float orc_bits2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint32_t orc_f2bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+/* ln(x) for normal x > 0: x = m * 2^e with m in (sqrt(1/2), sqrt(2)], ln m = 2 atanh((m-1)/(m+1)) */
+static float orc_log(float x) {
+    uint32_t b = orc_f2bits(x);
+    int32_t e = (int32_t)(b >> 23) - 127;
+    float m = orc_bits2f((b & 0x007FFFFFu) | 0x3F800000u);
+    if (m > 1.41421354f) { m = m * 0.5f; e += 1; }
+    float s = (m - 1.0f) / (m + 1.0f);
+    float z = s * s;
+    float p = z * (0.333333343f + z * (0.2f + z * (0.142857149f + z * (0.111111112f + z * 0.0909090936f))));
+    return (float)e * 0.693147182f + (s + s * p) * 2.0f;
+}
+
+/* cos(2*pi*u) for u in [0,1]: quadrant + Taylor polynomials on [0, pi/2) */
+static float orc_cos2pi(float u) {
+    float t = u * 4.0f;
+    float q = floorf(t);
+    float a = (t - q) * 1.57079637f;
+    float a2 = a * a;
+    float sn = a * (1.0f + a2 * (-0.166666672f + a2 * (0.00833333377f + a2 * (-0.000198412701f + a2 * (2.75573188e-06f + a2 * -2.50521079e-08f)))));
+    float cs = 1.0f + a2 * (-0.5f + a2 * (0.0416666679f + a2 * (-0.00138888892f + a2 * (2.48015876e-05f + a2 * (-2.75573199e-07f + a2 * 2.08767559e-09f)))));
+    switch ((int32_t)q & 3) {
+        case 0: return cs;
+        case 1: return -sn;
+        case 2: return -cs;
+        default: return sn;
+    }
+}
+
+/* rng_next_norm, path_tracer.wgsl:62-66 */
+static float rng_next_norm(uint32_t *state) {
+    float u1 = orc_rng_next(state);
+    float u2 = orc_rng_next(state);
+    if (u2 < 1.0e-10f) u2 = 1.0e-10f;
+    float rho = sqrtf(-2.0f * orc_log(u2));
+    return rho * orc_cos2pi(u1);
+}
+
+/* rng_next_dir, path_tracer.wgsl:67-72 */
+static v3 rng_next_dir(uint32_t *state) {
+    float x = rng_next_norm(state);
+    float y = rng_next_norm(state);
+    float z = rng_next_norm(state);
+    return orc_normalize(V3(x, y, z));
+}
+
+float orc_test_log(float x) { return orc_log(x); }
+float orc_test_cos2pi(float u) { return orc_cos2pi(u); }
+void orc_test_rng_dir(uint32_t *state, float *out3) { v3 d = rng_next_dir(state); out3[0] = d.x; out3[1] = d.y; out3[2] = d.z; }
+
+typedef struct {
+    uint32_t id;
+    v3 light;
+    uint32_t segments, steps;
+    uint64_t visits;
+    uint32_t steps_primary;
+    uint64_t visits_primary;
+    int primary_hit;
+} path_result;
+
+/* ray_color, path_tracer.wgsl:149-194 (see the block comment above for the deliberate differences) */
+static path_result trace_path(const orc_scene *s, uint32_t px, uint32_t py, uint32_t rng) {
+    path_result pr;
+    memset(&pr, 0, sizeof pr);
+    v3 origin, dir;
+    create_ray_from_screen(s, (int32_t)px, (int32_t)py, &origin, &dir);
+    v3 thr = V3(1.0f, 1.0f, 1.0f);
+    for (uint32_t bounce = 0; bounce < s->settings.max_ray_bounces; bounce++) {
+        hit_result rs = ray_world(s, origin, dir);
+        pr.segments += 1;
+        pr.steps += rs.iter_count;
+        pr.visits += rs.node_visits;
+        if (bounce == 0) {
+            pr.id = id_word(&rs);
+            pr.steps_primary = rs.iter_count;
+            pr.visits_primary = rs.node_visits;
+            pr.primary_hit = rs.hit;
+        }
+        if (!rs.hit) {
+            v3 sky = ray_sky(s, origin, dir);
+            pr.light.x += sky.x * thr.x;
+            pr.light.y += sky.y * thr.y;
+            pr.light.z += sky.z * thr.z;
+            break;
+        }
+        float d = orc_dot(rs.norm, dir);
+        v3 spec = V3(dir.x - 2.0f * rs.norm.x * d, dir.y - 2.0f * rs.norm.y * d, dir.z - 2.0f * rs.norm.z * d);
+        v3 rd = rng_next_dir(&rng);
+        v3 sc = orc_normalize(V3(rs.norm.x + rd.x, rs.norm.y + rd.y, rs.norm.z + rd.z));
+        float scatter = mat_at(s, rs.voxel)->scatter;
+        v3 nd = orc_normalize(V3(orc_mix(spec.x, sc.x, scatter), orc_mix(spec.y, sc.y, scatter), orc_mix(spec.z, sc.z, scatter)));
+        thr.x *= rs.color.x; thr.y *= rs.color.y; thr.z *= rs.color.z;
+        origin = V3(rs.pos.x + rs.norm.x * ORC_SHADOW_BIAS, rs.pos.y + rs.norm.y * ORC_SHADOW_BIAS, rs.pos.z + rs.norm.z * ORC_SHADOW_BIAS);
+        dir = nd;
+    }
+    return pr;
+}
+
+/* seed of sample s of pixel (px,py): path_tracer.wgsl:328 plus the per-sample stride of SURVEY §8d */
+static uint32_t path_seed(uint32_t px, uint32_t py, uint32_t w, uint32_t h, uint32_t sample, uint32_t seed) {
+    return py * w + px + sample * (w * h) + seed * 0x9E3779B9u;
+}
+
 uint32_t orc_trace_pixel(const orc_scene *scene, int mode, uint32_t px, uint32_t py,
                          float *rgb, float *dir, float *out) {
     pixel_result pr = trace_pixel(scene, mode, px, py);
@@ -446,7 +565,6 @@ void orc_render(const orc_scene *scene, int mode, uint32_t w, uint32_t h,
                 uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1,
                 float *rgb, uint32_t *ids, uint32_t *steps, orc_stats *stats,
                 int threads, uint32_t spp, uint32_t seed) {
-    (void)spp; (void)seed; (void)h;
     uint64_t t_prim = 0, t_sec = 0, t_hits = 0, t_steps = 0, t_visits = 0, t_psteps = 0, t_pvisits = 0;
 #ifdef _OPENMP
     if (threads > 0) omp_set_num_threads(threads);
@@ -461,8 +579,29 @@ void orc_render(const orc_scene *scene, int mode, uint32_t w, uint32_t h,
         uint32_t ya = y0 + (uint32_t)band * 8u, yb = ya + 8u > y1 ? y1 : ya + 8u;
         for (uint32_t py = ya; py < yb; py++) {
             for (uint32_t px = x0; px < x1; px++) {
-                pixel_result pr = trace_pixel(scene, mode, px, py);
                 size_t o = (size_t)py * w + px;
+                if (mode == ORC_MODE_PATH) {
+                    v3 sum = V3(0.0f, 0.0f, 0.0f);
+                    uint32_t id = 0, sp = 0, ss = 0;
+                    const uint32_t nspp = spp ? spp : 1u;
+                    for (uint32_t sm = 0; sm < nspp; sm++) {
+                        path_result p = trace_path(scene, px, py, path_seed(px, py, w, h, sm, seed));
+                        sum.x += p.light.x; sum.y += p.light.y; sum.z += p.light.z;
+                        if (sm == 0) { id = p.id; sp = p.steps_primary; t_hits += (uint64_t)(p.primary_hit != 0); }
+                        if (sm == 0) ss = p.steps - p.steps_primary;
+                        t_prim += 1;
+                        t_sec += p.segments - 1;
+                        t_steps += p.steps;
+                        t_visits += p.visits;
+                        t_psteps += p.steps_primary;
+                        t_pvisits += p.visits_primary;
+                    }
+                    if (rgb) { rgb[o * 3 + 0] = sum.x / (float)nspp; rgb[o * 3 + 1] = sum.y / (float)nspp; rgb[o * 3 + 2] = sum.z / (float)nspp; }
+                    if (ids) ids[o] = id;
+                    if (steps) steps[o] = sp | (ss << 16);
+                    continue;
+                }
+                pixel_result pr = trace_pixel(scene, mode, px, py);
                 if (rgb) { rgb[o * 3 + 0] = pr.color.x; rgb[o * 3 + 1] = pr.color.y; rgb[o * 3 + 2] = pr.color.z; }
                 if (ids) ids[o] = pr.id;
                 if (steps) steps[o] = pr.steps_primary | (pr.steps_shadow << 16);

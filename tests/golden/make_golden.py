@@ -21,7 +21,9 @@ CASES = {
     "c1_64": lambda: scenes.c1_flat((64, 64)),
     "c1_256": lambda: scenes.c1_flat((256, 256)),
     "c2_128x72": lambda: scenes.c2((128, 72)),
+    "c4_128x72": lambda: scenes.c4((128, 72), bounces=4),
 }
+PATH_SPP, PATH_SEED = 2, 11
 
 
 def main():
@@ -30,8 +32,9 @@ def main():
         sc = make()
         o = orc.from_package_scene(sc)
         out = {}
-        for mode, tag in ((orc.MODE_PRIMARY, "primary"), (orc.MODE_PRIMARY_SHADOW, "shadow")):
-            rgb, ids, steps, st = o.render(mode, *sc.size, want_steps=True)
+        modes = ((orc.MODE_PATH, "path"),) if name.startswith("c4") else ((orc.MODE_PRIMARY, "primary"), (orc.MODE_PRIMARY_SHADOW, "shadow"))
+        for mode, tag in modes:
+            rgb, ids, steps, st = o.render(mode, *sc.size, want_steps=True, spp=PATH_SPP, seed=PATH_SEED)
             out[f"{tag}_rgb"], out[f"{tag}_ids"], out[f"{tag}_steps"] = rgb, ids, steps
             out[f"{tag}_stats"] = np.array([st.primary_rays, st.secondary_rays, st.hits, st.steps, st.node_visits,
                                             st.primary_steps, st.primary_node_visits], dtype=np.uint64)

@@ -22,6 +22,9 @@ namespace vrt {
 bool variant_supported(uint32_t variant);
 void launch_primary(const FrameParams &P, uint32_t variant, bool stats, bool shadow, hipStream_t st);
 void launch_shadow(const FrameParams &P, uint32_t variant, bool stats, hipStream_t st);
+void launch_path_primary(const FrameParams &P, bool stats, hipStream_t st);
+void launch_path_bounce(const FrameParams &P, bool stats, hipStream_t st);
+void launch_path_finish(Texel *out, uint32_t n, uint32_t spp, hipStream_t st);
 void launch_quantize(const Texel *out, uint8_t *rgba8, uint32_t n, hipStream_t st);
 void launch_assemble(const Texel *gathered, Texel *dst, uint32_t width, uint32_t tiles_x, uint32_t tiles_total,
                      uint32_t shard_count, uint64_t rank_stride, hipStream_t st);
@@ -57,6 +60,7 @@ struct vrt_ctx {
     vrt::Texel *d_out = nullptr;    // where frames are written: own_out or caller-bound memory
     vrt::Texel *own_out = nullptr;
     uint4 *d_hits = nullptr;
+    uint4 *d_path = nullptr;  // path mode: 2 buffers x 3 planes x (kHitSegments * hit_seg_cap) records, lazily allocated
     unsigned long long *d_counters = nullptr;  // [kCtrCount] stats, then the hit-segment counters
     uint32_t hit_seg_cap = 0;
     uint32_t *d_steps = nullptr;
@@ -67,6 +71,7 @@ struct vrt_ctx {
     vrt_settings settings;
     vrt_world_data world;
 
+    uint32_t last_spp = 1;
     bool rendered = false;
     bool last_stats = false;
     uint32_t last_mode = 0;
@@ -77,7 +82,7 @@ struct vrt_ctx {
 };
 
 static constexpr size_t kSegBytes = (size_t)vrt::kHitSegments * vrt::kSegStride * sizeof(uint32_t);
-static constexpr size_t kCounterBytes = vrt::kCtrCount * sizeof(unsigned long long) + kSegBytes;
+static constexpr size_t kCounterBytes = vrt::kCtrCount * sizeof(unsigned long long) + 2 * kSegBytes;  // two counter sets (path ping-pong)
 
 static thread_local std::string g_create_err;
 
@@ -109,8 +114,8 @@ static void layout_tiles(vrt_ctx *c) {
 }
 
 static int alloc_output(vrt_ctx *c) {
-    (void)hipFree(c->own_out); (void)hipFree(c->d_hits); (void)hipFree(c->d_steps); (void)hipFree(c->d_rgba8);
-    c->own_out = nullptr; c->d_hits = nullptr; c->d_steps = nullptr; c->d_rgba8 = nullptr;
+    (void)hipFree(c->own_out); (void)hipFree(c->d_hits); (void)hipFree(c->d_steps); (void)hipFree(c->d_rgba8); (void)hipFree(c->d_path);
+    c->own_out = nullptr; c->d_hits = nullptr; c->d_steps = nullptr; c->d_rgba8 = nullptr; c->d_path = nullptr;
     layout_tiles(c);
     const size_t n = c->slots ? c->slots : 1;
     HIP_TRY(c, hipMalloc(&c->own_out, n * sizeof(vrt::Texel)));
@@ -210,7 +215,7 @@ void vrt_destroy(vrt_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->d_nodes); (void)hipFree(c->d_roots); (void)hipFree(c->d_mats); (void)hipFree(c->own_out);
-    (void)hipFree(c->d_hits); (void)hipFree(c->d_counters); (void)hipFree(c->d_steps); (void)hipFree(c->d_rgba8);
+    (void)hipFree(c->d_hits); (void)hipFree(c->d_counters); (void)hipFree(c->d_steps); (void)hipFree(c->d_rgba8); (void)hipFree(c->d_path);
     for (auto &t : c->ev_pool)
         for (auto &ev : t)
             if (ev) (void)hipEventDestroy(ev);
@@ -330,7 +335,8 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     vrt_render_opts o;
     memset(&o, 0, sizeof o);
     if (opts) o = *opts;
-    if (o.mode > VRT_MODE_PRIMARY_SHADOW) return fail(c, VRT_ERR_INVALID_ARG, "vrt_render: mode %u not supported", o.mode);
+    if (o.mode > VRT_MODE_PATH) return fail(c, VRT_ERR_INVALID_ARG, "vrt_render: mode %u not supported", o.mode);
+    if (o.mode == VRT_MODE_PATH && o.variant != 0) return fail(c, VRT_ERR_INVALID_ARG, "vrt_render: the path trace has one kernel variant");
     if (!vrt::variant_supported(o.variant)) return fail(c, VRT_ERR_INVALID_ARG, "vrt_render: unknown kernel variant %u", o.variant);
     int rc = validate_frame(c);
     if (rc) return rc;
@@ -382,15 +388,52 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     }
     auto &ev = c->ev_pool[c->ev_used++];
     HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, kCounterBytes, c->stream));
-    HIP_TRY(c, hipEventRecord(ev[0], c->stream));
-    vrt::launch_primary(P, o.variant, o.stats != 0, shadow, c->stream);
-    HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipEventRecord(ev[1], c->stream));
-    if (shadow) {
-        vrt::launch_shadow(P, o.variant, o.stats != 0, c->stream);
+    if (o.mode == VRT_MODE_PATH) {
+        // wavefront path trace: per sample one launch per bounce over the compacted live-path buffer
+        const uint32_t spp = o.spp ? o.spp : 1u, bounces = c->settings.max_ray_bounces;
+        const size_t cap = (size_t)vrt::kHitSegments * c->hit_seg_cap;
+        if (!c->d_path) HIP_TRY(c, hipMalloc(&c->d_path, 2 * 3 * cap * sizeof(uint4)));
+        uint32_t *seg[2] = {P.seg_counts, P.seg_counts + vrt::kHitSegments * vrt::kSegStride};
+        uint4 *buf[2] = {c->d_path, c->d_path + 3 * cap};
+        P.path_cap = (uint32_t)cap;
+        P.spp = spp;
+        P.seed = o.seed;
+        HIP_TRY(c, hipEventRecord(ev[0], c->stream));
+        if (bounces == 0) HIP_TRY(c, hipMemsetAsync(c->d_out, 0, (size_t)c->slots * sizeof(vrt::Texel), c->stream));
+        bool first = true;
+        for (uint32_t smp = 0; smp < spp && bounces > 0; smp++) {
+            P.sample = smp;
+            for (uint32_t b = 0; b < bounces; b++) {
+                if (!(smp == 0 && b == 0)) HIP_TRY(c, hipMemsetAsync(seg[b & 1], 0, kSegBytes, c->stream));
+                P.seg_counts = seg[b & 1];
+                P.path_out = buf[b & 1];
+                P.seg_in = seg[(b + 1) & 1];
+                P.path_in = buf[(b + 1) & 1];
+                P.last_bounce = b + 1 == bounces;
+                if (b == 0) vrt::launch_path_primary(P, o.stats != 0, c->stream);
+                else vrt::launch_path_bounce(P, o.stats != 0, c->stream);
+                HIP_TRY(c, hipGetLastError());
+                if (first) { HIP_TRY(c, hipEventRecord(ev[1], c->stream)); first = false; }
+            }
+        }
+        if (first) HIP_TRY(c, hipEventRecord(ev[1], c->stream));
+        if (bounces > 0) {
+            vrt::launch_path_finish(c->d_out, c->slots, spp, c->stream);
+            HIP_TRY(c, hipGetLastError());
+        }
+        HIP_TRY(c, hipEventRecord(ev[2], c->stream));
+        c->last_spp = spp;
+    } else {
+        HIP_TRY(c, hipEventRecord(ev[0], c->stream));
+        vrt::launch_primary(P, o.variant, o.stats != 0, shadow, c->stream);
         HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipEventRecord(ev[1], c->stream));
+        if (shadow) {
+            vrt::launch_shadow(P, o.variant, o.stats != 0, c->stream);
+            HIP_TRY(c, hipGetLastError());
+        }
+        HIP_TRY(c, hipEventRecord(ev[2], c->stream));
     }
-    HIP_TRY(c, hipEventRecord(ev[2], c->stream));
     c->rendered = true;
     c->last_stats = o.stats != 0;
     c->last_mode = o.mode;
@@ -471,8 +514,9 @@ int vrt_get_stats(vrt_ctx *c, vrt_stats *out) {
         for (uint32_t i = 0; i < vrt::kHitSegments; i++) launched += seg[i * vrt::kSegStride];
         vrt_stats s;
         memset(&s, 0, sizeof s);
-        s.primary_rays = (uint64_t)c->tiles_local * 64u;
+        s.primary_rays = (uint64_t)c->tiles_local * 64u * (c->last_mode == VRT_MODE_PATH ? c->last_spp : 1u);
         s.secondary_rays = c->last_mode == VRT_MODE_PRIMARY_SHADOW ? launched : 0;
+        if (c->last_mode == VRT_MODE_PATH && c->last_stats) s.secondary_rays = h[vrt::kCtrSecondary];
         if (c->last_stats) {
             s.hits = h[vrt::kCtrHits];
             s.steps = h[vrt::kCtrSteps];

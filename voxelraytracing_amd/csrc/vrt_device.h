@@ -30,6 +30,14 @@ struct FrameParams {
     uint32_t *seg_counts;    // records in segment s at seg_counts[s * kSegStride]
     unsigned long long *counters;  // see Counter
     uint32_t *steps;         // optional per-slot step counts (stats frames only), may be null
+    // path-trace mode: wavefront of live paths, ping-pong between bounces. A record is three uint4 planes
+    // {slot, origin.xyz} {dir.xyz, rng} {throughput.rgb, 0} of path_cap entries each, segmented like `hits`.
+    const uint4 *path_in;
+    uint4 *path_out;
+    const uint32_t *seg_in;  // segment counters of path_in
+    uint32_t path_cap;       // entries per plane = kHitSegments * hit_seg_cap
+    uint32_t spp, sample, seed;
+    uint32_t last_bounce;    // 1: paths that hit on this segment end (max_ray_bounces reached)
     uint32_t n_nodes, n_roots;
     uint32_t width, height;
     uint32_t tiles_x, tiles_total;
@@ -56,7 +64,7 @@ enum Counter : int {
     kCtrPrimarySteps = 3,
     kCtrPrimaryVisits = 4,
     kCtrHits = 5,
-    kCtrTileQueue = 6,      // persistent-kernel work queue head
+    kCtrSecondary = 6,      // path mode, stats frames: bounce segments traced
     kCtrCount = 8
 };
 

@@ -13,426 +13,9 @@
 //   * the step arithmetic is branch-free and algebraically reduced where the reduction is bit-exact;
 //   * chunk roots and the 256-bit liquid mask are staged in LDS; secondary rays are launched from a
 //     wave-compacted hit buffer; one 16-byte texel {r,g,b,id} per pixel so a wave stores 1 KiB contiguously.
-#include "vrt_device.h"
+#include "vrt_march.h"
 
 namespace vrt {
-
-// f32 -> i32 with the hardware's own NaN -> 0 (v_cvt_i32_f32; what WGSL's i32(f32) specifies), truncating.
-// For x >= 0 this is floor(x); the march never uses it for a negative coordinate (it has left the world).
-// Measured on MI355X: NaN -> 0, +-inf and |x| >= 2^31 saturate.  (v_cvt_flr_i32_f32 maps NaN to INT_MAX.)
-__device__ __forceinline__ int trunc2i(float x) {
-    int r;
-    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(x));
-    return r;
-}
-
-__device__ __forceinline__ bool is_liquid(const uint32_t *s_liquid, uint32_t voxel) {
-    // voxel_mats[voxel].is_liquid == 1 (ray_tracer.wgsl:226); ids >= 256 clamp to material 255.
-    const uint32_t v = min(voxel, 255u);
-    return (s_liquid[v >> 5] >> (v & 31u)) & 1u;
-}
-
-// ------------------------------------------------------------------------------------------------
-// MARCH = 1: literal restatement of ray_world (ray_tracer.wgsl:182-316) with the descent restarted from
-// the chunk root every step.  Kept as the A/B baseline for DESIGN.md's evidence table and as an
-// in-backend cross-check of the fast march.
-// ------------------------------------------------------------------------------------------------
-struct Leaf {
-    uint32_t node;   // the leaf's 16-bit word
-    uint32_t depth;  // 0..5
-    int bx, by, bz;  // world-local integer min corner of the leaf
-};
-
-template <bool LDS_ROOTS>
-__device__ __forceinline__ Leaf find_leaf(const FrameParams &P, const uint32_t *s_roots, int vx, int vy, int vz) {
-    const uint32_t S = P.world.size_in_chunks;
-    uint32_t cidx = (uint32_t)(vx >> 5) + (uint32_t)(vy >> 5) * S + (uint32_t)(vz >> 5) * S * S;
-    cidx = min(cidx, P.n_roots - 1u);
-    const uint32_t root = LDS_ROOTS ? s_roots[cidx] : P.roots[cidx];
-    const uint32_t last = P.n_nodes - 1u;
-    uint32_t idx = 0, depth = 0;
-    uint32_t node = P.nodes[min(root, last)];
-    while ((node & 0x8000u) && depth < 5u) {
-        const uint32_t sh = 4u - depth;
-        const uint32_t child = ((uint32_t)(vx >> sh) & 1u) | (((uint32_t)(vy >> sh) & 1u) << 1) |
-                               (((uint32_t)(vz >> sh) & 1u) << 2);
-        idx = (node & 0x7FFFu) + child;
-        node = P.nodes[min(root + idx, last)];
-        depth += 1u;
-    }
-    const int m = ~((32 >> depth) - 1);
-    Leaf L;
-    L.node = node;
-    L.depth = depth;
-    L.bx = vx & m;  // chunk bits pass through the mask unchanged
-    L.by = vy & m;
-    L.bz = vz & m;
-    return L;
-}
-
-template <bool LDS_ROOTS>
-__device__ __forceinline__ MarchResult march_literal(const FrameParams &P, const uint32_t *s_roots,
-                                                     const uint32_t *s_liquid, V3 origin, V3 dir) {
-    MarchResult R;
-    R.hit = false;
-    R.pos = V3{0.f, 0.f, 0.f};
-    R.norm = V3{0.f, 0.f, 0.f};
-    R.water_dist = 0.0f;
-    R.voxel = 0u;
-    R.iters = 0u;
-    R.visits = 0u;
-
-    const V3 mask{dir.x >= 0.0f ? 1.0f : 0.0f, dir.y >= 0.0f ? 1.0f : 0.0f, dir.z >= 0.0f ? 1.0f : 0.0f};
-    const V3 imask{1.0f - mask.x, 1.0f - mask.y, 1.0f - mask.z};
-
-    V3 pos = origin;
-    if (pos.x - floorf(pos.x) < 0.001f || pos.y - floorf(pos.y) < 0.001f || pos.z - floorf(pos.z) < 0.001f) {
-        pos.x += 0.001f * dir.x;
-        pos.y += 0.001f * dir.y;
-        pos.z += 0.001f * dir.z;
-    }
-    const float world_min = 0.0f;
-    const float world_max = world_min + (float)P.world.size;
-    if ((pos.x <= world_min || pos.y <= world_min || pos.z <= world_min) ||
-        (pos.x >= world_max || pos.y >= world_max || pos.z >= world_max)) {
-        return R;
-    }
-
-    const V3 unit{
-        sqrtf(1.0f + (dir.y / dir.x) * (dir.y / dir.x) + (dir.z / dir.x) * (dir.z / dir.x)),
-        sqrtf(1.0f + (dir.x / dir.y) * (dir.x / dir.y) + (dir.z / dir.y) * (dir.z / dir.y)),
-        sqrtf(1.0f + (dir.x / dir.z) * (dir.x / dir.z) + (dir.y / dir.z) * (dir.y / dir.z))};
-
-    uint32_t voxel = 0u;
-    float ex = 0.f, ey = 0.f, ez = 0.f;  // exit-axis flags of the last step (norm before the sign)
-    float dist_entered_water = -1.0f;
-    float total_len = 0.0f;
-    uint32_t iter = 0u;
-    bool left_world = false;
-
-    while (iter < kMaxSteps) {
-        iter += 1u;
-        const Leaf L = find_leaf<LDS_ROOTS>(P, s_roots, f2i(floorf(pos.x)), f2i(floorf(pos.y)), f2i(floorf(pos.z)));
-        voxel = L.node & 0x7FFFu;
-        R.visits += L.depth + 1u;
-
-        const bool liquid = is_liquid(s_liquid, voxel);
-        if (voxel != 0u && !liquid) break;
-        if (!liquid) {
-            if (dist_entered_water != -1.0f) {
-                R.water_dist += total_len - dist_entered_water;
-                dist_entered_water = -1.0f;
-            }
-        } else {
-            if (dist_entered_water == -1.0f) dist_entered_water = total_len;
-        }
-
-        const float size = (float)(32 >> L.depth);
-        const V3 nmin{(float)L.bx, (float)L.by, (float)L.bz};
-        const V3 nmax{nmin.x + size, nmin.y + size, nmin.z + size};
-        const V3 ad{((pos.x - nmin.x) * imask.x + (nmax.x - pos.x) * mask.x) * unit.x,
-                    ((pos.y - nmin.y) * imask.y + (nmax.y - pos.y) * mask.y) * unit.y,
-                    ((pos.z - nmin.z) * imask.z + (nmax.z - pos.z) * mask.z) * unit.z};
-
-        float step;
-        if (ad.x == 0.0f) {
-            if (ad.y == 0.0f) step = ad.z;
-            else if (ad.z == 0.0f) step = ad.y;
-            else step = vmin(ad.y, ad.z);
-        } else {
-            if (ad.y == 0.0f) {
-                if (ad.z == 0.0f) step = ad.x;
-                else step = vmin(ad.x, ad.z);
-            } else {
-                if (ad.z == 0.0f) step = vmin(ad.y, ad.x);
-                else step = vmin(ad.x, vmin(ad.y, ad.z));
-            }
-        }
-        total_len += step;
-        ex = step == ad.x ? 1.0f : 0.0f;
-        ey = step == ad.y ? 1.0f : 0.0f;
-        ez = step == ad.z ? 1.0f : 0.0f;
-        const float nx = step != ad.x ? 1.0f : 0.0f;
-        const float ny = step != ad.y ? 1.0f : 0.0f;
-        const float nz = step != ad.z ? 1.0f : 0.0f;
-        pos.x += dir.x * (step + 0.001f) * ex + dir.x * step * nx;
-        pos.y += dir.y * (step + 0.001f) * ey + dir.y * step * ny;
-        pos.z += dir.z * (step + 0.001f) * ez + dir.z * step * nz;
-
-        if ((pos.x < world_min || pos.y < world_min || pos.z < world_min) ||
-            (pos.x >= world_max || pos.y >= world_max || pos.z >= world_max)) {
-            if (dist_entered_water != -1.0f) R.water_dist += total_len - dist_entered_water;
-            left_world = true;
-            break;
-        }
-    }
-    R.iters = iter;
-    if (left_world) return R;  // hit = false, voxel = 0
-    const bool stepped = iter > 1u || voxel == 0u || is_liquid(s_liquid, voxel);  // a step ran before the exit
-
-    R.hit = true;
-    R.pos = pos;
-    // `norm` is only assigned inside the loop (:272): a hit on the very first lookup leaves it zero, which
-    // differs from 0 * -sign(dir) when dir is NaN
-    if (stepped) R.norm = V3{ex * -vsign(dir.x), ey * -vsign(dir.y), ez * -vsign(dir.z)};
-    R.voxel = voxel;
-    if (dist_entered_water != -1.0f) R.water_dist += total_len - dist_entered_water;
-    return R;
-}
-
-// ------------------------------------------------------------------------------------------------
-// MARCH = 0: the fast march.  Same positions, same leaves, same results, bit for bit; the reductions
-// used (each argued in DESIGN.md §Exact reductions):
-//   (a) `pos >= center` at depth d  ==  bit (4-d) of floor(pos) & 31            (centres are integers)
-//   (b) (pos-min)*imask + (max-pos)*mask  ==  mask ? max-pos : -(min-pos)         (x*0 adds a signed zero)
-//   (c) the :247-270 branch tree  ==  minNum over the non-zero axis distances, ad.z if all are zero
-//   (d) dir*(step+.001)*e + dir*step*(1-e)  ==  dir * (e ? step+.001 : step)       (the dropped term is a
-//       zero with dir's sign)
-//   (e) pos<0 || pos>=size  ==  (unsigned)floor(pos) >= size                      (size is an integer)
-//   (f) the leaf of the new position is found by resuming the descent below the deepest split ancestor
-//       it shares with the previous position instead of from the chunk root.
-// ------------------------------------------------------------------------------------------------
-template <bool LDS_ROOTS>
-__device__ __forceinline__ MarchResult march_fast(const FrameParams &P, const uint32_t *s_roots,
-                                                  const uint32_t *s_liquid, V3 origin, V3 dir) {
-    MarchResult R;
-    R.hit = false;
-    R.pos = V3{0.f, 0.f, 0.f};
-    R.norm = V3{0.f, 0.f, 0.f};
-    R.water_dist = 0.0f;
-    R.voxel = 0u;
-    R.iters = 0u;
-    R.visits = 0u;
-
-    const bool mx = dir.x >= 0.0f, my = dir.y >= 0.0f, mz = dir.z >= 0.0f;
-
-    V3 pos = origin;
-    if (pos.x - floorf(pos.x) < 0.001f || pos.y - floorf(pos.y) < 0.001f || pos.z - floorf(pos.z) < 0.001f) {
-        pos.x += 0.001f * dir.x;
-        pos.y += 0.001f * dir.y;
-        pos.z += 0.001f * dir.z;
-    }
-    const float world_max = 0.0f + (float)P.world.size;
-    if ((pos.x <= 0.0f || pos.y <= 0.0f || pos.z <= 0.0f) || (pos.x >= world_max || pos.y >= world_max || pos.z >= world_max))
-        return R;
-
-    const V3 unit{
-        sqrtf(1.0f + (dir.y / dir.x) * (dir.y / dir.x) + (dir.z / dir.x) * (dir.z / dir.x)),
-        sqrtf(1.0f + (dir.x / dir.y) * (dir.x / dir.y) + (dir.z / dir.y) * (dir.z / dir.y)),
-        sqrtf(1.0f + (dir.x / dir.z) * (dir.x / dir.z) + (dir.y / dir.z) * (dir.y / dir.z))};
-
-    const uint32_t S = P.world.size_in_chunks;
-    const uint32_t wsize = P.world.size;
-    const uint32_t last = P.n_nodes - 1u;
-    const float qnan = __builtin_nanf("");
-
-    int vx = trunc2i(pos.x), vy = trunc2i(pos.y), vz = trunc2i(pos.z);  // pos > 0 here (or NaN -> 0)
-    int pvx = ~vx, pvy = vy, pvz = vz;  // ~vx: the first lookup sees "another chunk"
-    uint32_t root = 0u, node = 0u, depth = 0u;
-    uint32_t b0 = 0u, b1 = 0u, b2 = 0u, b3 = 0u, b4 = 0u;  // child-block base of the split ancestor at depth 0..4
-    const int mxm = mx ? -1 : 0, mym = my ? -1 : 0, mzm = mz ? -1 : 0;
-
-    uint32_t voxel = 0u;
-    bool ex = false, ey = false, ez = false;
-    float dew = -1.0f;  // dist_entered_water
-    float total_len = 0.0f;
-    uint32_t iter = 0u;
-    bool left_world = false;
-
-    for (;;) {
-        iter += 1u;
-        // ---- find_node ----
-        const uint32_t diff = (uint32_t)((vx ^ pvx) | (vy ^ pvy) | (vz ^ pvz));
-        pvx = vx; pvy = vy; pvz = vz;
-        bool resume = false;
-        if (diff >= 32u) {  // another chunk (or the first lookup): start at that chunk's root
-            uint32_t cidx = __umul24(__umul24((uint32_t)(vz >> 5), S) + (uint32_t)(vy >> 5), S) + (uint32_t)(vx >> 5);
-            cidx = min(cidx, P.n_roots - 1u);
-            root = LDS_ROOTS ? s_roots[cidx] : P.roots[cidx];
-            node = P.nodes[min(root, last)];
-            depth = 0u;
-        } else {
-            // k = number of leading local-coordinate bits shared with the previous position (5 if none differ)
-            const uint32_t k = (uint32_t)__clz((int)diff) - 27u;
-            if (k < depth) { depth = k; resume = true; }
-        }
-#define VRT_LEVEL(D, BD)                                                                               \
-        if (depth == D && (resume || (node & 0x8000u))) {                                              \
-            if (!resume) BD = node & 0x7FFFu;                                                          \
-            resume = false;                                                                            \
-            const uint32_t sel = (((uint32_t)vx >> (4 - D)) & 1u) | ((((uint32_t)vy >> (4 - D)) & 1u) << 1) | \
-                                 ((((uint32_t)vz >> (4 - D)) & 1u) << 2);                               \
-            node = P.nodes[min(root + BD + sel, last)];                                                \
-            depth = D + 1u;                                                                            \
-        }
-        VRT_LEVEL(0, b0)
-        VRT_LEVEL(1, b1)
-        VRT_LEVEL(2, b2)
-        VRT_LEVEL(3, b3)
-        VRT_LEVEL(4, b4)
-#undef VRT_LEVEL
-        voxel = node & 0x7FFFu;
-        R.visits += depth + 1u;
-
-        bool liquid = false;
-        if (voxel != 0u) {
-            liquid = is_liquid(s_liquid, voxel);
-            if (!liquid) break;  // solid: the hit
-        }
-        if (liquid) {
-            if (dew == -1.0f) dew = total_len;
-        } else if (dew != -1.0f) {
-            R.water_dist += total_len - dew;
-            dew = -1.0f;
-        }
-
-        // ---- step to the leaf's exit face ----
-        const int sz = 32 >> depth;
-        const int m = ~(sz - 1);
-        const float tx = (float)((vx & m) + (sz & mxm)) - pos.x;
-        const float ty = (float)((vy & m) + (sz & mym)) - pos.y;
-        const float tz = (float)((vz & m) + (sz & mzm)) - pos.z;
-        const float adx = (mx ? tx : -tx) * unit.x;
-        const float ady = (my ? ty : -ty) * unit.y;
-        const float adz = (mz ? tz : -tz) * unit.z;
-        const bool zx = adx == 0.0f, zy = ady == 0.0f, zz = adz == 0.0f;
-        float step = __builtin_fminf(__builtin_fminf(zx ? qnan : adx, zy ? qnan : ady), zz ? qnan : adz);
-        if (zx && zy && zz) step = adz;
-        total_len += step;
-        ex = step == adx;
-        ey = step == ady;
-        ez = step == adz;
-        const float sp = step + 0.001f;
-        pos.x += dir.x * (ex ? sp : step);
-        pos.y += dir.y * (ey ? sp : step);
-        pos.z += dir.z * (ez ? sp : step);
-
-        // (e): pos < 0 on some axis (NaN-ignoring min: a NaN is not < 0), or floor(pos) >= size.  trunc == floor
-        // for the non-negative coordinates that survive the first test.
-        vx = trunc2i(pos.x);
-        vy = trunc2i(pos.y);
-        vz = trunc2i(pos.z);
-        if (__builtin_fminf(__builtin_fminf(pos.x, pos.y), pos.z) < 0.0f ||
-            max(max((uint32_t)vx, (uint32_t)vy), (uint32_t)vz) >= wsize) {
-            if (dew != -1.0f) R.water_dist += total_len - dew;
-            left_world = true;
-            break;
-        }
-        if (iter >= kMaxSteps) break;
-    }
-    R.iters = iter;
-    if (left_world) return R;
-    const bool stepped = iter > 1u || voxel == 0u || is_liquid(s_liquid, voxel);  // a step ran before the exit
-
-    R.hit = true;
-    R.pos = pos;
-    if (stepped)  // see march_literal: norm stays zero when no step was taken
-        R.norm = V3{(ex ? 1.0f : 0.0f) * -vsign(dir.x), (ey ? 1.0f : 0.0f) * -vsign(dir.y), (ez ? 1.0f : 0.0f) * -vsign(dir.z)};
-    R.voxel = voxel;
-    if (dew != -1.0f) R.water_dist += total_len - dew;
-    return R;
-}
-
-template <int MARCH, bool LDS_ROOTS>
-__device__ __forceinline__ MarchResult march(const FrameParams &P, const uint32_t *s_roots, const uint32_t *s_liquid,
-                                             V3 origin, V3 dir) {
-    if (MARCH == 1) return march_literal<LDS_ROOTS>(P, s_roots, s_liquid, origin, dir);
-    return march_fast<LDS_ROOTS>(P, s_roots, s_liquid, origin, dir);
-}
-
-// ray_sky, ray_tracer.wgsl:144-157
-__device__ __forceinline__ V3 ray_sky(const FrameParams &P, V3 origin, V3 dir) {
-    const float ground_to_sky_t = vsmoothstep(-0.01f, 0.0f, dir.y);
-    const float sky_gradient_t = powf(vsmoothstep(0.0f, 0.4f, dir.y), 0.35f);
-    const V3 grad{vmix(1.0f, P.settings.sky_color[0], sky_gradient_t), vmix(0.3f, P.settings.sky_color[1], sky_gradient_t),
-                  vmix(0.0f, P.settings.sky_color[2], sky_gradient_t)};
-    const V3 sun_dir = vnormalize(V3{P.settings.sun_pos[0] - (float)P.world.min[0] - origin.x,
-                                     P.settings.sun_pos[1] - (float)P.world.min[1] - origin.y,
-                                     P.settings.sun_pos[2] - (float)P.world.min[2] - origin.z});
-    const float sun = (vdot(dir, sun_dir) > (1.0f - 0.01f) && ground_to_sky_t >= 1.0f) ? 1.0f : 0.0f;
-    const float add = sun * P.settings.sun_intensity;
-    return V3{vmix(0.03f, grad.x, ground_to_sky_t) + add, vmix(0.03f, grad.y, ground_to_sky_t) + add,
-              vmix(0.03f, grad.z, ground_to_sky_t) + add};
-}
-
-// create_ray_from_screen, ray_tracer.wgsl:159-171 (WGSL v*M = dot with the columns of M)
-__device__ __forceinline__ void create_ray(const FrameParams &P, int sx, int sy, V3 &origin, V3 &dir) {
-    const float x = ((float)sx * 2.0f) / P.cam.proj_size[0] - 1.0f;
-    const float y = ((float)sy * 2.0f) / P.cam.proj_size[1] - 1.0f;
-    const float c0 = x, c1 = -y, c2 = -1.0f, c3 = 1.0f;
-    const float *ip = P.cam.inv_proj_mat;
-    const float e0 = c0 * ip[0] + c1 * ip[1] + c2 * ip[2] + c3 * ip[3];
-    const float e1 = c0 * ip[4] + c1 * ip[5] + c2 * ip[6] + c3 * ip[7];
-    const float *iv = P.cam.inv_view_mat;
-    const float e2 = -1.0f, e3 = 0.0f;
-    const V3 w{e0 * iv[0] + e1 * iv[1] + e2 * iv[2] + e3 * iv[3], e0 * iv[4] + e1 * iv[5] + e2 * iv[6] + e3 * iv[7],
-               e0 * iv[8] + e1 * iv[9] + e2 * iv[10] + e3 * iv[11]};
-    dir = vnormalize(w);
-    origin = V3{P.cam.pos[0] - (float)P.world.min[0], P.cam.pos[1] - (float)P.world.min[1],
-                P.cam.pos[2] - (float)P.world.min[2]};
-}
-
-// Face shading + ray_color + overlay, ray_tracer.wgsl:127-142, 296-314. Returns the id word.
-// `color = vox*f32(hit) + sky*f32(!hit)` (:135): with finite settings the sky term of a hit is a zero and
-// the material term of a miss is a zero, so only one side is evaluated (exact up to the sign of a zero).
-template <bool EXACT_SKY>
-__device__ __forceinline__ uint32_t shade(const FrameParams &P, const MarchResult &R, V3 origin, V3 dir, V3 &color) {
-    V3 mc{0.f, 0.f, 0.f};
-    if (R.hit) {
-        const vrt_material *m = &P.mats[min(R.voxel, 255u)];
-        mc = V3{m->color[0], m->color[1], m->color[2]};
-        if (R.norm.x != 0.0f) { mc.x *= 0.5f; mc.y *= 0.5f; mc.z *= 0.5f; }
-        if (R.norm.z != 0.0f) { mc.x *= 0.7f; mc.y *= 0.7f; mc.z *= 0.7f; }
-        if (R.norm.y == -1.0f) { mc.x *= 0.2f; mc.y *= 0.2f; mc.z *= 0.2f; }
-        if (P.settings.show_step_count == 1u) {
-            const float f = vclamp((float)R.iters / 500.0f, 0.0f, 1.0f);
-            mc = V3{f, f, f};
-        }
-    }
-    if (EXACT_SKY || !P.finite_settings) {
-        const V3 sky = ray_sky(P, origin, dir);
-        const float fh = R.hit ? 1.0f : 0.0f, fm = R.hit ? 0.0f : 1.0f;
-        color = V3{mc.x * fh + sky.x * fm, mc.y * fh + sky.y * fm, mc.z * fh + sky.z * fm};
-    } else if (R.hit) {
-        color = mc;
-    } else {
-        color = ray_sky(P, origin, dir);
-    }
-    if (R.water_dist != 0.0f) {
-        const float factor = vclamp(R.water_dist / 14.0f, 0.8f, 1.0f);
-        color.x = color.x * (1.0f - factor) + 0.2f * factor;
-        color.y = color.y * (1.0f - factor) + 0.5f * factor;
-        color.z = color.z * (1.0f - factor) + 1.0f * factor;
-    }
-    uint32_t id = R.voxel & VRT_ID_VOXEL_MASK;
-    if (R.hit) id |= VRT_ID_HIT;
-    if (R.norm.x != 0.0f) id |= VRT_ID_NX;
-    if (R.norm.y != 0.0f) id |= VRT_ID_NY;
-    if (R.norm.z != 0.0f) id |= VRT_ID_NZ;
-    if (R.water_dist != 0.0f) id |= VRT_ID_WATER;
-    return id;
-}
-
-__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
-__device__ __forceinline__ void stage_lds(const FrameParams &P, uint32_t *s_roots, uint32_t *s_liquid, bool lds_roots) {
-    if (lds_roots)
-        for (uint32_t i = threadIdx.x; i < P.n_roots; i += blockDim.x) s_roots[i] = P.roots[i];
-    if (threadIdx.x < 8) s_liquid[threadIdx.x] = P.liquid[threadIdx.x];
-    __syncthreads();
-}
-
-// stats frames: per-block reduction in LDS, then one atomic per counter per block
-__device__ __forceinline__ void block_add(unsigned long long *s_acc, int slot, unsigned long long v) {
-    const unsigned long long s = wave_sum(v);
-    if ((threadIdx.x & 63u) == 0 && s) atomicAdd(&s_acc[slot], s);
-}
-
-constexpr uint32_t kLdsRootsMax = 8192;  // entries (32 KiB): S <= 20
 
 // ------------------------------------------------------------------------------------------------
 // Primary rays: one wave per 8x8 tile, 4 tiles per 256-thread workgroup.

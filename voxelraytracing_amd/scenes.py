@@ -61,3 +61,27 @@ def c2(size=(1920, 1080)) -> Scene:
 
 def c3(size=(1920, 1080)) -> Scene:
     return procedural(16, size, g.MODE_PRIMARY_SHADOW, name=f"C3 {size[0]}x{size[1]} 16^3 procedural primary+shadow")
+
+
+def _diffuse(materials):
+    """All solids fully scattering (Material.scatter = 1): the 'diffuse path trace' of configs C4/C5.
+    Material::construct leaves scatter at 0.0 (graphics/mod.rs:44), which would make every voxel a mirror."""
+    for i in range(256):
+        materials[i].scatter = 1.0
+    return materials
+
+
+def c4(size=(1920, 1080), bounces=4) -> Scene:
+    """C4: 1920x1080, 8^3-chunk world, 4-bounce diffuse path trace (1 spp), 1 GPU."""
+    sc = procedural(8, size, g.MODE_PATH, name=f"C4 {size[0]}x{size[1]} 8^3 procedural {bounces}-bounce diffuse path trace")
+    sc.settings.max_ray_bounces = bounces
+    _diffuse(sc.materials)
+    return sc
+
+
+def c5(size=(3840, 2160), bounces=4, chunks=32) -> Scene:
+    """C5: 3840x2160, 16 spp, 32^3-chunk world, sharded over 8 GPUs (spp is a render option)."""
+    sc = procedural(chunks, size, g.MODE_PATH, name=f"C5 {size[0]}x{size[1]} {chunks}^3 procedural {bounces}-bounce path trace")
+    sc.settings.max_ray_bounces = bounces
+    _diffuse(sc.materials)
+    return sc
