@@ -46,6 +46,10 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--chunks", type=int, default=8, help="world size in chunks (8 = config C2)")
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--mode", choices=["shadow", "primary", "path"], default="shadow",
+                    help="shadow = the headline metric (config C2); path = the C4/C5 kernel family (not the headline)")
+    ap.add_argument("--spp", type=int, default=1)
+    ap.add_argument("--bounces", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development only: run the N > 1 code path with every rank on cuda:0 and a gloo gather staged "
@@ -53,7 +57,7 @@ def main():
     args = ap.parse_args()
 
     import torch
-    from voxelraytracing_amd import Gpu, MODE_PRIMARY_SHADOW, scenes
+    from voxelraytracing_amd import Gpu, MODE_PATH, MODE_PRIMARY, MODE_PRIMARY_SHADOW, scenes
     from voxelraytracing_amd.shard import FrameGather
 
     rank = int(os.environ.get("RANK", "0"))
@@ -87,7 +91,12 @@ def main():
         return t
 
     # ---- scene (deterministic, built by every rank) and upload: off the clock ----
-    sc = scenes.procedural(args.chunks, (args.width, args.height), MODE_PRIMARY_SHADOW)
+    MODE = {"shadow": MODE_PRIMARY_SHADOW, "primary": MODE_PRIMARY, "path": MODE_PATH}[args.mode]
+    rkw = dict(spp=args.spp, seed=0) if MODE == MODE_PATH else dict(variant=args.variant)
+    sc = scenes.procedural(args.chunks, (args.width, args.height), MODE)
+    if MODE == MODE_PATH:
+        sc.settings.max_ray_bounces = args.bounces
+        scenes._diffuse(sc.materials)
     gpu = Gpu(sc.world.max_nodes(), sc.world.size_in_chunks(), sc.size, device=local_rank, shard_rank=rank, shard_count=world)
     gpu.upload_world(sc.world, sc.materials)
     gpu.write_cam_data(sc.cam)
@@ -107,14 +116,14 @@ def main():
             fg.gather = staged_gather
 
     def frame():
-        gpu.render(MODE_PRIMARY_SHADOW, variant=args.variant)
+        gpu.render(MODE, **rkw)
         if fg is not None:
             fg.gather()
             if rank == 0:
                 fg.assemble(gpu)
 
     # exact ray / step / node-visit counts of this frame (deterministic; a stats frame is never timed)
-    gpu.render(MODE_PRIMARY_SHADOW, variant=args.variant, stats=True)
+    gpu.render(MODE, stats=True, **rkw)
     st = gpu.stats()
     counts = all_reduce(torch.tensor([st.primary_rays, st.secondary_rays], dtype=torch.int64, device="cuda"))
     rays_per_frame = int(counts[0] + counts[1])
@@ -142,7 +151,7 @@ def main():
         ref.upload_world(sc.world, sc.materials)
         ref.write_cam_data(sc.cam)
         ref.write_settings(sc.settings)
-        ref.render(MODE_PRIMARY_SHADOW, variant=args.variant)
+        ref.render(MODE, **rkw)
         r_rgb, r_ids, _ = ref.read_output()
         from voxelraytracing_amd.shard import texels_to_frame
         import numpy as np
@@ -188,7 +197,10 @@ def main():
                      "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
                      "kernels_ms": {"primary_march": ms_p, "shadow_march": ms_s}, "frames_timed": kst.frames},
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if args.mode != "shadow":
+        out["metric"] = f"Mrays/s at {args.width}x{args.height}, mode {args.mode}" + (f" {args.bounces} bounces {args.spp} spp" if args.mode == "path" else "")
+        out["config"]["workload"] = out["config"]["workload"].replace("C2:", "non-headline:").replace("1 primary + 1 shadow ray per solid hit", f"mode {args.mode}")
+    if world == 1 and not args.no_cpu_baseline and args.mode == "shadow":
         out["cpu_baseline"] = cpu_baseline(sc, args, rays_per_frame)
     print(json.dumps(out), flush=True)
     if world > 1:

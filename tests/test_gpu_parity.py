@@ -268,3 +268,27 @@ def test_path_trace_mirror_materials_and_sharding(orc):
         acc_ids |= s_ids
         sh.close()
     assert np.array_equal(acc_ids, ids) and np.array_equal(acc_rgb, rgb)
+
+
+def test_large_world_uses_global_chunk_table(orc):
+    """24^3 chunks = 13 824 chunk roots: more than the 8 192 entries staged in LDS, so the kernels read the
+    table from global memory (LDS_ROOTS = false); also a world.min away from the origin."""
+    from voxelraytracing_amd.world import ClientWorld, gen_height
+    w = ClientWorld((12, 12, 12), 1 << 25, 24)
+    w.generate(0, 1)
+    c = 24 * 16
+    eye = (c + 0.5, float(gen_height(1, c, c) + 30) + 0.5, c + 0.5)
+    sc = scenes._scene("24^3", w, (320, 184), eye, (25.0, 60.0, 0.0), MODE_PRIMARY_SHADOW)
+    gpu = gpu_for_scene(sc)
+    o = orc.from_package_scene(sc)
+    for mode, kw in ((MODE_PRIMARY_SHADOW, {}), (MODE_PATH, dict(spp=1, seed=3))):
+        gpu.render(mode, stats=True, **kw)
+        rgb, ids, _ = gpu.read_output()
+        r_rgb, r_ids, r_steps, st = o.render(mode, *sc.size, want_steps=True, **kw)
+        assert_frame_parity(rgb, ids, r_rgb, r_ids, f"24^3 mode {mode}")
+        assert np.array_equal(gpu.read_steps(), r_steps)
+        assert gpu.stats().steps == st.steps
+    gpu.render(MODE_PRIMARY_SHADOW, variant=1)
+    rgb1, ids1, _ = gpu.read_output()
+    r_rgb, r_ids, _, _ = o.render(MODE_PRIMARY_SHADOW, *sc.size)
+    assert_frame_parity(rgb1, ids1, r_rgb, r_ids, "24^3 literal")
