@@ -105,24 +105,37 @@ def main():
     if world > 1:
         gpu.set_stream(torch.cuda.current_stream().cuda_stream)
         fg = FrameGather(torch, dist, rank, world, args.width, args.height, torch.device("cuda", local_rank))
-        fg.bind(gpu)
         if args.rehearse_on_one_gpu:
-            def staged_gather():
+            def staged_gather(which=0, async_op=False):
                 torch.cuda.synchronize()
                 parts = [torch.empty(fg.msg.numel(), dtype=torch.int32) for _ in range(world)] if rank == 0 else None
-                dist.gather(fg.msg.cpu(), parts, dst=0)
+                dist.gather(fg.msgs[which].cpu(), parts, dst=0)
                 if rank == 0:
-                    fg.gathered.copy_(torch.stack(parts))
+                    fg.recv[which].copy_(torch.stack(parts))
             fg.gather = staged_gather
 
-    def frame():
+    def render():
         gpu.render(MODE, **rkw)
-        if fg is not None:
+
+    def frame():
+        if fg is None:
+            render()
+        elif args.rehearse_on_one_gpu:
+            fg.bind(gpu, 0)
+            render()
             fg.gather()
             if rank == 0:
-                fg.assemble(gpu)
+                fg.assemble(gpu, 0)
+        else:
+            fg.submit(gpu, render)   # gather of this frame overlaps the next render
+
+    def finish():
+        if fg is not None and not args.rehearse_on_one_gpu:
+            fg.drain(gpu)
 
     # exact ray / step / node-visit counts of this frame (deterministic; a stats frame is never timed)
+    if fg is not None:
+        fg.bind(gpu, 0)
     gpu.render(MODE, stats=True, **rkw)
     st = gpu.stats()
     counts = all_reduce(torch.tensor([st.primary_rays, st.secondary_rays], dtype=torch.int64, device="cuda"))
@@ -130,6 +143,7 @@ def main():
 
     for _ in range(args.warmup):
         frame()
+    finish()
     gpu.stats()  # drop the warm-up frames' kernel timings
     if world > 1:
         dist.barrier()
@@ -137,6 +151,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         frame()
+    finish()   # every timed frame is gathered and assembled on rank 0 before the clock stops
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

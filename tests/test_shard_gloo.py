@@ -34,10 +34,25 @@ for t in tiles:
     frame[ty*8:ty*8+8, tx*8:tx*8+8, 3] = ids[ty*8:ty*8+8, tx*8:tx*8+8]
 fg = shard.FrameGather(torch, dist, rank, world, w, h, torch.device("cpu"))
 assert fg.tiles_padded == padded and fg.msg.numel() == padded * 64 * 4
-fg.msg.copy_(torch.from_numpy(shard.pack_tiles_numpy(frame, rank, world).view(np.int32)))
+packed = torch.from_numpy(shard.pack_tiles_numpy(frame, rank, world).view(np.int32))
+fg.msg.copy_(packed)
 dist.barrier()
 fg.gather()
 dist.barrier()
+# the pipelined path bench.py uses: three frames through submit/drain with a stand-in backend
+class FakeGpu:
+    def __init__(self): self.assembled = []
+    def bind_output(self, ptr): self.bound = ptr
+    def assemble(self, gathered_ptr, dst_ptr, stride): self.assembled.append(gathered_ptr)
+fake = FakeGpu()
+for k in range(3):
+    fg.submit(fake, lambda: fg.msgs[fg.k & 1].copy_(packed + k))
+fg.drain(fake)
+assert fg.pending is None and fg.k == 3
+if rank == 0:
+    assert fake.assembled == [fg.recv[0].data_ptr(), fg.recv[1].data_ptr(), fg.recv[0].data_ptr()]
+    assert torch.equal(fg.recv[1][0], packed + 1) and torch.equal(fg.recv[0][0], packed + 2)
+    fg.recv[0].sub_(2)
 if rank == 0:
     got = shard.assemble_numpy(fg.gathered.numpy().view(np.uint32), w, h, world)
     rgb, ids = shard.texels_to_frame(got)

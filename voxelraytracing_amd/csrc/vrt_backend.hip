@@ -547,8 +547,8 @@ int vrt_set_stream(vrt_ctx *c, void *hip_stream) {
 int vrt_bind_output(vrt_ctx *c, void *texels) {
     if (!c) return VRT_ERR_INVALID_ARG;
     if (texels && ((uintptr_t)texels % 16u)) return fail(c, VRT_ERR_INVALID_ARG, "vrt_bind_output: texels must be 16-byte aligned");
-    HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // stream-ordered: launches capture the pointer, so frames already enqueued keep writing where they were
+    // told to and the next vrt_render uses the new buffer (lets a host ping-pong two gather messages)
     c->d_out = texels ? (vrt::Texel *)texels : c->own_out;
     c->rendered = false;
     return VRT_OK;

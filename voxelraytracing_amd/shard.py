@@ -53,27 +53,60 @@ def pack_tiles_numpy(frame: np.ndarray, rank: int, count: int) -> np.ndarray:
 
 
 class FrameGather:
-    """One process per GPU: owns the message tensor, binds the backend's output to it and gathers.
+    """One process per GPU: owns the message tensors, binds the backend's output to them and gathers.
 
-    `dist` is torch.distributed with an initialised process group (nccl = RCCL on the GPU box, gloo on CPU)."""
+    `dist` is torch.distributed with an initialised process group (nccl = RCCL on the GPU box, gloo on CPU).
+    Two message / receive buffers ping-pong so that the gather of frame k (on the collective's own stream)
+    overlaps the render of frame k+1 and the de-interleave of frame k-1 (`submit` / `drain`)."""
 
     def __init__(self, torch, dist, rank: int, count: int, width: int, height: int, device):
         self.torch, self.dist, self.rank, self.count = torch, dist, rank, count
         self.width, self.height = width, height
         _, self.tiles_padded, _ = tiles_of_rank(width, height, rank, count)
         self.slots = self.tiles_padded * 64
-        self.msg = torch.zeros(self.slots * 4, dtype=torch.int32, device=device)
-        self.gathered = torch.zeros((count, self.slots * 4), dtype=torch.int32, device=device) if rank == 0 else None
+        self.msgs = [torch.zeros(self.slots * 4, dtype=torch.int32, device=device) for _ in range(2)]
+        self.recv = [torch.zeros((count, self.slots * 4), dtype=torch.int32, device=device) if rank == 0 else None
+                     for _ in range(2)]
         self.frame = torch.zeros((height, width, 4), dtype=torch.int32, device=device) if rank == 0 else None
+        self.k = 0            # frames submitted
+        self.pending = None   # (work, buffer index) of the gather still in flight
+        # single-buffer aliases (tests, simple callers)
+        self.msg, self.gathered = self.msgs[0], self.recv[0]
 
-    def bind(self, gpu):
-        """Make the backend render straight into the message tensor."""
-        gpu.bind_output(self.msg.data_ptr())
+    def bind(self, gpu, which: int = 0):
+        """Make the backend render straight into message buffer `which`."""
+        gpu.bind_output(self.msgs[which].data_ptr())
 
-    def gather(self):
+    def gather(self, which: int = 0, async_op: bool = False):
         """One gather of equal-sized messages to rank 0 (RCCL: N-1 direct sends to the root)."""
-        self.dist.gather(self.msg, list(self.gathered.unbind(0)) if self.rank == 0 else None, dst=0)
+        return self.dist.gather(self.msgs[which], list(self.recv[which].unbind(0)) if self.rank == 0 else None, dst=0,
+                                async_op=async_op)
 
-    def assemble(self, gpu):
+    def assemble(self, gpu, which: int = 0):
         """Rank 0: scatter the gathered tile buffers into the row-major texel frame on the device."""
-        gpu.assemble(self.gathered.data_ptr(), self.frame.data_ptr(), self.slots * TEXEL_BYTES)
+        gpu.assemble(self.recv[which].data_ptr(), self.frame.data_ptr(), self.slots * TEXEL_BYTES)
+
+    # ---- pipelined frames ----
+    def submit(self, gpu, render):
+        """Render frame k into message k&1, start its gather, then finish frame k-1 (wait + assemble on rank 0).
+        Waiting for gather k-1 here also guarantees message (k+1)&1 is free before the next render overwrites it."""
+        w = self.k & 1
+        self.bind(gpu, w)
+        render()
+        work = self.gather(w, async_op=True)
+        self._finish_pending(gpu)
+        self.pending = (work, w)
+        self.k += 1
+
+    def _finish_pending(self, gpu):
+        if self.pending is None:
+            return
+        work, w = self.pending
+        work.wait()   # stream-ordered for RCCL (the current stream waits), host-blocking for gloo
+        if self.rank == 0:
+            self.assemble(gpu, w)
+        self.pending = None
+
+    def drain(self, gpu):
+        """Finish the last submitted frame."""
+        self._finish_pending(gpu)
