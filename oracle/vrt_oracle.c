@@ -70,10 +70,11 @@ uint32_t orc_get_node(const uint32_t *pairs, uint32_t idx) {
 }
 
 /* The pool is little-endian u16; reading nodes[idx] equals get_node on the u32-pair view
- * (tests/test_oracle_kat.py checks the equivalence). Out-of-range reads return node 0's value the
- * way wgpu's bounds-clamped storage reads cannot fault; scenes under test never trigger it. */
+ * (tests/test_oracle_kat.py checks the equivalence).  What a storage read past the end of the buffer
+ * yields is implementation-defined in WGSL (wgpu never faults); choice: it reads 0, an air leaf — what the
+ * HIP backend's range-checked buffer loads return.  Scenes under test never trigger it. */
 static inline uint32_t node_at(const orc_scene *s, uint32_t idx) {
-    if (idx >= s->n_nodes) idx = s->n_nodes - 1;
+    if (idx >= s->n_nodes) return 0;
     return s->nodes[idx];
 }
 static inline int node_is_split(uint32_t n) { return (n >> 15) != 0; }

@@ -148,7 +148,8 @@ extern "C" {
 int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     if (!cfg || !out) return fail(nullptr, VRT_ERR_INVALID_ARG, "vrt_create: null argument");
     *out = nullptr;
-    if (cfg->max_nodes < 2) return fail(nullptr, VRT_ERR_INVALID_ARG, "max_nodes must be >= 2");
+    if (cfg->max_nodes < 2 || cfg->max_nodes > 0x7FFFFFFEu)
+        return fail(nullptr, VRT_ERR_INVALID_ARG, "max_nodes must be in [2, 2^31 - 2] (the pool is addressed through a 32-bit byte offset)");
     if (cfg->width == 0 || cfg->height == 0 || (cfg->width % 8u) || (cfg->height % 8u))
         return fail(nullptr, VRT_ERR_INVALID_ARG,
                     "output %ux%u: dimensions must be non-zero multiples of 8 (the reference dispatches "

@@ -17,6 +17,17 @@ __device__ __forceinline__ int trunc2i(float x) {
     return r;
 }
 
+// Node words are read through a raw buffer descriptor over the pool: the hardware range check makes a read
+// past the end return 0 (an air leaf) instead of faulting, for free — no per-load clamp, 32-bit offsets.
+// (What a storage read past the end yields is implementation-defined in WGSL; the oracle reads 0 too.)
+using NodeBuf = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ NodeBuf node_buffer(const FrameParams &P) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(P.nodes), 0, P.n_nodes * 2u, 0x00020000);
+}
+__device__ __forceinline__ uint32_t load_node(NodeBuf nb, uint32_t idx) {
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(nb, idx * 2u, 0, 0);
+}
+
 __device__ __forceinline__ bool is_liquid(const uint32_t *s_liquid, uint32_t voxel) {
     // voxel_mats[voxel].is_liquid == 1 (ray_tracer.wgsl:226); ids >= 256 clamp to material 255.
     const uint32_t v = min(voxel, 255u);
@@ -40,15 +51,15 @@ __device__ __forceinline__ Leaf find_leaf(const FrameParams &P, const uint32_t *
     uint32_t cidx = (uint32_t)(vx >> 5) + (uint32_t)(vy >> 5) * S + (uint32_t)(vz >> 5) * S * S;
     cidx = min(cidx, P.n_roots - 1u);
     const uint32_t root = LDS_ROOTS ? s_roots[cidx] : P.roots[cidx];
-    const uint32_t last = P.n_nodes - 1u;
+    const NodeBuf nb = node_buffer(P);
     uint32_t idx = 0, depth = 0;
-    uint32_t node = P.nodes[min(root, last)];
+    uint32_t node = load_node(nb, root);
     while ((node & 0x8000u) && depth < 5u) {
         const uint32_t sh = 4u - depth;
         const uint32_t child = ((uint32_t)(vx >> sh) & 1u) | (((uint32_t)(vy >> sh) & 1u) << 1) |
                                (((uint32_t)(vz >> sh) & 1u) << 2);
         idx = (node & 0x7FFFu) + child;
-        node = P.nodes[min(root + idx, last)];
+        node = load_node(nb, root + idx);
         depth += 1u;
     }
     const int m = ~((32 >> depth) - 1);
@@ -214,7 +225,7 @@ __device__ __forceinline__ MarchResult march_fast(const FrameParams &P, const ui
 
     const uint32_t S = P.world.size_in_chunks;
     const uint32_t wsize = P.world.size;
-    const uint32_t last = P.n_nodes - 1u;
+    const NodeBuf nb = node_buffer(P);
     const float qnan = __builtin_nanf("");
 
     int vx = trunc2i(pos.x), vy = trunc2i(pos.y), vz = trunc2i(pos.z);  // pos > 0 here (or NaN -> 0)
@@ -240,7 +251,7 @@ __device__ __forceinline__ MarchResult march_fast(const FrameParams &P, const ui
             uint32_t cidx = __umul24(__umul24((uint32_t)(vz >> 5), S) + (uint32_t)(vy >> 5), S) + (uint32_t)(vx >> 5);
             cidx = min(cidx, P.n_roots - 1u);
             root = LDS_ROOTS ? s_roots[cidx] : P.roots[cidx];
-            node = P.nodes[min(root, last)];
+            node = load_node(nb, root);
             depth = 0u;
         } else {
             // k = number of leading local-coordinate bits shared with the previous position (5 if none differ)
@@ -253,7 +264,7 @@ __device__ __forceinline__ MarchResult march_fast(const FrameParams &P, const ui
             resume = false;                                                                            \
             const uint32_t sel = (((uint32_t)vx >> (4 - D)) & 1u) | ((((uint32_t)vy >> (4 - D)) & 1u) << 1) | \
                                  ((((uint32_t)vz >> (4 - D)) & 1u) << 2);                               \
-            node = P.nodes[min(root + BD + sel, last)];                                                \
+            node = load_node(nb, root + BD + sel);                                                     \
             depth = D + 1u;                                                                            \
         }
         VRT_LEVEL(0, b0)
