@@ -1,0 +1,46 @@
+"""The C++ host mirror end to end: voxelraytracing_amd/vrt_frame_loop runs the reference's join_game + frame
+loop (clientdesktop/src/main.rs:189-229, 340-362, 398-455) on csrc/host/*.hpp + libvrt.so; the same sequence
+driven through the Python bindings and the oracle must give the same frame."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from voxelraytracing_amd import MODE_PRIMARY_SHADOW, graphics as g, scenes
+
+from util import assert_frame_parity, gpu_for_scene
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "voxelraytracing_amd", "vrt_frame_loop")
+
+
+def test_frame_loop_binary_is_built():
+    assert os.path.exists(EXE), "run __graft_entry__.build()"
+
+
+@pytest.mark.gpu
+def test_cpp_frame_loop_matches_python_and_oracle(tmp_path, orc):
+    out = tmp_path / "frame.bin"
+    r = subprocess.run([EXE, str(out), "256", "256"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "frame_loop ok 256x256" in r.stdout
+    raw = np.fromfile(out, dtype=np.uint32)
+    w, h = int(raw[0]), int(raw[1])
+    ids = raw[2:2 + w * h].reshape(h, w)
+    rgb = raw[2 + w * h:].view(np.float32).reshape(h, w, 3)
+
+    sc = scenes.c1_flat((256, 256))   # same world, Player at (32.5,16.5,60.5) -> cam_pos y+4, rot (15,0,0)
+    assert sc.eye == (32.5, 20.5, 60.5)
+    for pos, v in (((32, 12, 40), 0), ((30, 13, 44), 4)):
+        sc.world.set_voxel(pos, v)
+    gpu = gpu_for_scene(sc)
+    gpu.render(MODE_PRIMARY_SHADOW)
+    p_rgb, p_ids, _ = gpu.read_output()
+    assert np.array_equal(ids, p_ids) and np.array_equal(rgb, p_rgb)
+    r_rgb, r_ids, _, _ = orc.from_package_scene(sc).render(orc.MODE_PRIMARY_SHADOW, 256, 256)
+    assert_frame_parity(rgb, ids, r_rgb, r_ids, "C++ frame loop")
+    # Player::facing == axis_rot_to_ray (client/src/player.rs:72-78)
+    fx, fy, fz = (float(t) for t in r.stdout.split("facing")[1].split())
+    import math
+    assert (fx, fy, fz) == pytest.approx(g.axis_rot_to_ray((math.radians(15.0), 0.0, 0.0)), abs=1e-6)
