@@ -92,6 +92,16 @@ void vrth_gen_dense_superflat(const int32_t chunk_pos[3], uint16_t *dense);
  * 1 = superflat built by set_node (config C1). threads <= 0: all cores. Returns 0 or a SetVoxelErr. */
 int vrth_world_generate(vrth_world *w, uint32_t kind, uint32_t seed, int threads);
 
+/* ---- region files of the reference server (servercli/src/main.rs:25-73; format in csrc/host/regionfile.hpp) ---- */
+/* Parse one `regions/r_X_Y_Z_.data` image and create_chunk every chunk of it that lies inside the world's grid.
+ * Returns 0, -1 for a malformed file, or a SetVoxelErr. */
+int vrth_region_load_into_world(vrth_world *w, const uint8_t *bytes, uint64_t n, const int32_t region_pos[3], uint32_t *chunks_loaded);
+/* Serialise the world's chunks of one region in the same format. Returns the byte count (writes if it fits cap). */
+uint64_t vrth_region_save_from_world(const vrth_world *w, const int32_t region_pos[3], uint8_t *out, uint64_t cap);
+/* ChunkPos::region (common/src/world/mod.rs:90-96) and region_path_by_pos (servercli/src/main.rs:25-27). */
+void vrth_region_of_chunk(const int32_t chunk_pos[3], int32_t region_pos[3], uint32_t pos_in_region[3]);
+uint32_t vrth_region_file_name(const int32_t region_pos[3], char *out, uint32_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,6 +6,7 @@
 #include "../../../include/vrt_host.h"
 #include "graphics.hpp"
 #include "materials.hpp"
+#include "regionfile.hpp"
 #include "worldgen.hpp"
 
 using namespace vrt;
@@ -218,6 +219,58 @@ int vrth_world_generate(vrth_world *w, uint32_t kind, uint32_t seed, int threads
         if (err != SetVoxelErr::Ok) return (int)err;
     }
     return 0;
+}
+
+
+// ---- region files (servercli/src/main.rs:25-73) ----
+
+int vrth_region_load_into_world(vrth_world *w, const uint8_t *bytes, uint64_t n, const int32_t region_pos[3], uint32_t *chunks_loaded) {
+    auto rf = RegionFile::from_file(bytes, (size_t)n);
+    if (!rf) return -1;
+    uint32_t loaded = 0;
+    for (auto &kv : rf->chunks) {
+        uint32_t cn = 0;
+        const Node *nodes = rf->read_chunk_data(kv.first, cn);
+        if (!nodes) return -1;
+        const ChunkPos cp{region_pos[0] * (int32_t)REGION_SIZE + (int32_t)kv.first[0], region_pos[1] * (int32_t)REGION_SIZE + (int32_t)kv.first[1],
+                          region_pos[2] * (int32_t)REGION_SIZE + (int32_t)kv.first[2]};
+        SetVoxelErr err;
+        w->w.create_chunk(cp, nodes, cn, err);
+        if (err == SetVoxelErr::PosOutOfBounds) continue;  // outside the client's grid, like received_oob_chunks (lib.rs:116)
+        if (err != SetVoxelErr::Ok) return (int)err;
+        loaded++;
+    }
+    if (chunks_loaded) *chunks_loaded = loaded;
+    return 0;
+}
+
+uint64_t vrth_region_save_from_world(const vrth_world *w, const int32_t region_pos[3], uint8_t *out, uint64_t cap) {
+    RegionFile rf;
+    const int32_t r = (int32_t)REGION_SIZE;
+    for (int32_t z = 0; z < r; z++)
+        for (int32_t y = 0; y < r; y++)
+            for (int32_t x = 0; x < r; x++) {
+                const ChunkPos cp{region_pos[0] * r + x, region_pos[1] * r + y, region_pos[2] * r + z};
+                const Chunk *c = w->w.get_chunk(cp);
+                if (!c) continue;
+                // what the server stores per chunk is its used node prefix (ServerChunk::used_nodes, server/src/world/mod.rs:109-112)
+                rf.append_chunk({(uint32_t)x, (uint32_t)y, (uint32_t)z}, w->w.nodes() + c->range.start, c->alloc.last_used_addr + 1);
+            }
+    const std::vector<uint8_t> bytes = rf.to_file();
+    if (out && bytes.size() <= cap) std::memcpy(out, bytes.data(), bytes.size());
+    return bytes.size();
+}
+
+void vrth_region_of_chunk(const int32_t chunk_pos[3], int32_t region_pos[3], uint32_t pos_in_region[3]) {
+    const auto rp = chunk_region(cp3(chunk_pos));
+    region_pos[0] = rp.first.x; region_pos[1] = rp.first.y; region_pos[2] = rp.first.z;
+    for (int i = 0; i < 3; i++) pos_in_region[i] = rp.second[i];
+}
+
+uint32_t vrth_region_file_name(const int32_t region_pos[3], char *out, uint32_t cap) {
+    const std::string s = region_file_name(cp3(region_pos));
+    if (out && cap > s.size()) std::memcpy(out, s.c_str(), s.size() + 1);
+    return (uint32_t)s.size();
 }
 
 }  // extern "C"

@@ -173,6 +173,24 @@ class ClientWorld:
         y = C.c_int32()
         return y.value if self._lib.vrth_world_highest_vox_at(self._h, x, z, C.byref(y)) else None
 
+    # --- region files (servercli/src/main.rs:25-73) ---
+    def load_region(self, data: bytes, region_pos) -> int:
+        """create_chunk every chunk of a reference region file that lies inside the grid; returns how many."""
+        n = C.c_uint32()
+        buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+        rc = self._lib.vrth_region_load_into_world(self._h, buf, len(data), _i3(region_pos), C.byref(n))
+        if rc < 0:
+            raise ValueError("malformed region file")
+        if rc:
+            raise SetVoxelErr(rc)
+        return n.value
+
+    def save_region(self, region_pos) -> bytes:
+        size = self._lib.vrth_region_save_from_world(self._h, _i3(region_pos), None, 0)
+        buf = (C.c_uint8 * size)()
+        self._lib.vrth_region_save_from_world(self._h, _i3(region_pos), buf, size)
+        return bytes(buf)
+
     def world_data(self) -> _ffi.WorldData:
         """WorldData::from(&world), clientdesktop/src/graphics/mod.rs:121-130."""
         wd = _ffi.WorldData()
@@ -223,3 +241,17 @@ def gen_dense_superflat(chunk_pos) -> np.ndarray:
 
 def gen_height(seed: int, x: int, z: int) -> int:
     return _ffi.host().vrth_gen_height(seed, x, z)
+
+
+def region_of_chunk(chunk_pos):
+    """ChunkPos::region — common/src/world/mod.rs:90-96: (region pos, position inside the 16^3 region)."""
+    rp, ip = (C.c_int32 * 3)(), (C.c_uint32 * 3)()
+    _ffi.host().vrth_region_of_chunk(_i3(chunk_pos), rp, ip)
+    return tuple(rp), tuple(ip)
+
+
+def region_file_name(region_pos) -> str:
+    """region_path_by_pos — servercli/src/main.rs:25-27."""
+    buf = C.create_string_buffer(128)
+    _ffi.host().vrth_region_file_name(_i3(region_pos), buf, 128)
+    return buf.value.decode()
