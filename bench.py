@@ -202,7 +202,7 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"C2: {args.width}x{args.height} frame, {args.chunks}x{args.chunks}x{args.chunks}-chunk procedural SVO "
+        "config": {"workload": f"{'C2' if (args.chunks, args.width, args.height) == (8, 1920, 1080) else 'C2-family'}: {args.width}x{args.height} frame, {args.chunks}x{args.chunks}x{args.chunks}-chunk procedural SVO "
                                f"world (seed 1), 1 primary + 1 shadow ray per solid hit",
                    "rays_per_frame_actual": rays_per_frame, "rays_per_frame_nominal": 2 * args.width * args.height,
                    "sharding": "whole frame" if world == 1 else f"8x8 tiles interleaved over {world} ranks + RCCL gather to rank 0",
