@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--spp", type=int, default=1)
     ap.add_argument("--bounces", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="development only: with --gpus 1, still run the pipelined RCCL gather + assemble path (one-rank group)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development only: run the N > 1 code path with every rank on cuda:0 and a gloo gather staged "
                          "through host memory (RCCL refuses two ranks on one device); never used for reported numbers")
@@ -71,8 +73,13 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    sharded = world > 1 or args.force_gather
+    if sharded:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.rehearse_on_one_gpu:
             dist.init_process_group("gloo")
         else:
@@ -97,13 +104,20 @@ def main():
     if MODE == MODE_PATH:
         sc.settings.max_ray_bounces = args.bounces
         scenes._diffuse(sc.materials)
-    gpu = Gpu(sc.world.max_nodes(), sc.world.size_in_chunks(), sc.size, device=local_rank, shard_rank=rank, shard_count=world)
+    gpu = Gpu(sc.world.max_nodes(), sc.world.size_in_chunks(), sc.size, device=local_rank, shard_rank=rank, shard_count=world,
+              tile_major=sharded)
     gpu.upload_world(sc.world, sc.materials)
     gpu.write_cam_data(sc.cam)
     gpu.write_settings(sc.settings)
     fg = None
-    if world > 1:
-        gpu.set_stream(torch.cuda.current_stream().cuda_stream)
+    if sharded:
+        # One non-default torch stream carries everything of this rank: the backend's kernels (vrt_set_stream), the
+        # tensors' initialisation and the RCCL calls' stream dependencies.  (The default stream's handle is 0, which
+        # vrt_set_stream reads as "use the context's own stream" — kernels there would not be ordered with RCCL.)
+        side = torch.cuda.Stream(device=local_rank)
+        torch.cuda.set_stream(side)
+        gpu.set_stream(side.cuda_stream)
+        assert side.cuda_stream != 0
         fg = FrameGather(torch, dist, rank, world, args.width, args.height, torch.device("cuda", local_rank))
         if args.rehearse_on_one_gpu:
             def staged_gather(which=0, async_op=False):
@@ -145,14 +159,14 @@ def main():
         frame()
     finish()
     gpu.stats()  # drop the warm-up frames' kernel timings
-    if world > 1:
+    if sharded:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         frame()
     finish()   # every timed frame is gathered and assembled on rank 0 before the clock stops
-    if world > 1:
+    if sharded:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -160,7 +174,7 @@ def main():
 
     # per-kernel durations over exactly the timed frames: HIP events on the stream the kernels ran on
     kst = gpu.stats()
-    if world > 1 and rank == 0 and os.environ.get("VRT_BENCH_VERIFY", "1") == "1":
+    if sharded and rank == 0 and os.environ.get("VRT_BENCH_VERIFY", "1") == "1":
         # off the clock: the assembled frame must equal an unsharded render of the same frame on this GPU
         ref = Gpu(sc.world.max_nodes(), sc.world.size_in_chunks(), sc.size, device=local_rank)
         ref.upload_world(sc.world, sc.materials)
@@ -175,8 +189,7 @@ def main():
             raise SystemExit("gathered frame differs from the unsharded render")
         ref.close()
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
     b_primary, b_shadow = algorithmic_bytes(st, args.width, args.height)  # rank 0's own launches (its shard when N > 1)
     ms_p = kst.sum_ms_primary / max(kst.frames, 1)
@@ -205,7 +218,7 @@ def main():
         "config": {"workload": f"{'C2' if (args.chunks, args.width, args.height) == (8, 1920, 1080) else 'C2-family'}: {args.width}x{args.height} frame, {args.chunks}x{args.chunks}x{args.chunks}-chunk procedural SVO "
                                f"world (seed 1), 1 primary + 1 shadow ray per solid hit",
                    "rays_per_frame_actual": rays_per_frame, "rays_per_frame_nominal": 2 * args.width * args.height,
-                   "sharding": "whole frame" if world == 1 else f"8x8 tiles interleaved over {world} ranks + RCCL gather to rank 0",
+                   "sharding": ("whole frame" if not sharded else "whole frame through the one-rank gather pipeline") if world == 1 else f"8x8 tiles interleaved over {world} ranks + RCCL gather to rank 0",
                    "kernel_variant": args.variant},
         "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -218,7 +231,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline and args.mode == "shadow":
         out["cpu_baseline"] = cpu_baseline(sc, args, rays_per_frame)
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 

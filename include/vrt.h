@@ -85,8 +85,11 @@ typedef struct {
     uint32_t width, height;      /* result texture size; multiples of 8 (main.rs:452) */
     int32_t device;              /* HIP device ordinal; -1 = current */
     uint32_t shard_rank, shard_count;
-    uint32_t flags;              /* reserved, 0 */
+    uint32_t flags;              /* VRT_FLAG_* */
 } vrt_config;
+
+/* Write the output in the tile-major shard layout even with shard_count = 1 (a one-rank gather pipeline). */
+#define VRT_FLAG_TILE_MAJOR 1u
 
 typedef enum {
     VRT_MODE_PRIMARY = 0,        /* the reference's live shader (ray_tracer.wgsl) */

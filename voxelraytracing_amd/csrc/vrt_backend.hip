@@ -51,6 +51,7 @@ struct vrt_ctx {
     uint32_t n_roots = 0;
     uint32_t width = 0, height = 0;
     uint32_t shard_rank = 0, shard_count = 1;
+    bool tile_major = false;  // output layout [t_local][64]: always when sharded, on request (VRT_FLAG_TILE_MAJOR) otherwise
     uint32_t tiles_x = 0, tiles_total = 0, tiles_local = 0, tiles_padded = 0;
     uint32_t slots = 0;  // pixel slots in the output buffer
 
@@ -110,7 +111,7 @@ static void layout_tiles(vrt_ctx *c) {
     c->tiles_total = c->tiles_x * (c->height / 8u);
     c->tiles_padded = (c->tiles_total + c->shard_count - 1u) / c->shard_count;
     c->tiles_local = c->shard_rank < c->tiles_total ? (c->tiles_total - c->shard_rank + c->shard_count - 1u) / c->shard_count : 0u;
-    c->slots = c->shard_count > 1u ? c->tiles_padded * 64u : c->width * c->height;
+    c->slots = c->tile_major ? c->tiles_padded * 64u : c->width * c->height;
 }
 
 static int alloc_output(vrt_ctx *c) {
@@ -174,6 +175,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     c->device = dev;
     c->shard_rank = cfg->shard_rank;
     c->shard_count = sc;
+    c->tile_major = sc > 1u || (cfg->flags & VRT_FLAG_TILE_MAJOR);
     c->width = cfg->width;
     c->height = cfg->height;
     c->max_nodes = cfg->max_nodes & ~1u;  // NodeBuffer::new forces an even size (shader.rs:10-12)
@@ -366,6 +368,7 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     P.shard_rank = c->shard_rank;
     P.shard_count = c->shard_count;
     P.tiles_local = c->tiles_local;
+    P.tile_major = c->tile_major ? 1u : 0u;
     P.cam = c->cam;
     P.settings = c->settings;
     P.world = c->world;
@@ -455,7 +458,7 @@ int vrt_read_output(vrt_ctx *c, float *rgb, uint32_t *ids, uint8_t *rgba8) {
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t npix = (size_t)c->width * c->height;
     if (rgba8) {
-        if (c->shard_count != 1u) return fail(c, VRT_ERR_STATE, "vrt_read_output: rgba8 readback is only available unsharded");
+        if (c->tile_major) return fail(c, VRT_ERR_STATE, "vrt_read_output: rgba8 readback needs the row-major (unsharded) layout");
         if (!c->d_rgba8) HIP_TRY(c, hipMalloc(&c->d_rgba8, npix * 4));
         vrt::launch_quantize(c->d_out, c->d_rgba8, (uint32_t)npix, c->stream);
         HIP_TRY(c, hipGetLastError());
@@ -472,7 +475,7 @@ int vrt_read_output(vrt_ctx *c, float *rgb, uint32_t *ids, uint8_t *rgba8) {
         if (rgb) { memcpy(rgb + dst * 3, &x, 12); }
         if (ids) ids[dst] = x.w;
     };
-    if (c->shard_count == 1u) {
+    if (!c->tile_major) {
         for (size_t i = 0; i < npix; i++) put(i, t[i]);
         return VRT_OK;
     }
@@ -491,7 +494,7 @@ int vrt_read_steps(vrt_ctx *c, uint32_t *steps) {
     if (!c || !steps) return fail(c, VRT_ERR_INVALID_ARG, "vrt_read_steps: null argument");
     if (!c->rendered || !c->last_stats || !c->d_steps)
         return fail(c, VRT_ERR_STATE, "vrt_read_steps: the last frame was not rendered with opts.stats = 1");
-    if (c->shard_count != 1u) return fail(c, VRT_ERR_STATE, "vrt_read_steps: only available unsharded");
+    if (c->tile_major) return fail(c, VRT_ERR_STATE, "vrt_read_steps: needs the row-major (unsharded) layout");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipMemcpyAsync(steps, c->d_steps, (size_t)c->width * c->height * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -43,6 +43,7 @@ struct FrameParams {
     uint32_t tiles_x, tiles_total;
     uint32_t shard_rank, shard_count, tiles_local;
     uint32_t hit_seg_cap;    // capacity of one hit-buffer segment, a multiple of 256
+    uint32_t tile_major;     // output slots are [t_local][64] (sharded, or VRT_FLAG_TILE_MAJOR) instead of row-major
     uint32_t finite_settings;  // 1: every Settings float is finite (lets hits skip the sky term exactly)
     vrt_cam_data cam;
     vrt_settings settings;

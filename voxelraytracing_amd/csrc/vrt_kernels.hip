@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(256) primary_tile_kernel(FrameParams P) {
         const uint32_t tile = P.shard_rank + t_local * P.shard_count;
         const uint32_t px = (tile % P.tiles_x) * 8u + (lane & 7u);
         const uint32_t py = (tile / P.tiles_x) * 8u + (lane >> 3);
-        slot = P.shard_count > 1u ? t_local * 64u + lane : py * P.width + px;
+        slot = P.tile_major ? t_local * 64u + lane : py * P.width + px;
 
         V3 origin, dir;
         create_ray(P, (int)px, (int)py, origin, dir);

@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(256) path_primary_kernel(FrameParams P) {
         const uint32_t px = (tile % P.tiles_x) * 8u + (lane & 7u);
         const uint32_t py = (tile / P.tiles_x) * 8u + (lane >> 3);
         PathState st;
-        st.slot = P.shard_count > 1u ? t_local * 64u + lane : py * P.width + px;
+        st.slot = P.tile_major ? t_local * 64u + lane : py * P.width + px;
         create_ray(P, (int)px, (int)py, st.origin, st.dir);
         st.thr = V3{1.0f, 1.0f, 1.0f};
         // seed: path_tracer.wgsl:328 (y*W + x) + the per-sample stride and frame seed of SURVEY §8d
