@@ -61,6 +61,8 @@ struct vrt_ctx {
     vrt::Texel *d_out = nullptr;    // where frames are written: own_out or caller-bound memory
     vrt::Texel *own_out = nullptr;
     uint4 *d_hits = nullptr;
+    uint32_t *d_blk_counts = nullptr;  // hit records per primary workgroup
+    uint32_t n_blocks = 0;
     uint4 *d_path = nullptr;  // path mode: 2 buffers x 3 planes x (kHitSegments * hit_seg_cap) records, lazily allocated
     unsigned long long *d_counters = nullptr;  // [kCtrCount] stats, then the hit-segment counters
     uint32_t hit_seg_cap = 0;
@@ -116,7 +118,8 @@ static void layout_tiles(vrt_ctx *c) {
 
 static int alloc_output(vrt_ctx *c) {
     (void)hipFree(c->own_out); (void)hipFree(c->d_hits); (void)hipFree(c->d_steps); (void)hipFree(c->d_rgba8); (void)hipFree(c->d_path);
-    c->own_out = nullptr; c->d_hits = nullptr; c->d_steps = nullptr; c->d_rgba8 = nullptr; c->d_path = nullptr;
+    (void)hipFree(c->d_blk_counts);
+    c->own_out = nullptr; c->d_hits = nullptr; c->d_steps = nullptr; c->d_rgba8 = nullptr; c->d_path = nullptr; c->d_blk_counts = nullptr;
     layout_tiles(c);
     const size_t n = c->slots ? c->slots : 1;
     HIP_TRY(c, hipMalloc(&c->own_out, n * sizeof(vrt::Texel)));
@@ -124,7 +127,10 @@ static int alloc_output(vrt_ctx *c) {
     const uint32_t nblocks = (c->tiles_local + 3u) / 4u;
     c->hit_seg_cap = ((nblocks + vrt::kHitSegments - 1u) / vrt::kHitSegments) * 256u;
     if (c->hit_seg_cap == 0) c->hit_seg_cap = 256u;
-    HIP_TRY(c, hipMalloc(&c->d_hits, (size_t)vrt::kHitSegments * c->hit_seg_cap * sizeof(uint4)));
+    HIP_TRY(c, hipMalloc(&c->d_hits, (size_t)vrt::kHitSegments * c->hit_seg_cap * sizeof(uint4)));  // >= nblocks * 256
+    c->n_blocks = nblocks;
+    HIP_TRY(c, hipMalloc(&c->d_blk_counts, (size_t)(nblocks ? nblocks : 1) * sizeof(uint32_t)));
+    HIP_TRY(c, hipMemsetAsync(c->d_blk_counts, 0, (size_t)(nblocks ? nblocks : 1) * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->own_out, 0, n * sizeof(vrt::Texel), c->stream));
     c->d_out = c->own_out;  // a resize drops any caller-bound output (its size no longer matches)
     c->rendered = false;
@@ -219,6 +225,7 @@ void vrt_destroy(vrt_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->d_nodes); (void)hipFree(c->d_roots); (void)hipFree(c->d_mats); (void)hipFree(c->own_out);
     (void)hipFree(c->d_hits); (void)hipFree(c->d_counters); (void)hipFree(c->d_steps); (void)hipFree(c->d_rgba8); (void)hipFree(c->d_path);
+    (void)hipFree(c->d_blk_counts);
     for (auto &t : c->ev_pool)
         for (auto &ev : t)
             if (ev) (void)hipEventDestroy(ev);
@@ -354,6 +361,7 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     P.mats = c->d_mats;
     P.out = c->d_out;
     P.hits = c->d_hits;
+    P.blk_counts = c->d_blk_counts;
     P.counters = c->d_counters;
     P.seg_counts = reinterpret_cast<uint32_t *>(c->d_counters + vrt::kCtrCount);
     P.hit_seg_cap = c->hit_seg_cap;
@@ -515,7 +523,13 @@ int vrt_get_stats(vrt_ctx *c, vrt_stats *out) {
         unsigned long long *h = hbuf.data();
         const uint32_t *seg = reinterpret_cast<const uint32_t *>(h + vrt::kCtrCount);
         unsigned long long launched = 0;
-        for (uint32_t i = 0; i < vrt::kHitSegments; i++) launched += seg[i * vrt::kSegStride];
+        if (c->last_mode == VRT_MODE_PRIMARY_SHADOW && c->n_blocks) {
+            std::vector<uint32_t> bc(c->n_blocks);
+            HIP_TRY(c, hipMemcpyAsync(bc.data(), c->d_blk_counts, bc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            for (uint32_t v : bc) launched += v;
+        }
+        (void)seg;
         vrt_stats s;
         memset(&s, 0, sizeof s);
         s.primary_rays = (uint64_t)c->tiles_local * 64u * (c->last_mode == VRT_MODE_PATH ? c->last_spp : 1u);

@@ -26,8 +26,9 @@ struct FrameParams {
     const uint32_t *roots;   // chunk_roots, S^3
     const vrt_material *mats;  // 256 x 32 B
     Texel *out;              // one texel per pixel slot
-    uint4 *hits;             // compacted hit buffer, kHitSegments segments of hit_seg_cap records: {slot, origin.xyz bits}
-    uint32_t *seg_counts;    // records in segment s at seg_counts[s * kSegStride]
+    uint4 *hits;             // hit buffer {slot, origin.xyz bits}: 256 records per primary workgroup, compacted per workgroup
+    uint32_t *blk_counts;    // records appended by primary workgroup b
+    uint32_t *seg_counts;    // path mode: records in segment s of the path buffer at seg_counts[s * kSegStride]
     unsigned long long *counters;  // see Counter
     uint32_t *steps;         // optional per-slot step counts (stats frames only), may be null
     // path-trace mode: wavefront of live paths, ping-pong between bounces. A record is three uint4 planes
@@ -51,10 +52,11 @@ struct FrameParams {
     uint32_t liquid[8];      // bit v set <=> materials[v].is_liquid == 1, v < 256
 };
 
-// The hit buffer is compacted per segment, not globally: one device-scope counter saturates at ~88
+// The path-trace buffers are compacted per segment, not globally: one device-scope counter saturates at ~88
 // returning atomics per microsecond (MI355X_MICROARCH.md "dequeue"), which made 32 400 per-wave atomics the
 // whole 0.37 ms of the first primary kernel.  Workgroup b appends to segment b % kHitSegments; each counter
-// sits on its own 64-byte line so the adds spread over the L2 channels.
+// sits on its own 64-byte line so the adds spread over the L2 channels.  (The shadow hit buffer is compacted
+// per workgroup in LDS instead: vrt_kernels.hip.)
 constexpr uint32_t kHitSegments = 256;
 constexpr uint32_t kSegStride = 16;  // u32 words between counters (64 B)
 
