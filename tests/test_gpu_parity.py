@@ -292,3 +292,57 @@ def test_large_world_uses_global_chunk_table(orc):
     rgb1, ids1, _ = gpu.read_output()
     r_rgb, r_ids, _, _ = o.render(MODE_PRIMARY_SHADOW, *sc.size)
     assert_frame_parity(rgb1, ids1, r_rgb, r_ids, "24^3 literal")
+
+
+def test_random_cameras_stress(orc):
+    """24 seeded random cameras (positions anywhere inside the 8^3 world incl. inside terrain and under water,
+    any yaw/pitch, some roll, fov 40..110) at 160x96, primary + shadow: id words and step counts bit-exact."""
+    sc = scenes.c2((160, 96))
+    gpu = gpu_for_scene(sc)
+    o = orc.from_package_scene(sc)
+    rng = np.random.default_rng(2026)
+    worst = 0.0
+    for i in range(24):
+        eye = tuple(float(v) for v in rng.uniform(1.0, 255.0, 3))
+        if i % 3 == 0:   # just above the terrain
+            from voxelraytracing_amd.world import gen_height
+            eye = (eye[0], float(gen_height(1, int(eye[0]), int(eye[2])) + rng.uniform(0.5, 12.0)), eye[2])
+        rot = (float(rng.uniform(-89, 89)), float(rng.uniform(0, 360)), float(rng.choice([0.0, 0.0, rng.uniform(-30, 30)])))
+        fov = float(rng.uniform(40, 110))
+        cam = g.cam_data_create(rot, eye, fov, (160.0, 96.0))
+        gpu.write_cam_data(cam)
+        gpu.render(MODE_PRIMARY_SHADOW, stats=True)
+        rgb, ids, _ = gpu.read_output()
+        o.set_cam(cam)
+        r_rgb, r_ids, r_steps, _ = o.render(MODE_PRIMARY_SHADOW, 160, 96, want_steps=True)
+        bad = np.argwhere(ids != r_ids)
+        assert bad.size == 0, f"camera {i} eye {eye} rot {rot} fov {fov}: {len(bad)} id words differ, first {tuple(bad[0])}"
+        assert np.array_equal(gpu.read_steps(), r_steps), f"camera {i}: step counts differ"
+        worst = max(worst, float(np.abs(rgb - r_rgb).max()))
+    assert worst <= 1e-4
+
+
+def test_random_edits_stress(orc):
+    """200 seeded random voxel edits (air / solids / water) near the camera, re-uploading each edited chunk's range."""
+    sc = scenes.c2((160, 96))
+    gpu = gpu_for_scene(sc)
+    rng = np.random.default_rng(7)
+    ex, ey, ez = (int(v) for v in sc.eye)
+    n_ok = 0
+    for _ in range(200):
+        p = (ex + int(rng.integers(-20, 21)), ey + int(rng.integers(-24, 6)), ez + int(rng.integers(-20, 21)))
+        v = int(rng.choice([0, 0, 3, 4, 40, 47, 62]))
+        try:
+            start, n = sc.world.set_voxel(p, v)
+        except Exception as e:   # NoChange / NoChunk (an all-air chunk has no storage) / OutOfMemory (slack used up)
+            assert getattr(e, "kind", "") in ("NoChange", "NoChunk", "OutOfMemory")
+            continue
+        gpu.write_nodes(sc.world.nodes_ptr(), start, start + n)
+        n_ok += 1
+    assert n_ok > 100
+    gpu.write_chunk_roots(sc.world.chunk_roots())
+    gpu.render(MODE_PRIMARY_SHADOW, stats=True)
+    rgb, ids, _ = gpu.read_output()
+    r_rgb, r_ids, r_steps, _ = orc.from_package_scene(sc).render(MODE_PRIMARY_SHADOW, 160, 96, want_steps=True)
+    assert_frame_parity(rgb, ids, r_rgb, r_ids, "after 200 edits")
+    assert np.array_equal(gpu.read_steps(), r_steps)
