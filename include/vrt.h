@@ -99,7 +99,8 @@ typedef enum {
 
 typedef struct {
     uint32_t mode;     /* vrt_mode */
-    uint32_t variant;  /* kernel variant, 0 = default */
+    uint32_t variant;  /* kernel variant: 0 = default (grid march over the derived cell grid / brick pool),
+                        * 1 = literal octree walk (the shader's text), 2 = ancestor-cache octree walk; DESIGN.md §Kernels */
     uint32_t stats;    /* 1: also count steps / node visits this frame (slower; not for timing) */
     uint32_t spp;      /* VRT_MODE_PATH only */
     uint32_t seed;     /* VRT_MODE_PATH only */
@@ -181,6 +182,21 @@ int vrt_synchronize(vrt_ctx *ctx);
 int vrt_read_output(vrt_ctx *ctx, float *rgb, uint32_t *ids, uint8_t *rgba8);
 
 int vrt_get_stats(vrt_ctx *ctx, vrt_stats *out);
+
+/* New relative to the reference: the lookup tables the default march derives on the device from the node pool
+ * and chunk_roots (rebuilt before the next frame after any vrt_write_nodes / changed vrt_write_chunk_roots /
+ * world resize; DESIGN.md §HBM layout).  `available` = 0 while a rebuild is pending or when the world is too
+ * large for them (variant 0 then runs as variant 2). */
+typedef struct {
+    uint32_t available;
+    uint32_t world_size_chunks;
+    uint64_t cells;        /* depth-3 cells in the grid: (8S)^3, 4 B each */
+    uint64_t bricks;       /* split cells: 64 x 2 B each */
+    uint64_t bytes;
+    uint32_t builds;       /* rebuilds since vrt_create */
+    float last_build_ms;   /* hipEvent time of the last rebuild */
+} vrt_accel_info;
+int vrt_get_accel_info(vrt_ctx *ctx, vrt_accel_info *out);
 
 /* Per-pixel march-loop iteration counts of the last frame (primary | shadow << 16); the frame must
  * have been rendered with opts.stats = 1.  Numeric twin of the reference's F2 step-count heat-map

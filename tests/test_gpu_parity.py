@@ -23,7 +23,7 @@ def c2_small():
     return scenes.c2((640, 360))
 
 
-VARIANTS = [0, 1]  # 0 = fast march (default), 1 = literal restatement (A/B baseline)
+VARIANTS = [0, 1, 2]  # 0 = grid march over the derived tables (default), 1 = literal octree walk, 2 = ancestor-cache octree walk
 
 
 @pytest.mark.parametrize("variant", VARIANTS)

@@ -59,6 +59,11 @@ class Stats(C.Structure):
                 ("sum_ms_secondary", C.c_double), ("sum_ms_total", C.c_double)]
 
 
+class AccelInfo(C.Structure):
+    _fields_ = [("available", C.c_uint32), ("world_size_chunks", C.c_uint32), ("cells", C.c_uint64),
+                ("bricks", C.c_uint64), ("bytes", C.c_uint64), ("builds", C.c_uint32), ("last_build_ms", C.c_float)]
+
+
 assert C.sizeof(Material) == 32 and C.sizeof(CamData) == 160
 assert C.sizeof(WorldData) == 32 and C.sizeof(Settings) == 48
 
@@ -86,6 +91,7 @@ VRT_SYMBOLS = {
     "vrt_synchronize": (C.c_int, [_P]),
     "vrt_read_output": (C.c_int, [_P, _P, _P, _P]),
     "vrt_get_stats": (C.c_int, [_P, C.POINTER(Stats)]),
+    "vrt_get_accel_info": (C.c_int, [_P, C.POINTER(AccelInfo)]),
     "vrt_read_steps": (C.c_int, [_P, _P]),
     "vrt_set_stream": (C.c_int, [_P, _P]),
     "vrt_bind_output": (C.c_int, [_P, _P]),

@@ -28,6 +28,10 @@ void launch_path_finish(Texel *out, uint32_t n, uint32_t spp, hipStream_t st);
 void launch_quantize(const Texel *out, uint8_t *rgba8, uint32_t n, hipStream_t st);
 void launch_assemble(const Texel *gathered, Texel *dst, uint32_t width, uint32_t tiles_x, uint32_t tiles_total,
                      uint32_t shard_count, uint64_t rank_stride, hipStream_t st);
+void launch_accel_cells(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S, uint32_t *grid,
+                        uint32_t *chunk_bricks, uint32_t *chunk_offsets, uint32_t *total, hipStream_t st);
+void launch_accel_bricks(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S, uint32_t *grid,
+                         const uint32_t *chunk_offsets, uint16_t *bricks, uint32_t brick_cap, hipStream_t st);
 }  // namespace vrt
 
 static_assert(sizeof(vrt_material) == 32, "Material layout (mod.rs:20-28)");
@@ -68,6 +72,20 @@ struct vrt_ctx {
     uint32_t hit_seg_cap = 0;
     uint32_t *d_steps = nullptr;
     uint8_t *d_rgba8 = nullptr;
+
+    // derived lookup tables of the grid march (vrt_accel.hip), rebuilt lazily when their inputs changed
+    uint32_t *d_grid = nullptr;
+    size_t grid_cap = 0;          // cells allocated
+    uint16_t *d_bricks = nullptr;
+    uint32_t brick_cap = 0, n_bricks = 0;
+    uint32_t *d_chunk_bricks = nullptr, *d_chunk_offsets = nullptr, *d_brick_total = nullptr;
+    uint32_t chunk_cap = 0;
+    uint32_t accel_S = 0;         // world size the tables were built for
+    bool accel_dirty = true;
+    bool accel_ok = false;        // false: world too large for the tables, variant 0 runs as variant 2
+    uint32_t accel_builds = 0;
+    float accel_last_ms = 0.f;
+    std::vector<uint32_t> h_roots;  // what chunk_roots holds, to recognise the reference's per-frame rewrite of the same table
 
     vrt_material h_mats[256];
     vrt_cam_data cam;
@@ -147,7 +165,76 @@ static int alloc_roots(vrt_ctx *c, uint32_t world_size) {
     HIP_TRY(c, hipMemsetAsync(c->d_roots, 0, n * sizeof(uint32_t), c->stream));
     c->world_size = world_size;
     c->n_roots = (uint32_t)n;
+    c->h_roots.assign((size_t)n, 0u);
+    c->accel_dirty = true;
     return VRT_OK;
+}
+
+// Largest world the grid march's tables cover: the cell grid is addressed by a 32-bit byte offset built with
+// 24-bit multiplies ((8S)^3 * 4 B < 2^32, (8S)^2 * 4 < 2^24), bricks by brick * 128 B < 2^32.
+static constexpr uint32_t kAccelMaxS = 100;
+static constexpr uint32_t kAccelMaxBricks = (1u << 25) - 1u;
+
+// (Re)build the cell grid and brick pool from the node pool and chunk_roots when they changed (vrt_accel.hip).
+static int ensure_accel(vrt_ctx *c) {
+    const uint32_t S = c->world.size_in_chunks;
+    if (!c->accel_dirty && c->accel_S == S) return VRT_OK;
+    c->accel_ok = false;
+    c->accel_S = S;
+    c->accel_dirty = false;
+    if (S > kAccelMaxS) return VRT_OK;
+    const uint32_t n_chunks = S * S * S;
+    const size_t cells = (size_t)n_chunks * 512u;
+    if (cells > c->grid_cap) {
+        (void)hipFree(c->d_grid);
+        c->d_grid = nullptr; c->grid_cap = 0;
+        HIP_TRY(c, hipMalloc(&c->d_grid, cells * sizeof(uint32_t)));
+        c->grid_cap = cells;
+    }
+    if (n_chunks > c->chunk_cap) {
+        (void)hipFree(c->d_chunk_bricks); (void)hipFree(c->d_chunk_offsets);
+        c->d_chunk_bricks = c->d_chunk_offsets = nullptr; c->chunk_cap = 0;
+        HIP_TRY(c, hipMalloc(&c->d_chunk_bricks, (size_t)n_chunks * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc(&c->d_chunk_offsets, (size_t)n_chunks * sizeof(uint32_t)));
+        c->chunk_cap = n_chunks;
+    }
+    if (!c->d_brick_total) HIP_TRY(c, hipMalloc(&c->d_brick_total, sizeof(uint32_t)));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(c, hipEventCreate(&e0));
+    HIP_TRY(c, hipEventCreate(&e1));
+    auto body = [&]() -> int {
+        HIP_TRY(c, hipEventRecord(e0, c->stream));
+        vrt::launch_accel_cells(c->d_nodes, c->max_nodes, c->d_roots, S, c->d_grid, c->d_chunk_bricks, c->d_chunk_offsets,
+                                c->d_brick_total, c->stream);
+        HIP_TRY(c, hipGetLastError());
+        uint32_t total = 0;
+        HIP_TRY(c, hipMemcpyAsync(&total, c->d_brick_total, sizeof total, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (total > kAccelMaxBricks) return VRT_OK;  // accel_ok stays false
+        if (total > c->brick_cap || !c->d_bricks) {
+            (void)hipFree(c->d_bricks);
+            c->d_bricks = nullptr; c->brick_cap = 0;
+            uint64_t cap = (uint64_t)total + total / 4u + 1024u;  // slack: voxel edits split a few more cells
+            if (cap > kAccelMaxBricks) cap = kAccelMaxBricks;
+            HIP_TRY(c, hipMalloc(&c->d_bricks, (size_t)cap * 64u * sizeof(uint16_t)));
+            c->brick_cap = (uint32_t)cap;
+        }
+        vrt::launch_accel_bricks(c->d_nodes, c->max_nodes, c->d_roots, S, c->d_grid, c->d_chunk_offsets, c->d_bricks, c->brick_cap,
+                                 c->stream);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipEventRecord(e1, c->stream));
+        HIP_TRY(c, hipEventSynchronize(e1));
+        HIP_TRY(c, hipEventElapsedTime(&c->accel_last_ms, e0, e1));
+        c->n_bricks = total;
+        c->accel_builds += 1;
+        c->accel_ok = true;
+        return VRT_OK;
+    };
+    const int rc = body();
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc) c->accel_dirty = true;
+    return rc;
 }
 
 extern "C" {
@@ -226,6 +313,8 @@ void vrt_destroy(vrt_ctx *c) {
     (void)hipFree(c->d_nodes); (void)hipFree(c->d_roots); (void)hipFree(c->d_mats); (void)hipFree(c->own_out);
     (void)hipFree(c->d_hits); (void)hipFree(c->d_counters); (void)hipFree(c->d_steps); (void)hipFree(c->d_rgba8); (void)hipFree(c->d_path);
     (void)hipFree(c->d_blk_counts);
+    (void)hipFree(c->d_grid); (void)hipFree(c->d_bricks); (void)hipFree(c->d_chunk_bricks); (void)hipFree(c->d_chunk_offsets);
+    (void)hipFree(c->d_brick_total);
     for (auto &t : c->ev_pool)
         for (auto &ev : t)
             if (ev) (void)hipEventDestroy(ev);
@@ -250,6 +339,7 @@ int vrt_write_nodes(vrt_ctx *c, const uint16_t *pool, uint32_t start, uint32_t e
     // semantics: the caller may reuse `pool` as soon as this returns)
     HIP_TRY(c, hipMemcpyAsync(c->d_nodes + root, pool + root, (size_t)count * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->accel_dirty = true;
     return VRT_OK;
 }
 
@@ -259,9 +349,13 @@ int vrt_write_chunk_roots(vrt_ctx *c, uint32_t offset, const uint32_t *roots, ui
     // ArrayBuffer::write truncates to capacity (shader.rs:134-135)
     const uint32_t cut = n < c->n_roots - offset ? n : c->n_roots - offset;
     if (cut == 0) return VRT_OK;
+    // the reference rewrites the whole table every frame (main.rs:446); an identical rewrite changes nothing
+    if (memcmp(c->h_roots.data() + offset, roots, (size_t)cut * sizeof(uint32_t)) == 0) return VRT_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipMemcpyAsync(c->d_roots + offset, roots, (size_t)cut * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    memcpy(c->h_roots.data() + offset, roots, (size_t)cut * sizeof(uint32_t));
+    c->accel_dirty = true;
     return VRT_OK;
 }
 
@@ -353,12 +447,25 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     HIP_TRY(c, hipSetDevice(c->device));
 
     if (o.stats && !c->d_steps) HIP_TRY(c, hipMalloc(&c->d_steps, (size_t)(c->slots ? c->slots : 1) * sizeof(uint32_t)));
+    uint32_t variant = o.variant;
+    if (variant == 0u || o.mode == VRT_MODE_PATH) {
+        rc = ensure_accel(c);
+        if (rc) return rc;
+        if (!c->accel_ok && variant == 0u) variant = 2u;  // world too large for the tables: walk the octree
+    }
 
     vrt::FrameParams P;
     memset(&P, 0, sizeof P);
     P.nodes = c->d_nodes;
     P.roots = c->d_roots;
     P.mats = c->d_mats;
+    if (c->accel_ok && c->accel_S == c->world.size_in_chunks && !c->accel_dirty) {
+        P.grid = c->d_grid;
+        P.bricks = c->d_bricks;
+        P.grid_dim = c->accel_S * 8u;
+        P.grid_bytes = (uint32_t)((size_t)c->accel_S * c->accel_S * c->accel_S * 512u * sizeof(uint32_t));
+        P.brick_bytes = (uint32_t)((size_t)c->brick_cap * 64u * sizeof(uint16_t));
+    }
     P.out = c->d_out;
     P.hits = c->d_hits;
     P.blk_counts = c->d_blk_counts;
@@ -437,11 +544,11 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
         c->last_spp = spp;
     } else {
         HIP_TRY(c, hipEventRecord(ev[0], c->stream));
-        vrt::launch_primary(P, o.variant, o.stats != 0, shadow, c->stream);
+        vrt::launch_primary(P, variant, o.stats != 0, shadow, c->stream);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipEventRecord(ev[1], c->stream));
         if (shadow) {
-            vrt::launch_shadow(P, o.variant, o.stats != 0, c->stream);
+            vrt::launch_shadow(P, variant, o.stats != 0, c->stream);
             HIP_TRY(c, hipGetLastError());
         }
         HIP_TRY(c, hipEventRecord(ev[2], c->stream));
@@ -551,6 +658,19 @@ int vrt_get_stats(vrt_ctx *c, vrt_stats *out) {
         c->timing_pending = false;
     }
     *out = c->stats;
+    return VRT_OK;
+}
+
+int vrt_get_accel_info(vrt_ctx *c, vrt_accel_info *out) {
+    if (!c || !out) return fail(c, VRT_ERR_INVALID_ARG, "vrt_get_accel_info: null argument");
+    memset(out, 0, sizeof *out);
+    out->available = c->accel_ok && !c->accel_dirty ? 1u : 0u;
+    out->world_size_chunks = c->accel_S;
+    out->cells = (uint64_t)c->accel_S * c->accel_S * c->accel_S * 512u;
+    out->bricks = c->n_bricks;
+    out->bytes = out->cells * sizeof(uint32_t) + (uint64_t)c->n_bricks * 64u * sizeof(uint16_t);
+    out->builds = c->accel_builds;
+    out->last_build_ms = c->accel_last_ms;
     return VRT_OK;
 }
 

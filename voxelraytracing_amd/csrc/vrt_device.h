@@ -25,6 +25,12 @@ struct FrameParams {
     const uint16_t *nodes;   // flat node pool, little-endian u16 == the reference's packed u32 pairs
     const uint32_t *roots;   // chunk_roots, S^3
     const vrt_material *mats;  // 256 x 32 B
+    // derived lookup tables of the default march (vrt_accel.hip): one u32 per depth-3 cell of the world, x-major,
+    // and 64 u16 per split cell
+    const uint32_t *grid;
+    const uint16_t *bricks;
+    uint32_t grid_dim;       // cells per world axis = 8 * size_in_chunks
+    uint32_t grid_bytes, brick_bytes;
     Texel *out;              // one texel per pixel slot
     uint4 *hits;             // hit buffer {slot, origin.xyz bits}: 256 records per primary workgroup, compacted per workgroup
     uint32_t *blk_counts;    // records appended by primary workgroup b

@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(256) primary_tile_kernel(FrameParams P) {
 
         V3 origin, dir;
         create_ray(P, (int)px, (int)py, origin, dir);
-        R = march<MARCH, LDS_ROOTS>(P, s_roots, s_liquid, origin, dir);
+        R = march<MARCH, LDS_ROOTS, STATS>(P, s_roots, s_liquid, origin, dir);
         V3 color;
         uint32_t id = shade<MARCH == 1>(P, R, origin, dir, color);
 
@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(256) shadow_kernel(FrameParams P) {
         const V3 sd = vnormalize(V3{P.settings.sun_pos[0] - (float)P.world.min[0] - so.x,
                                     P.settings.sun_pos[1] - (float)P.world.min[1] - so.y,
                                     P.settings.sun_pos[2] - (float)P.world.min[2] - so.z});
-        R = march<MARCH, LDS_ROOTS>(P, s_roots, s_liquid, so, sd);
+        R = march<MARCH, LDS_ROOTS, STATS>(P, s_roots, s_liquid, so, sd);
         if (R.hit) {
             uint4 t = P.out[slot];
             t.x = __float_as_uint(__uint_as_float(t.x) * kShadowFactor);
@@ -198,7 +198,9 @@ static void launch_shadow_t(const FrameParams &P, bool stats, hipStream_t st) {
     else hipLaunchKernelGGL((shadow_kernel<MARCH, LDS_ROOTS, false>), grid, block, lds, st, P);
 }
 
-bool variant_supported(uint32_t variant) { return variant <= 1u; }
+// variant 0: grid march over the derived cell grid / brick pool (needs P.grid); 1: literal octree walk;
+// 2: ancestor-cache octree walk
+bool variant_supported(uint32_t variant) { return variant <= 2u; }
 
 void launch_primary(const FrameParams &P, uint32_t variant, bool stats, bool shadow, hipStream_t st) {
     if (P.tiles_local == 0) return;
@@ -206,9 +208,11 @@ void launch_primary(const FrameParams &P, uint32_t variant, bool stats, bool sha
     if (variant == 1u) {
         if (lds) launch_primary_t<1, true>(P, stats, shadow, st);
         else launch_primary_t<1, false>(P, stats, shadow, st);
+    } else if (variant == 2u) {
+        if (lds) launch_primary_t<2, true>(P, stats, shadow, st);
+        else launch_primary_t<2, false>(P, stats, shadow, st);
     } else {
-        if (lds) launch_primary_t<0, true>(P, stats, shadow, st);
-        else launch_primary_t<0, false>(P, stats, shadow, st);
+        launch_primary_t<0, false>(P, stats, shadow, st);
     }
 }
 
@@ -218,9 +222,11 @@ void launch_shadow(const FrameParams &P, uint32_t variant, bool stats, hipStream
     if (variant == 1u) {
         if (lds) launch_shadow_t<1, true>(P, stats, st);
         else launch_shadow_t<1, false>(P, stats, st);
+    } else if (variant == 2u) {
+        if (lds) launch_shadow_t<2, true>(P, stats, st);
+        else launch_shadow_t<2, false>(P, stats, st);
     } else {
-        if (lds) launch_shadow_t<0, true>(P, stats, st);
-        else launch_shadow_t<0, false>(P, stats, st);
+        launch_shadow_t<0, false>(P, stats, st);
     }
 }
 

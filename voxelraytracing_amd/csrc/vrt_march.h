@@ -183,7 +183,7 @@ __device__ __forceinline__ MarchResult march_literal(const FrameParams &P, const
 }
 
 // ------------------------------------------------------------------------------------------------
-// MARCH = 0: the fast march.  Same positions, same leaves, same results, bit for bit; the reductions
+// MARCH = 2: the ancestor-cache march (reads the octree itself).  Same positions, same leaves, same results, bit for bit; the reductions
 // used (each argued in DESIGN.md §Exact reductions):
 //   (a) `pos >= center` at depth d  ==  bit (4-d) of floor(pos) & 31            (centres are integers)
 //   (b) (pos-min)*imask + (max-pos)*mask  ==  mask ? max-pos : -(min-pos)         (x*0 adds a signed zero)
@@ -335,11 +335,141 @@ __device__ __forceinline__ MarchResult march_fast(const FrameParams &P, const ui
     return R;
 }
 
-template <int MARCH, bool LDS_ROOTS>
+// ------------------------------------------------------------------------------------------------
+// MARCH = 0 (default): the grid march.  Same positions, same leaves, same results as the two above, bit for
+// bit; the leaf under a position comes from the derived cell grid / brick pool of vrt_accel.hip (at most two
+// loads, no loop, nothing carried between steps) instead of a walk of the octree.  Reductions (b)-(e) as in
+// march_fast, plus:
+//   (b') (mask ? t : -t) * unit  ==  t * (mask ? unit : -unit)                   ((-a)*b and a*(-b) are the same bits)
+//   (h)  leaf bounds from the leaf size s (a power of two): low = v & ~(s-1), high = (v | (s-1)) + 1, chosen per
+//        axis by one bit-field insert with the direction mask
+//   (i)  the exit-axis flags and "left the world" are not carried through the loop: they are functions of the
+//        last step's operands, which each lane still holds when it leaves
+// ------------------------------------------------------------------------------------------------
+using TableBuf = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ TableBuf table_buffer(const void *p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float min3_nan_ignoring(float a, float b, float c) {
+    float r;  // IEEE mode: a quiet-NaN operand is ignored; every operand here is the result of an arithmetic op
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+template <bool STATS>
+__device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const uint32_t *s_liquid, V3 origin, V3 dir) {
+    MarchResult R;
+    R.hit = false;
+    R.pos = V3{0.f, 0.f, 0.f};
+    R.norm = V3{0.f, 0.f, 0.f};
+    R.water_dist = 0.0f;
+    R.voxel = 0u;
+    R.iters = 0u;
+    R.visits = 0u;
+
+    const bool mx = dir.x >= 0.0f, my = dir.y >= 0.0f, mz = dir.z >= 0.0f;
+
+    V3 pos = origin;
+    if (pos.x - floorf(pos.x) < 0.001f || pos.y - floorf(pos.y) < 0.001f || pos.z - floorf(pos.z) < 0.001f) {
+        pos.x += 0.001f * dir.x;
+        pos.y += 0.001f * dir.y;
+        pos.z += 0.001f * dir.z;
+    }
+    const float world_max = 0.0f + (float)P.world.size;
+    if ((pos.x <= 0.0f || pos.y <= 0.0f || pos.z <= 0.0f) || (pos.x >= world_max || pos.y >= world_max || pos.z >= world_max))
+        return R;
+
+    const V3 unit{
+        sqrtf(1.0f + (dir.y / dir.x) * (dir.y / dir.x) + (dir.z / dir.x) * (dir.z / dir.x)),
+        sqrtf(1.0f + (dir.x / dir.y) * (dir.x / dir.y) + (dir.z / dir.y) * (dir.z / dir.y)),
+        sqrtf(1.0f + (dir.x / dir.z) * (dir.x / dir.z) + (dir.y / dir.z) * (dir.y / dir.z))};
+    const float sux = mx ? unit.x : -unit.x, suy = my ? unit.y : -unit.y, suz = mz ? unit.z : -unit.z;
+    const uint32_t mxm = mx ? ~0u : 0u, mym = my ? ~0u : 0u, mzm = mz ? ~0u : 0u;
+    const uint32_t mx1 = mx ? 1u : 0u, my1 = my ? 1u : 0u, mz1 = mz ? 1u : 0u;
+
+    const uint32_t wsize = P.world.size;
+    const TableBuf gb = table_buffer(P.grid, P.grid_bytes), bb = table_buffer(P.bricks, P.brick_bytes);
+    const uint32_t row_bytes = P.grid_dim * 4u, slab_bytes = P.grid_dim * P.grid_dim * 4u;  // < 2^24: grid_dim <= 800
+    const float qnan = __builtin_nanf("");
+
+    int vx = trunc2i(pos.x), vy = trunc2i(pos.y), vz = trunc2i(pos.z);  // pos > 0 here (or NaN -> 0)
+    uint32_t voxel = 0u;
+    float step = 0.0f, adx = 0.0f, ady = 0.0f, adz = 0.0f;  // operands of the last step taken
+    float dew = -1.0f;  // dist_entered_water
+    float total_len = 0.0f;
+    uint32_t iter = 0u;
+
+    for (;;) {
+        iter += 1u;
+        // ---- find_node: cell, then brick ----
+        const uint32_t coff = __umul24((uint32_t)vz >> 2, slab_bytes) + (__umul24((uint32_t)vy >> 2, row_bytes) + ((uint32_t)vx & ~3u));
+        const uint32_t e = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(gb, coff, 0, 0);
+        voxel = e & 0x7FFFu;
+        uint32_t sz = e >> 15;  // leaf size in voxels: 32 >> depth
+        if ((int)e < 0) {
+            const uint32_t u = ((uint32_t)vx & 3u) | (((uint32_t)vy & 3u) << 2) | (((uint32_t)vz & 3u) << 4);
+            const uint32_t b = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(bb, (e + u) << 1, 0, 0);  // the shift drops bit 31
+            voxel = b & 0x7FFFu;
+            sz = 1u + (b >> 15);
+        }
+        if (STATS) R.visits += (uint32_t)__clz((int)sz) - 25u;  // depth + 1 node words on the reference's walk
+
+        bool liquid = false;
+        if (voxel != 0u) {
+            liquid = is_liquid(s_liquid, voxel);
+            if (!liquid) break;  // solid: the hit
+        }
+        if (liquid) {
+            if (dew == -1.0f) dew = total_len;
+        } else if (dew != -1.0f) {
+            R.water_dist += total_len - dew;
+            dew = -1.0f;
+        }
+
+        // ---- step to the leaf's exit face ----
+        const uint32_t lo = sz - 1u;
+        const float tx = (float)(int)(((lo & mxm) | (~lo & (uint32_t)vx)) + mx1) - pos.x;
+        const float ty = (float)(int)(((lo & mym) | (~lo & (uint32_t)vy)) + my1) - pos.y;
+        const float tz = (float)(int)(((lo & mzm) | (~lo & (uint32_t)vz)) + mz1) - pos.z;
+        adx = tx * sux;
+        ady = ty * suy;
+        adz = tz * suz;
+        const bool zx = adx == 0.0f, zy = ady == 0.0f, zz = adz == 0.0f;
+        step = min3_nan_ignoring(zx ? qnan : adx, zy ? qnan : ady, zz ? qnan : adz);
+        if (zx && zy && zz) step = adz;
+        total_len += step;
+        const float sp = step + 0.001f;
+        pos.x += dir.x * (step == adx ? sp : step);
+        pos.y += dir.y * (step == ady ? sp : step);
+        pos.z += dir.z * (step == adz ? sp : step);
+
+        vx = trunc2i(pos.x);
+        vy = trunc2i(pos.y);
+        vz = trunc2i(pos.z);
+        if (min3_nan_ignoring(pos.x, pos.y, pos.z) < 0.0f || max(max((uint32_t)vx, (uint32_t)vy), (uint32_t)vz) >= wsize) break;
+        if (iter >= kMaxSteps) break;
+    }
+    R.iters = iter;
+    if (dew != -1.0f) R.water_dist += total_len - dew;
+    // (i): a lane that left through a solid leaf or by exhaustion holds a position that passed this test
+    if (min3_nan_ignoring(pos.x, pos.y, pos.z) < 0.0f || max(max((uint32_t)vx, (uint32_t)vy), (uint32_t)vz) >= wsize) return R;
+    const bool stepped = iter > 1u || voxel == 0u || is_liquid(s_liquid, voxel);  // a step ran before the exit
+
+    R.hit = true;
+    R.pos = pos;
+    if (stepped)  // see march_literal: norm stays zero when no step was taken
+        R.norm = V3{(step == adx ? 1.0f : 0.0f) * -vsign(dir.x), (step == ady ? 1.0f : 0.0f) * -vsign(dir.y),
+                    (step == adz ? 1.0f : 0.0f) * -vsign(dir.z)};
+    R.voxel = voxel;
+    return R;
+}
+
+template <int MARCH, bool LDS_ROOTS, bool STATS = false>
 __device__ __forceinline__ MarchResult march(const FrameParams &P, const uint32_t *s_roots, const uint32_t *s_liquid,
                                              V3 origin, V3 dir) {
     if (MARCH == 1) return march_literal<LDS_ROOTS>(P, s_roots, s_liquid, origin, dir);
-    return march_fast<LDS_ROOTS>(P, s_roots, s_liquid, origin, dir);
+    if (MARCH == 2) return march_fast<LDS_ROOTS>(P, s_roots, s_liquid, origin, dir);
+    return march_grid<STATS>(P, s_liquid, origin, dir);
 }
 
 // ray_sky, ray_tracer.wgsl:144-157

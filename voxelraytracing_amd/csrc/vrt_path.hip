@@ -84,10 +84,10 @@ struct PathState {
 
 // One segment of a path (the body of ray_color's loop, path_tracer.wgsl:155-192). Returns true if the path
 // goes on (st updated to the next segment); adds a miss's sky light to `light`.
-template <bool LDS_ROOTS>
+template <int MARCH, bool LDS_ROOTS, bool STATS>
 __device__ __forceinline__ bool path_segment(const FrameParams &P, const uint32_t *s_roots, const uint32_t *s_liquid,
                                              PathState &st, MarchResult &R, V3 &light, bool &missed) {
-    R = march_fast<LDS_ROOTS>(P, s_roots, s_liquid, st.origin, st.dir);
+    R = march<MARCH, LDS_ROOTS, STATS>(P, s_roots, s_liquid, st.origin, st.dir);
     missed = !R.hit;
     if (!R.hit) {
         const V3 sky = ray_sky(P, st.origin, st.dir);
@@ -126,7 +126,7 @@ __device__ __forceinline__ void append_paths(const FrameParams &P, bool alive, c
 }
 
 // Bounce 0: primary rays of sample P.sample. Sample 0 initialises the texel {light, id}; later samples add.
-template <bool LDS_ROOTS, bool STATS>
+template <int MARCH, bool LDS_ROOTS, bool STATS>
 __global__ void __launch_bounds__(256) path_primary_kernel(FrameParams P) {
     extern __shared__ uint32_t smem[];
     uint32_t *s_liquid = smem, *s_roots = smem + 24;
@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(256) path_primary_kernel(FrameParams P) {
         const V3 o0 = st.origin, d0 = st.dir;
         V3 light{0.f, 0.f, 0.f};
         bool missed;
-        const bool alive = path_segment<LDS_ROOTS>(P, s_roots, s_liquid, st, R, light, missed) && !P.last_bounce;
+        const bool alive = path_segment<MARCH, LDS_ROOTS, STATS>(P, s_roots, s_liquid, st, R, light, missed) && !P.last_bounce;
         if (P.sample == 0u) {
             // the id word of the primary segment, composed as shade() does
             uint32_t id = R.voxel & VRT_ID_VOXEL_MASK;
@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(256) path_primary_kernel(FrameParams P) {
 }
 
 // Bounce b >= 1: lane = one live path of the in buffer.
-template <bool LDS_ROOTS, bool STATS>
+template <int MARCH, bool LDS_ROOTS, bool STATS>
 __global__ void __launch_bounds__(256) path_bounce_kernel(FrameParams P) {
     extern __shared__ uint32_t smem[];
     uint32_t *s_liquid = smem, *s_roots = smem + 24;
@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(256) path_bounce_kernel(FrameParams P) {
         st.thr = V3{__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z)};
         V3 light{0.f, 0.f, 0.f};
         bool missed;
-        alive = path_segment<LDS_ROOTS>(P, s_roots, s_liquid, st, R, light, missed) && !P.last_bounce;
+        alive = path_segment<MARCH, LDS_ROOTS, STATS>(P, s_roots, s_liquid, st, R, light, missed) && !P.last_bounce;
         if (missed) {
             uint4 t = P.out[st.slot];
             t.x = __float_as_uint(__uint_as_float(t.x) + light.x);
@@ -257,31 +257,38 @@ __global__ void path_finish_kernel(Texel *out, uint32_t n, float spp) {
 
 static size_t lds_bytes_path(const FrameParams &P, bool lds_roots) { return (24u + (lds_roots ? P.n_roots : 0u)) * 4u; }
 
+// The path trace marches with the grid march when the derived tables exist (P.grid), else with the ancestor-cache walk.
 void launch_path_primary(const FrameParams &P, bool stats, hipStream_t st) {
     if (P.tiles_local == 0) return;
     const dim3 grid((P.tiles_local + 3u) / 4u), block(256);
-    const bool lds = P.n_roots <= kLdsRootsMax;
+    const bool lds = !P.grid && P.n_roots <= kLdsRootsMax;
     const size_t sh = lds_bytes_path(P, lds);
-    if (lds) {
-        if (stats) hipLaunchKernelGGL((path_primary_kernel<true, true>), grid, block, sh, st, P);
-        else hipLaunchKernelGGL((path_primary_kernel<true, false>), grid, block, sh, st, P);
+    if (P.grid) {
+        if (stats) hipLaunchKernelGGL((path_primary_kernel<0, false, true>), grid, block, sh, st, P);
+        else hipLaunchKernelGGL((path_primary_kernel<0, false, false>), grid, block, sh, st, P);
+    } else if (lds) {
+        if (stats) hipLaunchKernelGGL((path_primary_kernel<2, true, true>), grid, block, sh, st, P);
+        else hipLaunchKernelGGL((path_primary_kernel<2, true, false>), grid, block, sh, st, P);
     } else {
-        if (stats) hipLaunchKernelGGL((path_primary_kernel<false, true>), grid, block, sh, st, P);
-        else hipLaunchKernelGGL((path_primary_kernel<false, false>), grid, block, sh, st, P);
+        if (stats) hipLaunchKernelGGL((path_primary_kernel<2, false, true>), grid, block, sh, st, P);
+        else hipLaunchKernelGGL((path_primary_kernel<2, false, false>), grid, block, sh, st, P);
     }
 }
 
 void launch_path_bounce(const FrameParams &P, bool stats, hipStream_t st) {
     if (P.tiles_local == 0) return;
     const dim3 grid(kHitSegments * (P.hit_seg_cap / 256u)), block(256);
-    const bool lds = P.n_roots <= kLdsRootsMax;
+    const bool lds = !P.grid && P.n_roots <= kLdsRootsMax;
     const size_t sh = lds_bytes_path(P, lds);
-    if (lds) {
-        if (stats) hipLaunchKernelGGL((path_bounce_kernel<true, true>), grid, block, sh, st, P);
-        else hipLaunchKernelGGL((path_bounce_kernel<true, false>), grid, block, sh, st, P);
+    if (P.grid) {
+        if (stats) hipLaunchKernelGGL((path_bounce_kernel<0, false, true>), grid, block, sh, st, P);
+        else hipLaunchKernelGGL((path_bounce_kernel<0, false, false>), grid, block, sh, st, P);
+    } else if (lds) {
+        if (stats) hipLaunchKernelGGL((path_bounce_kernel<2, true, true>), grid, block, sh, st, P);
+        else hipLaunchKernelGGL((path_bounce_kernel<2, true, false>), grid, block, sh, st, P);
     } else {
-        if (stats) hipLaunchKernelGGL((path_bounce_kernel<false, true>), grid, block, sh, st, P);
-        else hipLaunchKernelGGL((path_bounce_kernel<false, false>), grid, block, sh, st, P);
+        if (stats) hipLaunchKernelGGL((path_bounce_kernel<2, false, true>), grid, block, sh, st, P);
+        else hipLaunchKernelGGL((path_bounce_kernel<2, false, false>), grid, block, sh, st, P);
     }
 }
 

@@ -150,6 +150,12 @@ class Gpu:
         self._ck(self._lib.vrt_get_stats(self._h, C.byref(s)))
         return s
 
+    def accel_info(self) -> "_ffi.AccelInfo":
+        """The derived lookup tables of the default march (cell grid + brick pool); rebuilt lazily by render()."""
+        a = _ffi.AccelInfo()
+        self._ck(self._lib.vrt_get_accel_info(self._h, C.byref(a)))
+        return a
+
     # --- device plumbing for torch / RCCL ---
     def set_stream(self, hip_stream: int):
         self._ck(self._lib.vrt_set_stream(self._h, C.c_void_p(hip_stream)))
