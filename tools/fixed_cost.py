@@ -1,7 +1,8 @@
 """Fixed (non-march) cost of the primary kernel: frames where every ray stops immediately.
 Run under rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES to read VALU instructions per wave for each case."""
 import sys
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from voxelraytracing_amd import Gpu, MODE_PRIMARY_SHADOW, MODE_PRIMARY, graphics as g, scenes
 
 sc = scenes.c2()

@@ -87,6 +87,10 @@ struct vrt_ctx {
     float accel_last_ms = 0.f;
     std::vector<uint32_t> h_roots;  // what chunk_roots holds, to recognise the reference's per-frame rewrite of the same table
 
+    float *d_ndc = nullptr;       // ndc_x[width] then ndc_y[height] (FrameParams), rebuilt when proj_size or the output size change
+    uint32_t ndc_w = 0, ndc_h = 0;
+    float ndc_proj[2] = {0.f, 0.f};
+
     vrt_material h_mats[256];
     vrt_cam_data cam;
     vrt_settings settings;
@@ -314,7 +318,7 @@ void vrt_destroy(vrt_ctx *c) {
     (void)hipFree(c->d_hits); (void)hipFree(c->d_counters); (void)hipFree(c->d_steps); (void)hipFree(c->d_rgba8); (void)hipFree(c->d_path);
     (void)hipFree(c->d_blk_counts);
     (void)hipFree(c->d_grid); (void)hipFree(c->d_bricks); (void)hipFree(c->d_chunk_bricks); (void)hipFree(c->d_chunk_offsets);
-    (void)hipFree(c->d_brick_total);
+    (void)hipFree(c->d_brick_total); (void)hipFree(c->d_ndc);
     for (auto &t : c->ev_pool)
         for (auto &ev : t)
             if (ev) (void)hipEventDestroy(ev);
@@ -416,6 +420,45 @@ static int validate_frame(vrt_ctx *c) {
     return VRT_OK;
 }
 
+// Frame-uniform pieces of create_ray_from_screen (ray_tracer.wgsl:160-161): one IEEE divide per column and row
+// instead of two per pixel.  Same operations in the same order as the shader text, in binary32.
+static int ensure_ndc(vrt_ctx *c) {
+    if (c->d_ndc && c->ndc_w == c->width && c->ndc_h == c->height &&
+        memcmp(c->ndc_proj, c->cam.proj_size, sizeof c->ndc_proj) == 0)
+        return VRT_OK;
+    if (!c->d_ndc || c->ndc_w + c->ndc_h < c->width + c->height) {
+        (void)hipFree(c->d_ndc);
+        c->d_ndc = nullptr;
+        HIP_TRY(c, hipMalloc(&c->d_ndc, (size_t)(c->width + c->height) * sizeof(float)));
+    }
+    std::vector<float> t((size_t)c->width + c->height);
+    volatile float px = c->cam.proj_size[0], py = c->cam.proj_size[1];
+    for (uint32_t i = 0; i < c->width; i++) { volatile float q = ((float)(int)i * 2.0f) / px; t[i] = q - 1.0f; }
+    for (uint32_t i = 0; i < c->height; i++) { volatile float q = ((float)(int)i * 2.0f) / py; t[c->width + i] = q - 1.0f; }
+    HIP_TRY(c, hipMemcpyAsync(c->d_ndc, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->ndc_w = c->width;
+    c->ndc_h = c->height;
+    memcpy(c->ndc_proj, c->cam.proj_size, sizeof c->ndc_proj);
+    return VRT_OK;
+}
+
+// ray_sky's sun_dir for a ray starting at the camera (ray_tracer.wgsl:149, origin = cam.pos - world.min :169).
+static void cam_sun_dir(const vrt_ctx *c, float out[3]) {
+    volatile float d[3];
+    for (int k = 0; k < 3; k++) {
+        volatile float wm = (float)c->world.min[k];
+        volatile float origin = c->cam.pos[k] - wm;
+        volatile float a = c->settings.sun_pos[k] - wm;
+        d[k] = a - origin;
+    }
+    volatile float xx = d[0] * d[0], yy = d[1] * d[1], zz = d[2] * d[2];
+    volatile float s = xx + yy;
+    volatile float dot = s + zz;
+    volatile float len = sqrtf(dot);
+    for (int k = 0; k < 3; k++) { volatile float q = d[k] / len; out[k] = q; }
+}
+
 // Fold the event triples of all frames rendered since the last call into acc_ms (synchronises).
 static int fold_events(vrt_ctx *c, float last[3]) {
     if (c->ev_used == 0) return VRT_OK;
@@ -447,6 +490,8 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     HIP_TRY(c, hipSetDevice(c->device));
 
     if (o.stats && !c->d_steps) HIP_TRY(c, hipMalloc(&c->d_steps, (size_t)(c->slots ? c->slots : 1) * sizeof(uint32_t)));
+    rc = ensure_ndc(c);
+    if (rc) return rc;
     uint32_t variant = o.variant;
     if (variant == 0u || o.mode == VRT_MODE_PATH) {
         rc = ensure_accel(c);
@@ -493,6 +538,10 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
                         std::isfinite(s.sun_pos[2]);
     for (int v = 0; v < 256; v++)
         if (c->h_mats[v].is_liquid == 1u) P.liquid[v >> 5] |= 1u << (v & 31);
+
+    P.ndc_x = c->d_ndc;
+    P.ndc_y = c->d_ndc + c->width;
+    cam_sun_dir(c, P.cam_sun_dir);
 
     const bool shadow = o.mode == VRT_MODE_PRIMARY_SHADOW;
     if (c->ev_used == c->ev_pool.size()) {

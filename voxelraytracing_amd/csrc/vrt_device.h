@@ -56,6 +56,11 @@ struct FrameParams {
     vrt_settings settings;
     vrt_world_data world;
     uint32_t liquid[8];      // bit v set <=> materials[v].is_liquid == 1, v < 256
+    // frame-uniform subexpressions of the shader, evaluated once on the host in the same IEEE binary32 operations
+    // (the host half of vrt_backend.hip is built with -ffp-contract=off like the kernels):
+    const float *ndc_x;      // [width]  ((float)px * 2) / proj_size.x - 1        (create_ray_from_screen :160)
+    const float *ndc_y;      // [height] ((float)py * 2) / proj_size.y - 1        (:161)
+    float cam_sun_dir[3];    // normalize(sun_pos - world.min - (cam.pos - world.min)): ray_sky's sun_dir for primary rays (:149)
 };
 
 // The path-trace buffers are compacted per segment, not globally: one device-scope counter saturates at ~88

@@ -356,6 +356,18 @@ __device__ __forceinline__ float min3_nan_ignoring(float a, float b, float c) {
     return r;
 }
 
+__device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t uniform_b, uint32_t c) {
+    uint32_t r;  // a * b + c on 24-bit operands, b wave-uniform
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(uniform_b), "v"(c));
+    return r;
+}
+
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {
+    uint32_t r;  // (mask & a) | (~mask & b)
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
+    return r;
+}
+
 template <bool STATS>
 __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const uint32_t *s_liquid, V3 origin, V3 dir) {
     MarchResult R;
@@ -402,7 +414,7 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
     for (;;) {
         iter += 1u;
         // ---- find_node: cell, then brick ----
-        const uint32_t coff = __umul24((uint32_t)vz >> 2, slab_bytes) + (__umul24((uint32_t)vy >> 2, row_bytes) + ((uint32_t)vx & ~3u));
+        const uint32_t coff = mad_u24((uint32_t)vz >> 2, slab_bytes, mad_u24((uint32_t)vy >> 2, row_bytes, (uint32_t)vx & ~3u));
         const uint32_t e = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(gb, coff, 0, 0);
         voxel = e & 0x7FFFu;
         uint32_t sz = e >> 15;  // leaf size in voxels: 32 >> depth
@@ -428,9 +440,9 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
 
         // ---- step to the leaf's exit face ----
         const uint32_t lo = sz - 1u;
-        const float tx = (float)(int)(((lo & mxm) | (~lo & (uint32_t)vx)) + mx1) - pos.x;
-        const float ty = (float)(int)(((lo & mym) | (~lo & (uint32_t)vy)) + my1) - pos.y;
-        const float tz = (float)(int)(((lo & mzm) | (~lo & (uint32_t)vz)) + mz1) - pos.z;
+        const float tx = (float)(int)(bfi(lo, mxm, (uint32_t)vx) + mx1) - pos.x;
+        const float ty = (float)(int)(bfi(lo, mym, (uint32_t)vy) + my1) - pos.y;
+        const float tz = (float)(int)(bfi(lo, mzm, (uint32_t)vz) + mz1) - pos.z;
         adx = tx * sux;
         ady = ty * suy;
         adz = tz * suz;
@@ -473,14 +485,19 @@ __device__ __forceinline__ MarchResult march(const FrameParams &P, const uint32_
 }
 
 // ray_sky, ray_tracer.wgsl:144-157
+// CAM_ORIGIN: `origin` is the camera (a primary ray), whose sun direction the host evaluated once (P.cam_sun_dir).
+template <bool CAM_ORIGIN = false>
 __device__ __forceinline__ V3 ray_sky(const FrameParams &P, V3 origin, V3 dir) {
     const float ground_to_sky_t = vsmoothstep(-0.01f, 0.0f, dir.y);
-    const float sky_gradient_t = powf(vsmoothstep(0.0f, 0.4f, dir.y), 0.35f);
+    // pow(t, 0.35), t in [0, 1], as exp2(0.35 * log2 t) on the hardware transcendentals (what a GPU's WGSL pow is);
+    // nothing branches on it and it stays within 1e-6 of libm's (bar: 1e-4). ocml's powf is ~190 instructions.
+    const float sky_gradient_t = __builtin_amdgcn_exp2f(0.35f * __builtin_amdgcn_logf(vsmoothstep(0.0f, 0.4f, dir.y)));
     const V3 grad{vmix(1.0f, P.settings.sky_color[0], sky_gradient_t), vmix(0.3f, P.settings.sky_color[1], sky_gradient_t),
                   vmix(0.0f, P.settings.sky_color[2], sky_gradient_t)};
-    const V3 sun_dir = vnormalize(V3{P.settings.sun_pos[0] - (float)P.world.min[0] - origin.x,
-                                     P.settings.sun_pos[1] - (float)P.world.min[1] - origin.y,
-                                     P.settings.sun_pos[2] - (float)P.world.min[2] - origin.z});
+    const V3 sun_dir = CAM_ORIGIN ? V3{P.cam_sun_dir[0], P.cam_sun_dir[1], P.cam_sun_dir[2]}
+                                  : vnormalize(V3{P.settings.sun_pos[0] - (float)P.world.min[0] - origin.x,
+                                                  P.settings.sun_pos[1] - (float)P.world.min[1] - origin.y,
+                                                  P.settings.sun_pos[2] - (float)P.world.min[2] - origin.z});
     const float sun = (vdot(dir, sun_dir) > (1.0f - 0.01f) && ground_to_sky_t >= 1.0f) ? 1.0f : 0.0f;
     const float add = sun * P.settings.sun_intensity;
     return V3{vmix(0.03f, grad.x, ground_to_sky_t) + add, vmix(0.03f, grad.y, ground_to_sky_t) + add,
@@ -489,8 +506,8 @@ __device__ __forceinline__ V3 ray_sky(const FrameParams &P, V3 origin, V3 dir) {
 
 // create_ray_from_screen, ray_tracer.wgsl:159-171 (WGSL v*M = dot with the columns of M)
 __device__ __forceinline__ void create_ray(const FrameParams &P, int sx, int sy, V3 &origin, V3 &dir) {
-    const float x = ((float)sx * 2.0f) / P.cam.proj_size[0] - 1.0f;
-    const float y = ((float)sy * 2.0f) / P.cam.proj_size[1] - 1.0f;
+    const float x = P.ndc_x[sx];  // ((float)sx * 2.0f) / P.cam.proj_size[0] - 1.0f, tabulated per frame
+    const float y = P.ndc_y[sy];  // ((float)sy * 2.0f) / P.cam.proj_size[1] - 1.0f
     const float c0 = x, c1 = -y, c2 = -1.0f, c3 = 1.0f;
     const float *ip = P.cam.inv_proj_mat;
     const float e0 = c0 * ip[0] + c1 * ip[1] + c2 * ip[2] + c3 * ip[3];
@@ -507,6 +524,7 @@ __device__ __forceinline__ void create_ray(const FrameParams &P, int sx, int sy,
 // Face shading + ray_color + overlay, ray_tracer.wgsl:127-142, 296-314. Returns the id word.
 // `color = vox*f32(hit) + sky*f32(!hit)` (:135): with finite settings the sky term of a hit is a zero and
 // the material term of a miss is a zero, so only one side is evaluated (exact up to the sign of a zero).
+// Primary rays only (the sky's origin is the camera).
 template <bool EXACT_SKY>
 __device__ __forceinline__ uint32_t shade(const FrameParams &P, const MarchResult &R, V3 origin, V3 dir, V3 &color) {
     V3 mc{0.f, 0.f, 0.f};
@@ -522,13 +540,13 @@ __device__ __forceinline__ uint32_t shade(const FrameParams &P, const MarchResul
         }
     }
     if (EXACT_SKY || !P.finite_settings) {
-        const V3 sky = ray_sky(P, origin, dir);
+        const V3 sky = ray_sky<true>(P, origin, dir);
         const float fh = R.hit ? 1.0f : 0.0f, fm = R.hit ? 0.0f : 1.0f;
         color = V3{mc.x * fh + sky.x * fm, mc.y * fh + sky.y * fm, mc.z * fh + sky.z * fm};
     } else if (R.hit) {
         color = mc;
     } else {
-        color = ray_sky(P, origin, dir);
+        color = ray_sky<true>(P, origin, dir);
     }
     if (R.water_dist != 0.0f) {
         const float factor = vclamp(R.water_dist / 14.0f, 0.8f, 1.0f);
