@@ -198,6 +198,11 @@ typedef struct {
 } vrt_accel_info;
 int vrt_get_accel_info(vrt_ctx *ctx, vrt_accel_info *out);
 
+/* Copy the tables to host memory for inspection (synchronises): grid[cells] entries, x-major over the whole world
+ * (leaf: voxel | leaf_size << 15; split depth-3 cell: 0x80000000 | brick * 64), bricks[bricks * 64] entries
+ * ((x&3) | (y&3) << 2 | (z&3) << 4 inside the cell; voxel | 0x8000 for a size-2 leaf).  Either pointer may be NULL. */
+int vrt_read_accel(vrt_ctx *ctx, uint32_t *grid, uint16_t *bricks);
+
 /* Per-pixel march-loop iteration counts of the last frame (primary | shadow << 16); the frame must
  * have been rendered with opts.stats = 1.  Numeric twin of the reference's F2 step-count heat-map
  * (main.rs:368-370, ray_tracer.wgsl:311-314). */

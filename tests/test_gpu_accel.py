@@ -1,0 +1,143 @@
+"""The default march's derived lookup tables (cell grid + brick pool, csrc/vrt_accel.hip) against the octree they
+are derived from: every voxel of the world must resolve to the node word and depth the reference's walk
+(find_node / find_chunk_node, ray_tracer.wgsl:76-125) finds — checked here with an independent numpy walk of
+the host pool — plus the rebuild bookkeeping and the fallback for worlds too large for the tables.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from voxelraytracing_amd import MODE_PRIMARY_SHADOW, scenes
+
+from util import assert_frame_parity, gpu_for_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def walk_octree(nodes: np.ndarray, roots: np.ndarray, S: int):
+    """(voxel, depth) of the leaf under every voxel of the world, arrays [z, y, x]: the reference's descent, vectorised."""
+    n = S * 32
+    z, y, x = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
+    root = roots[(x >> 5) + (y >> 5) * S + (z >> 5) * S * S].astype(np.int64)
+    pool = np.concatenate([nodes.astype(np.int64), np.zeros(1, np.int64)])   # a read past the end is 0
+    rd = lambda i: pool[np.minimum(i, len(nodes))]  # noqa: E731
+    node = rd(root)
+    depth = np.zeros_like(node)
+    for d in range(5):
+        go = ((node & 0x8000) != 0) & (depth == d)
+        sh = 4 - d
+        sel = ((x >> sh) & 1) | (((y >> sh) & 1) << 1) | (((z >> sh) & 1) << 2)
+        child = rd(root + (node & 0x7FFF) + sel)
+        node = np.where(go, child, node)
+        depth = np.where(go, d + 1, depth)
+    return (node & 0x7FFF).astype(np.uint32), depth.astype(np.uint32)
+
+
+def lookup_tables(grid: np.ndarray, bricks: np.ndarray, S: int):
+    """What the grid march reads for every voxel: (voxel, leaf size)."""
+    n = S * 32
+    z, y, x = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
+    e = grid[z >> 2, y >> 2, x >> 2]
+    is_brick = (e & 0x80000000) != 0
+    voxel = e & 0x7FFF
+    size = (e >> 15) & 0xFFFF
+    if is_brick.any():
+        assert ((e[is_brick] & 0x3F) == 0).all()
+        b = (e[is_brick] & 0x7FFFFFFF) >> 6
+        assert b.max() < len(bricks)
+        w = bricks[b, (x[is_brick] & 3) | ((y[is_brick] & 3) << 2) | ((z[is_brick] & 3) << 4)].astype(np.uint32)
+        voxel[is_brick] = w & 0x7FFF
+        size[is_brick] = 1 + (w >> 15)
+    return voxel, size
+
+
+def check_tables(gpu, world):
+    S = world.size_in_chunks()
+    grid, bricks = gpu.read_accel()
+    v_ref, d_ref = walk_octree(world.nodes(), world.chunk_roots(), S)
+    v, size = lookup_tables(grid, bricks, S)
+    assert np.array_equal(v, v_ref)
+    assert np.array_equal(size, 32 >> d_ref)
+    return grid, bricks
+
+
+def test_tables_equal_the_octree_walk_for_every_voxel():
+    sc = scenes.c1_flat((64, 64))   # 2^3 chunks: 262 144 voxels, Superflat built by set_node
+    gpu = gpu_for_scene(sc)
+    gpu.render(MODE_PRIMARY_SHADOW)
+    a = gpu.accel_info()
+    assert (a.available, a.world_size_chunks, a.cells, a.builds) == (1, 2, 16 ** 3, 1)
+    assert a.bytes == a.cells * 4 + a.bricks * 128 and a.bricks > 0
+    grid, bricks = check_tables(gpu, sc.world)
+    assert len(bricks) == a.bricks
+    # bricks are laid out per chunk, cells in x-major order: the pool positions are 0, 64, 128, ... in that order
+    order = []
+    for chunk in range(8):
+        cx, cy, cz = chunk % 2, (chunk // 2) % 2, chunk // 4
+        sub = grid[cz * 8:(cz + 1) * 8, cy * 8:(cy + 1) * 8, cx * 8:(cx + 1) * 8].reshape(-1)
+        order += [int(e & 0x7FFFFFFF) for e in sub if e & 0x80000000]
+    assert order == [64 * i for i in range(len(order))]
+
+
+def test_tables_follow_edits_and_skip_identical_root_rewrites(orc):
+    sc = scenes.c1_flat((128, 128))
+    gpu = gpu_for_scene(sc)
+    gpu.render(MODE_PRIMARY_SHADOW)
+    assert gpu.accel_info().builds == 1
+    # the reference rewrites chunk_roots every frame (main.rs:446): identical contents must not trigger a rebuild
+    gpu.write_chunk_roots(sc.world.chunk_roots())
+    gpu.render(MODE_PRIMARY_SHADOW)
+    assert gpu.accel_info().builds == 1
+    # a voxel edit re-uploads the chunk's range: the tables are stale until the next frame, then rebuilt once
+    for pos, v in [((32, 12, 40), 0), ((30, 13, 44), 4), ((34, 13, 44), 3), ((33, 14, 41), 62)]:
+        start, n = sc.world.set_voxel(pos, v)
+        gpu.write_nodes(sc.world.nodes_ptr(), start, start + n)
+    assert gpu.accel_info().available == 0
+    gpu.render(MODE_PRIMARY_SHADOW)
+    a = gpu.accel_info()
+    assert (a.available, a.builds) == (1, 2)
+    check_tables(gpu, sc.world)
+    rgb, ids, _ = gpu.read_output()
+    r_rgb, r_ids, _, _ = orc.from_package_scene(sc).render(MODE_PRIMARY_SHADOW, 128, 128)
+    assert_frame_parity(rgb, ids, r_rgb, r_ids, "after edits")
+    # all three marches agree bit for bit on the edited world
+    for variant in (1, 2):
+        gpu.render(MODE_PRIMARY_SHADOW, variant=variant)
+        _, ids_v, _ = gpu.read_output()
+        assert np.array_equal(ids_v, ids)
+    assert gpu.accel_info().builds == 2
+    # moving a chunk root (here: dropping one chunk) is a real change
+    roots = sc.world.chunk_roots().copy()
+    roots[0] = 0
+    gpu.write_chunk_roots(roots)
+    gpu.render(MODE_PRIMARY_SHADOW)
+    assert gpu.accel_info().builds == 3
+    grid, _ = gpu.read_accel()
+    assert (grid[:8, :8, :8] == (32 << 15)).all()   # the dropped chunk is one 32^3 air leaf
+
+
+def test_procedural_world_tables_and_shrinking_world(orc):
+    sc = scenes.procedural(4, (160, 96), MODE_PRIMARY_SHADOW)   # 4^3 chunks = 2 M voxels
+    gpu = gpu_for_scene(sc)
+    gpu.render(MODE_PRIMARY_SHADOW)
+    check_tables(gpu, sc.world)
+    a = gpu.accel_info()
+    assert a.cells == 32 ** 3 and a.last_build_ms > 0.0
+
+
+def test_world_too_large_for_the_tables_walks_the_octree(orc, monkeypatch):
+    """Past kAccelMaxS (here forced down to 1) variant 0 runs the ancestor-cache walk; same frame."""
+    sc = scenes.c1_flat((128, 128))
+    monkeypatch.setenv("VRT_ACCEL_MAX_S", "1")
+    gpu = gpu_for_scene(sc)
+    monkeypatch.delenv("VRT_ACCEL_MAX_S")
+    gpu.render(MODE_PRIMARY_SHADOW, stats=True)
+    a = gpu.accel_info()
+    assert (a.available, a.builds) == (0, 0)
+    rgb, ids, _ = gpu.read_output()
+    r_rgb, r_ids, r_steps, st = orc.from_package_scene(sc).render(MODE_PRIMARY_SHADOW, 128, 128, want_steps=True)
+    assert_frame_parity(rgb, ids, r_rgb, r_ids, "fallback")
+    assert np.array_equal(gpu.read_steps(), r_steps) and gpu.stats().node_visits == st.node_visits
+    with pytest.raises(Exception):
+        gpu.read_accel()

@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -83,6 +84,7 @@ struct vrt_ctx {
     uint32_t accel_S = 0;         // world size the tables were built for
     bool accel_dirty = true;
     bool accel_ok = false;        // false: world too large for the tables, variant 0 runs as variant 2
+    uint32_t accel_max_s = 0;     // kAccelMaxS, or less through VRT_ACCEL_MAX_S (tests of the fallback)
     uint32_t accel_builds = 0;
     float accel_last_ms = 0.f;
     std::vector<uint32_t> h_roots;  // what chunk_roots holds, to recognise the reference's per-frame rewrite of the same table
@@ -186,7 +188,7 @@ static int ensure_accel(vrt_ctx *c) {
     c->accel_ok = false;
     c->accel_S = S;
     c->accel_dirty = false;
-    if (S > kAccelMaxS) return VRT_OK;
+    if (S > c->accel_max_s) return VRT_OK;
     const uint32_t n_chunks = S * S * S;
     const size_t cells = (size_t)n_chunks * 512u;
     if (cells > c->grid_cap) {
@@ -276,6 +278,11 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     c->width = cfg->width;
     c->height = cfg->height;
     c->max_nodes = cfg->max_nodes & ~1u;  // NodeBuffer::new forces an even size (shader.rs:10-12)
+    c->accel_max_s = kAccelMaxS;
+    if (const char *e = getenv("VRT_ACCEL_MAX_S")) {
+        const long v = strtol(e, nullptr, 10);
+        if (v >= 0 && v < (long)kAccelMaxS) c->accel_max_s = (uint32_t)v;
+    }
     memset(c->h_mats, 0, sizeof c->h_mats);
     memset(&c->cam, 0, sizeof c->cam);
     memset(&c->settings, 0, sizeof c->settings);
@@ -555,7 +562,8 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
         }
     }
     auto &ev = c->ev_pool[c->ev_used++];
-    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, kCounterBytes, c->stream));
+    // the counters feed stats frames and the path trace's segment cursors; a plain primary(+shadow) frame reads none
+    if (o.stats || o.mode == VRT_MODE_PATH) HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, kCounterBytes, c->stream));
     if (o.mode == VRT_MODE_PATH) {
         // wavefront path trace: per sample one launch per bounce over the compacted live-path buffer
         const uint32_t spp = o.spp ? o.spp : 1u, bounces = c->settings.max_ray_bounces;
@@ -720,6 +728,18 @@ int vrt_get_accel_info(vrt_ctx *c, vrt_accel_info *out) {
     out->bytes = out->cells * sizeof(uint32_t) + (uint64_t)c->n_bricks * 64u * sizeof(uint16_t);
     out->builds = c->accel_builds;
     out->last_build_ms = c->accel_last_ms;
+    return VRT_OK;
+}
+
+int vrt_read_accel(vrt_ctx *c, uint32_t *grid, uint16_t *bricks) {
+    if (!c) return VRT_ERR_INVALID_ARG;
+    if (!c->accel_ok || c->accel_dirty) return fail(c, VRT_ERR_STATE, "vrt_read_accel: the tables are not built (render a frame first)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t cells = (size_t)c->accel_S * c->accel_S * c->accel_S * 512u;
+    if (grid) HIP_TRY(c, hipMemcpyAsync(grid, c->d_grid, cells * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    if (bricks && c->n_bricks)
+        HIP_TRY(c, hipMemcpyAsync(bricks, c->d_bricks, (size_t)c->n_bricks * 64u * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return VRT_OK;
 }
 

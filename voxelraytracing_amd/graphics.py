@@ -156,6 +156,15 @@ class Gpu:
         self._ck(self._lib.vrt_get_accel_info(self._h, C.byref(a)))
         return a
 
+    def read_accel(self):
+        """(grid[G,G,G] indexed [z,y,x], bricks[n,64]) as built on the device — see vrt_read_accel in include/vrt.h."""
+        a = self.accel_info()
+        g = a.world_size_chunks * 8
+        grid = np.empty((g, g, g), dtype=np.uint32)
+        bricks = np.empty((int(a.bricks), 64), dtype=np.uint16)
+        self._ck(self._lib.vrt_read_accel(self._h, grid.ctypes.data_as(C.c_void_p), bricks.ctypes.data_as(C.c_void_p)))
+        return grid, bricks
+
     # --- device plumbing for torch / RCCL ---
     def set_stream(self, hip_stream: int):
         self._ck(self._lib.vrt_set_stream(self._h, C.c_void_p(hip_stream)))
