@@ -59,7 +59,7 @@ def test_oracle_is_thread_count_independent(orc):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("name", list(CASES))
 def test_gpu_matches_golden(name, variant):
     g, sc = _load(name), CASES[name]()

@@ -23,7 +23,7 @@ def c2_small():
     return scenes.c2((640, 360))
 
 
-VARIANTS = [0, 1, 2]  # 0 = grid march over the derived tables (default), 1 = literal octree walk, 2 = ancestor-cache octree walk
+VARIANTS = [0, 1, 2, 3]  # 0 = grid march, primary+shadow fused (default); 1 = literal octree walk; 2 = ancestor-cache octree walk; 3 = grid march, two launches
 
 
 @pytest.mark.parametrize("variant", VARIANTS)

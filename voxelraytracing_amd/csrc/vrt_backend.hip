@@ -23,6 +23,7 @@ namespace vrt {
 bool variant_supported(uint32_t variant);
 void launch_primary(const FrameParams &P, uint32_t variant, bool stats, bool shadow, hipStream_t st);
 void launch_shadow(const FrameParams &P, uint32_t variant, bool stats, hipStream_t st);
+void launch_primary_shadow_fused(const FrameParams &P, bool stats, hipStream_t st);
 void launch_path_primary(const FrameParams &P, bool stats, hipStream_t st);
 void launch_path_bounce(const FrameParams &P, bool stats, hipStream_t st);
 void launch_path_finish(Texel *out, uint32_t n, uint32_t spp, hipStream_t st);
@@ -47,6 +48,7 @@ struct vrt_ctx {
     hipStream_t stream = nullptr;
     // one hipEvent triple {start, after primary, end} per frame rendered since the last vrt_get_stats
     std::vector<std::array<hipEvent_t, 3>> ev_pool;
+    std::vector<uint8_t> ev_single;  // the frame was one launch: only events 0 and 1 were recorded
     size_t ev_used = 0;
     double acc_ms[3] = {0, 0, 0};
     uint32_t acc_frames = 0;
@@ -469,13 +471,17 @@ static void cam_sun_dir(const vrt_ctx *c, float out[3]) {
 // Fold the event triples of all frames rendered since the last call into acc_ms (synchronises).
 static int fold_events(vrt_ctx *c, float last[3]) {
     if (c->ev_used == 0) return VRT_OK;
-    HIP_TRY(c, hipEventSynchronize(c->ev_pool[c->ev_used - 1][2]));
+    HIP_TRY(c, hipEventSynchronize(c->ev_pool[c->ev_used - 1][c->ev_single[c->ev_used - 1] ? 1 : 2]));
     for (size_t i = 0; i < c->ev_used; i++) {
         auto &t = c->ev_pool[i];
         float a = 0, b = 0, tot = 0;
         HIP_TRY(c, hipEventElapsedTime(&a, t[0], t[1]));
-        HIP_TRY(c, hipEventElapsedTime(&b, t[1], t[2]));
-        HIP_TRY(c, hipEventElapsedTime(&tot, t[0], t[2]));
+        if (c->ev_single[i]) {
+            tot = a;
+        } else {
+            HIP_TRY(c, hipEventElapsedTime(&b, t[1], t[2]));
+            HIP_TRY(c, hipEventElapsedTime(&tot, t[0], t[2]));
+        }
         c->acc_ms[0] += a; c->acc_ms[1] += b; c->acc_ms[2] += tot;
         c->acc_frames += 1;
         if (last) { last[0] = a; last[1] = b; last[2] = tot; }
@@ -500,10 +506,10 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     rc = ensure_ndc(c);
     if (rc) return rc;
     uint32_t variant = o.variant;
-    if (variant == 0u || o.mode == VRT_MODE_PATH) {
+    if (variant == 0u || variant == 3u || o.mode == VRT_MODE_PATH) {
         rc = ensure_accel(c);
         if (rc) return rc;
-        if (!c->accel_ok && variant == 0u) variant = 2u;  // world too large for the tables: walk the octree
+        if (!c->accel_ok && (variant == 0u || variant == 3u)) variant = 2u;  // world too large for the tables: walk the octree
     }
 
     vrt::FrameParams P;
@@ -559,8 +565,10 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
             std::array<hipEvent_t, 3> t{nullptr, nullptr, nullptr};
             for (auto &ev : t) HIP_TRY(c, hipEventCreate(&ev));
             c->ev_pool.push_back(t);
+            c->ev_single.push_back(0);
         }
     }
+    c->ev_single[c->ev_used] = 0;
     auto &ev = c->ev_pool[c->ev_used++];
     // the counters feed stats frames and the path trace's segment cursors; a plain primary(+shadow) frame reads none
     if (o.stats || o.mode == VRT_MODE_PATH) HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, kCounterBytes, c->stream));
@@ -601,14 +609,17 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
         c->last_spp = spp;
     } else {
         HIP_TRY(c, hipEventRecord(ev[0], c->stream));
-        vrt::launch_primary(P, variant, o.stats != 0, shadow, c->stream);
+        const bool fused = shadow && variant == 0u;  // primary + shadow in one launch, hit records in LDS
+        if (fused) vrt::launch_primary_shadow_fused(P, o.stats != 0, c->stream);
+        else vrt::launch_primary(P, variant == 3u ? 0u : variant, o.stats != 0, shadow, c->stream);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipEventRecord(ev[1], c->stream));
-        if (shadow) {
-            vrt::launch_shadow(P, variant, o.stats != 0, c->stream);
+        if (shadow && !fused) {
+            vrt::launch_shadow(P, variant == 3u ? 0u : variant, o.stats != 0, c->stream);
             HIP_TRY(c, hipGetLastError());
         }
-        HIP_TRY(c, hipEventRecord(ev[2], c->stream));
+        if (shadow && !fused) HIP_TRY(c, hipEventRecord(ev[2], c->stream));
+        else c->ev_single[c->ev_used - 1] = 1;
     }
     c->rendered = true;
     c->last_stats = o.stats != 0;
