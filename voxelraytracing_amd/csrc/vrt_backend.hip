@@ -557,6 +557,9 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     cam_sun_dir(c, P.cam_sun_dir);
 
     const bool shadow = o.mode == VRT_MODE_PRIMARY_SHADOW;
+    // per-lane iteration counts exist in the STATS kernels only; the step-count debug view (F2 in the reference,
+    // main.rs:368-370) needs them, so it runs those kernels too
+    const bool kstats = o.stats != 0 || c->settings.show_step_count == 1u;
     if (c->ev_used == c->ev_pool.size()) {
         if (c->ev_pool.size() >= 1024) {
             rc = fold_events(c, nullptr);
@@ -571,7 +574,7 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     c->ev_single[c->ev_used] = 0;
     auto &ev = c->ev_pool[c->ev_used++];
     // the counters feed stats frames and the path trace's segment cursors; a plain primary(+shadow) frame reads none
-    if (o.stats || o.mode == VRT_MODE_PATH) HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, kCounterBytes, c->stream));
+    if (kstats || o.mode == VRT_MODE_PATH) HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, kCounterBytes, c->stream));
     if (o.mode == VRT_MODE_PATH) {
         // wavefront path trace: per sample one launch per bounce over the compacted live-path buffer
         const uint32_t spp = o.spp ? o.spp : 1u, bounces = c->settings.max_ray_bounces;
@@ -594,8 +597,8 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
                 P.seg_in = seg[(b + 1) & 1];
                 P.path_in = buf[(b + 1) & 1];
                 P.last_bounce = b + 1 == bounces;
-                if (b == 0) vrt::launch_path_primary(P, o.stats != 0, c->stream);
-                else vrt::launch_path_bounce(P, o.stats != 0, c->stream);
+                if (b == 0) vrt::launch_path_primary(P, kstats, c->stream);
+                else vrt::launch_path_bounce(P, kstats, c->stream);
                 HIP_TRY(c, hipGetLastError());
                 if (first) { HIP_TRY(c, hipEventRecord(ev[1], c->stream)); first = false; }
             }
@@ -610,12 +613,12 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     } else {
         HIP_TRY(c, hipEventRecord(ev[0], c->stream));
         const bool fused = shadow && variant == 0u;  // primary + shadow in one launch, hit records in LDS
-        if (fused) vrt::launch_primary_shadow_fused(P, o.stats != 0, c->stream);
-        else vrt::launch_primary(P, variant == 3u ? 0u : variant, o.stats != 0, shadow, c->stream);
+        if (fused) vrt::launch_primary_shadow_fused(P, kstats, c->stream);
+        else vrt::launch_primary(P, variant == 3u ? 0u : variant, kstats, shadow, c->stream);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipEventRecord(ev[1], c->stream));
         if (shadow && !fused) {
-            vrt::launch_shadow(P, variant == 3u ? 0u : variant, o.stats != 0, c->stream);
+            vrt::launch_shadow(P, variant == 3u ? 0u : variant, kstats, c->stream);
             HIP_TRY(c, hipGetLastError());
         }
         if (shadow && !fused) HIP_TRY(c, hipEventRecord(ev[2], c->stream));

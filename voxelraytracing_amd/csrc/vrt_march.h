@@ -406,7 +406,8 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
 
     int vx = trunc2i(pos.x), vy = trunc2i(pos.y), vz = trunc2i(pos.z);  // pos > 0 here (or NaN -> 0)
     uint32_t voxel = 0u;
-    float step = 0.0f, adx = 0.0f, ady = 0.0f, adz = 0.0f;  // operands of the last step taken
+    // operands of the last step taken; a step is never negative, so -1 says "none yet" (the normal then stays zero, :272)
+    float step = -1.0f, adx = 0.0f, ady = 0.0f, adz = 0.0f;
     float dew = -1.0f;  // dist_entered_water
     float total_len = 0.0f;
     uint32_t iter = 0u;
@@ -461,11 +462,13 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
         if (min3_nan_ignoring(pos.x, pos.y, pos.z) < 0.0f || max(max((uint32_t)vx, (uint32_t)vy), (uint32_t)vz) >= wsize) break;
         if (iter >= kMaxSteps) break;
     }
-    R.iters = iter;
+    // per-lane iteration counts are kept by the STATS kernels only (counters, step-count debug view); without them
+    // `iter` is one scalar loop counter per wave
+    R.iters = STATS ? iter : 0u;
     if (dew != -1.0f) R.water_dist += total_len - dew;
     // (i): a lane that left through a solid leaf or by exhaustion holds a position that passed this test
     if (min3_nan_ignoring(pos.x, pos.y, pos.z) < 0.0f || max(max((uint32_t)vx, (uint32_t)vy), (uint32_t)vz) >= wsize) return R;
-    const bool stepped = iter > 1u || voxel == 0u || is_liquid(s_liquid, voxel);  // a step ran before the exit
+    const bool stepped = step != -1.0f;
 
     R.hit = true;
     R.pos = pos;
