@@ -21,9 +21,9 @@
 
 namespace vrt {
 bool variant_supported(uint32_t variant);
-void launch_primary(const FrameParams &P, uint32_t variant, bool stats, bool shadow, hipStream_t st);
-void launch_shadow(const FrameParams &P, uint32_t variant, bool stats, hipStream_t st);
-void launch_primary_shadow_fused(const FrameParams &P, bool stats, hipStream_t st);
+void launch_primary(const FrameParams &P, uint32_t variant, bool stats, bool shadow, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
+void launch_shadow(const FrameParams &P, uint32_t variant, bool stats, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
+void launch_primary_shadow_fused(const FrameParams &P, bool stats, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
 void launch_path_primary(const FrameParams &P, bool stats, hipStream_t st);
 void launch_path_bounce(const FrameParams &P, bool stats, hipStream_t st);
 void launch_path_finish(Texel *out, uint32_t n, uint32_t spp, hipStream_t st);
@@ -46,9 +46,11 @@ struct vrt_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    // one hipEvent triple {start, after primary, end} per frame rendered since the last vrt_get_stats
-    std::vector<std::array<hipEvent_t, 3>> ev_pool;
-    std::vector<uint8_t> ev_single;  // the frame was one launch: only events 0 and 1 were recorded
+    // four hipEvents per frame rendered since the last vrt_get_stats.  Primary(+shadow) frames: {begin, end} of the first
+    // kernel and {begin, end} of the second, stamped by the dispatches themselves (hipExtLaunchKernel), so the stream
+    // carries no marker packets between frames.  Path frames: [0], [1], [3] recorded around the launches.
+    std::vector<std::array<hipEvent_t, 4>> ev_pool;
+    std::vector<uint8_t> ev_kind;  // EvKind
     size_t ev_used = 0;
     double acc_ms[3] = {0, 0, 0};
     uint32_t acc_frames = 0;
@@ -112,6 +114,8 @@ struct vrt_ctx {
 
 static constexpr size_t kSegBytes = (size_t)vrt::kHitSegments * vrt::kSegStride * sizeof(uint32_t);
 static constexpr size_t kCounterBytes = vrt::kCtrCount * sizeof(unsigned long long) + 2 * kSegBytes;  // two counter sets (path ping-pong)
+
+enum EvKind : uint8_t { kEvNone = 0, kEvOneKernel = 1, kEvTwoKernels = 2, kEvRecorded = 3 };
 
 static thread_local std::string g_create_err;
 
@@ -471,16 +475,27 @@ static void cam_sun_dir(const vrt_ctx *c, float out[3]) {
 // Fold the event triples of all frames rendered since the last call into acc_ms (synchronises).
 static int fold_events(vrt_ctx *c, float last[3]) {
     if (c->ev_used == 0) return VRT_OK;
-    HIP_TRY(c, hipEventSynchronize(c->ev_pool[c->ev_used - 1][c->ev_single[c->ev_used - 1] ? 1 : 2]));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (size_t i = 0; i < c->ev_used; i++) {
         auto &t = c->ev_pool[i];
         float a = 0, b = 0, tot = 0;
-        HIP_TRY(c, hipEventElapsedTime(&a, t[0], t[1]));
-        if (c->ev_single[i]) {
-            tot = a;
-        } else {
-            HIP_TRY(c, hipEventElapsedTime(&b, t[1], t[2]));
-            HIP_TRY(c, hipEventElapsedTime(&tot, t[0], t[2]));
+        switch (c->ev_kind[i]) {
+            case kEvOneKernel:
+                HIP_TRY(c, hipEventElapsedTime(&a, t[0], t[1]));
+                tot = a;
+                break;
+            case kEvTwoKernels:
+                HIP_TRY(c, hipEventElapsedTime(&a, t[0], t[1]));
+                HIP_TRY(c, hipEventElapsedTime(&b, t[2], t[3]));
+                HIP_TRY(c, hipEventElapsedTime(&tot, t[0], t[3]));
+                break;
+            case kEvRecorded:
+                HIP_TRY(c, hipEventElapsedTime(&a, t[0], t[1]));
+                HIP_TRY(c, hipEventElapsedTime(&b, t[1], t[3]));
+                HIP_TRY(c, hipEventElapsedTime(&tot, t[0], t[3]));
+                break;
+            default:
+                continue;  // an empty shard: nothing was launched
         }
         c->acc_ms[0] += a; c->acc_ms[1] += b; c->acc_ms[2] += tot;
         c->acc_frames += 1;
@@ -565,13 +580,14 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
             rc = fold_events(c, nullptr);
             if (rc) return rc;
         } else {
-            std::array<hipEvent_t, 3> t{nullptr, nullptr, nullptr};
+            std::array<hipEvent_t, 4> t{nullptr, nullptr, nullptr, nullptr};
             for (auto &ev : t) HIP_TRY(c, hipEventCreate(&ev));
             c->ev_pool.push_back(t);
-            c->ev_single.push_back(0);
+            c->ev_kind.push_back(kEvNone);
         }
     }
-    c->ev_single[c->ev_used] = 0;
+    uint8_t &ev_kind = c->ev_kind[c->ev_used];
+    ev_kind = kEvNone;
     auto &ev = c->ev_pool[c->ev_used++];
     // the counters feed stats frames and the path trace's segment cursors; a plain primary(+shadow) frame reads none
     if (kstats || o.mode == VRT_MODE_PATH) HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, kCounterBytes, c->stream));
@@ -608,21 +624,22 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
             vrt::launch_path_finish(c->d_out, c->slots, spp, c->stream);
             HIP_TRY(c, hipGetLastError());
         }
-        HIP_TRY(c, hipEventRecord(ev[2], c->stream));
+        HIP_TRY(c, hipEventRecord(ev[3], c->stream));
+        ev_kind = kEvRecorded;
         c->last_spp = spp;
     } else {
-        HIP_TRY(c, hipEventRecord(ev[0], c->stream));
         const bool fused = shadow && variant == 0u;  // primary + shadow in one launch, hit records in LDS
-        if (fused) vrt::launch_primary_shadow_fused(P, kstats, c->stream);
-        else vrt::launch_primary(P, variant == 3u ? 0u : variant, kstats, shadow, c->stream);
-        HIP_TRY(c, hipGetLastError());
-        HIP_TRY(c, hipEventRecord(ev[1], c->stream));
-        if (shadow && !fused) {
-            vrt::launch_shadow(P, variant == 3u ? 0u : variant, kstats, c->stream);
+        if (c->tiles_local) {
+            if (fused) vrt::launch_primary_shadow_fused(P, kstats, c->stream, ev[0], ev[1]);
+            else vrt::launch_primary(P, variant == 3u ? 0u : variant, kstats, shadow, c->stream, ev[0], ev[1]);
             HIP_TRY(c, hipGetLastError());
+            ev_kind = kEvOneKernel;
+            if (shadow && !fused) {
+                vrt::launch_shadow(P, variant == 3u ? 0u : variant, kstats, c->stream, ev[2], ev[3]);
+                HIP_TRY(c, hipGetLastError());
+                ev_kind = kEvTwoKernels;
+            }
         }
-        if (shadow && !fused) HIP_TRY(c, hipEventRecord(ev[2], c->stream));
-        else c->ev_single[c->ev_used - 1] = 1;
     }
     c->rendered = true;
     c->last_stats = o.stats != 0;

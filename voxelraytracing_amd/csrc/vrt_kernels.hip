@@ -13,6 +13,8 @@
 //   * the step arithmetic is branch-free and algebraically reduced where the reduction is bit-exact;
 //   * chunk roots and the 256-bit liquid mask are staged in LDS; secondary rays are launched from a
 //     wave-compacted hit buffer; one 16-byte texel {r,g,b,id} per pixel so a wave stores 1 KiB contiguously.
+#include <hip/hip_ext.h>
+
 #include "vrt_march.h"
 
 namespace vrt {
@@ -286,32 +288,32 @@ __global__ void assemble_kernel(const Texel *gathered, Texel *dst, uint32_t widt
 static size_t lds_bytes(const FrameParams &P, bool lds_roots) { return (24u + (lds_roots ? P.n_roots : 0u)) * 4u; }
 
 template <int MARCH, bool LDS_ROOTS>
-static void launch_primary_t(const FrameParams &P, bool stats, bool shadow, hipStream_t st) {
+static void launch_primary_t(const FrameParams &P, bool stats, bool shadow, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
     const dim3 grid((P.tiles_local + 3u) / 4u), block(256);
     const size_t lds = lds_bytes(P, LDS_ROOTS);
     if (stats) {
-        if (shadow) hipLaunchKernelGGL((primary_tile_kernel<MARCH, LDS_ROOTS, true, true>), grid, block, lds, st, P);
-        else hipLaunchKernelGGL((primary_tile_kernel<MARCH, LDS_ROOTS, true, false>), grid, block, lds, st, P);
+        if (shadow) hipExtLaunchKernelGGL((primary_tile_kernel<MARCH, LDS_ROOTS, true, true>), grid, block, (uint32_t)lds, st, e0, e1, 0, P);
+        else hipExtLaunchKernelGGL((primary_tile_kernel<MARCH, LDS_ROOTS, true, false>), grid, block, (uint32_t)lds, st, e0, e1, 0, P);
     } else {
-        if (shadow) hipLaunchKernelGGL((primary_tile_kernel<MARCH, LDS_ROOTS, false, true>), grid, block, lds, st, P);
-        else hipLaunchKernelGGL((primary_tile_kernel<MARCH, LDS_ROOTS, false, false>), grid, block, lds, st, P);
+        if (shadow) hipExtLaunchKernelGGL((primary_tile_kernel<MARCH, LDS_ROOTS, false, true>), grid, block, (uint32_t)lds, st, e0, e1, 0, P);
+        else hipExtLaunchKernelGGL((primary_tile_kernel<MARCH, LDS_ROOTS, false, false>), grid, block, (uint32_t)lds, st, e0, e1, 0, P);
     }
 }
 
 template <int MARCH, bool LDS_ROOTS>
-static void launch_shadow_t(const FrameParams &P, bool stats, hipStream_t st) {
+static void launch_shadow_t(const FrameParams &P, bool stats, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
     const dim3 grid((P.tiles_local + 3u) / 4u), block(256);  // one workgroup per primary workgroup
     const size_t lds = lds_bytes(P, LDS_ROOTS);
-    if (stats) hipLaunchKernelGGL((shadow_kernel<MARCH, LDS_ROOTS, true>), grid, block, lds, st, P);
-    else hipLaunchKernelGGL((shadow_kernel<MARCH, LDS_ROOTS, false>), grid, block, lds, st, P);
+    if (stats) hipExtLaunchKernelGGL((shadow_kernel<MARCH, LDS_ROOTS, true>), grid, block, (uint32_t)lds, st, e0, e1, 0, P);
+    else hipExtLaunchKernelGGL((shadow_kernel<MARCH, LDS_ROOTS, false>), grid, block, (uint32_t)lds, st, e0, e1, 0, P);
 }
 
 template <int MARCH, bool LDS_ROOTS>
-static void launch_fused_t(const FrameParams &P, bool stats, hipStream_t st) {
+static void launch_fused_t(const FrameParams &P, bool stats, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
     const dim3 grid((P.tiles_local + 3u) / 4u), block(256);
     const size_t lds = (1304u + (LDS_ROOTS ? P.n_roots : 0u)) * 4u;
-    if (stats) hipLaunchKernelGGL((primary_shadow_kernel<MARCH, LDS_ROOTS, true>), grid, block, lds, st, P);
-    else hipLaunchKernelGGL((primary_shadow_kernel<MARCH, LDS_ROOTS, false>), grid, block, lds, st, P);
+    if (stats) hipExtLaunchKernelGGL((primary_shadow_kernel<MARCH, LDS_ROOTS, true>), grid, block, (uint32_t)lds, st, e0, e1, 0, P);
+    else hipExtLaunchKernelGGL((primary_shadow_kernel<MARCH, LDS_ROOTS, false>), grid, block, (uint32_t)lds, st, e0, e1, 0, P);
 }
 
 // variant 0: grid march over the derived cell grid / brick pool (needs P.grid), primary + shadow fused into one launch;
@@ -320,36 +322,34 @@ static void launch_fused_t(const FrameParams &P, bool stats, hipStream_t st) {
 bool variant_supported(uint32_t variant) { return variant <= 3u; }
 
 // One launch for primary + shadow (variant 0 only).
-void launch_primary_shadow_fused(const FrameParams &P, bool stats, hipStream_t st) {
-    if (P.tiles_local == 0) return;
-    launch_fused_t<0, false>(P, stats, st);
+void launch_primary_shadow_fused(const FrameParams &P, bool stats, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+    launch_fused_t<0, false>(P, stats, st, e0, e1);
 }
 
-void launch_primary(const FrameParams &P, uint32_t variant, bool stats, bool shadow, hipStream_t st) {
-    if (P.tiles_local == 0) return;
+// e0 / e1: events the dispatch itself stamps with the kernel's begin and end (no separate marker packets on the stream)
+void launch_primary(const FrameParams &P, uint32_t variant, bool stats, bool shadow, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
     const bool lds = P.n_roots <= kLdsRootsMax;
     if (variant == 1u) {
-        if (lds) launch_primary_t<1, true>(P, stats, shadow, st);
-        else launch_primary_t<1, false>(P, stats, shadow, st);
+        if (lds) launch_primary_t<1, true>(P, stats, shadow, st, e0, e1);
+        else launch_primary_t<1, false>(P, stats, shadow, st, e0, e1);
     } else if (variant == 2u) {
-        if (lds) launch_primary_t<2, true>(P, stats, shadow, st);
-        else launch_primary_t<2, false>(P, stats, shadow, st);
+        if (lds) launch_primary_t<2, true>(P, stats, shadow, st, e0, e1);
+        else launch_primary_t<2, false>(P, stats, shadow, st, e0, e1);
     } else {
-        launch_primary_t<0, false>(P, stats, shadow, st);
+        launch_primary_t<0, false>(P, stats, shadow, st, e0, e1);
     }
 }
 
-void launch_shadow(const FrameParams &P, uint32_t variant, bool stats, hipStream_t st) {
-    if (P.tiles_local == 0) return;
+void launch_shadow(const FrameParams &P, uint32_t variant, bool stats, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
     const bool lds = P.n_roots <= kLdsRootsMax;
     if (variant == 1u) {
-        if (lds) launch_shadow_t<1, true>(P, stats, st);
-        else launch_shadow_t<1, false>(P, stats, st);
+        if (lds) launch_shadow_t<1, true>(P, stats, st, e0, e1);
+        else launch_shadow_t<1, false>(P, stats, st, e0, e1);
     } else if (variant == 2u) {
-        if (lds) launch_shadow_t<2, true>(P, stats, st);
-        else launch_shadow_t<2, false>(P, stats, st);
+        if (lds) launch_shadow_t<2, true>(P, stats, st, e0, e1);
+        else launch_shadow_t<2, false>(P, stats, st, e0, e1);
     } else {
-        launch_shadow_t<0, false>(P, stats, st);
+        launch_shadow_t<0, false>(P, stats, st, e0, e1);
     }
 }
 
