@@ -193,6 +193,9 @@ def main():
     if rank != 0:
         dist.destroy_process_group()
         return
+    ai = gpu.accel_info()
+    derived = {"available": bool(ai.available), "cells": int(ai.cells), "bricks": int(ai.bricks), "bytes": int(ai.bytes),
+               "builds": int(ai.builds), "last_build_ms": round(float(ai.last_build_ms), 4)}
     b_primary, b_shadow, b_fused = algorithmic_bytes(st, args.width, args.height)  # rank 0's own launches (its shard when N > 1)
     ms_p = kst.sum_ms_primary / max(kst.frames, 1)
     ms_s = kst.sum_ms_secondary / max(kst.frames, 1)
@@ -225,7 +228,7 @@ def main():
                                f"world (seed 1), 1 primary + 1 shadow ray per solid hit",
                    "rays_per_frame_actual": rays_per_frame, "rays_per_frame_nominal": 2 * args.width * args.height,
                    "sharding": ("whole frame" if not sharded else "whole frame through the one-rank gather pipeline") if world == 1 else f"8x8 tiles interleaved over {world} ranks + RCCL gather to rank 0",
-                   "kernel_variant": args.variant},
+                   "kernel_variant": args.variant, "derived_tables": derived},
         "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
