@@ -53,6 +53,9 @@ def main():
     ap.add_argument("--spp", type=int, default=1)
     ap.add_argument("--bounces", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--root-weight", type=int, default=0,
+                    help="N > 1: tiles per period dealt to the gather root (vrt_config.shard_root_weight); 0 = measure "
+                         "a few candidates off the clock and keep the fastest")
     ap.add_argument("--force-gather", action="store_true",
                     help="development only: with --gpus 1, still run the pipelined RCCL gather + assemble path (one-rank group)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -106,48 +109,76 @@ def main():
     if MODE == MODE_PATH:
         sc.settings.max_ray_bounces = args.bounces
         scenes._diffuse(sc.materials)
-    gpu = Gpu(sc.world.max_nodes(), sc.world.size_in_chunks(), sc.size, device=local_rank, shard_rank=rank, shard_count=world,
-              tile_major=sharded)
-    gpu.upload_world(sc.world, sc.materials)
-    gpu.write_cam_data(sc.cam)
-    gpu.write_settings(sc.settings)
-    fg = None
+    side = None
     if sharded:
         # One non-default torch stream carries everything of this rank: the backend's kernels (vrt_set_stream), the
         # tensors' initialisation and the RCCL calls' stream dependencies.  (The default stream's handle is 0, which
         # vrt_set_stream reads as "use the context's own stream" — kernels there would not be ordered with RCCL.)
         side = torch.cuda.Stream(device=local_rank)
         torch.cuda.set_stream(side)
-        gpu.set_stream(side.cuda_stream)
         assert side.cuda_stream != 0
-        fg = FrameGather(torch, dist, rank, world, args.width, args.height, torch.device("cuda", local_rank))
-        if args.rehearse_on_one_gpu:
-            def staged_gather(which=0, async_op=False):
-                torch.cuda.synchronize()
-                parts = [torch.empty(fg.msg.numel(), dtype=torch.int32) for _ in range(world)] if rank == 0 else None
-                dist.gather(fg.msgs[which].cpu(), parts, dst=0)
+
+    def make_pipeline(root_weight):
+        """(backend context, FrameGather) for this rank.  N > 1: the root renders its own tiles straight into the
+        row-major frame (VRT_FLAG_ROW_MAJOR) and takes root_weight tiles of every root_weight + N - 1."""
+        in_place = world > 1
+        g = Gpu(sc.world.max_nodes(), sc.world.size_in_chunks(), sc.size, device=local_rank, shard_rank=rank, shard_count=world,
+                tile_major=sharded and not (in_place and rank == 0), root_weight=root_weight, row_major=in_place and rank == 0)
+        g.upload_world(sc.world, sc.materials)
+        g.write_cam_data(sc.cam)
+        g.write_settings(sc.settings)
+        f = None
+        if sharded:
+            g.set_stream(side.cuda_stream)
+            f = FrameGather(torch, dist, rank, world, args.width, args.height, torch.device("cuda", local_rank),
+                            root_weight=root_weight, in_place=in_place)
+            if args.rehearse_on_one_gpu:
+                def staged_gather(which=0, async_op=False, f=f):
+                    torch.cuda.synchronize()
+                    parts = [torch.empty(f.msg.numel(), dtype=torch.int32) for _ in range(world)] if rank == 0 else None
+                    dist.gather(f.msgs[which].cpu(), parts, dst=0)
+                    if rank == 0:
+                        f.recv[which].copy_(torch.stack(parts))
+                f.gather = staged_gather
+        return g, f
+
+    def run_frames(g, f, n):
+        for _ in range(n):
+            if f is None:
+                g.render(MODE, **rkw)
+            elif args.rehearse_on_one_gpu:
+                f.bind(g, 0)
+                g.render(MODE, **rkw)
+                f.gather()
                 if rank == 0:
-                    fg.recv[which].copy_(torch.stack(parts))
-            fg.gather = staged_gather
+                    f.assemble(g, 0)
+            else:
+                f.submit(g, lambda: g.render(MODE, **rkw))   # gather of this frame overlaps the next render
+        if f is not None and not args.rehearse_on_one_gpu:
+            f.drain(g)
 
-    def render():
-        gpu.render(MODE, **rkw)
-
-    def frame():
-        if fg is None:
-            render()
-        elif args.rehearse_on_one_gpu:
-            fg.bind(gpu, 0)
-            render()
-            fg.gather()
-            if rank == 0:
-                fg.assemble(gpu, 0)
+    # ---- N > 1: how much of the frame the gather root should trace itself (off the clock) ----
+    root_weight, tuning = 1, None
+    if world > 1:
+        if args.root_weight > 0:
+            root_weight = args.root_weight
         else:
-            fg.submit(gpu, render)   # gather of this frame overlaps the next render
-
-    def finish():
-        if fg is not None and not args.rehearse_on_one_gpu:
-            fg.drain(gpu)
+            tuning = {}
+            for w0 in (1, 2, 3, 4, 6, 8, 12, 16):
+                g, f = make_pipeline(w0)
+                run_frames(g, f, 5)
+                dist.barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                run_frames(g, f, 40)
+                dist.barrier()
+                torch.cuda.synchronize()
+                dt = all_reduce(torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda"), dist.ReduceOp.MAX)
+                tuning[w0] = float(dt[0]) / 40 * 1e3
+                g.close()
+                del g, f
+            root_weight = min(tuning, key=lambda k: (tuning[k], k))   # the all-reduced times are identical on every rank
+    gpu, fg = make_pipeline(root_weight)
 
     # exact ray / step / node-visit counts of this frame (deterministic; a stats frame is never timed)
     if fg is not None:
@@ -157,17 +188,13 @@ def main():
     counts = all_reduce(torch.tensor([st.primary_rays, st.secondary_rays], dtype=torch.int64, device="cuda"))
     rays_per_frame = int(counts[0] + counts[1])
 
-    for _ in range(args.warmup):
-        frame()
-    finish()
+    run_frames(gpu, fg, args.warmup)
     gpu.stats()  # drop the warm-up frames' kernel timings
     if sharded:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        frame()
-    finish()   # every timed frame is gathered and assembled on rank 0 before the clock stops
+    run_frames(gpu, fg, args.steps)   # every timed frame is gathered and assembled on rank 0 before the clock stops
     if sharded:
         dist.barrier()
     torch.cuda.synchronize()
@@ -227,7 +254,10 @@ def main():
         "config": {"workload": f"{'C2' if (args.chunks, args.width, args.height) == (8, 1920, 1080) else 'C2-family'}: {args.width}x{args.height} frame, {args.chunks}x{args.chunks}x{args.chunks}-chunk procedural SVO "
                                f"world (seed 1), 1 primary + 1 shadow ray per solid hit",
                    "rays_per_frame_actual": rays_per_frame, "rays_per_frame_nominal": 2 * args.width * args.height,
-                   "sharding": ("whole frame" if not sharded else "whole frame through the one-rank gather pipeline") if world == 1 else f"8x8 tiles interleaved over {world} ranks + RCCL gather to rank 0",
+                   "sharding": ("whole frame" if not sharded else "whole frame through the one-rank gather pipeline") if world == 1 else
+                               f"8x8 tiles interleaved over {world} ranks ({root_weight} of every {root_weight + world - 1} to the gather root, "
+                               f"which renders them in place) + RCCL gather of the other ranks' tile buffers to rank 0",
+                   "root_weight": root_weight, "root_weight_tuning_ms_per_frame": tuning,
                    "kernel_variant": args.variant, "derived_tables": derived},
         "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -77,8 +77,12 @@ typedef struct {
 } vrt_settings;
 
 /* Replaces the arguments of GpuResources::new(gpu, fmt, result_size, max_nodes, world_size)
- * (mod.rs:155-195).  shard_rank/shard_count: this context traces only the 8x8 screen tiles t with
- * t % shard_count == shard_rank (tile-interleaved multi-GPU sharding; 0/1 = whole frame). */
+ * (mod.rs:155-195).  shard_rank/shard_count: this context traces only its share of the 8x8 screen tiles
+ * (tile-interleaved multi-GPU sharding; 0/1 = whole frame).  Tiles are dealt out in periods of
+ * P = shard_root_weight + shard_count - 1: the first shard_root_weight tiles of every period belong to rank 0, the
+ * next ones to ranks 1, 2, ... one each.  shard_root_weight 0 or 1 = equal shares (tile t belongs to rank t % N).
+ * A weight > 1 lets the gather root, whose own tiles never cross a link, take more of the frame than the ranks
+ * whose tiles all arrive over one xGMI link each. */
 typedef struct {
     uint32_t max_nodes;          /* NodeBuffer capacity in nodes (shader.rs:9-16; forced even) */
     uint32_t world_size_chunks;  /* S: chunk_roots holds S^3 entries (shader.rs:59,67) */
@@ -86,10 +90,14 @@ typedef struct {
     int32_t device;              /* HIP device ordinal; -1 = current */
     uint32_t shard_rank, shard_count;
     uint32_t flags;              /* VRT_FLAG_* */
+    uint32_t shard_root_weight;  /* tiles per period dealt to rank 0; 0 = 1 */
 } vrt_config;
 
 /* Write the output in the tile-major shard layout even with shard_count = 1 (a one-rank gather pipeline). */
 #define VRT_FLAG_TILE_MAJOR 1u
+/* A sharded context that writes its tiles at their final positions of a row-major full-frame buffer instead of a
+ * compact tile-major one: the gather root rendering straight into the frame (vrt_assemble then skips its tiles). */
+#define VRT_FLAG_ROW_MAJOR 2u
 
 typedef enum {
     VRT_MODE_PRIMARY = 0,        /* the reference's live shader (ray_tracer.wgsl) */
@@ -216,8 +224,9 @@ int vrt_set_stream(vrt_ctx *ctx, void *hip_stream);
 
 /* The device output is one 16-byte texel per pixel slot: {r, g, b as f32, id word as u32}.
  * Unsharded: texel[height][width] row-major.  Sharded: the compact tile-major shard buffer
- * texel[tiles_padded][64] (tile t_local <-> screen tile shard_rank + t_local*shard_count; pixel p of a tile =
- * (p&7, p>>3)); tiles_padded = ceil(total_tiles / shard_count), so every rank's buffer has the same size. */
+ * texel[tiles_padded][64] (tile t_local <-> the context's t_local-th screen tile in increasing order; pixel p of a
+ * tile = (p&7, p>>3)); tiles_padded = ceil(total_tiles / P) is the largest count of any rank >= 1, so every gathered
+ * message has the same size (with equal shares also rank 0's). */
 
 /* Render into caller-owned device memory (e.g. a torch tensor handed to an RCCL gather) instead of the
  * context's own buffer: `texels` must hold the byte count vrt_device_output reports and be 16-byte
@@ -228,12 +237,13 @@ int vrt_bind_output(vrt_ctx *ctx, void *texels);
 int vrt_device_output(vrt_ctx *ctx, void **texels, uint64_t *bytes);
 
 /* Number of 8x8 tiles this context traces, the padded per-rank count used for equal-sized gathers
- * (ceil(total_tiles / shard_count)) and the total. */
+ * (ceil(total_tiles / P)) and the total. */
 int vrt_shard_info(vrt_ctx *ctx, uint32_t *tiles_local, uint32_t *tiles_padded, uint32_t *tiles_total);
 
 /* On the gather root: scatter the shard_count gathered tile-major buffers (rank r's texels start at
  * gathered + r*rank_stride_bytes; 0 = densely packed, tiles_padded*64*16 bytes apart) into the
- * row-major device frame dst = texel[height][width].  Asynchronous on the context's stream. */
+ * row-major device frame dst = texel[height][width].  A root created with VRT_FLAG_ROW_MAJOR has already written
+ * its own tiles there: slot 0 of `gathered` is then ignored.  Asynchronous on the context's stream. */
 int vrt_assemble(vrt_ctx *ctx, const void *gathered, uint64_t rank_stride_bytes, void *dst);
 
 #ifdef __cplusplus

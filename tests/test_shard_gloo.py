@@ -59,6 +59,28 @@ if rank == 0:
     f_rgb, f_ids, _, _ = o.render(orc.MODE_PRIMARY_SHADOW, w, h, threads=2)
     assert np.array_equal(ids, f_ids) and np.array_equal(rgb, f_rgb), "assembled frame differs from the unsharded one"
     print("GLOO_SHARD_OK", world, int((ids != 0).sum()))
+# ---- the weighted, in-place root bench.py uses for N > 1: rank 0 holds w0 of every w0 + N - 1 tiles in the frame itself ----
+W0 = 3
+tiles, padded, total = shard.tiles_of_rank(w, h, rank, world, W0)
+frame = np.zeros((h, w, 4), dtype=np.uint32)
+for t in tiles:
+    ty, tx = divmod(int(t), w // 8)
+    rgb, ids, _, _ = o.render(orc.MODE_PRIMARY_SHADOW, w, h, rect=(tx * 8, ty * 8, tx * 8 + 8, ty * 8 + 8), threads=1)
+    frame[ty*8:ty*8+8, tx*8:tx*8+8, :3] = rgb[ty*8:ty*8+8, tx*8:tx*8+8].view(np.uint32)
+    frame[ty*8:ty*8+8, tx*8:tx*8+8, 3] = ids[ty*8:ty*8+8, tx*8:tx*8+8]
+fgw = shard.FrameGather(torch, dist, rank, world, w, h, torch.device("cpu"), root_weight=W0, in_place=True)
+assert fgw.tiles_padded == padded and (rank == 0 or len(tiles) <= padded)
+if rank == 0:
+    fgw.frames[0].copy_(torch.from_numpy(frame.view(np.int32)))    # what the in-place root's render leaves in the frame
+else:
+    fgw.msgs[0].copy_(torch.from_numpy(shard.pack_tiles_numpy(frame, rank, world, W0).view(np.int32)[:fgw.msgs[0].numel()]))
+fgw.gather(0)
+dist.barrier()
+if rank == 0:
+    got = shard.assemble_numpy(fgw.recv[0].numpy().view(np.uint32), w, h, world, W0, frame=fgw.frames[0].numpy().view(np.uint32).copy())
+    rgb, ids = shard.texels_to_frame(got)
+    assert np.array_equal(ids, f_ids) and np.array_equal(rgb, f_rgb), "weighted in-place frame differs from the unsharded one"
+    print("GLOO_WEIGHTED_OK", world)
 dist.destroy_process_group()
 '''
 
@@ -92,7 +114,7 @@ def test_tile_shard_gather_over_gloo(world, tmp_path):
         outs.append(out.decode())
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{out[-2000:]}"
-    assert f"GLOO_SHARD_OK {world}" in outs[0]
+    assert f"GLOO_SHARD_OK {world}" in outs[0] and f"GLOO_WEIGHTED_OK {world}" in outs[0]
 
 
 def test_layout_helpers_round_trip():
@@ -106,3 +128,22 @@ def test_layout_helpers_round_trip():
         assert np.array_equal(shard.assemble_numpy(msgs, w, h, n), frame)
         owned = np.concatenate([shard.tiles_of_rank(w, h, r, n)[0] for r in range(n)])
         assert sorted(owned.tolist()) == list(range((w // 8) * (h // 8)))
+    for n, w0 in ((2, 4), (3, 2), (8, 2), (5, 9)):   # weighted root: still a partition, ranks >= 1 fit the padded message
+        msgs = [shard.pack_tiles_numpy(frame, r, n, w0) for r in range(n)]
+        assert len({m.size for m in msgs[1:]}) == 1
+        assert np.array_equal(shard.assemble_numpy(msgs, w, h, n, w0), frame)
+        root_only = shard.assemble_numpy([None] + msgs[1:], w, h, n, w0, frame=np.zeros_like(frame))
+        mine = shard.tiles_of_rank(w, h, 0, n, w0)[0]
+        keep = np.ones((h // 8, w // 8), dtype=bool)
+        keep[np.divmod(mine, w // 8)] = False
+        px = np.kron(keep, np.ones((8, 8), dtype=bool))
+        assert np.array_equal(root_only[px], frame[px]) and not root_only[~px].any()
+
+
+def test_root_weight_model():
+    """The root takes more of the frame the slower the links are relative to the render; never less than an equal share."""
+    assert shard.root_weight_model(1, 0.14, 33e6) == 1
+    fast_links = [shard.root_weight_model(n, 0.14, 33e6, link_gbs=1e4) for n in (2, 4, 8)]
+    slow_links = [shard.root_weight_model(n, 0.14, 33e6, link_gbs=20.0) for n in (2, 4, 8)]
+    assert fast_links == [1, 1, 1] and all(s > 1 for s in slow_links)
+    assert slow_links[0] >= slow_links[1] >= slow_links[2]

@@ -6,9 +6,9 @@ from voxelraytracing_amd import Gpu
 RADIANCE_TOL = 1e-4  # BASELINE.json north_star: "within 1e-4 on float radiance"
 
 
-def gpu_for_scene(scene, size=None, shard_rank=0, shard_count=1) -> Gpu:
+def gpu_for_scene(scene, size=None, shard_rank=0, shard_count=1, **kw) -> Gpu:
     size = size or scene.size
-    g = Gpu(scene.world.max_nodes(), scene.world.size_in_chunks(), size, shard_rank=shard_rank, shard_count=shard_count)
+    g = Gpu(scene.world.max_nodes(), scene.world.size_in_chunks(), size, shard_rank=shard_rank, shard_count=shard_count, **kw)
     g.upload_world(scene.world, scene.materials)
     g.write_cam_data(scene.cam)
     g.write_settings(scene.settings)

@@ -43,7 +43,7 @@ class Settings(C.Structure):
 class Config(C.Structure):
     _fields_ = [("max_nodes", C.c_uint32), ("world_size_chunks", C.c_uint32), ("width", C.c_uint32),
                 ("height", C.c_uint32), ("device", C.c_int32), ("shard_rank", C.c_uint32),
-                ("shard_count", C.c_uint32), ("flags", C.c_uint32)]
+                ("shard_count", C.c_uint32), ("flags", C.c_uint32), ("shard_root_weight", C.c_uint32)]
 
 
 class RenderOpts(C.Structure):

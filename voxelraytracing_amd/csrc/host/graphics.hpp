@@ -110,7 +110,7 @@ struct GpuError : std::runtime_error { using std::runtime_error::runtime_error; 
 class Gpu {
 public:
     Gpu(uint32_t max_nodes, uint32_t world_size, UVec2 result_size, int device = -1, uint32_t shard_rank = 0, uint32_t shard_count = 1) {
-        vrt_config cfg{max_nodes, world_size, result_size.x, result_size.y, device, shard_rank, shard_count, 0};
+        vrt_config cfg{max_nodes, world_size, result_size.x, result_size.y, device, shard_rank, shard_count, 0, 0};
         if (vrt_create(&cfg, &ctx_) != VRT_OK) throw GpuError(vrt_last_error(nullptr));
     }
     ~Gpu() { vrt_destroy(ctx_); }

@@ -29,7 +29,7 @@ void launch_path_bounce(const FrameParams &P, bool stats, hipStream_t st);
 void launch_path_finish(Texel *out, uint32_t n, uint32_t spp, hipStream_t st);
 void launch_quantize(const Texel *out, uint8_t *rgba8, uint32_t n, hipStream_t st);
 void launch_assemble(const Texel *gathered, Texel *dst, uint32_t width, uint32_t tiles_x, uint32_t tiles_total,
-                     uint32_t shard_count, uint64_t rank_stride, hipStream_t st);
+                     uint32_t root_weight, uint32_t period, bool skip_root, uint64_t rank_stride, hipStream_t st);
 void launch_accel_cells(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S, uint32_t *grid,
                         uint32_t *chunk_bricks, uint32_t *chunk_offsets, uint32_t *total, hipStream_t st);
 void launch_accel_bricks(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S, uint32_t *grid,
@@ -59,7 +59,8 @@ struct vrt_ctx {
     uint32_t world_size = 0;
     uint32_t n_roots = 0;
     uint32_t width = 0, height = 0;
-    uint32_t shard_rank = 0, shard_count = 1;
+    uint32_t shard_rank = 0, shard_count = 1, shard_w0 = 1;
+    uint32_t shard_first = 0, shard_run = 1, shard_period = 1;  // vrt_device.h shard_tile()
     bool tile_major = false;  // output layout [t_local][64]: always when sharded, on request (VRT_FLAG_TILE_MAJOR) otherwise
     uint32_t tiles_x = 0, tiles_total = 0, tiles_local = 0, tiles_padded = 0;
     uint32_t slots = 0;  // pixel slots in the output buffer
@@ -141,9 +142,16 @@ static int fail(vrt_ctx *ctx, int code, const char *fmt, ...) {
 static void layout_tiles(vrt_ctx *c) {
     c->tiles_x = c->width / 8u;
     c->tiles_total = c->tiles_x * (c->height / 8u);
-    c->tiles_padded = (c->tiles_total + c->shard_count - 1u) / c->shard_count;
-    c->tiles_local = c->shard_rank < c->tiles_total ? (c->tiles_total - c->shard_rank + c->shard_count - 1u) / c->shard_count : 0u;
-    c->slots = c->tile_major ? c->tiles_padded * 64u : c->width * c->height;
+    // tiles are dealt out in periods of P = w0 + N - 1: w0 to rank 0, then one to each of ranks 1..N-1
+    const uint32_t P = c->shard_w0 + c->shard_count - 1u;
+    c->shard_period = P;
+    c->shard_run = c->shard_rank == 0 ? c->shard_w0 : 1u;
+    c->shard_first = c->shard_rank == 0 ? 0u : c->shard_w0 + c->shard_rank - 1u;
+    const uint32_t full = c->tiles_total / P, rem = c->tiles_total % P;
+    c->tiles_padded = (c->tiles_total + P - 1u) / P;
+    c->tiles_local = full * c->shard_run + (rem > c->shard_first ? (rem - c->shard_first < c->shard_run ? rem - c->shard_first : c->shard_run) : 0u);
+    const uint32_t tm_tiles = c->tiles_local > c->tiles_padded ? c->tiles_local : c->tiles_padded;
+    c->slots = c->tile_major ? tm_tiles * 64u : c->width * c->height;
 }
 
 static int alloc_output(vrt_ctx *c) {
@@ -264,6 +272,9 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         return fail(nullptr, VRT_ERR_INVALID_ARG, "output too large");
     const uint32_t sc = cfg->shard_count ? cfg->shard_count : 1u;
     if (cfg->shard_rank >= sc) return fail(nullptr, VRT_ERR_INVALID_ARG, "shard_rank %u >= shard_count %u", cfg->shard_rank, sc);
+    if (cfg->shard_root_weight > 4096u) return fail(nullptr, VRT_ERR_INVALID_ARG, "shard_root_weight %u out of range", cfg->shard_root_weight);
+    if ((cfg->flags & VRT_FLAG_ROW_MAJOR) && (cfg->flags & VRT_FLAG_TILE_MAJOR))
+        return fail(nullptr, VRT_ERR_INVALID_ARG, "VRT_FLAG_ROW_MAJOR and VRT_FLAG_TILE_MAJOR exclude each other");
 
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -280,7 +291,8 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     c->device = dev;
     c->shard_rank = cfg->shard_rank;
     c->shard_count = sc;
-    c->tile_major = sc > 1u || (cfg->flags & VRT_FLAG_TILE_MAJOR);
+    c->shard_w0 = cfg->shard_root_weight ? cfg->shard_root_weight : 1u;
+    c->tile_major = (sc > 1u && !(cfg->flags & VRT_FLAG_ROW_MAJOR)) || (cfg->flags & VRT_FLAG_TILE_MAJOR);
     c->width = cfg->width;
     c->height = cfg->height;
     c->max_nodes = cfg->max_nodes & ~1u;  // NodeBuffer::new forces an even size (shader.rs:10-12)
@@ -553,8 +565,9 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     P.height = c->height;
     P.tiles_x = c->tiles_x;
     P.tiles_total = c->tiles_total;
-    P.shard_rank = c->shard_rank;
-    P.shard_count = c->shard_count;
+    P.shard_first = c->shard_first;
+    P.shard_run = c->shard_run;
+    P.shard_period = c->shard_period;
     P.tiles_local = c->tiles_local;
     P.tile_major = c->tile_major ? 1u : 0u;
     P.cam = c->cam;
@@ -686,7 +699,7 @@ int vrt_read_output(vrt_ctx *c, float *rgb, uint32_t *ids, uint8_t *rgba8) {
     if (rgb) memset(rgb, 0, npix * 3 * sizeof(float));
     if (ids) memset(ids, 0, npix * sizeof(uint32_t));
     for (uint32_t tl = 0; tl < c->tiles_local; tl++) {
-        const uint32_t tile = c->shard_rank + tl * c->shard_count;
+        const uint32_t tile = vrt::shard_tile(tl, c->shard_first, c->shard_run, c->shard_period);
         const uint32_t tx = (tile % c->tiles_x) * 8u, ty = (tile / c->tiles_x) * 8u;
         for (uint32_t p = 0; p < 64; p++) put((size_t)(ty + (p >> 3)) * c->width + tx + (p & 7u), t[(size_t)tl * 64 + p]);
     }
@@ -813,8 +826,9 @@ int vrt_assemble(vrt_ctx *c, const void *gathered, uint64_t rank_stride_bytes, v
     if (rank_stride_bytes % 16u) return fail(c, VRT_ERR_INVALID_ARG, "vrt_assemble: rank stride must be a multiple of 16 bytes");
     HIP_TRY(c, hipSetDevice(c->device));
     const uint64_t stride = rank_stride_bytes ? rank_stride_bytes / 16u : (uint64_t)c->tiles_padded * 64u;
-    vrt::launch_assemble((const vrt::Texel *)gathered, (vrt::Texel *)dst, c->width, c->tiles_x, c->tiles_total, c->shard_count,
-                         stride, c->stream);
+    const bool in_place = c->shard_count > 1u && !c->tile_major;  // VRT_FLAG_ROW_MAJOR root: its tiles are already in dst
+    vrt::launch_assemble((const vrt::Texel *)gathered, (vrt::Texel *)dst, c->width, c->tiles_x, c->tiles_total, c->shard_w0,
+                         c->shard_period, in_place, stride, c->stream);
     HIP_TRY(c, hipGetLastError());
     return VRT_OK;
 }

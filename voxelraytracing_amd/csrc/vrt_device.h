@@ -48,7 +48,8 @@ struct FrameParams {
     uint32_t n_nodes, n_roots;
     uint32_t width, height;
     uint32_t tiles_x, tiles_total;
-    uint32_t shard_rank, shard_count, tiles_local;
+    // this context's t_local-th tile is screen tile (t_local / shard_run) * shard_period + shard_first + t_local % shard_run
+    uint32_t shard_first, shard_run, shard_period, tiles_local;
     uint32_t hit_seg_cap;    // capacity of one hit-buffer segment, a multiple of 256
     uint32_t tile_major;     // output slots are [t_local][64] (sharded, or VRT_FLAG_TILE_MAJOR) instead of row-major
     uint32_t finite_settings;  // 1: every Settings float is finite (lets hits skip the sky term exactly)
@@ -81,6 +82,11 @@ enum Counter : int {
     kCtrSecondary = 6,      // path mode, stats frames: bounce segments traced
     kCtrCount = 8
 };
+
+// screen tile of the context's t_local-th tile (vrt_config: shard_rank / shard_count / shard_root_weight)
+__host__ __device__ __forceinline__ uint32_t shard_tile(uint32_t t_local, uint32_t first, uint32_t run, uint32_t period) {
+    return run == 1u ? t_local * period + first : (t_local / run) * period + first + t_local % run;
+}
 
 struct V3 { float x, y, z; };
 

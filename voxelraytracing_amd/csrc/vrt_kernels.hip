@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(256) primary_tile_kernel(FrameParams P) {
     MarchResult R;
     R.iters = 0; R.visits = 0; R.hit = false;
     if (live) {
-        const uint32_t tile = P.shard_rank + t_local * P.shard_count;
+        const uint32_t tile = shard_tile(t_local, P.shard_first, P.shard_run, P.shard_period);
         const uint32_t px = (tile % P.tiles_x) * 8u + (lane & 7u);
         const uint32_t py = (tile / P.tiles_x) * 8u + (lane >> 3);
         const uint32_t slot = P.tile_major ? t_local * 64u + lane : py * P.width + px;
@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(256) primary_shadow_kernel(FrameParams P) {
     V3 color{0.f, 0.f, 0.f};
     uint32_t id = 0u, slot = 0u;
     if (live) {
-        const uint32_t tile = P.shard_rank + t_local * P.shard_count;
+        const uint32_t tile = shard_tile(t_local, P.shard_first, P.shard_run, P.shard_period);
         const uint32_t px = (tile % P.tiles_x) * 8u + (lane & 7u);
         const uint32_t py = (tile / P.tiles_x) * 8u + (lane >> 3);
         slot = P.tile_major ? t_local * 64u + lane : py * P.width + px;
@@ -270,13 +270,23 @@ __global__ void quantize_rgba8_kernel(const Texel *out, uint8_t *rgba8, uint32_t
     reinterpret_cast<uint32_t *>(rgba8)[i] = q;
 }
 
-// Gather root: tile-major [rank][slots_per_rank] texels -> row-major frame of texels.
+// Gather root: tile-major [rank][slots_per_rank] texels -> row-major frame of texels.  Tiles are dealt out in periods
+// of `period` = root_weight + N - 1 (vrt_config); skip_root: the root rendered its own tiles in place.
 __global__ void assemble_kernel(const Texel *gathered, Texel *dst, uint32_t width, uint32_t tiles_x, uint32_t tiles_total,
-                                uint32_t shard_count, uint64_t rank_stride) {
+                                uint32_t root_weight, uint32_t period, uint32_t skip_root, uint64_t rank_stride) {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t tile = gid >> 6, p = gid & 63u;
     if (tile >= tiles_total) return;
-    const uint32_t rank = tile % shard_count, t_local = tile / shard_count;
+    const uint32_t q = tile / period, r = tile % period;
+    uint32_t rank, t_local;
+    if (r < root_weight) {
+        if (skip_root) return;
+        rank = 0u;
+        t_local = q * root_weight + r;
+    } else {
+        rank = r - root_weight + 1u;
+        t_local = q;
+    }
     const uint32_t px = (tile % tiles_x) * 8u + (p & 7u), py = (tile / tiles_x) * 8u + (p >> 3);
     dst[py * width + px] = gathered[rank * rank_stride + (uint64_t)t_local * 64u + p];
 }
@@ -359,10 +369,10 @@ void launch_quantize(const Texel *out, uint8_t *rgba8, uint32_t n, hipStream_t s
 }
 
 void launch_assemble(const Texel *gathered, Texel *dst, uint32_t width, uint32_t tiles_x, uint32_t tiles_total,
-                     uint32_t shard_count, uint64_t rank_stride, hipStream_t st) {
+                     uint32_t root_weight, uint32_t period, bool skip_root, uint64_t rank_stride, hipStream_t st) {
     if (!tiles_total) return;
     hipLaunchKernelGGL(assemble_kernel, dim3((tiles_total * 64u + 255u) / 256u), dim3(256), 0, st, gathered, dst, width,
-                       tiles_x, tiles_total, shard_count, rank_stride);
+                       tiles_x, tiles_total, root_weight, period, skip_root ? 1u : 0u, rank_stride);
 }
 
 }  // namespace vrt

@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(256) path_primary_kernel(FrameParams P) {
     MarchResult R;
     R.iters = 0; R.visits = 0; R.hit = false;
     if (live) {
-        const uint32_t tile = P.shard_rank + t_local * P.shard_count;
+        const uint32_t tile = shard_tile(t_local, P.shard_first, P.shard_run, P.shard_period);
         const uint32_t px = (tile % P.tiles_x) * 8u + (lane & 7u);
         const uint32_t py = (tile / P.tiles_x) * 8u + (lane >> 3);
         PathState st;

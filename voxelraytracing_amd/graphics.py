@@ -65,10 +65,11 @@ class Gpu:
     Arguments are GpuResources::new's (mod.rs:155-161) plus the tile shard of this process."""
 
     def __init__(self, max_nodes: int, world_size: int, result_size, device: int = -1,
-                 shard_rank: int = 0, shard_count: int = 1, tile_major: bool = False):
+                 shard_rank: int = 0, shard_count: int = 1, tile_major: bool = False, root_weight: int = 1,
+                 row_major: bool = False):
         self._lib = _ffi.vrt()
         cfg = _ffi.Config(max_nodes, world_size, result_size[0], result_size[1], device, shard_rank, shard_count,
-                          1 if tile_major else 0)
+                          (1 if tile_major else 0) | (2 if row_major else 0), root_weight)
         h = C.c_void_p()
         rc = self._lib.vrt_create(C.byref(cfg), C.byref(h))
         if rc:

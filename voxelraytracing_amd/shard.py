@@ -15,10 +15,17 @@ import numpy as np
 TEXEL_BYTES = 16
 
 
-def tiles_of_rank(width: int, height: int, rank: int, count: int):
-    """(tile indices owned by `rank`, padded per-rank tile count, total tiles)."""
+def tiles_of_rank(width: int, height: int, rank: int, count: int, root_weight: int = 1):
+    """(tile indices owned by `rank` in increasing order, padded per-rank tile count of ranks >= 1, total tiles).
+
+    Tiles are dealt out in periods of P = root_weight + count - 1: the first root_weight of every period to rank 0,
+    then one to each of ranks 1..count-1 (include/vrt.h, vrt_config.shard_root_weight); weight 1 = t % count."""
     total = (width // 8) * (height // 8)
-    return np.arange(rank, total, count), -(-total // count), total
+    period = root_weight + count - 1
+    t = np.arange(total)
+    r = t % period
+    mine = t[r < root_weight] if rank == 0 else t[r == root_weight + rank - 1]
+    return mine, -(-total // period), total
 
 
 def texels_to_frame(texels: np.ndarray):
@@ -27,24 +34,27 @@ def texels_to_frame(texels: np.ndarray):
     return t[..., :3].copy().view(np.float32), t[..., 3].copy()
 
 
-def assemble_numpy(msgs, width: int, height: int, count: int) -> np.ndarray:
-    """Host twin of vrt_assemble for CPU (gloo) tests: msgs[r] = rank r's message as uint32[slots*4]."""
+def assemble_numpy(msgs, width: int, height: int, count: int, root_weight: int = 1, frame: np.ndarray | None = None) -> np.ndarray:
+    """Host twin of vrt_assemble for CPU (gloo) tests: msgs[r] = rank r's message as uint32[slots*4].
+    With `frame` given, rank 0's tiles are already in it (the in-place root) and msgs[0] is ignored."""
     tiles_x = width // 8
-    frame = np.zeros((height, width, 4), dtype=np.uint32)
-    for r in range(count):
-        tl, padded, _ = tiles_of_rank(width, height, r, count)
-        m = np.asarray(msgs[r], dtype=np.uint32).reshape(padded, 8, 8, 4)
+    in_place = frame is not None
+    if frame is None:
+        frame = np.zeros((height, width, 4), dtype=np.uint32)
+    for r in range(1 if in_place else 0, count):
+        tl, _, _ = tiles_of_rank(width, height, r, count, root_weight)
+        m = np.asarray(msgs[r], dtype=np.uint32).reshape(-1, 8, 8, 4)
         for k, t in enumerate(tl):
             ty, tx = divmod(int(t), tiles_x)
             frame[ty * 8:ty * 8 + 8, tx * 8:tx * 8 + 8] = m[k]
     return frame
 
 
-def pack_tiles_numpy(frame: np.ndarray, rank: int, count: int) -> np.ndarray:
+def pack_tiles_numpy(frame: np.ndarray, rank: int, count: int, root_weight: int = 1) -> np.ndarray:
     """Inverse of assemble_numpy for one rank: cut the rank's tiles out of a texel frame uint32[h][w][4]."""
     h, w, _ = frame.shape
-    tl, padded, _ = tiles_of_rank(w, h, rank, count)
-    m = np.zeros((padded, 8, 8, 4), dtype=np.uint32)
+    tl, padded, _ = tiles_of_rank(w, h, rank, count, root_weight)
+    m = np.zeros((max(padded, len(tl)), 8, 8, 4), dtype=np.uint32)
     tiles_x = w // 8
     for k, t in enumerate(tl):
         ty, tx = divmod(int(t), tiles_x)
@@ -52,30 +62,63 @@ def pack_tiles_numpy(frame: np.ndarray, rank: int, count: int) -> np.ndarray:
     return m.reshape(-1)
 
 
+def root_weight_model(count: int, frame_ms: float, message_bytes_total: float, link_gbs: float = 60.0, assemble_ms: float = 0.02) -> int:
+    """First guess for vrt_config.shard_root_weight (bench.py then measures the neighbours): the root's own tiles
+    never cross a link, every other rank's tiles all arrive over that rank's one xGMI link, so the root should
+    trace w0 of every w0 + N - 1 tiles such that its render + de-interleave time matches one link's transfer time:
+        w0/P * frame_ms + assemble_ms  =  (message_bytes_total / P) / link_gbs        (P = w0 + N - 1)."""
+    if count <= 1:
+        return 1
+    link_ms = message_bytes_total / (link_gbs * 1e9) * 1e3   # the whole frame over one link
+    best, best_t = 1, None
+    for w0 in range(1, 65):
+        period = w0 + count - 1
+        t = max(w0 / period * frame_ms + assemble_ms, link_ms / period, frame_ms / period)
+        if best_t is None or t < best_t - 1e-9:
+            best, best_t = w0, t
+    return best
+
+
 class FrameGather:
     """One process per GPU: owns the message tensors, binds the backend's output to them and gathers.
 
     `dist` is torch.distributed with an initialised process group (nccl = RCCL on the GPU box, gloo on CPU).
-    Two message / receive buffers ping-pong so that the gather of frame k (on the collective's own stream)
-    overlaps the render of frame k+1 and the de-interleave of frame k-1 (`submit` / `drain`)."""
+    Two message / receive / frame buffers ping-pong so that the gather of frame k (on the collective's own stream)
+    overlaps the render of frame k+1 and the de-interleave of frame k-1 (`submit` / `drain`).
 
-    def __init__(self, torch, dist, rank: int, count: int, width: int, height: int, device):
+    in_place (needs a root context created with row_major=True): rank 0 renders its own tiles straight into the
+    row-major frame and contributes nothing to the gather but an unused message-sized slot; with root_weight > 1
+    it also takes a larger share of the tiles than the ranks whose tiles have to cross a link."""
+
+    def __init__(self, torch, dist, rank: int, count: int, width: int, height: int, device, root_weight: int = 1,
+                 in_place: bool = False):
         self.torch, self.dist, self.rank, self.count = torch, dist, rank, count
         self.width, self.height = width, height
-        _, self.tiles_padded, _ = tiles_of_rank(width, height, rank, count)
+        self.root_weight, self.in_place = root_weight, in_place
+        assert in_place or root_weight == 1, "a weighted root renders in place"
+        _, self.tiles_padded, _ = tiles_of_rank(width, height, rank, count, root_weight)
         self.slots = self.tiles_padded * 64
         self.msgs = [torch.zeros(self.slots * 4, dtype=torch.int32, device=device) for _ in range(2)]
         self.recv = [torch.zeros((count, self.slots * 4), dtype=torch.int32, device=device) if rank == 0 else None
                      for _ in range(2)]
-        self.frame = torch.zeros((height, width, 4), dtype=torch.int32, device=device) if rank == 0 else None
+        n_frames = 2 if in_place else 1
+        self.frames = [torch.zeros((height, width, 4), dtype=torch.int32, device=device) if rank == 0 else None
+                       for _ in range(n_frames)]
+        self.frame = self.frames[0]   # the last completed frame (rank 0)
         self.k = 0            # frames submitted
         self.pending = None   # (work, buffer index) of the gather still in flight
         # single-buffer aliases (tests, simple callers)
         self.msg, self.gathered = self.msgs[0], self.recv[0]
 
+    def _frame_of(self, which: int):
+        return self.frames[which % len(self.frames)]
+
     def bind(self, gpu, which: int = 0):
-        """Make the backend render straight into message buffer `which`."""
-        gpu.bind_output(self.msgs[which].data_ptr())
+        """Make the backend render straight into message buffer `which` (the in-place root: into frame `which`)."""
+        if self.in_place and self.rank == 0:
+            gpu.bind_output(self._frame_of(which).data_ptr())
+        else:
+            gpu.bind_output(self.msgs[which].data_ptr())
 
     def gather(self, which: int = 0, async_op: bool = False):
         """One gather of equal-sized messages to rank 0 (RCCL: N-1 direct sends to the root)."""
@@ -84,7 +127,9 @@ class FrameGather:
 
     def assemble(self, gpu, which: int = 0):
         """Rank 0: scatter the gathered tile buffers into the row-major texel frame on the device."""
-        gpu.assemble(self.recv[which].data_ptr(), self.frame.data_ptr(), self.slots * TEXEL_BYTES)
+        f = self._frame_of(which)
+        gpu.assemble(self.recv[which].data_ptr(), f.data_ptr(), self.slots * TEXEL_BYTES)
+        self.frame = f
 
     # ---- pipelined frames ----
     def submit(self, gpu, render):
