@@ -102,6 +102,19 @@ uint64_t vrth_region_save_from_world(const vrth_world *w, const int32_t region_p
 void vrth_region_of_chunk(const int32_t chunk_pos[3], int32_t region_pos[3], uint32_t pos_in_region[3]);
 uint32_t vrth_region_file_name(const int32_t region_pos[3], char *out, uint32_t cap);
 
+/* ---- the chunk payload of the reference's wire protocol (common/src/net.rs:46-55; encoding in csrc/host/netmsg.hpp) ---- */
+/* Decode one `ClientCmd::GiveChunkData(pos, nodes, node_alloc)` from the front of a received-byte queue and do what
+ * GameState::process_cmd does with it (client/src/lib.rs:110-118): create_chunk(pos, nodes).  On 0 the caller uploads
+ * pool[root, root + node_count) (clientdesktop/src/main.rs:289-295) and drops `consumed` bytes.
+ * Returns 0, a SetVoxelErr (> 0; the message is consumed: 1 = PosOutOfBounds is `received_oob_chunks`), -1 malformed,
+ * -2 incomplete (bincode's UnexpectedEnd: wait for more bytes), -3 another ClientCmd variant. */
+int vrth_chunk_msg_ingest(vrth_world *w, const uint8_t *bytes, uint64_t n, uint64_t *consumed, int32_t chunk_pos[3], uint32_t *root,
+                          uint32_t *node_count);
+/* What the server sends for a chunk of this world (server/src/lib.rs:229-233: its used node prefix + the placeholder
+ * NodeAlloc::new(0..1, 1..2)).
+ * Returns the byte count (writes if it fits cap), 0 if the world has no such chunk. */
+uint64_t vrth_chunk_msg_encode(const vrth_world *w, const int32_t chunk_pos[3], uint8_t *out, uint64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -166,6 +166,8 @@ VRTH_SYMBOLS = {
     "vrth_world_generate": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_int]),
     "vrth_region_load_into_world": (C.c_int, [_P, _P, C.c_uint64, _I32P, _U32P]),
     "vrth_region_save_from_world": (C.c_uint64, [_P, _I32P, _P, C.c_uint64]),
+    "vrth_chunk_msg_ingest": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(C.c_uint64), _I32P, _U32P, _U32P]),
+    "vrth_chunk_msg_encode": (C.c_uint64, [_P, _I32P, _P, C.c_uint64]),
     "vrth_region_of_chunk": (None, [_I32P, _I32P, _U32P]),
     "vrth_region_file_name": (C.c_uint32, [_I32P, C.c_char_p, C.c_uint32]),
 }

@@ -6,6 +6,7 @@
 #include "../../../include/vrt_host.h"
 #include "graphics.hpp"
 #include "materials.hpp"
+#include "netmsg.hpp"
 #include "regionfile.hpp"
 #include "worldgen.hpp"
 
@@ -271,6 +272,43 @@ uint32_t vrth_region_file_name(const int32_t region_pos[3], char *out, uint32_t 
     const std::string s = region_file_name(cp3(region_pos));
     if (out && cap > s.size()) std::memcpy(out, s.c_str(), s.size() + 1);
     return (uint32_t)s.size();
+}
+
+int vrth_chunk_msg_ingest(vrth_world *w, const uint8_t *bytes, uint64_t n, uint64_t *consumed, int32_t chunk_pos[3], uint32_t *root,
+                          uint32_t *node_count) {
+    GiveChunkData m;
+    size_t used = 0;
+    switch (GiveChunkData::decode(bytes, (size_t)n, m, used)) {
+        case GiveChunkData::Status::NeedMore: return -2;
+        case GiveChunkData::Status::NotChunkData: return -3;
+        case GiveChunkData::Status::Malformed: return -1;
+        case GiveChunkData::Status::Ok: break;
+    }
+    if (consumed) *consumed = used;
+    if (chunk_pos) { chunk_pos[0] = m.pos.x; chunk_pos[1] = m.pos.y; chunk_pos[2] = m.pos.z; }
+    // GameState::process_cmd, client/src/lib.rs:112-118
+    SetVoxelErr err;
+    const NodeAddr addr = w->w.create_chunk(m.pos, m.nodes.data(), (uint32_t)m.nodes.size(), err);
+    if (root) *root = addr;
+    if (node_count) *node_count = (uint32_t)m.nodes.size();
+    return (int)err;
+}
+
+uint64_t vrth_chunk_msg_encode(const vrth_world *w, const int32_t chunk_pos[3], uint8_t *out, uint64_t cap) {
+    const Chunk *c = w->w.get_chunk(cp3(chunk_pos));
+    if (!c) return 0;
+    // server/src/lib.rs:229-233, 292-296: GiveChunkData(pos, Cow::Borrowed(chunk.used_nodes()), NodeAlloc::new(0..1, 1..2))
+    // — the allocator field is a placeholder on the wire; the client rebuilds its own (world.rs:323)
+    GiveChunkData m;
+    m.pos = cp3(chunk_pos);
+    const uint32_t used = c->alloc.last_used_addr + 1;
+    m.nodes.assign(w->w.nodes() + c->range.start, w->w.nodes() + c->range.start + used);
+    m.range = {0, 2};
+    m.free_mem = {NodeRange{1, 2}};
+    m.last_used_addr = 0;
+    const std::vector<uint8_t> bytes = m.encode();
+    if (out && bytes.size() <= cap) std::memcpy(out, bytes.data(), bytes.size());
+    return bytes.size();
 }
 
 }  // extern "C"

@@ -191,6 +191,34 @@ class ClientWorld:
         self._lib.vrth_region_save_from_world(self._h, _i3(region_pos), buf, size)
         return bytes(buf)
 
+    # --- the wire protocol's chunk payload (common/src/net.rs:46-55) ---
+    def ingest_chunk_msg(self, data: bytes):
+        """GameState::process_cmd for one `ClientCmd::GiveChunkData` at the front of `data` (client/src/lib.rs:110-118).
+        -> (consumed bytes, chunk pos, root, node count): upload pool[root, root + count) afterwards (main.rs:289-295).
+        None if the message is incomplete; ValueError if it is malformed or another command; SetVoxelErr from create_chunk
+        (PosOutOfBounds = the reference's `received_oob_chunks`)."""
+        used, pos, root, n = C.c_uint64(), (C.c_int32 * 3)(), C.c_uint32(), C.c_uint32()
+        buf = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data or b"\0")
+        rc = self._lib.vrth_chunk_msg_ingest(self._h, buf, len(data), C.byref(used), pos, C.byref(root), C.byref(n))
+        if rc == -2:
+            return None
+        if rc < 0:
+            raise ValueError("malformed GiveChunkData" if rc == -1 else "not a GiveChunkData message")
+        if rc:
+            e = SetVoxelErr(rc)
+            e.consumed = used.value
+            raise e
+        return used.value, tuple(pos), root.value, n.value
+
+    def encode_chunk_msg(self, pos) -> bytes:
+        """What the reference server sends for this chunk (server/src/lib.rs:229-233)."""
+        size = self._lib.vrth_chunk_msg_encode(self._h, _i3(pos), None, 0)
+        if size == 0:
+            raise KeyError(f"no chunk at {tuple(pos)}")
+        buf = (C.c_uint8 * size)()
+        self._lib.vrth_chunk_msg_encode(self._h, _i3(pos), buf, size)
+        return bytes(buf)
+
     def world_data(self) -> _ffi.WorldData:
         """WorldData::from(&world), clientdesktop/src/graphics/mod.rs:121-130."""
         wd = _ffi.WorldData()
