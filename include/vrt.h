@@ -76,6 +76,14 @@ typedef struct {
     uint32_t _padding2;
 } vrt_settings;
 
+/* Crosshair — mod.rs:63-70 (32 B). style: 0 off, 1 dot, 2 cross (screen_shader.wgsl:9-13). */
+typedef struct {
+    float color[4];
+    uint32_t style;
+    float size;
+    uint32_t _padding[2];
+} vrt_crosshair;
+
 /* Replaces the arguments of GpuResources::new(gpu, fmt, result_size, max_nodes, world_size)
  * (mod.rs:155-195).  shard_rank/shard_count: this context traces only its share of the 8x8 screen tiles
  * (tile-interleaved multi-GPU sharding; 0/1 = whole frame).  Tiles are dealt out in periods of
@@ -189,6 +197,12 @@ int vrt_synchronize(vrt_ctx *ctx);
  * put in the reference's rgba8unorm texture (ray_tracer.wgsl:179).
  * With shard_count > 1 only this context's tiles are defined; the rest reads as zero. */
 int vrt_read_output(vrt_ctx *ctx, float *rgb, uint32_t *ids, uint8_t *rgba8);
+
+/* ScreenShader::encode_pass (shader.rs:273-293, main.rs:454) into host memory: for every pixel of a screen_w x
+ * screen_h target, fs_main of screen_shader.wgsl:43-65 — the rgba8unorm result texture sampled at the pixel centre
+ * (Nearest, the sampler's magnification filter: the screen must be at least the texture's size) blended with the
+ * crosshair — written as unorm8 RGBA, screen_w*screen_h*4 bytes (synchronises).  Unsharded contexts only. */
+int vrt_present(vrt_ctx *ctx, const vrt_crosshair *crosshair, uint32_t screen_w, uint32_t screen_h, uint8_t *rgba8);
 
 int vrt_get_stats(vrt_ctx *ctx, vrt_stats *out);
 

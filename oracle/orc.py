@@ -41,6 +41,10 @@ class Settings(C.Structure):
                 ("sun_pos", C.c_float * 3), ("_padding2", C.c_uint32)]
 
 
+class Crosshair(C.Structure):
+    _fields_ = [("color", C.c_float * 4), ("style", C.c_uint32), ("size", C.c_float), ("_padding", C.c_uint32 * 2)]
+
+
 class Scene(C.Structure):
     _fields_ = [("nodes", C.c_void_p), ("n_nodes", C.c_uint32), ("chunk_roots", C.c_void_p), ("n_chunk_roots", C.c_uint32),
                 ("materials", C.c_void_p), ("cam", CamData), ("settings", Settings), ("world", WorldData)]
@@ -84,6 +88,8 @@ def lib() -> C.CDLL:
         L.orc_get_node.restype = u32
         L.orc_find_node.argtypes = [C.POINTER(Scene), f32p, u32, vp]
         L.orc_find_node.restype = None
+        L.orc_present.argtypes = [f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(Crosshair), C.POINTER(C.c_uint8)]
+        L.orc_present.restype = None
         L.orc_ray_sky.argtypes = [C.POINTER(Scene), f32p, f32p, f32p]
         L.orc_ray_sky.restype = None
         L.orc_cam_data_create.argtypes = [f32p, f32p, C.c_float, f32p, C.POINTER(CamData)]
@@ -174,6 +180,17 @@ class OracleScene:
         rgb = (C.c_float * 3)()
         lib().orc_ray_sky(C.byref(self.c), _f(origin, 3), _f(direction, 3), rgb)
         return tuple(rgb)
+
+
+def present(rgb: np.ndarray, screen_size, color=(1.0, 1.0, 1.0, 0.33), style=2, size=5.0) -> np.ndarray:
+    """orc_present: rgba8 [screen_h, screen_w, 4] of a traced f32 frame [h, w, 3] under a crosshair."""
+    rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+    h, w, _ = rgb.shape
+    ch = Crosshair((C.c_float * 4)(*color), style, size)
+    out = np.empty((screen_size[1], screen_size[0], 4), dtype=np.uint8)
+    lib().orc_present(rgb.ctypes.data_as(C.POINTER(C.c_float)), w, h, screen_size[0], screen_size[1], C.byref(ch),
+                      out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out
 
 
 def from_package_scene(scene) -> OracleScene:

@@ -301,6 +301,46 @@ static v3 ray_sky(const orc_scene *s, v3 origin, v3 dir) {
               orc_mix(void_color, sky_gradient.z, ground_to_sky_t) + add);
 }
 
+static uint32_t orc_unorm8(float x) {
+    /* float -> unorm8 conversion of a colour attachment / storage texture: clamp, scale, round to nearest even */
+    float c = x > 0.0f ? x : 0.0f;   /* NaN -> 0 */
+    c = c < 1.0f ? c : 1.0f;
+    return (uint32_t)rintf(c * 255.0f) & 0xFFu;
+}
+
+/* screen_shader.wgsl:43-65 over the rgba8unorm result texture (ray_tracer.wgsl:179). */
+void orc_present(const float *rgb, uint32_t w, uint32_t h, uint32_t screen_w, uint32_t screen_h,
+                 const orc_crosshair *ch, uint8_t *rgba8) {
+    const float ssx = (float)screen_w, ssy = (float)screen_h;
+    const float cx = ssx * 0.5f, cy = ssy * 0.5f;            /* screen_center (:45) */
+    for (uint32_t sy = 0; sy < screen_h; sy++)
+        for (uint32_t sx = 0; sx < screen_w; sx++) {
+            /* tex_coord at the pixel centre (the interpolated vs_main output, :33-40) */
+            const float u = ((float)sx + 0.5f) / ssx, v = ((float)sy + 0.5f) / ssy;
+            const float px = u * ssx, py = v * ssy;          /* screen_pos (:44) */
+            float mask = 0.0f;
+            if (ch->style == 1u) {                           /* dot (:48-50) */
+                const float dx = cx - px, dy = cy - py;
+                mask = (sqrtf(dx * dx + dy * dy) < ch->size ? 1.0f : 0.0f) * ch->color[3];
+            }
+            if (ch->style == 2u) {                           /* cross (:51-59) */
+                const float dx = fabsf(cx - px), dy = fabsf(cy - py);
+                const float wd = ch->size * 0.25f;
+                mask = (((dx < ch->size && dy < wd) || (dy < ch->size && dx < wd)) ? 1.0f : 0.0f) * ch->color[3];
+            }
+            /* textureSample, Nearest: the texel containing the sample point */
+            uint32_t tx = (uint32_t)floorf(u * (float)w), ty = (uint32_t)floorf(v * (float)h);
+            if (tx > w - 1u) tx = w - 1u;
+            if (ty > h - 1u) ty = h - 1u;
+            const float *t = rgb + ((size_t)ty * w + tx) * 3;
+            float texel[4] = {(float)orc_unorm8(t[0]) / 255.0f, (float)orc_unorm8(t[1]) / 255.0f,
+                              (float)orc_unorm8(t[2]) / 255.0f, 1.0f};
+            const float cc[4] = {ch->color[0], ch->color[1], ch->color[2], 1.0f};
+            uint8_t *o = rgba8 + ((size_t)sy * screen_w + sx) * 4;
+            for (int k = 0; k < 4; k++) o[k] = (uint8_t)orc_unorm8(texel[k] * (1.0f - mask) + cc[k] * mask);  /* :60-63 */
+        }
+}
+
 void orc_ray_sky(const orc_scene *scene, const float origin[3], const float dir[3], float *rgb) {
     v3 c = ray_sky(scene, V3(origin[0], origin[1], origin[2]), V3(dir[0], dir[1], dir[2]));
     rgb[0] = c.x; rgb[1] = c.y; rgb[2] = c.z;

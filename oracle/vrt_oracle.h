@@ -142,6 +142,22 @@ void orc_find_node(const orc_scene *scene, const float pos[3], uint32_t max_dept
 /* ray_sky, ray_tracer.wgsl:144-157. */
 void orc_ray_sky(const orc_scene *scene, const float origin[3], const float dir[3], float *rgb);
 
+/* Crosshair — clientdesktop/src/graphics/mod.rs:63-70 (32 B). style: 0 off, 1 dot, 2 cross. */
+typedef struct {
+    float color[4];
+    uint32_t style;
+    float size;
+    uint32_t _padding[2];
+} orc_crosshair;
+
+/* Presentation of a traced frame: `textureStore` of the f32 colour into the rgba8unorm result texture
+ * (ray_tracer.wgsl:179: clamp to [0,1], x255, round to nearest even) followed by fs_main of screen_shader.wgsl:43-65 for
+ * every pixel of a screen_w x screen_h target: the result texture sampled at the pixel centre (Nearest: the
+ * magnification filter, texture.rs:36 — screen >= texture on both axes) blended with the crosshair.  The fragment's
+ * vec4 is written as unorm8 RGBA (what a non-sRGB Rgba8Unorm target stores). */
+void orc_present(const float *rgb, uint32_t w, uint32_t h, uint32_t screen_w, uint32_t screen_h,
+                 const orc_crosshair *crosshair, uint8_t *rgba8);
+
 /* CamData::create, mod.rs:92-111, on a restatement of glam 0.31.0's Mat4 routines. */
 void orc_cam_data_create(const float rot_deg[3], const float eye[3], float fov_deg,
                          const float proj_size[2], orc_cam_data *out);

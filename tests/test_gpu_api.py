@@ -111,3 +111,24 @@ def test_two_contexts_are_independent():
     assert np.array_equal(ga.read_output()[1], ia) and not np.array_equal(ia, ib)
     s = ga.stats()
     assert s.frames >= 1 and s.ms_total > 0 and s.primary_rays == 64 * 64
+
+
+def test_present_quantise_and_crosshair_blit(orc):
+    """vrt_present = textureStore to rgba8unorm + fs_main of screen_shader.wgsl, byte for byte what the oracle's
+    restatement gives from the same f32 frame: default cross, a dot, no crosshair, and a 2x magnified window."""
+    sc = scenes.c2((128, 72))
+    gpu = gpu_for_scene(sc)
+    gpu.render(MODE_PRIMARY_SHADOW)
+    rgb, _, q = gpu.read_output(rgba8=True)
+    for kw in (dict(), dict(style=1, size=9.5, color=(1.0, 0.2, 0.1, 0.75)), dict(style=0), dict(style=2, size=17.0, color=(0.0, 0.0, 0.0, 1.0))):
+        for screen in ((128, 72), (256, 144), (200, 100)):
+            got = gpu.present(screen, **kw)
+            want = orc.present(rgb, screen, **kw)
+            assert got.shape == (screen[1], screen[0], 4) and np.array_equal(got, want), (kw, screen)
+    plain = gpu.present(style=0)
+    assert np.array_equal(plain, q)                     # without a crosshair the blit is the rgba8 texture itself
+    cross = gpu.present()                                 # Crosshair::default(): white, alpha 0.33, size 5
+    changed = np.argwhere((cross != q).any(axis=2))
+    assert 0 < len(changed) <= 2 * (10 * 3) and np.abs(changed - np.array([36, 64])).max() <= 5
+    with pytest.raises(VrtError):
+        gpu.present((64, 36))                             # minification (the sampler's Linear filter) is not offered

@@ -273,3 +273,24 @@ def test_shadow_ray_definition(orc):
     s.set_cam(cam)
     idw, _, _, _ = s.trace_pixel(orc.MODE_PRIMARY_SHADOW, 32, 32)
     assert idw == 0
+
+
+def test_present_known_answers(orc):
+    """screen_shader.wgsl:43-65 over the rgba8unorm texture: quantisation (clamp, x255, ties to even), the default
+    cross (size 5, arm half-width 1.25, alpha 0.33 white), a dot, and Nearest magnification."""
+    rgb = np.zeros((8, 16, 3), dtype=np.float32)
+    rgb[..., 0], rgb[..., 1], rgb[..., 2] = 0.5, 2.0, -1.0
+    plain = orc.present(rgb, (16, 8), style=0)
+    assert (plain == np.array([128, 255, 0, 255], dtype=np.uint8)).all()       # 127.5 -> 128 (even), clamps, alpha 1
+    cross = orc.present(rgb, (16, 8))
+    # pixel centres at +-0.5 from the screen centre (8, 4): |dx| < 5 and |dy| < 1.25 -> 10 x 2 pixels, and the vertical arm
+    on = (cross != plain).any(axis=2)
+    assert on[3:5, 3:13].all() and on[:, 7:9].all() and on.sum() == 10 * 2 + 2 * 8 - 4
+    # 128/255 * 0.67 + 0.33 = 0.66631 -> 170;  1 * 0.67 + 0.33 -> 255;  0 * 0.67 + 0.33 = 0.33 -> 84
+    assert (cross[on] == np.array([170, 255, 84, 255], dtype=np.uint8)).all()
+    dot = orc.present(rgb, (16, 8), style=1, size=1.0, color=(0.0, 0.0, 0.0, 1.0))
+    assert (dot[3:5, 7:9] == np.array([0, 0, 0, 255], dtype=np.uint8)).all() and (dot != plain).any(axis=2).sum() == 4   # distance sqrt(0.5) < 1
+    ramp = np.zeros((2, 2, 3), dtype=np.float32)
+    ramp[0, 1, 0] = ramp[1, 0, 1] = 1.0
+    big = orc.present(ramp, (6, 4), style=0)                                    # 3x / 2x magnification, Nearest
+    assert (big[:2, 3:, 0] == 255).all() and (big[:2, :3, 0] == 0).all() and (big[2:, :3, 1] == 255).all() and (big[2:, 3:, 1] == 0).all()

@@ -59,6 +59,11 @@ class Stats(C.Structure):
                 ("sum_ms_secondary", C.c_double), ("sum_ms_total", C.c_double)]
 
 
+class Crosshair(C.Structure):
+    """clientdesktop/src/graphics/mod.rs:63-80"""
+    _fields_ = [("color", C.c_float * 4), ("style", C.c_uint32), ("size", C.c_float), ("_padding", C.c_uint32 * 2)]
+
+
 class AccelInfo(C.Structure):
     _fields_ = [("available", C.c_uint32), ("world_size_chunks", C.c_uint32), ("cells", C.c_uint64),
                 ("bricks", C.c_uint64), ("bytes", C.c_uint64), ("builds", C.c_uint32), ("last_build_ms", C.c_float)]
@@ -90,6 +95,7 @@ VRT_SYMBOLS = {
     "vrt_render": (C.c_int, [_P, C.POINTER(RenderOpts)]),
     "vrt_synchronize": (C.c_int, [_P]),
     "vrt_read_output": (C.c_int, [_P, _P, _P, _P]),
+    "vrt_present": (C.c_int, [_P, C.POINTER(Crosshair), C.c_uint32, C.c_uint32, _P]),
     "vrt_get_stats": (C.c_int, [_P, C.POINTER(Stats)]),
     "vrt_get_accel_info": (C.c_int, [_P, C.POINTER(AccelInfo)]),
     "vrt_read_accel": (C.c_int, [_P, _P, _P]),

@@ -30,6 +30,8 @@ void launch_path_finish(Texel *out, uint32_t n, uint32_t spp, hipStream_t st);
 void launch_quantize(const Texel *out, uint8_t *rgba8, uint32_t n, hipStream_t st);
 void launch_assemble(const Texel *gathered, Texel *dst, uint32_t width, uint32_t tiles_x, uint32_t tiles_total,
                      uint32_t root_weight, uint32_t period, bool skip_root, uint64_t rank_stride, hipStream_t st);
+void launch_present(const Texel *out, uint32_t w, uint32_t h, uint32_t screen_w, uint32_t screen_h, const vrt_crosshair &ch,
+                    uint8_t *rgba8, hipStream_t st);
 void launch_accel_cells(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S, uint32_t *grid,
                         uint32_t *chunk_bricks, uint32_t *chunk_offsets, uint32_t *total, hipStream_t st);
 void launch_accel_bricks(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S, uint32_t *grid,
@@ -40,6 +42,7 @@ static_assert(sizeof(vrt_material) == 32, "Material layout (mod.rs:20-28)");
 static_assert(sizeof(vrt_cam_data) == 160, "CamData layout (mod.rs:82-91)");
 static_assert(sizeof(vrt_world_data) == 32, "WorldData layout (mod.rs:113-120)");
 static_assert(sizeof(vrt_settings) == 48, "Settings layout (mod.rs:132-143)");
+static_assert(sizeof(vrt_crosshair) == 32, "Crosshair layout (mod.rs:63-70)");
 static_assert(sizeof(vrt::Texel) == 16, "texel");
 
 struct vrt_ctx {
@@ -78,6 +81,8 @@ struct vrt_ctx {
     uint32_t hit_seg_cap = 0;
     uint32_t *d_steps = nullptr;
     uint8_t *d_rgba8 = nullptr;
+    uint8_t *d_screen = nullptr;   // vrt_present's target
+    size_t screen_cap = 0;
 
     // derived lookup tables of the grid march (vrt_accel.hip), rebuilt lazily when their inputs changed
     uint32_t *d_grid = nullptr;
@@ -343,7 +348,7 @@ void vrt_destroy(vrt_ctx *c) {
     (void)hipFree(c->d_hits); (void)hipFree(c->d_counters); (void)hipFree(c->d_steps); (void)hipFree(c->d_rgba8); (void)hipFree(c->d_path);
     (void)hipFree(c->d_blk_counts);
     (void)hipFree(c->d_grid); (void)hipFree(c->d_bricks); (void)hipFree(c->d_chunk_bricks); (void)hipFree(c->d_chunk_offsets);
-    (void)hipFree(c->d_brick_total); (void)hipFree(c->d_ndc);
+    (void)hipFree(c->d_brick_total); (void)hipFree(c->d_ndc); (void)hipFree(c->d_screen);
     for (auto &t : c->ev_pool)
         for (auto &ev : t)
             if (ev) (void)hipEventDestroy(ev);
@@ -703,6 +708,28 @@ int vrt_read_output(vrt_ctx *c, float *rgb, uint32_t *ids, uint8_t *rgba8) {
         const uint32_t tx = (tile % c->tiles_x) * 8u, ty = (tile / c->tiles_x) * 8u;
         for (uint32_t p = 0; p < 64; p++) put((size_t)(ty + (p >> 3)) * c->width + tx + (p & 7u), t[(size_t)tl * 64 + p]);
     }
+    return VRT_OK;
+}
+
+int vrt_present(vrt_ctx *c, const vrt_crosshair *crosshair, uint32_t screen_w, uint32_t screen_h, uint8_t *rgba8) {
+    if (!c || !crosshair || !rgba8) return fail(c, VRT_ERR_INVALID_ARG, "vrt_present: null argument");
+    if (!c->rendered) return fail(c, VRT_ERR_STATE, "vrt_present: nothing rendered yet");
+    if (c->tile_major || c->shard_count > 1u) return fail(c, VRT_ERR_STATE, "vrt_present: needs the whole row-major frame");
+    if (screen_w < c->width || screen_h < c->height || (uint64_t)screen_w * screen_h > (1ull << 28))
+        return fail(c, VRT_ERR_INVALID_ARG, "vrt_present: screen %ux%u must be at least the %ux%u result texture (the sampler magnifies "
+                    "with Nearest; its Linear minification is not implemented)", screen_w, screen_h, c->width, c->height);
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t bytes = (size_t)screen_w * screen_h * 4u;
+    if (bytes > c->screen_cap) {
+        (void)hipFree(c->d_screen);
+        c->d_screen = nullptr; c->screen_cap = 0;
+        HIP_TRY(c, hipMalloc(&c->d_screen, bytes));
+        c->screen_cap = bytes;
+    }
+    vrt::launch_present(c->d_out, c->width, c->height, screen_w, screen_h, *crosshair, c->d_screen, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(rgba8, c->d_screen, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return VRT_OK;
 }
 

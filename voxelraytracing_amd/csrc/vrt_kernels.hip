@@ -270,6 +270,39 @@ __global__ void quantize_rgba8_kernel(const Texel *out, uint8_t *rgba8, uint32_t
     reinterpret_cast<uint32_t *>(rgba8)[i] = q;
 }
 
+// Presentation: fs_main of screen_shader.wgsl:43-65 over the rgba8unorm result texture (ray_tracer.wgsl:179), one lane
+// per screen pixel: Nearest sample of the texture at the pixel centre, crosshair mask, blend, unorm8 store.
+__device__ __forceinline__ uint32_t unorm8(float x) { return (uint32_t)rintf(vclamp(x, 0.0f, 1.0f) * 255.0f) & 0xFFu; }
+
+__global__ void present_kernel(const Texel *out, uint32_t w, uint32_t h, uint32_t screen_w, uint32_t screen_h, vrt_crosshair ch,
+                               uint8_t *rgba8) {
+    const uint32_t sx = blockIdx.x * blockDim.x + threadIdx.x, sy = blockIdx.y;
+    if (sx >= screen_w) return;
+    const float ssx = (float)screen_w, ssy = (float)screen_h;
+    const float cx = ssx * 0.5f, cy = ssy * 0.5f;
+    const float u = ((float)sx + 0.5f) / ssx, v = ((float)sy + 0.5f) / ssy;
+    const float px = u * ssx, py = v * ssy;
+    float mask = 0.0f;
+    if (ch.style == 1u) {
+        const float dx = cx - px, dy = cy - py;
+        mask = (sqrtf(dx * dx + dy * dy) < ch.size ? 1.0f : 0.0f) * ch.color[3];
+    }
+    if (ch.style == 2u) {
+        const float dx = fabsf(cx - px), dy = fabsf(cy - py);
+        const float wd = ch.size * 0.25f;
+        mask = (((dx < ch.size && dy < wd) || (dy < ch.size && dx < wd)) ? 1.0f : 0.0f) * ch.color[3];
+    }
+    const uint32_t tx = min((uint32_t)floorf(u * (float)w), w - 1u), ty = min((uint32_t)floorf(v * (float)h), h - 1u);
+    const Texel t = out[(size_t)ty * w + tx];
+    const float texel[4] = {(float)unorm8(__uint_as_float(t.x)) / 255.0f, (float)unorm8(__uint_as_float(t.y)) / 255.0f,
+                            (float)unorm8(__uint_as_float(t.z)) / 255.0f, 1.0f};
+    const float cc[4] = {ch.color[0], ch.color[1], ch.color[2], 1.0f};
+    uint32_t q = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; k++) q |= unorm8(texel[k] * (1.0f - mask) + cc[k] * mask) << (8 * k);
+    reinterpret_cast<uint32_t *>(rgba8)[(size_t)sy * screen_w + sx] = q;
+}
+
 // Gather root: tile-major [rank][slots_per_rank] texels -> row-major frame of texels.  Tiles are dealt out in periods
 // of `period` = root_weight + N - 1 (vrt_config); skip_root: the root rendered its own tiles in place.
 __global__ void assemble_kernel(const Texel *gathered, Texel *dst, uint32_t width, uint32_t tiles_x, uint32_t tiles_total,
@@ -366,6 +399,12 @@ void launch_shadow(const FrameParams &P, uint32_t variant, bool stats, hipStream
 void launch_quantize(const Texel *out, uint8_t *rgba8, uint32_t n, hipStream_t st) {
     if (!n) return;
     hipLaunchKernelGGL(quantize_rgba8_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, out, rgba8, n);
+}
+
+void launch_present(const Texel *out, uint32_t w, uint32_t h, uint32_t screen_w, uint32_t screen_h, const vrt_crosshair &ch,
+                    uint8_t *rgba8, hipStream_t st) {
+    hipLaunchKernelGGL(present_kernel, dim3((screen_w + 255u) / 256u, screen_h), dim3(256), 0, st, out, w, h, screen_w, screen_h, ch,
+                       rgba8);
 }
 
 void launch_assemble(const Texel *gathered, Texel *dst, uint32_t width, uint32_t tiles_x, uint32_t tiles_total,

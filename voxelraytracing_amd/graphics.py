@@ -140,6 +140,15 @@ class Gpu:
         self._ck(self._lib.vrt_read_output(self._h, p(a_rgb), p(a_ids), p(a_q)))
         return a_rgb, a_ids, a_q
 
+    def present(self, screen_size=None, color=(1.0, 1.0, 1.0, 0.33), style: int = 2, size: float = 5.0) -> np.ndarray:
+        """ScreenShader::encode_pass into host memory: rgba8 [screen_h, screen_w, 4] of the last frame under the
+        crosshair (defaults = Crosshair::default(), mod.rs:71-80)."""
+        sw, sh = screen_size or self.result_size
+        ch = _ffi.Crosshair((C.c_float * 4)(*color), style, size)
+        out = np.empty((sh, sw, 4), dtype=np.uint8)
+        self._ck(self._lib.vrt_present(self._h, C.byref(ch), sw, sh, out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def read_steps(self) -> np.ndarray:
         w, h = self.result_size
         a = np.empty((h, w), dtype=np.uint32)
