@@ -85,6 +85,82 @@ dist.destroy_process_group()
 '''
 
 
+REPLICA_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["VRT_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+from voxelraytracing_amd import shard
+from voxelraytracing_amd.world import ClientWorld
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+class FakeGpu:                       # records what would go to the device
+    def __init__(self): self.ranges, self.roots = [], None
+    def write_nodes(self, ptr, a, b): self.ranges.append((a, b))
+    def write_chunk_roots(self, r): self.roots = r.copy()
+    def write_world_data(self, w): self.wd = w
+# the "server": a generated world whose chunks are sent as GiveChunkData messages (rank 0 holds the connection)
+server = ClientWorld((2, 1, 2), 1 << 22, 4)
+server.generate(0, 11)
+cw, gpu = ClientWorld((1, 1, 1), 1 << 21, 2), FakeGpu()       # the client sees chunks (0..1)^3 at first
+rw = shard.ReplicatedWorld(torch, dist, rank, world, cw, gpu)
+stream = b"".join(server.encode_chunk_msg((x, y, z)) for z in range(3) for y in range(2) for x in range(3)) if rank == 0 else b""
+cut = len(stream) - 7 if rank == 0 else 0                     # the last message arrives in two TCP reads
+updated, used = rw.ingest_chunk_msgs(stream[:cut])
+assert len(updated) == 8 and cw.populated_count() == 8, (len(updated), cw.populated_count())   # 10 of the 18 were outside the grid
+assert [b - a for a, b in gpu.ranges] == [n for _, _, n in updated] and gpu.roots is not None
+assert rw.verify()
+# edits near the terrain surface, decided on rank 0
+rng = np.random.default_rng(3)
+done = 0
+for _ in range(40):
+    p = rng.integers(0, 64, 3) if rank == 0 else (0, 0, 0)
+    r = rw.set_voxel(tuple(int(v) for v in p), int(rng.choice([0, 4, 3])) if rank == 0 else 0)
+    done += r is not None
+assert done > 10 and rw.verify()
+# the player walks +x: the grid follows, one slab of chunks falls out, new ones arrive
+removed = rw.recenter((2, 1, 1))
+assert removed == 4 and cw.populated_count() == 4
+more = b"".join(server.encode_chunk_msg((2, y, z)) for z in range(2) for y in range(2)) if rank == 0 else b""
+updated, _ = rw.ingest_chunk_msgs(more)
+assert len(updated) == 4 and cw.populated_count() == 8 and rw.verify()
+assert cw.get_voxel((70, 5, 20)) == server.get_voxel((70, 5, 20))
+# a replica that drifts is noticed
+if rank == world - 1:
+    cw.set_voxel((40, 60, 40), 4 if cw.get_voxel((40, 60, 40)) != 4 else 47)
+assert not rw.verify()
+total = rw.uploaded_nodes
+if rank == 0:
+    print("REPLICA_OK", world, total, cw.max_nodes())
+dist.destroy_process_group()
+'''
+
+
+def test_replicated_world_stays_coherent_over_gloo(tmp_path):
+    """Chunk streaming, voxel edits and recentring on 2 replicas: commands are broadcast, pools stay byte-identical,
+    and only the touched ranges are uploaded."""
+    script = tmp_path / "replica_worker.py"
+    script.write_text(REPLICA_WORKER)
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   VRT_ROOT=ROOT, OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out.decode())
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{out[-3000:]}"
+    line = [ln for ln in outs[0].splitlines() if ln.startswith("REPLICA_OK")][0].split()
+    assert int(line[2]) < int(line[3])   # everything uploaded in the whole session is less than one whole-pool upload
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -155,3 +155,108 @@ class FrameGather:
     def drain(self, gpu):
         """Finish the last submitted frame."""
         self._finish_pending(gpu)
+
+
+class ReplicatedWorld:
+    """Keeps the N replicas of the scene coherent while the world changes.
+
+    The scene is read-only during a frame and replicated on every GPU; between frames the reference's client
+    mutates it in three ways — chunks arrive from the server (`GiveChunkData`, client/src/lib.rs:110-118), the grid is
+    recentred on the player (`center_chunks`, lib.rs:55-65 / world.rs:297-308) and voxels are edited (`set_voxel`,
+    main.rs:352-362).  Rank 0 is the process that talks to the server and reads the input; it broadcasts the *command*
+    (the message bytes, the anchor, the edit), every rank applies it to its own host world — the allocators are
+    deterministic, so the pools stay byte-identical — and uploads only the range the command touched
+    (`vrt_write_nodes`, as the reference does).  `verify()` compares a digest of every replica's pool and chunk table.
+    No node data crosses a link except the server's own messages (a few KB per chunk)."""
+
+    CMD_CHUNKS, CMD_EDIT, CMD_RECENTER = 1, 2, 3
+
+    def __init__(self, torch, dist, rank: int, count: int, world, gpu, device="cpu"):
+        self.torch, self.dist, self.rank, self.count = torch, dist, rank, count
+        self.world, self.gpu, self.device = world, gpu, device
+        self.uploaded_nodes = 0   # node words re-uploaded so far (what a whole-pool upload would have cost: max_nodes each time)
+
+    # ---- transport: rank 0's command to everybody ----
+    def _bcast(self, kind: int, ints=(), payload: bytes = b""):
+        t = self.torch
+        if self.count > 1:
+            hdr = t.zeros(8, dtype=t.int64, device=self.device)
+            if self.rank == 0:
+                hdr[0], hdr[1] = kind, len(payload)
+                for i, v in enumerate(ints):
+                    hdr[2 + i] = int(v)
+            self.dist.broadcast(hdr, src=0)
+            kind, n = int(hdr[0]), int(hdr[1])
+            ints = [int(v) for v in hdr[2:]]
+            if n:
+                buf = t.frombuffer(bytearray(payload), dtype=t.uint8).to(self.device) if self.rank == 0 else t.empty(n, dtype=t.uint8, device=self.device)
+                self.dist.broadcast(buf, src=0)
+                payload = bytes(buf.cpu().numpy().tobytes())
+        return kind, list(ints), payload
+
+    def _upload(self, start: int, n: int):
+        self.gpu.write_nodes(self.world.nodes_ptr(), start, start + n)
+        self.uploaded_nodes += n
+
+    def _roots(self):
+        self.gpu.write_chunk_roots(self.world.chunk_roots())
+        self.gpu.write_world_data(self.world.world_data())
+
+    # ---- the three mutations; arguments are read on rank 0 only ----
+    def ingest_chunk_msgs(self, data: bytes = b""):
+        """Rank 0 passes the bytes received from the server; every rank creates the chunks and uploads their ranges.
+        Returns [(chunk pos, root, node count)] (CmdResult.updated_chunks) and leaves an incomplete tail unconsumed."""
+        _, _, data = self._bcast(self.CMD_CHUNKS, (), data)
+        updated, off = [], 0
+        while off < len(data):
+            try:
+                got = self.world.ingest_chunk_msg(data[off:])
+            except Exception as e:      # PosOutOfBounds = received_oob_chunks: the message is consumed, nothing to upload
+                if getattr(e, "kind", "") != "PosOutOfBounds":
+                    raise
+                off += e.consumed
+                continue
+            if got is None:
+                break
+            used, pos, root, n = got
+            self._upload(root, n)
+            updated.append((pos, root, n))
+            off += used
+        if updated:
+            self._roots()
+        return updated, off
+
+    def set_voxel(self, pos=(0, 0, 0), voxel: int = 0):
+        """The edit of main.rs:352-362 on every replica; returns the re-uploaded (start, count) or None (NoChange...)."""
+        _, v, _ = self._bcast(self.CMD_EDIT, (pos[0], pos[1], pos[2], voxel))
+        try:
+            start, n = self.world.set_voxel((v[0], v[1], v[2]), v[3])
+        except Exception as e:
+            if getattr(e, "kind", "") in ("NoChange", "NoChunk", "PosOutOfBounds", "OutOfMemory"):
+                return None
+            raise
+        self._upload(start, n)
+        return start, n
+
+    def recenter(self, anchor=(0, 0, 0)):
+        """GameState::center_chunks: the grid follows the player; chunks that fell out are freed, the table moves."""
+        _, v, _ = self._bcast(self.CMD_RECENTER, anchor)
+        removed = self.world.center_chunks((v[0], v[1], v[2]))
+        self._roots()
+        return removed
+
+    # ---- coherence check ----
+    def digest(self) -> int:
+        import zlib
+        return zlib.crc32(self.world.chunk_roots().tobytes(), zlib.crc32(memoryview(self.world.nodes())))
+
+    def verify(self) -> bool:
+        """True when every replica's pool and chunk table have the same digest."""
+        if self.count == 1:
+            return True
+        t = self.torch
+        d = t.tensor([self.digest()], dtype=t.int64, device=self.device)
+        lo, hi = d.clone(), d.clone()
+        self.dist.all_reduce(lo, op=self.dist.ReduceOp.MIN)
+        self.dist.all_reduce(hi, op=self.dist.ReduceOp.MAX)
+        return int(lo[0]) == int(hi[0])
