@@ -53,6 +53,8 @@ def main():
     ap.add_argument("--spp", type=int, default=1)
     ap.add_argument("--bounces", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frames-in-flight", type=int, default=2,
+                    help="N = 1: frames the backend keeps in flight (vrt_set_frames_in_flight; 1 = one launch at a time)")
     ap.add_argument("--root-weight", type=int, default=0,
                     help="N > 1: tiles per period dealt to the gather root (vrt_config.shard_root_weight); 0 = measure "
                          "a few candidates off the clock and keep the fastest")
@@ -127,6 +129,7 @@ def main():
         g.upload_world(sc.world, sc.materials)
         g.write_cam_data(sc.cam)
         g.write_settings(sc.settings)
+        g.set_frames_in_flight(args.frames_in_flight)
         f = None
         if sharded:
             g.set_stream(side.cuda_stream)

@@ -189,6 +189,13 @@ int vrt_resize_output(vrt_ctx *ctx, uint32_t width, uint32_t height);
  * Asynchronous: enqueues the frame's kernels on the context's stream. opts NULL = primary, default. */
 int vrt_render(vrt_ctx *ctx, const vrt_render_opts *opts);
 
+/* How many frames the context keeps in flight (1..4, default 2 — a swapchain gives the reference's wgpu path the same):
+ * consecutive vrt_render calls of plain single-launch frames (no stats, not the path trace, the context's own stream and
+ * output buffers) alternate between that many internal streams, each with its own output buffer, so one frame's tail
+ * overlaps the next one's ramp-up.  Every other call waits for all of them first; vrt_read_output / vrt_present /
+ * vrt_device_output refer to the most recent frame.  1 = strictly one frame at a time. */
+int vrt_set_frames_in_flight(vrt_ctx *ctx, uint32_t n);
+
 /* Block until everything enqueued on the context's stream has finished. */
 int vrt_synchronize(vrt_ctx *ctx);
 

@@ -1,0 +1,80 @@
+// tools/valu_rates.hip — issue rate of the VALU instruction classes the march uses, on a full chip at 8 waves / SIMD.
+// Each kernel is a loop of 32 copies of one instruction on independent registers; cycles per wave-instruction per SIMD
+// = elapsed * clock / (instructions per SIMD).  hipcc --offload-arch=gfx950 -O2 tools/valu_rates.hip -o tools/valu_rates
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+#define REP4(x) x x x x
+#define REP32(x) REP4(REP4(x)) REP4(REP4(x))
+
+#define KERNEL(name, body)                                                        \
+    __global__ void __launch_bounds__(256) name(float *out, int iters) {          \
+        float a = threadIdx.x * 0.001f + 1.0f, b = 1.0001f, c = 0.5f, d = 2.0f;   \
+        float e = a + 1.0f, f = a + 2.0f, g = a + 3.0f, h = a + 4.0f;             \
+        int i0 = threadIdx.x, i1 = 7, i2 = 3, i3 = 11;                            \
+        for (int it = 0; it < iters; it++) {                                      \
+            asm volatile(REP4(body) : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3) : : "vcc", "s10", "s11", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29"); \
+        }                                                                         \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = a + b + c + d + e + f + g + h + (float)(i0 + i1 + i2 + i3); \
+    }
+
+// 8 instructions per body (x4 = 32 per loop trip)
+KERNEL(k_add_f32, "v_add_f32 %0, %0, %1\n v_add_f32 %2, %2, %1\n v_add_f32 %3, %3, %1\n v_add_f32 %4, %4, %1\n v_add_f32 %5, %5, %1\n v_add_f32 %6, %6, %1\n v_add_f32 %7, %7, %1\n v_add_f32 %0, %0, %2\n")
+KERNEL(k_mul_f32, "v_mul_f32 %0, %0, %1\n v_mul_f32 %2, %2, %1\n v_mul_f32 %3, %3, %1\n v_mul_f32 %4, %4, %1\n v_mul_f32 %5, %5, %1\n v_mul_f32 %6, %6, %1\n v_mul_f32 %7, %7, %1\n v_mul_f32 %0, %0, %2\n")
+KERNEL(k_fma_f32, "v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %2, %2, %1, %3\n v_fma_f32 %3, %3, %1, %4\n v_fma_f32 %4, %4, %1, %5\n v_fma_f32 %5, %5, %1, %6\n v_fma_f32 %6, %6, %1, %7\n v_fma_f32 %7, %7, %1, %0\n v_fma_f32 %0, %0, %2, %3\n")
+KERNEL(k_min3_f32, "v_min3_f32 %0, %0, %1, %2\n v_min3_f32 %2, %2, %1, %3\n v_min3_f32 %3, %3, %1, %4\n v_min3_f32 %4, %4, %1, %5\n v_min3_f32 %5, %5, %1, %6\n v_min3_f32 %6, %6, %1, %7\n v_min3_f32 %7, %7, %1, %0\n v_min3_f32 %0, %0, %2, %3\n")
+KERNEL(k_cndmask_vcc, "v_cndmask_b32 %0, %2, %1, vcc\n v_cndmask_b32 %2, %3, %1, vcc\n v_cndmask_b32 %3, %4, %1, vcc\n v_cndmask_b32 %4, %5, %1, vcc\n v_cndmask_b32 %5, %6, %1, vcc\n v_cndmask_b32 %6, %7, %1, vcc\n v_cndmask_b32 %7, %0, %1, vcc\n v_cndmask_b32 %0, %3, %2, vcc\n")
+KERNEL(k_cndmask_e64, "v_cndmask_b32 %0, %2, %1, s[10:11]\n v_cndmask_b32 %2, %3, %1, s[10:11]\n v_cndmask_b32 %3, %4, %1, s[10:11]\n v_cndmask_b32 %4, %5, %1, s[10:11]\n v_cndmask_b32 %5, %6, %1, s[10:11]\n v_cndmask_b32 %6, %7, %1, s[10:11]\n v_cndmask_b32 %7, %0, %1, s[10:11]\n v_cndmask_b32 %0, %3, %2, s[10:11]\n")
+KERNEL(k_min_f32, "v_min_f32 %0, %0, %1\n v_min_f32 %2, %2, %1\n v_min_f32 %3, %3, %1\n v_min_f32 %4, %4, %1\n v_min_f32 %5, %5, %1\n v_min_f32 %6, %6, %1\n v_min_f32 %7, %7, %1\n v_min_f32 %0, %0, %2\n")
+KERNEL(k_lshl_or, "v_lshl_or_b32 %8, %8, 2, %9\n v_lshl_or_b32 %9, %9, 2, %10\n v_lshl_or_b32 %10, %10, 2, %11\n v_lshl_or_b32 %11, %11, 2, %8\n v_lshl_or_b32 %8, %8, 1, %10\n v_lshl_or_b32 %9, %9, 1, %11\n v_lshl_or_b32 %10, %10, 1, %8\n v_lshl_or_b32 %11, %11, 1, %9\n")
+KERNEL(k_add3_u32, "v_add3_u32 %8, %8, %9, %10\n v_add3_u32 %9, %9, %10, %11\n v_add3_u32 %10, %10, %11, %8\n v_add3_u32 %11, %11, %8, %9\n v_add3_u32 %8, %8, %10, %11\n v_add3_u32 %9, %9, %11, %8\n v_add3_u32 %10, %10, %8, %9\n v_add3_u32 %11, %11, %9, %10\n")
+KERNEL(k_cvt_flr, "v_cvt_flr_i32_f32 %8, %0\n v_cvt_flr_i32_f32 %9, %2\n v_cvt_flr_i32_f32 %10, %3\n v_cvt_flr_i32_f32 %11, %4\n v_cvt_flr_i32_f32 %8, %5\n v_cvt_flr_i32_f32 %9, %6\n v_cvt_flr_i32_f32 %10, %7\n v_cvt_flr_i32_f32 %11, %1\n")
+KERNEL(k_cmp_u32, "v_cmp_lt_u32 vcc, %8, %9\n v_cmp_lt_u32 vcc, %9, %10\n v_cmp_lt_u32 vcc, %10, %11\n v_cmp_lt_u32 vcc, %11, %8\n v_cmp_lt_u32 vcc, %8, %10\n v_cmp_lt_u32 vcc, %9, %11\n v_cmp_lt_u32 vcc, %10, %8\n v_cmp_lt_u32 vcc, %11, %9\n")
+KERNEL(k_pk_add_f32, "v_pk_add_f32 v[20:21], v[20:21], v[22:23]\n v_pk_add_f32 v[24:25], v[24:25], v[22:23]\n v_pk_add_f32 v[26:27], v[26:27], v[22:23]\n v_pk_add_f32 v[28:29], v[28:29], v[22:23]\n v_pk_add_f32 v[20:21], v[20:21], v[24:25]\n v_pk_add_f32 v[24:25], v[24:25], v[26:27]\n v_pk_add_f32 v[26:27], v[26:27], v[28:29]\n v_pk_add_f32 v[28:29], v[28:29], v[20:21]\n")
+KERNEL(k_sqrt_f32, "v_sqrt_f32 %0, %0\n v_sqrt_f32 %2, %2\n v_sqrt_f32 %3, %3\n v_sqrt_f32 %4, %4\n v_sqrt_f32 %5, %5\n v_sqrt_f32 %6, %6\n v_sqrt_f32 %7, %7\n v_sqrt_f32 %1, %1\n")
+KERNEL(k_div_fixup, "v_div_fixup_f32 %0, %0, %1, %2\n v_div_fixup_f32 %2, %2, %1, %3\n v_div_fixup_f32 %3, %3, %1, %4\n v_div_fixup_f32 %4, %4, %1, %5\n v_div_fixup_f32 %5, %5, %1, %6\n v_div_fixup_f32 %6, %6, %1, %7\n v_div_fixup_f32 %7, %7, %1, %0\n v_div_fixup_f32 %0, %0, %2, %3\n")
+KERNEL(k_cmp_f32, "v_cmp_eq_f32 vcc, %0, %1\n v_cmp_eq_f32 vcc, %2, %1\n v_cmp_eq_f32 vcc, %3, %1\n v_cmp_eq_f32 vcc, %4, %1\n v_cmp_eq_f32 vcc, %5, %1\n v_cmp_eq_f32 vcc, %6, %1\n v_cmp_eq_f32 vcc, %7, %1\n v_cmp_eq_f32 vcc, %0, %2\n")
+KERNEL(k_cvt_i32_f32, "v_cvt_i32_f32 %8, %0\n v_cvt_i32_f32 %9, %2\n v_cvt_i32_f32 %10, %3\n v_cvt_i32_f32 %11, %4\n v_cvt_i32_f32 %8, %5\n v_cvt_i32_f32 %9, %6\n v_cvt_i32_f32 %10, %7\n v_cvt_i32_f32 %11, %1\n")
+KERNEL(k_cvt_f32_i32, "v_cvt_f32_i32 %0, %8\n v_cvt_f32_i32 %2, %9\n v_cvt_f32_i32 %3, %10\n v_cvt_f32_i32 %4, %11\n v_cvt_f32_i32 %5, %8\n v_cvt_f32_i32 %6, %9\n v_cvt_f32_i32 %7, %10\n v_cvt_f32_i32 %1, %11\n")
+KERNEL(k_and_b32, "v_and_b32 %8, %8, %9\n v_and_b32 %9, %9, %10\n v_and_b32 %10, %10, %11\n v_and_b32 %11, %11, %8\n v_and_b32 %8, %8, %10\n v_and_b32 %9, %9, %11\n v_and_b32 %10, %10, %8\n v_and_b32 %11, %11, %9\n")
+KERNEL(k_add_u32, "v_add_u32 %8, %8, %9\n v_add_u32 %9, %9, %10\n v_add_u32 %10, %10, %11\n v_add_u32 %11, %11, %8\n v_add_u32 %8, %8, %10\n v_add_u32 %9, %9, %11\n v_add_u32 %10, %10, %8\n v_add_u32 %11, %11, %9\n")
+KERNEL(k_lshr_b32, "v_lshrrev_b32 %8, 2, %8\n v_lshrrev_b32 %9, 2, %9\n v_lshrrev_b32 %10, 2, %10\n v_lshrrev_b32 %11, 2, %11\n v_lshrrev_b32 %8, 1, %8\n v_lshrrev_b32 %9, 1, %9\n v_lshrrev_b32 %10, 1, %10\n v_lshrrev_b32 %11, 1, %11\n")
+KERNEL(k_bfi_b32, "v_bfi_b32 %8, %8, %9, %10\n v_bfi_b32 %9, %9, %10, %11\n v_bfi_b32 %10, %10, %11, %8\n v_bfi_b32 %11, %11, %8, %9\n v_bfi_b32 %8, %8, %10, %11\n v_bfi_b32 %9, %9, %11, %8\n v_bfi_b32 %10, %10, %8, %9\n v_bfi_b32 %11, %11, %9, %10\n")
+KERNEL(k_mad_u24, "v_mad_u32_u24 %8, %8, %9, %10\n v_mad_u32_u24 %9, %9, %10, %11\n v_mad_u32_u24 %10, %10, %11, %8\n v_mad_u32_u24 %11, %11, %8, %9\n v_mad_u32_u24 %8, %8, %10, %11\n v_mad_u32_u24 %9, %9, %11, %8\n v_mad_u32_u24 %10, %10, %8, %9\n v_mad_u32_u24 %11, %11, %9, %10\n")
+KERNEL(k_max3_u32, "v_max3_u32 %8, %8, %9, %10\n v_max3_u32 %9, %9, %10, %11\n v_max3_u32 %10, %10, %11, %8\n v_max3_u32 %11, %11, %8, %9\n v_max3_u32 %8, %8, %10, %11\n v_max3_u32 %9, %9, %11, %8\n v_max3_u32 %10, %10, %8, %9\n v_max3_u32 %11, %11, %9, %10\n")
+KERNEL(k_floor_f32, "v_floor_f32 %0, %0\n v_floor_f32 %2, %2\n v_floor_f32 %3, %3\n v_floor_f32 %4, %4\n v_floor_f32 %5, %5\n v_floor_f32 %6, %6\n v_floor_f32 %7, %7\n v_floor_f32 %1, %1\n")
+KERNEL(k_rcp_f32, "v_rcp_f32 %0, %0\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3\n v_rcp_f32 %4, %4\n v_rcp_f32 %5, %5\n v_rcp_f32 %6, %6\n v_rcp_f32 %7, %7\n v_rcp_f32 %1, %1\n")
+KERNEL(k_mov_b32, "v_mov_b32 %0, %1\n v_mov_b32 %2, %3\n v_mov_b32 %3, %4\n v_mov_b32 %4, %5\n v_mov_b32 %5, %6\n v_mov_b32 %6, %7\n v_mov_b32 %7, %0\n v_mov_b32 %1, %2\n")
+
+template <typename K>
+static void run(const char *name, K kernel, float *d_out, double ghz, int sms) {
+    const int iters = 4000, blocks = sms * 8;  // 8 workgroups of 4 waves per CU = 8 waves per SIMD
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, d_out, 100);
+    hipDeviceSynchronize();
+    float best = 1e30f;
+    for (int r = 0; r < 5; r++) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, d_out, iters);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    const double insts_per_simd = 8.0 * iters * 32.0;  // 8 waves x iters x 32 instructions
+    printf("%-16s %.3f ms  %.2f cycles per wave-instruction per SIMD at %.2f GHz\n", name, best, best * 1e-3 * ghz * 1e9 / insts_per_simd, ghz);
+}
+
+int main() {
+    hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
+    const double ghz = p.clockRate * 1e-6;
+    float *d; hipMalloc(&d, (size_t)p.multiProcessorCount * 8 * 256 * 4);
+    printf("%s, %d CUs, %.2f GHz\n", p.name, p.multiProcessorCount, ghz);
+#define RUN(k) run(#k, k, d, ghz, p.multiProcessorCount)
+    RUN(k_add_f32); RUN(k_mul_f32); RUN(k_fma_f32); RUN(k_min3_f32); RUN(k_cndmask_vcc); RUN(k_cndmask_e64); RUN(k_min_f32); RUN(k_lshl_or); RUN(k_add3_u32); RUN(k_cvt_flr); RUN(k_cmp_u32); RUN(k_pk_add_f32); RUN(k_sqrt_f32); RUN(k_div_fixup); RUN(k_cmp_f32);
+    RUN(k_cvt_i32_f32); RUN(k_cvt_f32_i32); RUN(k_and_b32); RUN(k_add_u32); RUN(k_lshr_b32); RUN(k_bfi_b32); RUN(k_mad_u24);
+    RUN(k_max3_u32); RUN(k_floor_f32); RUN(k_rcp_f32); RUN(k_mov_b32);
+    return 0;
+}

@@ -93,6 +93,7 @@ VRT_SYMBOLS = {
     "vrt_set_world": (C.c_int, [_P, C.POINTER(WorldData)]),
     "vrt_resize_output": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
     "vrt_render": (C.c_int, [_P, C.POINTER(RenderOpts)]),
+    "vrt_set_frames_in_flight": (C.c_int, [_P, C.c_uint32]),
     "vrt_synchronize": (C.c_int, [_P]),
     "vrt_read_output": (C.c_int, [_P, _P, _P, _P]),
     "vrt_present": (C.c_int, [_P, C.POINTER(Crosshair), C.c_uint32, C.c_uint32, _P]),

@@ -23,7 +23,7 @@ namespace vrt {
 bool variant_supported(uint32_t variant);
 void launch_primary(const FrameParams &P, uint32_t variant, bool stats, bool shadow, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
 void launch_shadow(const FrameParams &P, uint32_t variant, bool stats, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
-void launch_primary_shadow_fused(const FrameParams &P, bool stats, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
+void launch_primary_shadow_fused(const FrameParams &P, bool stats, uint32_t form, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
 void launch_path_primary(const FrameParams &P, bool stats, hipStream_t st);
 void launch_path_bounce(const FrameParams &P, bool stats, hipStream_t st);
 void launch_path_finish(Texel *out, uint32_t n, uint32_t spp, hipStream_t st);
@@ -48,6 +48,16 @@ static_assert(sizeof(vrt::Texel) == 16, "texel");
 struct vrt_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
+    // Two frames in flight (what a swapchain gives the reference): consecutive plain frames alternate between the
+    // context's two streams, each with its own output buffer, so one frame's tail overlaps the next one's ramp-up
+    // instead of the in-order queue's ~5 us hand-over.  Everything else on the context waits for both (quiesce()).
+    static constexpr uint32_t kMaxInFlight = 4;
+    hipStream_t extra_stream[kMaxInFlight - 1] = {nullptr, nullptr, nullptr};
+    vrt::Texel *extra_out[kMaxInFlight - 1] = {nullptr, nullptr, nullptr};
+    uint32_t *extra_blk[kMaxInFlight - 1] = {nullptr, nullptr, nullptr};
+    uint32_t in_flight = 2;        // vrt_set_frames_in_flight
+    bool alt_pending = false;      // frames may still be running on the extra streams
+    uint32_t flip = 0;             // which (stream, output, counts) set the next pipelined frame takes
     hipStream_t stream = nullptr;
     // four hipEvents per frame rendered since the last vrt_get_stats.  Primary(+shadow) frames: {begin, end} of the first
     // kernel and {begin, end} of the second, stamped by the dispatches themselves (hipExtLaunchKernel), so the stream
@@ -73,9 +83,13 @@ struct vrt_ctx {
     vrt_material *d_mats = nullptr;
     vrt::Texel *d_out = nullptr;    // where frames are written: own_out or caller-bound memory
     vrt::Texel *own_out = nullptr;
+    vrt::Texel *last_out = nullptr;  // the buffer holding the most recent frame
+    uint32_t *last_blk = nullptr;
     uint4 *d_hits = nullptr;
     uint32_t *d_blk_counts = nullptr;  // hit records per primary workgroup
     uint32_t n_blocks = 0;
+    uint32_t n_counts = 0;          // entries of blk_counts the last primary + shadow frame wrote (per workgroup or per tile)
+    uint32_t fused_form = 0;        // VRT_FUSED_FORM: 0 wave-local (default), 1 workgroup phases, 2 wave-local 1 tile / workgroup
     uint4 *d_path = nullptr;  // path mode: 2 buffers x 3 planes x (kHitSegments * hit_seg_cap) records, lazily allocated
     unsigned long long *d_counters = nullptr;  // [kCtrCount] stats, then the hit-segment counters
     uint32_t hit_seg_cap = 0;
@@ -144,6 +158,21 @@ static int fail(vrt_ctx *ctx, int code, const char *fmt, ...) {
                         hipGetErrorString(e_));                                                     \
     } while (0)
 
+// Wait for the frame that may still be running on the second stream.
+static int quiesce(vrt_ctx *c) {
+    if (c->alt_pending) {
+        for (hipStream_t st : c->extra_stream)
+            if (st) HIP_TRY(c, hipStreamSynchronize(st));
+        c->alt_pending = false;
+    }
+    return VRT_OK;
+}
+#define QUIESCE(c)                     \
+    do {                               \
+        const int q_ = quiesce(c);     \
+        if (q_) return q_;             \
+    } while (0)
+
 static void layout_tiles(vrt_ctx *c) {
     c->tiles_x = c->width / 8u;
     c->tiles_total = c->tiles_x * (c->height / 8u);
@@ -163,6 +192,8 @@ static int alloc_output(vrt_ctx *c) {
     (void)hipFree(c->own_out); (void)hipFree(c->d_hits); (void)hipFree(c->d_steps); (void)hipFree(c->d_rgba8); (void)hipFree(c->d_path);
     (void)hipFree(c->d_blk_counts);
     c->own_out = nullptr; c->d_hits = nullptr; c->d_steps = nullptr; c->d_rgba8 = nullptr; c->d_path = nullptr; c->d_blk_counts = nullptr;
+    for (auto &p : c->extra_out) { (void)hipFree(p); p = nullptr; }
+    for (auto &p : c->extra_blk) { (void)hipFree(p); p = nullptr; }
     layout_tiles(c);
     const size_t n = c->slots ? c->slots : 1;
     HIP_TRY(c, hipMalloc(&c->own_out, n * sizeof(vrt::Texel)));
@@ -172,10 +203,15 @@ static int alloc_output(vrt_ctx *c) {
     if (c->hit_seg_cap == 0) c->hit_seg_cap = 256u;
     HIP_TRY(c, hipMalloc(&c->d_hits, (size_t)vrt::kHitSegments * c->hit_seg_cap * sizeof(uint4)));  // >= nblocks * 256
     c->n_blocks = nblocks;
-    HIP_TRY(c, hipMalloc(&c->d_blk_counts, (size_t)(nblocks ? nblocks : 1) * sizeof(uint32_t)));
-    HIP_TRY(c, hipMemsetAsync(c->d_blk_counts, 0, (size_t)(nblocks ? nblocks : 1) * sizeof(uint32_t), c->stream));
+    // one count per primary workgroup (two-launch variants, workgroup-phase form) or per tile (wave-local form)
+    const size_t ncnt = c->tiles_local ? c->tiles_local : 1;
+    HIP_TRY(c, hipMalloc(&c->d_blk_counts, ncnt * sizeof(uint32_t)));
+    HIP_TRY(c, hipMemsetAsync(c->d_blk_counts, 0, ncnt * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->own_out, 0, n * sizeof(vrt::Texel), c->stream));
+    // the extra (output, counts) sets of frames in flight are allocated when first used (ensure_in_flight_sets)
     c->d_out = c->own_out;  // a resize drops any caller-bound output (its size no longer matches)
+    c->last_out = c->own_out;
+    c->last_blk = c->d_blk_counts;
     c->rendered = false;
     return VRT_OK;
 }
@@ -204,6 +240,7 @@ static constexpr uint32_t kAccelMaxBricks = (1u << 25) - 1u;
 static int ensure_accel(vrt_ctx *c) {
     const uint32_t S = c->world.size_in_chunks;
     if (!c->accel_dirty && c->accel_S == S) return VRT_OK;
+    QUIESCE(c);  // a frame on the second stream may still be reading the old tables
     c->accel_ok = false;
     c->accel_S = S;
     c->accel_dirty = false;
@@ -301,6 +338,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     c->width = cfg->width;
     c->height = cfg->height;
     c->max_nodes = cfg->max_nodes & ~1u;  // NodeBuffer::new forces an even size (shader.rs:10-12)
+    if (const char *e = getenv("VRT_FUSED_FORM")) c->fused_form = (uint32_t)strtoul(e, nullptr, 10) % 3u;
     c->accel_max_s = kAccelMaxS;
     if (const char *e = getenv("VRT_ACCEL_MAX_S")) {
         const long v = strtol(e, nullptr, 10);
@@ -344,6 +382,10 @@ void vrt_destroy(vrt_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (hipStream_t st : c->extra_stream)
+        if (st) (void)hipStreamSynchronize(st);
+    for (auto p : c->extra_out) (void)hipFree(p);
+    for (auto p : c->extra_blk) (void)hipFree(p);
     (void)hipFree(c->d_nodes); (void)hipFree(c->d_roots); (void)hipFree(c->d_mats); (void)hipFree(c->own_out);
     (void)hipFree(c->d_hits); (void)hipFree(c->d_counters); (void)hipFree(c->d_steps); (void)hipFree(c->d_rgba8); (void)hipFree(c->d_path);
     (void)hipFree(c->d_blk_counts);
@@ -353,6 +395,8 @@ void vrt_destroy(vrt_ctx *c) {
         for (auto &ev : t)
             if (ev) (void)hipEventDestroy(ev);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    for (hipStream_t st : c->extra_stream)
+        if (st) (void)hipStreamDestroy(st);
     delete c;
 }
 
@@ -369,6 +413,7 @@ int vrt_write_nodes(vrt_ctx *c, const uint16_t *pool, uint32_t start, uint32_t e
     if ((uint64_t)root + count > c->max_nodes)
         return fail(c, VRT_ERR_OUT_OF_RANGE, "vrt_write_nodes: [%u,%u) exceeds the %u-node buffer", start, end, c->max_nodes);
     HIP_TRY(c, hipSetDevice(c->device));
+    QUIESCE(c);
     // stream-ordered after earlier renders; the sync makes it copy-at-call-time (write_buffer
     // semantics: the caller may reuse `pool` as soon as this returns)
     HIP_TRY(c, hipMemcpyAsync(c->d_nodes + root, pool + root, (size_t)count * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
@@ -386,6 +431,7 @@ int vrt_write_chunk_roots(vrt_ctx *c, uint32_t offset, const uint32_t *roots, ui
     // the reference rewrites the whole table every frame (main.rs:446); an identical rewrite changes nothing
     if (memcmp(c->h_roots.data() + offset, roots, (size_t)cut * sizeof(uint32_t)) == 0) return VRT_OK;
     HIP_TRY(c, hipSetDevice(c->device));
+    QUIESCE(c);
     HIP_TRY(c, hipMemcpyAsync(c->d_roots + offset, roots, (size_t)cut * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     memcpy(c->h_roots.data() + offset, roots, (size_t)cut * sizeof(uint32_t));
@@ -396,6 +442,7 @@ int vrt_write_chunk_roots(vrt_ctx *c, uint32_t offset, const uint32_t *roots, ui
 int vrt_resize_world(vrt_ctx *c, uint32_t world_size_chunks) {
     if (!c) return VRT_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
+    QUIESCE(c);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return alloc_roots(c, world_size_chunks);
 }
@@ -406,6 +453,7 @@ int vrt_write_materials(vrt_ctx *c, uint32_t first, const vrt_material *mats, ui
     if (n == 0) return VRT_OK;
     memcpy(c->h_mats + first, mats, (size_t)n * sizeof(vrt_material));
     HIP_TRY(c, hipSetDevice(c->device));
+    QUIESCE(c);
     HIP_TRY(c, hipMemcpyAsync(c->d_mats + first, mats, (size_t)n * sizeof(vrt_material), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return VRT_OK;
@@ -434,6 +482,7 @@ int vrt_resize_output(vrt_ctx *c, uint32_t width, uint32_t height) {
     if (width == 0 || height == 0 || (width % 8u) || (height % 8u) || (uint64_t)width * height > (1ull << 28))
         return fail(c, VRT_ERR_INVALID_ARG, "output %ux%u: dimensions must be non-zero multiples of 8", width, height);
     HIP_TRY(c, hipSetDevice(c->device));
+    QUIESCE(c);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->width = width;
     c->height = height;
@@ -456,6 +505,7 @@ static int ensure_ndc(vrt_ctx *c) {
     if (c->d_ndc && c->ndc_w == c->width && c->ndc_h == c->height &&
         memcmp(c->ndc_proj, c->cam.proj_size, sizeof c->ndc_proj) == 0)
         return VRT_OK;
+    QUIESCE(c);
     if (!c->d_ndc || c->ndc_w + c->ndc_h < c->width + c->height) {
         (void)hipFree(c->d_ndc);
         c->d_ndc = nullptr;
@@ -492,6 +542,7 @@ static void cam_sun_dir(const vrt_ctx *c, float out[3]) {
 // Fold the event triples of all frames rendered since the last call into acc_ms (synchronises).
 static int fold_events(vrt_ctx *c, float last[3]) {
     if (c->ev_used == 0) return VRT_OK;
+    QUIESCE(c);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (size_t i = 0; i < c->ev_used; i++) {
         auto &t = c->ev_pool[i];
@@ -556,9 +607,32 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
         P.grid_bytes = (uint32_t)((size_t)c->accel_S * c->accel_S * c->accel_S * 512u * sizeof(uint32_t));
         P.brick_bytes = (uint32_t)((size_t)c->brick_cap * 64u * sizeof(uint16_t));
     }
-    P.out = c->d_out;
+    // two frames in flight: plain frames into the context's own buffers alternate between the two (stream, output, counts)
+    // sets; anything else (stats, path trace, two-launch variants, a caller's stream or buffer) runs alone on c->stream
+    const bool kstats_early = o.stats != 0 || c->settings.show_step_count == 1u;
+    const bool one_launch = o.mode == VRT_MODE_PRIMARY || (o.mode == VRT_MODE_PRIMARY_SHADOW && variant == 0u);
+    const bool pipelined = c->in_flight > 1u && one_launch && !kstats_early && c->stream == c->own_stream && c->d_out == c->own_out;
+    hipStream_t st = c->stream;
+    vrt::Texel *out = c->d_out;
+    uint32_t *blk = c->d_blk_counts;
+    if (pipelined) {
+        if (c->flip) {
+            const uint32_t k = c->flip - 1u;
+            if (!c->extra_stream[k]) HIP_TRY(c, hipStreamCreateWithFlags(&c->extra_stream[k], hipStreamNonBlocking));
+            if (!c->extra_out[k]) HIP_TRY(c, hipMalloc(&c->extra_out[k], (size_t)(c->slots ? c->slots : 1) * sizeof(vrt::Texel)));
+            if (!c->extra_blk[k]) HIP_TRY(c, hipMalloc(&c->extra_blk[k], (size_t)(c->tiles_local ? c->tiles_local : 1) * sizeof(uint32_t)));
+            st = c->extra_stream[k]; out = c->extra_out[k]; blk = c->extra_blk[k];
+            c->alt_pending = true;
+        }
+        c->flip = (c->flip + 1u) % c->in_flight;
+    } else {
+        QUIESCE(c);
+    }
+    c->last_out = out;
+    c->last_blk = blk;
+    P.out = out;
     P.hits = c->d_hits;
-    P.blk_counts = c->d_blk_counts;
+    P.blk_counts = blk;
     P.counters = c->d_counters;
     P.seg_counts = reinterpret_cast<uint32_t *>(c->d_counters + vrt::kCtrCount);
     P.hit_seg_cap = c->hit_seg_cap;
@@ -648,8 +722,9 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     } else {
         const bool fused = shadow && variant == 0u;  // primary + shadow in one launch, hit records in LDS
         if (c->tiles_local) {
-            if (fused) vrt::launch_primary_shadow_fused(P, kstats, c->stream, ev[0], ev[1]);
-            else vrt::launch_primary(P, variant == 3u ? 0u : variant, kstats, shadow, c->stream, ev[0], ev[1]);
+            c->n_counts = fused && c->fused_form != 1u ? c->tiles_local : c->n_blocks;
+            if (fused) vrt::launch_primary_shadow_fused(P, kstats, c->fused_form, st, ev[0], ev[1]);
+            else vrt::launch_primary(P, variant == 3u ? 0u : variant, kstats, shadow, st, ev[0], ev[1]);
             HIP_TRY(c, hipGetLastError());
             ev_kind = kEvOneKernel;
             if (shadow && !fused) {
@@ -669,6 +744,7 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
 int vrt_synchronize(vrt_ctx *c) {
     if (!c) return VRT_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
+    QUIESCE(c);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return VRT_OK;
 }
@@ -677,18 +753,19 @@ int vrt_read_output(vrt_ctx *c, float *rgb, uint32_t *ids, uint8_t *rgba8) {
     if (!c) return VRT_ERR_INVALID_ARG;
     if (!c->rendered) return fail(c, VRT_ERR_STATE, "vrt_read_output: nothing rendered yet");
     HIP_TRY(c, hipSetDevice(c->device));
+    QUIESCE(c);
     const size_t npix = (size_t)c->width * c->height;
     if (rgba8) {
         if (c->tile_major) return fail(c, VRT_ERR_STATE, "vrt_read_output: rgba8 readback needs the row-major (unsharded) layout");
         if (!c->d_rgba8) HIP_TRY(c, hipMalloc(&c->d_rgba8, npix * 4));
-        vrt::launch_quantize(c->d_out, c->d_rgba8, (uint32_t)npix, c->stream);
+        vrt::launch_quantize(c->last_out, c->d_rgba8, (uint32_t)npix, c->stream);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipMemcpyAsync(rgba8, c->d_rgba8, npix * 4, hipMemcpyDeviceToHost, c->stream));
     }
     std::vector<vrt::Texel> t;
     if (rgb || ids) {
         t.resize(c->slots);
-        HIP_TRY(c, hipMemcpyAsync(t.data(), c->d_out, t.size() * sizeof(vrt::Texel), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(t.data(), c->last_out, t.size() * sizeof(vrt::Texel), hipMemcpyDeviceToHost, c->stream));
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (!rgb && !ids) return VRT_OK;
@@ -719,6 +796,7 @@ int vrt_present(vrt_ctx *c, const vrt_crosshair *crosshair, uint32_t screen_w, u
         return fail(c, VRT_ERR_INVALID_ARG, "vrt_present: screen %ux%u must be at least the %ux%u result texture (the sampler magnifies "
                     "with Nearest; its Linear minification is not implemented)", screen_w, screen_h, c->width, c->height);
     HIP_TRY(c, hipSetDevice(c->device));
+    QUIESCE(c);
     const size_t bytes = (size_t)screen_w * screen_h * 4u;
     if (bytes > c->screen_cap) {
         (void)hipFree(c->d_screen);
@@ -726,7 +804,7 @@ int vrt_present(vrt_ctx *c, const vrt_crosshair *crosshair, uint32_t screen_w, u
         HIP_TRY(c, hipMalloc(&c->d_screen, bytes));
         c->screen_cap = bytes;
     }
-    vrt::launch_present(c->d_out, c->width, c->height, screen_w, screen_h, *crosshair, c->d_screen, c->stream);
+    vrt::launch_present(c->last_out, c->width, c->height, screen_w, screen_h, *crosshair, c->d_screen, c->stream);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(rgba8, c->d_screen, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -758,9 +836,9 @@ int vrt_get_stats(vrt_ctx *c, vrt_stats *out) {
         unsigned long long *h = hbuf.data();
         const uint32_t *seg = reinterpret_cast<const uint32_t *>(h + vrt::kCtrCount);
         unsigned long long launched = 0;
-        if (c->last_mode == VRT_MODE_PRIMARY_SHADOW && c->n_blocks) {
-            std::vector<uint32_t> bc(c->n_blocks);
-            HIP_TRY(c, hipMemcpyAsync(bc.data(), c->d_blk_counts, bc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        if (c->last_mode == VRT_MODE_PRIMARY_SHADOW && c->n_counts) {
+            std::vector<uint32_t> bc(c->n_counts);
+            HIP_TRY(c, hipMemcpyAsync(bc.data(), c->last_blk, bc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             for (uint32_t v : bc) launched += v;
         }
@@ -814,9 +892,21 @@ int vrt_read_accel(vrt_ctx *c, uint32_t *grid, uint16_t *bricks) {
     return VRT_OK;
 }
 
+int vrt_set_frames_in_flight(vrt_ctx *c, uint32_t n) {
+    if (!c) return VRT_ERR_INVALID_ARG;
+    if (n < 1u || n > vrt_ctx::kMaxInFlight) return fail(c, VRT_ERR_INVALID_ARG, "vrt_set_frames_in_flight: 1..%u", vrt_ctx::kMaxInFlight);
+    HIP_TRY(c, hipSetDevice(c->device));
+    QUIESCE(c);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->in_flight = n;
+    c->flip = 0;
+    return VRT_OK;
+}
+
 int vrt_set_stream(vrt_ctx *c, void *hip_stream) {
     if (!c) return VRT_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
+    QUIESCE(c);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return VRT_OK;
@@ -827,14 +917,16 @@ int vrt_bind_output(vrt_ctx *c, void *texels) {
     if (texels && ((uintptr_t)texels % 16u)) return fail(c, VRT_ERR_INVALID_ARG, "vrt_bind_output: texels must be 16-byte aligned");
     // stream-ordered: launches capture the pointer, so frames already enqueued keep writing where they were
     // told to and the next vrt_render uses the new buffer (lets a host ping-pong two gather messages)
+    QUIESCE(c);
     c->d_out = texels ? (vrt::Texel *)texels : c->own_out;
+    c->last_out = c->d_out;
     c->rendered = false;
     return VRT_OK;
 }
 
 int vrt_device_output(vrt_ctx *c, void **texels, uint64_t *bytes) {
     if (!c) return VRT_ERR_INVALID_ARG;
-    if (texels) *texels = c->d_out;
+    if (texels) *texels = c->d_out == c->own_out ? c->last_out : c->d_out;  // own buffers: the one holding the last frame
     if (bytes) *bytes = (uint64_t)c->slots * sizeof(vrt::Texel);
     return VRT_OK;
 }

@@ -255,6 +255,75 @@ __global__ void __launch_bounds__(256) primary_shadow_kernel(FrameParams P) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Primary + shadow, wave-local (no workgroup cooperation at all): each lane marches its pixel's primary ray and, if
+// that ended on a solid voxel, its shadow ray right after, then stores the finished texel.  No hit records, no
+// barriers, no atomics; a shadow wave is exactly one 8x8 tile's hits — the most coherent grouping there is — and its
+// lane utilisation is the tile's hit fraction (1.0 for the terrain tiles that make up most of a frame).
+// ------------------------------------------------------------------------------------------------
+template <int MARCH, bool LDS_ROOTS, bool STATS, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) primary_shadow_wave_kernel(FrameParams P) {
+    extern __shared__ uint32_t smem[];  // [0,8) liquid mask, [8,24) stats scratch, [24, ...) chunk roots
+    uint32_t *s_liquid = smem, *s_roots = smem + 24;
+    unsigned long long *s_acc = reinterpret_cast<unsigned long long *>(smem + 8);
+    if (STATS && threadIdx.x < 6) s_acc[threadIdx.x] = 0ull;
+    stage_lds(P, s_roots, s_liquid, LDS_ROOTS);
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t t_local = blockIdx.x * (uint32_t)WAVES + (threadIdx.x >> 6);
+    const bool live = t_local < P.tiles_local;
+    MarchResult R, S;
+    R.iters = 0; R.visits = 0; R.hit = false;
+    S.iters = 0; S.visits = 0; S.hit = false;
+    if (live) {
+        const uint32_t tile = shard_tile(t_local, P.shard_first, P.shard_run, P.shard_period);
+        const uint32_t px = (tile % P.tiles_x) * 8u + (lane & 7u);
+        const uint32_t py = (tile / P.tiles_x) * 8u + (lane >> 3);
+        const uint32_t slot = P.tile_major ? t_local * 64u + lane : py * P.width + px;
+
+        V3 origin, dir;
+        create_ray(P, (int)px, (int)py, origin, dir);
+        R = march<MARCH, LDS_ROOTS, STATS>(P, s_roots, s_liquid, origin, dir);
+        V3 color;
+        uint32_t id = shade<MARCH == 1>(P, R, origin, dir, color);
+
+        const bool launch = R.hit && R.voxel != 0u && !is_liquid(s_liquid, R.voxel);
+        if (launch) {
+            id |= VRT_ID_SHADOW_RAY;
+            const V3 so{R.pos.x + R.norm.x * kShadowBias, R.pos.y + R.norm.y * kShadowBias, R.pos.z + R.norm.z * kShadowBias};
+            const V3 sd = vnormalize(V3{P.settings.sun_pos[0] - (float)P.world.min[0] - so.x,
+                                        P.settings.sun_pos[1] - (float)P.world.min[1] - so.y,
+                                        P.settings.sun_pos[2] - (float)P.world.min[2] - so.z});
+            S = march<MARCH, LDS_ROOTS, STATS>(P, s_roots, s_liquid, so, sd);
+            if (S.hit) {
+                color.x *= kShadowFactor;
+                color.y *= kShadowFactor;
+                color.z *= kShadowFactor;
+                id |= VRT_ID_SHADOWED;
+            }
+        }
+        P.out[slot] = make_uint4(__float_as_uint(color.x), __float_as_uint(color.y), __float_as_uint(color.z), id);
+        if (STATS && P.steps) P.steps[slot] = R.iters | (S.iters << 16);
+        const unsigned long long ballot = __ballot(launch);
+        if (lane == 0) P.blk_counts[t_local] = (uint32_t)__popcll(ballot);  // per tile here: the launched-ray count of vrt_get_stats
+    }
+    if (STATS) {
+        block_add(s_acc, 0, R.iters);
+        block_add(s_acc, 1, R.visits);
+        block_add(s_acc, 2, R.hit ? 1ull : 0ull);
+        block_add(s_acc, 3, S.iters);
+        block_add(s_acc, 4, S.visits);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            atomicAdd(&P.counters[kCtrSteps], s_acc[0] + s_acc[3]);
+            atomicAdd(&P.counters[kCtrVisits], s_acc[1] + s_acc[4]);
+            atomicAdd(&P.counters[kCtrPrimarySteps], s_acc[0]);
+            atomicAdd(&P.counters[kCtrPrimaryVisits], s_acc[1]);
+            atomicAdd(&P.counters[kCtrHits], s_acc[2]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Output helpers
 // ------------------------------------------------------------------------------------------------
 
@@ -364,9 +433,20 @@ static void launch_fused_t(const FrameParams &P, bool stats, hipStream_t st, hip
 // in HBM (the wavefront form the path trace is built from)
 bool variant_supported(uint32_t variant) { return variant <= 3u; }
 
-// One launch for primary + shadow (variant 0 only).
-void launch_primary_shadow_fused(const FrameParams &P, bool stats, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
-    launch_fused_t<0, false>(P, stats, st, e0, e1);
+template <int WAVES>
+static void launch_wave_t(const FrameParams &P, bool stats, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+    const dim3 grid((P.tiles_local + WAVES - 1u) / WAVES), block(64 * WAVES);
+    const uint32_t lds = 24u * 4u;
+    if (stats) hipExtLaunchKernelGGL((primary_shadow_wave_kernel<0, false, true, WAVES>), grid, block, lds, st, e0, e1, 0, P);
+    else hipExtLaunchKernelGGL((primary_shadow_wave_kernel<0, false, false, WAVES>), grid, block, lds, st, e0, e1, 0, P);
+}
+
+// One launch for primary + shadow (variant 0 only). form 0: wave-local (counts per tile in blk_counts); 1: workgroup
+// phases with the hit records in LDS (counts per 4-tile workgroup); 2: wave-local, one tile per workgroup.
+void launch_primary_shadow_fused(const FrameParams &P, bool stats, uint32_t form, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+    if (form == 1u) launch_fused_t<0, false>(P, stats, st, e0, e1);
+    else if (form == 2u) launch_wave_t<1>(P, stats, st, e0, e1);
+    else launch_wave_t<4>(P, stats, st, e0, e1);
 }
 
 // e0 / e1: events the dispatch itself stamps with the kernel's begin and end (no separate marker packets on the stream)

@@ -368,6 +368,24 @@ __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {
     return r;
 }
 
+// f32 -> i32 rounding towards -inf (v_cvt_flr_i32_f32).  Used where only "is the coordinate inside [0, size)" and, if
+// so, its integer part matter: equal to trunc2i for every non-negative input, negative for every negative one.
+__device__ __forceinline__ int flr2i(float x) {
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ uint32_t max3_u32(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_max3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t min3_u32(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 template <bool STATS>
 __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const uint32_t *s_liquid, V3 origin, V3 dir) {
     MarchResult R;
@@ -395,14 +413,13 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
         sqrtf(1.0f + (dir.y / dir.x) * (dir.y / dir.x) + (dir.z / dir.x) * (dir.z / dir.x)),
         sqrtf(1.0f + (dir.x / dir.y) * (dir.x / dir.y) + (dir.z / dir.y) * (dir.z / dir.y)),
         sqrtf(1.0f + (dir.x / dir.z) * (dir.x / dir.z) + (dir.y / dir.z) * (dir.y / dir.z))};
-    const float sux = mx ? unit.x : -unit.x, suy = my ? unit.y : -unit.y, suz = mz ? unit.z : -unit.z;
     const uint32_t mxm = mx ? ~0u : 0u, mym = my ? ~0u : 0u, mzm = mz ? ~0u : 0u;
     const uint32_t mx1 = mx ? 1u : 0u, my1 = my ? 1u : 0u, mz1 = mz ? 1u : 0u;
 
     const uint32_t wsize = P.world.size;
     const TableBuf gb = table_buffer(P.grid, P.grid_bytes), bb = table_buffer(P.bricks, P.brick_bytes);
     const uint32_t row_bytes = P.grid_dim * 4u, slab_bytes = P.grid_dim * P.grid_dim * 4u;  // < 2^24: grid_dim <= 800
-    const float qnan = __builtin_nanf("");
+    bool wave_in_water = false;  // wave-uniform: some lane of the wave has met a liquid voxel (nothing to book-keep before)
 
     int vx = trunc2i(pos.x), vy = trunc2i(pos.y), vz = trunc2i(pos.z);  // pos > 0 here (or NaN -> 0)
     uint32_t voxel = 0u;
@@ -432,11 +449,14 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
             liquid = is_liquid(s_liquid, voxel);
             if (!liquid) break;  // solid: the hit
         }
-        if (liquid) {
-            if (dew == -1.0f) dew = total_len;
-        } else if (dew != -1.0f) {
-            R.water_dist += total_len - dew;
-            dew = -1.0f;
+        if (__ballot(liquid) != 0ull) wave_in_water = true;  // scalar
+        if (wave_in_water) {
+            if (liquid) {
+                if (dew == -1.0f) dew = total_len;
+            } else if (dew != -1.0f) {
+                R.water_dist += total_len - dew;
+                dew = -1.0f;
+            }
         }
 
         // ---- step to the leaf's exit face ----
@@ -444,22 +464,32 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
         const float tx = (float)(int)(bfi(lo, mxm, (uint32_t)vx) + mx1) - pos.x;
         const float ty = (float)(int)(bfi(lo, mym, (uint32_t)vy) + my1) - pos.y;
         const float tz = (float)(int)(bfi(lo, mzm, (uint32_t)vz) + mz1) - pos.z;
-        adx = tx * sux;
-        ady = ty * suy;
-        adz = tz * suz;
-        const bool zx = adx == 0.0f, zy = ady == 0.0f, zz = adz == 0.0f;
-        step = min3_nan_ignoring(zx ? qnan : adx, zy ? qnan : ady, zz ? qnan : adz);
-        if (zx && zy && zz) step = adz;
+        // (b'') |t| * |unit| has the bits of (mask ? t : -t) * unit, except that a zero is always +0 (never observed)
+        adx = fabsf(tx) * fabsf(unit.x);
+        ady = fabsf(ty) * fabsf(unit.y);
+        adz = fabsf(tz) * fabsf(unit.z);
+        // (c') the minimum over the non-zero distances, on bit patterns: non-negative floats order like unsigned integers,
+        // NaNs above every number, and bits - 1 sends +0 to the very top, so one unsigned min3 replaces the shader's
+        // branch tree (:247-270): the smallest non-zero number; a NaN only if nothing else is non-zero; +0 if all are zero
+        step = __uint_as_float(min3_u32(__float_as_uint(adx) - 1u, __float_as_uint(ady) - 1u, __float_as_uint(adz) - 1u) + 1u);
         total_len += step;
         const float sp = step + 0.001f;
         pos.x += dir.x * (step == adx ? sp : step);
         pos.y += dir.y * (step == ady ? sp : step);
         pos.z += dir.z * (step == adz ? sp : step);
 
-        vx = trunc2i(pos.x);
-        vy = trunc2i(pos.y);
-        vz = trunc2i(pos.z);
-        if (min3_nan_ignoring(pos.x, pos.y, pos.z) < 0.0f || max(max((uint32_t)vx, (uint32_t)vy), (uint32_t)vz) >= wsize) break;
+        // (e') floor instead of trunc: one unsigned compare sees both "pos < 0" (negative integer = huge) and "pos >= size".
+        // It is only a filter — whatever it flags (and whatever the instruction makes of a NaN) is re-examined with the
+        // exact test (e) — and for every position that stays inside, floor == trunc.
+        vx = flr2i(pos.x);
+        vy = flr2i(pos.y);
+        vz = flr2i(pos.z);
+        if (max3_u32((uint32_t)vx, (uint32_t)vy, (uint32_t)vz) >= wsize) {
+            vx = trunc2i(pos.x);
+            vy = trunc2i(pos.y);
+            vz = trunc2i(pos.z);
+            if (min3_nan_ignoring(pos.x, pos.y, pos.z) < 0.0f || max(max((uint32_t)vx, (uint32_t)vy), (uint32_t)vz) >= wsize) break;
+        }
         if (iter >= kMaxSteps) break;
     }
     // per-lane iteration counts are kept by the STATS kernels only (counters, step-count debug view); without them

@@ -127,6 +127,10 @@ class Gpu:
 
     render = encode_pass
 
+    def set_frames_in_flight(self, n: int):
+        """1..4 frames in flight (default 2); see vrt_set_frames_in_flight in include/vrt.h."""
+        self._ck(self._lib.vrt_set_frames_in_flight(self._h, n))
+
     def synchronize(self):
         self._ck(self._lib.vrt_synchronize(self._h))
 
