@@ -15,7 +15,7 @@ for line in open(summary):
         m = re.match(r"\s+(\S+)\s+dispatches=\s*\d+ mean/dispatch=(\S+)", line)
         if m and cur:
             vals[cur][m.group(1)] = float(m.group(2))
-pick = {"primary_shadow_march": "primary_shadow_kernel<0, false, false>",
+pick = {"primary_shadow_march": "primary_shadow_wave_kernel<0, false, false, 4>",
         "primary_march": "primary_tile_kernel<0, false, false, true>", "shadow_march": "shadow_kernel<0, false, false>"}
 res = {k: (vals[v]["FETCH_SIZE"] * 2 + vals[v]["WRITE_SIZE"]) * 1024.0 for k, v in pick.items() if v in vals and "FETCH_SIZE" in vals[v]}
 res["_source"] = f"{summary} (FETCH_SIZE*2 + WRITE_SIZE, KB -> bytes per launch; separate --pmc passes, tools/pmc.sh)"

@@ -419,7 +419,6 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
     const uint32_t wsize = P.world.size;
     const TableBuf gb = table_buffer(P.grid, P.grid_bytes), bb = table_buffer(P.bricks, P.brick_bytes);
     const uint32_t row_bytes = P.grid_dim * 4u, slab_bytes = P.grid_dim * P.grid_dim * 4u;  // < 2^24: grid_dim <= 800
-    bool wave_in_water = false;  // wave-uniform: some lane of the wave has met a liquid voxel (nothing to book-keep before)
 
     int vx = trunc2i(pos.x), vy = trunc2i(pos.y), vz = trunc2i(pos.z);  // pos > 0 here (or NaN -> 0)
     uint32_t voxel = 0u;
@@ -449,14 +448,11 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
             liquid = is_liquid(s_liquid, voxel);
             if (!liquid) break;  // solid: the hit
         }
-        if (__ballot(liquid) != 0ull) wave_in_water = true;  // scalar
-        if (wave_in_water) {
-            if (liquid) {
-                if (dew == -1.0f) dew = total_len;
-            } else if (dew != -1.0f) {
-                R.water_dist += total_len - dew;
-                dew = -1.0f;
-            }
+        if (liquid) {
+            if (dew == -1.0f) dew = total_len;
+        } else if (dew != -1.0f) {
+            R.water_dist += total_len - dew;
+            dew = -1.0f;
         }
 
         // ---- step to the leaf's exit face ----
