@@ -23,7 +23,7 @@ namespace vrt {
 bool variant_supported(uint32_t variant);
 void launch_primary(const FrameParams &P, uint32_t variant, bool stats, bool shadow, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
 void launch_shadow(const FrameParams &P, uint32_t variant, bool stats, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
-void launch_primary_shadow_fused(const FrameParams &P, bool stats, uint32_t form, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
+void launch_primary_shadow_fused(const FrameParams &P, bool stats, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
 void launch_path_primary(const FrameParams &P, bool stats, hipStream_t st);
 void launch_path_bounce(const FrameParams &P, bool stats, hipStream_t st);
 void launch_path_finish(Texel *out, uint32_t n, uint32_t spp, hipStream_t st);
@@ -89,7 +89,6 @@ struct vrt_ctx {
     uint32_t *d_blk_counts = nullptr;  // hit records per primary workgroup
     uint32_t n_blocks = 0;
     uint32_t n_counts = 0;          // entries of blk_counts the last primary + shadow frame wrote (per workgroup or per tile)
-    uint32_t fused_form = 0;        // VRT_FUSED_FORM: 0 wave-local (default), 1 workgroup phases, 2 wave-local 1 tile / workgroup
     uint4 *d_path = nullptr;  // path mode: 2 buffers x 3 planes x (kHitSegments * hit_seg_cap) records, lazily allocated
     unsigned long long *d_counters = nullptr;  // [kCtrCount] stats, then the hit-segment counters
     uint32_t hit_seg_cap = 0;
@@ -338,7 +337,6 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     c->width = cfg->width;
     c->height = cfg->height;
     c->max_nodes = cfg->max_nodes & ~1u;  // NodeBuffer::new forces an even size (shader.rs:10-12)
-    if (const char *e = getenv("VRT_FUSED_FORM")) c->fused_form = (uint32_t)strtoul(e, nullptr, 10) % 3u;
     c->accel_max_s = kAccelMaxS;
     if (const char *e = getenv("VRT_ACCEL_MAX_S")) {
         const long v = strtol(e, nullptr, 10);
@@ -722,8 +720,8 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     } else {
         const bool fused = shadow && variant == 0u;  // primary + shadow in one launch, hit records in LDS
         if (c->tiles_local) {
-            c->n_counts = fused && c->fused_form != 1u ? c->tiles_local : c->n_blocks;
-            if (fused) vrt::launch_primary_shadow_fused(P, kstats, c->fused_form, st, ev[0], ev[1]);
+            c->n_counts = fused ? c->tiles_local : c->n_blocks;
+            if (fused) vrt::launch_primary_shadow_fused(P, kstats, st, ev[0], ev[1]);
             else vrt::launch_primary(P, variant == 3u ? 0u : variant, kstats, shadow, st, ev[0], ev[1]);
             HIP_TRY(c, hipGetLastError());
             ev_kind = kEvOneKernel;

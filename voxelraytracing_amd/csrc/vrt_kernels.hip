@@ -147,118 +147,12 @@ __global__ void __launch_bounds__(256) shadow_kernel(FrameParams P) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Primary + shadow in one launch (the default for VRT_MODE_PRIMARY_SHADOW): the workgroup that traced four tiles
-// also marches their shadow rays.  The compacted hit buffer lives in LDS (256 records of 16 B), the occlusion
-// flags come back through LDS, and every texel is stored exactly once with the shadow factor already applied:
-// no hit records or texel read-modify-writes through HBM, no second launch with its own ramp-up and tail.
-// Phase 1: primary march, compaction (ballot + prefix popcount, one LDS atomic per wave).  Phase 2: lane = record.
-// Phase 3: lane = pixel again, store.  Same records in the same order as the two-kernel form (variant 3), so the
-// shadow waves are the same waves and the frame is bit-identical.
-// ------------------------------------------------------------------------------------------------
-template <int MARCH, bool LDS_ROOTS, bool STATS>
-__global__ void __launch_bounds__(256) primary_shadow_kernel(FrameParams P) {
-    // [0,8) liquid mask, [8,24) stats scratch + hit count, [24,1048) hit records, [1048,1304) occlusion flags, then chunk roots
-    extern __shared__ uint32_t smem[];
-    uint32_t *s_liquid = smem, *s_roots = smem + 1304;
-    unsigned long long *s_acc = reinterpret_cast<unsigned long long *>(smem + 8);
-    uint32_t *s_hits = smem + 22;
-    uint4 *s_rec = reinterpret_cast<uint4 *>(smem + 24);
-    uint32_t *s_occ = smem + 1048;
-    if (STATS && threadIdx.x < 6) s_acc[threadIdx.x] = 0ull;
-    if (threadIdx.x == 0) *s_hits = 0u;
-    s_occ[threadIdx.x] = 0u;
-    stage_lds(P, s_roots, s_liquid, LDS_ROOTS);
-
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t t_local = blockIdx.x * 4u + (threadIdx.x >> 6);
-    const bool live = t_local < P.tiles_local;
-    MarchResult R;
-    R.iters = 0; R.visits = 0; R.hit = false;
-    V3 color{0.f, 0.f, 0.f};
-    uint32_t id = 0u, slot = 0u;
-    if (live) {
-        const uint32_t tile = shard_tile(t_local, P.shard_first, P.shard_run, P.shard_period);
-        const uint32_t px = (tile % P.tiles_x) * 8u + (lane & 7u);
-        const uint32_t py = (tile / P.tiles_x) * 8u + (lane >> 3);
-        slot = P.tile_major ? t_local * 64u + lane : py * P.width + px;
-
-        V3 origin, dir;
-        create_ray(P, (int)px, (int)py, origin, dir);
-        R = march<MARCH, LDS_ROOTS, STATS>(P, s_roots, s_liquid, origin, dir);
-        id = shade<MARCH == 1>(P, R, origin, dir, color);
-
-        const bool launch = R.hit && R.voxel != 0u && !is_liquid(s_liquid, R.voxel);
-        if (launch) id |= VRT_ID_SHADOW_RAY;
-        const unsigned long long ballot = __ballot(launch);
-        const uint32_t n = (uint32_t)__popcll(ballot);
-        if (n) {
-            const int leader = __ffsll((long long)ballot) - 1;
-            uint32_t base = 0;
-            if ((int)lane == leader) base = atomicAdd(s_hits, n);
-            base = __shfl(base, leader, 64);
-            if (launch) {
-                const uint32_t rank = (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
-                const V3 so{R.pos.x + R.norm.x * kShadowBias, R.pos.y + R.norm.y * kShadowBias, R.pos.z + R.norm.z * kShadowBias};
-                s_rec[base + rank] = make_uint4(threadIdx.x, __float_as_uint(so.x), __float_as_uint(so.y), __float_as_uint(so.z));
-            }
-        }
-        if (STATS && P.steps) P.steps[slot] = R.iters;
-    }
-    if (STATS) {
-        block_add(s_acc, 0, R.iters);
-        block_add(s_acc, 1, R.visits);
-        block_add(s_acc, 2, R.hit ? 1ull : 0ull);
-    }
-    __syncthreads();
-
-    // ---- phase 2: lane = record ----
-    const uint32_t count = *s_hits;
-    MarchResult S;
-    S.iters = 0; S.visits = 0; S.hit = false;
-    if (threadIdx.x < count) {
-        const uint4 rec = s_rec[threadIdx.x];
-        const V3 so{__uint_as_float(rec.y), __uint_as_float(rec.z), __uint_as_float(rec.w)};
-        const V3 sd = vnormalize(V3{P.settings.sun_pos[0] - (float)P.world.min[0] - so.x,
-                                    P.settings.sun_pos[1] - (float)P.world.min[1] - so.y,
-                                    P.settings.sun_pos[2] - (float)P.world.min[2] - so.z});
-        S = march<MARCH, LDS_ROOTS, STATS>(P, s_roots, s_liquid, so, sd);
-        s_occ[rec.x] = (S.hit ? 1u : 0u) | (STATS ? S.iters << 16 : 0u);
-    }
-    if (STATS) {
-        block_add(s_acc, 3, S.iters);
-        block_add(s_acc, 4, S.visits);
-    }
-    __syncthreads();
-
-    // ---- phase 3: lane = pixel ----
-    if (live) {
-        const uint32_t occ = s_occ[threadIdx.x];
-        if (occ & 1u) {
-            color.x *= kShadowFactor;
-            color.y *= kShadowFactor;
-            color.z *= kShadowFactor;
-            id |= VRT_ID_SHADOWED;
-        }
-        P.out[slot] = make_uint4(__float_as_uint(color.x), __float_as_uint(color.y), __float_as_uint(color.z), id);
-        if (STATS && P.steps) P.steps[slot] |= occ & 0xFFFF0000u;
-    }
-    if (threadIdx.x == 0) {
-        P.blk_counts[blockIdx.x] = count;  // the launched-ray count of vrt_get_stats
-        if (STATS) {
-            atomicAdd(&P.counters[kCtrSteps], s_acc[0] + s_acc[3]);
-            atomicAdd(&P.counters[kCtrVisits], s_acc[1] + s_acc[4]);
-            atomicAdd(&P.counters[kCtrPrimarySteps], s_acc[0]);
-            atomicAdd(&P.counters[kCtrPrimaryVisits], s_acc[1]);
-            atomicAdd(&P.counters[kCtrHits], s_acc[2]);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Primary + shadow, wave-local (no workgroup cooperation at all): each lane marches its pixel's primary ray and, if
-// that ended on a solid voxel, its shadow ray right after, then stores the finished texel.  No hit records, no
-// barriers, no atomics; a shadow wave is exactly one 8x8 tile's hits — the most coherent grouping there is — and its
-// lane utilisation is the tile's hit fraction (1.0 for the terrain tiles that make up most of a frame).
+// Primary + shadow in one launch (the default for VRT_MODE_PRIMARY_SHADOW), wave-local: each lane marches its pixel's
+// primary ray and, if that ended on a solid voxel, its shadow ray right after, then stores the finished texel once, with
+// the shadow factor applied.  No hit records, no barriers, no atomics, no second launch; a shadow wave is exactly one
+// 8x8 tile's hits — the most coherent grouping there is — and its lane utilisation is the tile's hit fraction (1.0 for
+// the terrain tiles that make up most of a frame).  (A workgroup-phase form — compact the four tiles' hits into an LDS
+// hit buffer, lane = record, flags back through LDS — ran in exactly the same time and was dropped: DESIGN.md §5.)
 // ------------------------------------------------------------------------------------------------
 template <int MARCH, bool LDS_ROOTS, bool STATS, int WAVES>
 __global__ void __launch_bounds__(64 * WAVES) primary_shadow_wave_kernel(FrameParams P) {
@@ -420,33 +314,18 @@ static void launch_shadow_t(const FrameParams &P, bool stats, hipStream_t st, hi
     else hipExtLaunchKernelGGL((shadow_kernel<MARCH, LDS_ROOTS, false>), grid, block, (uint32_t)lds, st, e0, e1, 0, P);
 }
 
-template <int MARCH, bool LDS_ROOTS>
-static void launch_fused_t(const FrameParams &P, bool stats, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
-    const dim3 grid((P.tiles_local + 3u) / 4u), block(256);
-    const size_t lds = (1304u + (LDS_ROOTS ? P.n_roots : 0u)) * 4u;
-    if (stats) hipExtLaunchKernelGGL((primary_shadow_kernel<MARCH, LDS_ROOTS, true>), grid, block, (uint32_t)lds, st, e0, e1, 0, P);
-    else hipExtLaunchKernelGGL((primary_shadow_kernel<MARCH, LDS_ROOTS, false>), grid, block, (uint32_t)lds, st, e0, e1, 0, P);
-}
-
 // variant 0: grid march over the derived cell grid / brick pool (needs P.grid), primary + shadow fused into one launch;
 // 1: literal octree walk; 2: ancestor-cache octree walk; 3: grid march, shadow rays as a second launch from a hit buffer
 // in HBM (the wavefront form the path trace is built from)
 bool variant_supported(uint32_t variant) { return variant <= 3u; }
 
-template <int WAVES>
-static void launch_wave_t(const FrameParams &P, bool stats, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+// One launch for primary + shadow (variant 0 only); blk_counts gets one launched-ray count per tile.
+void launch_primary_shadow_fused(const FrameParams &P, bool stats, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+    constexpr int WAVES = 4;
     const dim3 grid((P.tiles_local + WAVES - 1u) / WAVES), block(64 * WAVES);
     const uint32_t lds = 24u * 4u;
     if (stats) hipExtLaunchKernelGGL((primary_shadow_wave_kernel<0, false, true, WAVES>), grid, block, lds, st, e0, e1, 0, P);
     else hipExtLaunchKernelGGL((primary_shadow_wave_kernel<0, false, false, WAVES>), grid, block, lds, st, e0, e1, 0, P);
-}
-
-// One launch for primary + shadow (variant 0 only). form 0: wave-local (counts per tile in blk_counts); 1: workgroup
-// phases with the hit records in LDS (counts per 4-tile workgroup); 2: wave-local, one tile per workgroup.
-void launch_primary_shadow_fused(const FrameParams &P, bool stats, uint32_t form, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
-    if (form == 1u) launch_fused_t<0, false>(P, stats, st, e0, e1);
-    else if (form == 2u) launch_wave_t<1>(P, stats, st, e0, e1);
-    else launch_wave_t<4>(P, stats, st, e0, e1);
 }
 
 // e0 / e1: events the dispatch itself stamps with the kernel's begin and end (no separate marker packets on the stream)
