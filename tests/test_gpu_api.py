@@ -7,7 +7,7 @@ import pytest
 
 from voxelraytracing_amd import Gpu, MODE_PRIMARY, MODE_PRIMARY_SHADOW, VrtError, graphics as g, scenes
 
-from util import gpu_for_scene
+from util import assert_frame_parity, gpu_for_scene
 
 pytestmark = pytest.mark.gpu
 
@@ -132,3 +132,40 @@ def test_present_quantise_and_crosshair_blit(orc):
     assert 0 < len(changed) <= 2 * (10 * 3) and np.abs(changed - np.array([36, 64])).max() <= 5
     with pytest.raises(VrtError):
         gpu.present((64, 36))                             # minification (the sampler's Linear filter) is not offered
+
+
+@pytest.mark.parametrize("in_flight", [1, 2, 3, 4])
+def test_frames_in_flight_keep_frames_apart(orc, in_flight):
+    """Back-to-back vrt_render calls with different cameras and no synchronisation in between: every read-back is the
+    frame of the most recent call, whatever number of frames the context keeps in flight; uploads wait for them."""
+    sc = scenes.c2((160, 96))
+    gpu = gpu_for_scene(sc)
+    gpu.set_frames_in_flight(in_flight)
+    o = orc.from_package_scene(sc)
+    cams = [g.cam_data_create((20.0 + 7 * k, 35.0 + 50 * k, 0.0), (sc.eye[0] + 3 * k, sc.eye[1] + k, sc.eye[2] - 2 * k), 70.0, (160.0, 96.0))
+            for k in range(5)]
+    refs = []
+    for cam in cams:
+        o.set_cam(cam)
+        refs.append(o.render(orc.MODE_PRIMARY_SHADOW, 160, 96)[:2])
+    for last in range(len(cams)):
+        for k in range(last + 1):              # k + 1 frames enqueued with nothing waiting in between
+            gpu.write_cam_data(cams[k])
+            gpu.render(MODE_PRIMARY_SHADOW)
+        rgb, ids, _ = gpu.read_output()
+        assert_frame_parity(rgb, ids, refs[last][0], refs[last][1], f"{in_flight} in flight, frame {last}")
+        assert gpu.stats().secondary_rays == int(((refs[last][1] >> 21) & 1).sum())
+    # an edit between two frames: the upload (and the table rebuild) must not overtake the frame before it
+    gpu.write_cam_data(cams[0])
+    gpu.render(MODE_PRIMARY_SHADOW)
+    start, n = sc.world.set_voxel((int(sc.eye[0]) + 4, int(sc.eye[1]) - 6, int(sc.eye[2]) + 9), 4)
+    gpu.write_nodes(sc.world.nodes_ptr(), start, start + n)
+    gpu.render(MODE_PRIMARY_SHADOW)
+    gpu.render(MODE_PRIMARY)                    # and a primary-only frame right behind it
+    rgb, ids, _ = gpu.read_output()
+    o2 = orc.from_package_scene(sc)
+    o2.set_cam(cams[0])
+    r_rgb, r_ids, _, _ = o2.render(orc.MODE_PRIMARY, 160, 96)
+    assert_frame_parity(rgb, ids, r_rgb, r_ids, "after an edit")
+    with pytest.raises(VrtError):
+        gpu.set_frames_in_flight(5)

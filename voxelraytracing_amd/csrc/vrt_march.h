@@ -443,13 +443,9 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
         }
         if (STATS) R.visits += (uint32_t)__clz((int)sz) - 25u;  // depth + 1 node words on the reference's walk
 
-        bool liquid = false;
         if (voxel != 0u) {
-            liquid = is_liquid(s_liquid, voxel);
-            if (!liquid) break;  // solid: the hit
-        }
-        if (liquid) {
-            if (dew == -1.0f) dew = total_len;
+            if (!is_liquid(s_liquid, voxel)) break;  // solid: the hit
+            if (dew == -1.0f) dew = total_len;       // liquid: water bookkeeping (:231-242)
         } else if (dew != -1.0f) {
             R.water_dist += total_len - dew;
             dew = -1.0f;
