@@ -88,7 +88,7 @@ struct vrt_ctx {
     uint4 *d_hits = nullptr;
     uint32_t *d_blk_counts = nullptr;  // hit records per primary workgroup
     uint32_t n_blocks = 0;
-    uint32_t n_counts = 0;          // entries of blk_counts the last primary + shadow frame wrote (per workgroup or per tile)
+    uint32_t n_counts = 0;          // entries of blk_counts the last primary + shadow frame wrote
     uint4 *d_path = nullptr;  // path mode: 2 buffers x 3 planes x (kHitSegments * hit_seg_cap) records, lazily allocated
     unsigned long long *d_counters = nullptr;  // [kCtrCount] stats, then the hit-segment counters
     uint32_t hit_seg_cap = 0;
@@ -202,12 +202,12 @@ static int alloc_output(vrt_ctx *c) {
     if (c->hit_seg_cap == 0) c->hit_seg_cap = 256u;
     HIP_TRY(c, hipMalloc(&c->d_hits, (size_t)vrt::kHitSegments * c->hit_seg_cap * sizeof(uint4)));  // >= nblocks * 256
     c->n_blocks = nblocks;
-    // one count per primary workgroup (two-launch variants, workgroup-phase form) or per tile (wave-local form)
+    // launched-ray counts: one per primary workgroup (two-launch variants) or one per tile (the one-launch kernel)
     const size_t ncnt = c->tiles_local ? c->tiles_local : 1;
     HIP_TRY(c, hipMalloc(&c->d_blk_counts, ncnt * sizeof(uint32_t)));
     HIP_TRY(c, hipMemsetAsync(c->d_blk_counts, 0, ncnt * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->own_out, 0, n * sizeof(vrt::Texel), c->stream));
-    // the extra (output, counts) sets of frames in flight are allocated when first used (ensure_in_flight_sets)
+    // the extra (stream, output, counts) sets of frames in flight are created when first used (vrt_render)
     c->d_out = c->own_out;  // a resize drops any caller-bound output (its size no longer matches)
     c->last_out = c->own_out;
     c->last_blk = c->d_blk_counts;
