@@ -124,8 +124,10 @@ def main():
         """(backend context, FrameGather) for this rank.  N > 1: the root renders its own tiles straight into the
         row-major frame (VRT_FLAG_ROW_MAJOR) and takes root_weight tiles of every root_weight + N - 1."""
         in_place = world > 1
+        compact = in_place and MODE != MODE_PATH and args.variant == 0   # 8 B/pixel over the links, shaded at the root
         g = Gpu(sc.world.max_nodes(), sc.world.size_in_chunks(), sc.size, device=local_rank, shard_rank=rank, shard_count=world,
-                tile_major=sharded and not (in_place and rank == 0), root_weight=root_weight, row_major=in_place and rank == 0)
+                tile_major=sharded and not (in_place and rank == 0), root_weight=root_weight, row_major=in_place and rank == 0,
+                compact=compact and rank != 0)
         g.upload_world(sc.world, sc.materials)
         g.write_cam_data(sc.cam)
         g.write_settings(sc.settings)
@@ -134,7 +136,7 @@ def main():
         if sharded:
             g.set_stream(side.cuda_stream)
             f = FrameGather(torch, dist, rank, world, args.width, args.height, torch.device("cuda", local_rank),
-                            root_weight=root_weight, in_place=in_place)
+                            root_weight=root_weight, in_place=in_place, compact=compact)
             if args.rehearse_on_one_gpu:
                 def staged_gather(which=0, async_op=False, f=f):
                     torch.cuda.synchronize()
@@ -267,7 +269,8 @@ def main():
                    "rays_per_frame_actual": rays_per_frame, "rays_per_frame_nominal": 2 * args.width * args.height,
                    "sharding": ("whole frame" if not sharded else "whole frame through the one-rank gather pipeline") if world == 1 else
                                f"8x8 tiles interleaved over {world} ranks ({root_weight} of every {root_weight + world - 1} to the gather root, "
-                               f"which renders them in place) + RCCL gather of the other ranks' tile buffers to rank 0",
+                               f"which renders them in place) + RCCL gather of the other ranks' tile buffers "
+                               f"({'8-byte records shaded at the root' if MODE != MODE_PATH and args.variant == 0 else '16-byte texels'}) to rank 0",
                    "root_weight": root_weight, "root_weight_tuning_ms_per_frame": tuning,
                    "kernel_variant": args.variant, "derived_tables": derived},
         "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

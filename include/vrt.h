@@ -106,6 +106,11 @@ typedef struct {
 /* A sharded context that writes its tiles at their final positions of a row-major full-frame buffer instead of a
  * compact tile-major one: the gather root rendering straight into the frame (vrt_assemble then skips its tiles). */
 #define VRT_FLAG_ROW_MAJOR 2u
+/* A tile-major shard context whose buffer travels over a link: store 8 bytes per pixel slot instead of the 16-byte
+ * texel — {id word | bit 23 (norm.y < 0), water_dist as f32} — which is all the gather root needs, beside the frame's
+ * uniforms it holds anyway, to shade the pixel itself bit for bit (vrt_assemble_compact).  Plain primary(+shadow)
+ * frames with the default march only; vrt_read_output is not available on such a context. */
+#define VRT_FLAG_COMPACT 4u
 
 typedef enum {
     VRT_MODE_PRIMARY = 0,        /* the reference's live shader (ray_tracer.wgsl) */
@@ -266,6 +271,11 @@ int vrt_shard_info(vrt_ctx *ctx, uint32_t *tiles_local, uint32_t *tiles_padded, 
  * row-major device frame dst = texel[height][width].  A root created with VRT_FLAG_ROW_MAJOR has already written
  * its own tiles there: slot 0 of `gathered` is then ignored.  Asynchronous on the context's stream. */
 int vrt_assemble(vrt_ctx *ctx, const void *gathered, uint64_t rank_stride_bytes, void *dst);
+
+/* The same for VRT_FLAG_COMPACT messages (8 bytes per pixel slot; stride 0 = tiles_padded*64*8 bytes apart): the root —
+ * a VRT_FLAG_ROW_MAJOR shard context holding the same camera / settings / world / materials as the senders — shades
+ * every gathered pixel with the code the sender would have run and writes the texel into dst. */
+int vrt_assemble_compact(vrt_ctx *ctx, const void *gathered, uint64_t rank_stride_bytes, void *dst);
 
 #ifdef __cplusplus
 }

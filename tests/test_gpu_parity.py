@@ -202,8 +202,9 @@ def test_device_side_gather_and_assemble(c2_small):
             c.close()
 
 
+@pytest.mark.parametrize("compact", [False, True])
 @pytest.mark.parametrize("n,w0", [(2, 4), (4, 3), (8, 2), (3, 7)])
-def test_weighted_in_place_root_gather_and_assemble(c2_small, n, w0):
+def test_weighted_in_place_root_gather_and_assemble(c2_small, n, w0, compact):
     """The bench's N > 1 data path on one GPU with a weighted root: rank 0 takes w0 tiles of every w0 + n - 1 and
     renders them straight into the row-major frame (VRT_FLAG_ROW_MAJOR); the other ranks render tile-major messages
     into slices of the receive tensor; vrt_assemble scatters those and leaves the root's tiles alone."""
@@ -214,11 +215,11 @@ def test_weighted_in_place_root_gather_and_assemble(c2_small, n, w0):
     full = gpu_for_scene(c2_small)
     full.render(MODE_PRIMARY_SHADOW)
     rgb, ids, _ = full.read_output()
-    fg0 = FrameGather(torch, None, 0, n, w, h, torch.device("cuda", 0), root_weight=w0, in_place=True)
+    fg0 = FrameGather(torch, None, 0, n, w, h, torch.device("cuda", 0), root_weight=w0, in_place=True, compact=compact)
     ctxs = []
     total = 0
     for r in range(n):
-        sh = gpu_for_scene(c2_small, shard_rank=r, shard_count=n, root_weight=w0, row_major=(r == 0))
+        sh = gpu_for_scene(c2_small, shard_rank=r, shard_count=n, root_weight=w0, row_major=(r == 0), compact=compact and r != 0)
         tl, tp, tt = sh.shard_info()
         mine, padded, tot = shard.tiles_of_rank(w, h, r, n, w0)
         assert (tl, tp, tt) == (len(mine), padded, tot)
@@ -227,7 +228,7 @@ def test_weighted_in_place_root_gather_and_assemble(c2_small, n, w0):
             fg0.bind(sh, 1)                      # frame buffer 1, as frame k = 1 of the pipeline would
             assert sh.device_output()[1] == w * h * 16
         else:
-            assert sh.device_output()[1] == padded * 64 * 16
+            assert sh.device_output()[1] == padded * 64 * (8 if compact else 16)
             sh.bind_output(fg0.recv[1][r].data_ptr())
         sh.render(MODE_PRIMARY_SHADOW)
         sh.synchronize()
@@ -237,6 +238,12 @@ def test_weighted_in_place_root_gather_and_assemble(c2_small, n, w0):
     ctxs[0].synchronize()
     a_rgb, a_ids = texels_to_frame(fg0.frame.cpu().numpy().view(np.uint32))
     assert np.array_equal(a_ids, ids) and np.array_equal(a_rgb, rgb)
+    if compact:   # the records are shaded on the device only; what was checked above is the whole point
+        with pytest.raises(g.VrtError):
+            ctxs[1].read_output()
+        for c in ctxs:
+            c.close()
+        return
     # the host twin used by the gloo tests agrees with the device scatter
     host = shard.assemble_numpy(fg0.recv[1].cpu().numpy().view(np.uint32), w, h, n, w0,
                                 frame=np.zeros((h, w, 4), dtype=np.uint32))

@@ -81,6 +81,16 @@ if rank == 0:
     rgb, ids = shard.texels_to_frame(got)
     assert np.array_equal(ids, f_ids) and np.array_equal(rgb, f_rgb), "weighted in-place frame differs from the unsharded one"
     print("GLOO_WEIGHTED_OK", world)
+# ---- compact messages (8 bytes per pixel slot, shaded at the root on the GPU): half the size, same transport ----
+fgc = shard.FrameGather(torch, dist, rank, world, w, h, torch.device("cpu"), root_weight=W0, in_place=True, compact=True)
+assert fgc.msgs[0].numel() * 2 == fgw.msgs[0].numel() and fgc.slot_bytes == 8
+fgc.msgs[1].copy_(torch.arange(fgc.msgs[1].numel(), dtype=torch.int32) * (rank + 1))
+fgc.gather(1)
+dist.barrier()
+if rank == 0:
+    for r in range(1, world):
+        assert torch.equal(fgc.recv[1][r], torch.arange(fgc.msgs[1].numel(), dtype=torch.int32) * (r + 1))
+    print("GLOO_COMPACT_OK", world)
 dist.destroy_process_group()
 '''
 
@@ -190,7 +200,7 @@ def test_tile_shard_gather_over_gloo(world, tmp_path):
         outs.append(out.decode())
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{out[-2000:]}"
-    assert f"GLOO_SHARD_OK {world}" in outs[0] and f"GLOO_WEIGHTED_OK {world}" in outs[0]
+    assert f"GLOO_SHARD_OK {world}" in outs[0] and f"GLOO_WEIGHTED_OK {world}" in outs[0] and f"GLOO_COMPACT_OK {world}" in outs[0]
 
 
 def test_layout_helpers_round_trip():

@@ -106,6 +106,7 @@ VRT_SYMBOLS = {
     "vrt_device_output": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     "vrt_shard_info": (C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "vrt_assemble": (C.c_int, [_P, _P, C.c_uint64, _P]),
+    "vrt_assemble_compact": (C.c_int, [_P, _P, C.c_uint64, _P]),
 }
 
 

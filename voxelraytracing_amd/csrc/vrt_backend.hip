@@ -32,6 +32,8 @@ void launch_assemble(const Texel *gathered, Texel *dst, uint32_t width, uint32_t
                      uint32_t root_weight, uint32_t period, bool skip_root, uint64_t rank_stride, hipStream_t st);
 void launch_present(const Texel *out, uint32_t w, uint32_t h, uint32_t screen_w, uint32_t screen_h, const vrt_crosshair &ch,
                     uint8_t *rgba8, hipStream_t st);
+void launch_assemble_shade(const FrameParams &P, const void *gathered, Texel *dst, uint32_t root_weight, uint32_t period,
+                           uint64_t rank_stride, hipStream_t st);
 void launch_accel_cells(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S, uint32_t *grid,
                         uint32_t *chunk_bricks, uint32_t *chunk_offsets, uint32_t *total, hipStream_t st);
 void launch_accel_bricks(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S, uint32_t *grid,
@@ -74,6 +76,7 @@ struct vrt_ctx {
     uint32_t width = 0, height = 0;
     uint32_t shard_rank = 0, shard_count = 1, shard_w0 = 1;
     uint32_t shard_first = 0, shard_run = 1, shard_period = 1;  // vrt_device.h shard_tile()
+    bool compact = false;     // VRT_FLAG_COMPACT: 8-byte records instead of texels (a sharded, tile-major context whose tiles cross a link)
     bool tile_major = false;  // output layout [t_local][64]: always when sharded, on request (VRT_FLAG_TILE_MAJOR) otherwise
     uint32_t tiles_x = 0, tiles_total = 0, tiles_local = 0, tiles_padded = 0;
     uint32_t slots = 0;  // pixel slots in the output buffer
@@ -316,6 +319,8 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     if (cfg->shard_root_weight > 4096u) return fail(nullptr, VRT_ERR_INVALID_ARG, "shard_root_weight %u out of range", cfg->shard_root_weight);
     if ((cfg->flags & VRT_FLAG_ROW_MAJOR) && (cfg->flags & VRT_FLAG_TILE_MAJOR))
         return fail(nullptr, VRT_ERR_INVALID_ARG, "VRT_FLAG_ROW_MAJOR and VRT_FLAG_TILE_MAJOR exclude each other");
+    if ((cfg->flags & VRT_FLAG_COMPACT) && ((cfg->flags & VRT_FLAG_ROW_MAJOR) || (sc == 1u && !(cfg->flags & VRT_FLAG_TILE_MAJOR))))
+        return fail(nullptr, VRT_ERR_INVALID_ARG, "VRT_FLAG_COMPACT is for tile-major shard buffers");
 
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -334,6 +339,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     c->shard_count = sc;
     c->shard_w0 = cfg->shard_root_weight ? cfg->shard_root_weight : 1u;
     c->tile_major = (sc > 1u && !(cfg->flags & VRT_FLAG_ROW_MAJOR)) || (cfg->flags & VRT_FLAG_TILE_MAJOR);
+    c->compact = (cfg->flags & VRT_FLAG_COMPACT) != 0;
     c->width = cfg->width;
     c->height = cfg->height;
     c->max_nodes = cfg->max_nodes & ~1u;  // NodeBuffer::new forces an even size (shader.rs:10-12)
@@ -571,6 +577,37 @@ static int fold_events(vrt_ctx *c, float last[3]) {
     return VRT_OK;
 }
 
+// The frame's uniforms and scene pointers (everything of FrameParams that does not depend on where a frame is written).
+static void fill_uniforms(const vrt_ctx *c, vrt::FrameParams &P) {
+    P.n_nodes = c->max_nodes;
+    // only the S^3 entries the frame's WorldData describes are addressable (find_node :120-123)
+    P.n_roots = c->world.size_in_chunks * c->world.size_in_chunks * c->world.size_in_chunks;
+    P.width = c->width;
+    P.height = c->height;
+    P.tiles_x = c->tiles_x;
+    P.tiles_total = c->tiles_total;
+    P.shard_first = c->shard_first;
+    P.shard_run = c->shard_run;
+    P.shard_period = c->shard_period;
+    P.tiles_local = c->tiles_local;
+    P.tile_major = c->tile_major ? 1u : 0u;
+    P.compact = c->compact ? 1u : 0u;
+    P.cam = c->cam;
+    P.settings = c->settings;
+    P.world = c->world;
+    const vrt_settings &s = c->settings;
+    P.finite_settings = std::isfinite(s.sun_intensity) && std::isfinite(s.sky_color[0]) && std::isfinite(s.sky_color[1]) &&
+                        std::isfinite(s.sky_color[2]) && std::isfinite(s.sun_pos[0]) && std::isfinite(s.sun_pos[1]) &&
+                        std::isfinite(s.sun_pos[2]);
+    for (int v = 0; v < 256; v++)
+        if (c->h_mats[v].is_liquid == 1u) P.liquid[v >> 5] |= 1u << (v & 31);
+
+    P.ndc_x = c->d_ndc;
+    P.ndc_y = c->d_ndc + c->width;
+    cam_sun_dir(c, P.cam_sun_dir);
+
+}
+
 int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     if (!c) return VRT_ERR_INVALID_ARG;
     vrt_render_opts o;
@@ -583,6 +620,9 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     if (rc) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
 
+    if (c->compact && (o.mode == VRT_MODE_PATH || (o.variant != 0u && o.variant != 2u) || c->settings.show_step_count == 1u))
+        return fail(c, VRT_ERR_STATE, "vrt_render: a VRT_FLAG_COMPACT context renders primary(+shadow) frames with the default march "
+                    "only (no path trace, step-count view, literal or two-launch variants)");
     if (o.stats && !c->d_steps) HIP_TRY(c, hipMalloc(&c->d_steps, (size_t)(c->slots ? c->slots : 1) * sizeof(uint32_t)));
     rc = ensure_ndc(c);
     if (rc) return rc;
@@ -635,31 +675,7 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     P.seg_counts = reinterpret_cast<uint32_t *>(c->d_counters + vrt::kCtrCount);
     P.hit_seg_cap = c->hit_seg_cap;
     P.steps = o.stats ? c->d_steps : nullptr;
-    P.n_nodes = c->max_nodes;
-    // only the S^3 entries the frame's WorldData describes are addressable (find_node :120-123)
-    P.n_roots = c->world.size_in_chunks * c->world.size_in_chunks * c->world.size_in_chunks;
-    P.width = c->width;
-    P.height = c->height;
-    P.tiles_x = c->tiles_x;
-    P.tiles_total = c->tiles_total;
-    P.shard_first = c->shard_first;
-    P.shard_run = c->shard_run;
-    P.shard_period = c->shard_period;
-    P.tiles_local = c->tiles_local;
-    P.tile_major = c->tile_major ? 1u : 0u;
-    P.cam = c->cam;
-    P.settings = c->settings;
-    P.world = c->world;
-    const vrt_settings &s = c->settings;
-    P.finite_settings = std::isfinite(s.sun_intensity) && std::isfinite(s.sky_color[0]) && std::isfinite(s.sky_color[1]) &&
-                        std::isfinite(s.sky_color[2]) && std::isfinite(s.sun_pos[0]) && std::isfinite(s.sun_pos[1]) &&
-                        std::isfinite(s.sun_pos[2]);
-    for (int v = 0; v < 256; v++)
-        if (c->h_mats[v].is_liquid == 1u) P.liquid[v >> 5] |= 1u << (v & 31);
-
-    P.ndc_x = c->d_ndc;
-    P.ndc_y = c->d_ndc + c->width;
-    cam_sun_dir(c, P.cam_sun_dir);
+    fill_uniforms(c, P);
 
     const bool shadow = o.mode == VRT_MODE_PRIMARY_SHADOW;
     // per-lane iteration counts exist in the STATS kernels only; the step-count debug view (F2 in the reference,
@@ -750,6 +766,7 @@ int vrt_synchronize(vrt_ctx *c) {
 int vrt_read_output(vrt_ctx *c, float *rgb, uint32_t *ids, uint8_t *rgba8) {
     if (!c) return VRT_ERR_INVALID_ARG;
     if (!c->rendered) return fail(c, VRT_ERR_STATE, "vrt_read_output: nothing rendered yet");
+    if (c->compact) return fail(c, VRT_ERR_STATE, "vrt_read_output: a VRT_FLAG_COMPACT context holds 8-byte records, not texels (vrt_assemble_compact shades them)");
     HIP_TRY(c, hipSetDevice(c->device));
     QUIESCE(c);
     const size_t npix = (size_t)c->width * c->height;
@@ -925,7 +942,7 @@ int vrt_bind_output(vrt_ctx *c, void *texels) {
 int vrt_device_output(vrt_ctx *c, void **texels, uint64_t *bytes) {
     if (!c) return VRT_ERR_INVALID_ARG;
     if (texels) *texels = c->d_out == c->own_out ? c->last_out : c->d_out;  // own buffers: the one holding the last frame
-    if (bytes) *bytes = (uint64_t)c->slots * sizeof(vrt::Texel);
+    if (bytes) *bytes = (uint64_t)c->slots * (c->compact ? 8u : sizeof(vrt::Texel));
     return VRT_OK;
 }
 
@@ -946,6 +963,28 @@ int vrt_assemble(vrt_ctx *c, const void *gathered, uint64_t rank_stride_bytes, v
     const bool in_place = c->shard_count > 1u && !c->tile_major;  // VRT_FLAG_ROW_MAJOR root: its tiles are already in dst
     vrt::launch_assemble((const vrt::Texel *)gathered, (vrt::Texel *)dst, c->width, c->tiles_x, c->tiles_total, c->shard_w0,
                          c->shard_period, in_place, stride, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    return VRT_OK;
+}
+
+int vrt_assemble_compact(vrt_ctx *c, const void *gathered, uint64_t rank_stride_bytes, void *dst) {
+    if (!c) return VRT_ERR_INVALID_ARG;
+    if (!gathered || !dst) return fail(c, VRT_ERR_INVALID_ARG, "vrt_assemble_compact: null argument");
+    if (rank_stride_bytes % 8u) return fail(c, VRT_ERR_INVALID_ARG, "vrt_assemble_compact: rank stride must be a multiple of 8 bytes");
+    if (!(c->shard_count > 1u && !c->tile_major))
+        return fail(c, VRT_ERR_STATE, "vrt_assemble_compact: the gather root must be a VRT_FLAG_ROW_MAJOR shard context (it shades the "
+                    "other ranks' records with its own uniforms and has its own tiles in the frame already)");
+    int rc = validate_frame(c);
+    if (rc) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    rc = ensure_ndc(c);
+    if (rc) return rc;
+    vrt::FrameParams P;
+    memset(&P, 0, sizeof P);
+    P.mats = c->d_mats;
+    fill_uniforms(c, P);
+    const uint64_t stride = rank_stride_bytes ? rank_stride_bytes / 8u : (uint64_t)c->tiles_padded * 64u;
+    vrt::launch_assemble_shade(P, gathered, (vrt::Texel *)dst, c->shard_w0, c->shard_period, stride, c->stream);
     HIP_TRY(c, hipGetLastError());
     return VRT_OK;
 }

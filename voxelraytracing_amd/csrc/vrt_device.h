@@ -16,6 +16,8 @@ namespace vrt {
 constexpr float kShadowBias = 0.002f;   // DESIGN.md §Shadow rays (build-defined)
 constexpr float kShadowFactor = 0.35f;
 constexpr uint32_t kMaxSteps = 500u;    // ray_tracer.wgsl:220
+// compact records only: norm.y == -1 (the one thing face shading needs beyond the id word's norm flags, :298-306)
+constexpr uint32_t kIdNormYNeg = 1u << 23;
 
 // One output texel: {r, g, b as f32 bits, id word}. 16 B so that a wave stores 1 KiB contiguously.
 using Texel = uint4;
@@ -52,6 +54,7 @@ struct FrameParams {
     uint32_t shard_first, shard_run, shard_period, tiles_local;
     uint32_t hit_seg_cap;    // capacity of one hit-buffer segment, a multiple of 256
     uint32_t tile_major;     // output slots are [t_local][64] (sharded, or VRT_FLAG_TILE_MAJOR) instead of row-major
+    uint32_t compact;        // VRT_FLAG_COMPACT: a slot is an 8-byte record {id word | kIdNormYNeg, water_dist} instead of a texel
     uint32_t finite_settings;  // 1: every Settings float is finite (lets hits skip the sky term exactly)
     vrt_cam_data cam;
     vrt_settings settings;

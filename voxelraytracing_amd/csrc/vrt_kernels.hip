@@ -19,6 +19,17 @@
 
 namespace vrt {
 
+// One finished pixel: the 16-byte texel, or (VRT_FLAG_COMPACT, a shard whose tiles go over a link) the 8 bytes the
+// gather root needs to shade it itself: the id word (+ the sign of norm.y) and water_dist.  Everything else the colour
+// depends on — material, face factors, shadow factor, the sky of a miss — is a function of those and of the frame's
+// uniforms, which the root holds too (assemble_shade_kernel).
+__device__ __forceinline__ void store_pixel(const FrameParams &P, uint32_t slot, V3 color, uint32_t id, const MarchResult &R) {
+    if (P.compact)
+        reinterpret_cast<uint2 *>(P.out)[slot] = make_uint2(id | (R.norm.y < 0.0f ? kIdNormYNeg : 0u), __float_as_uint(R.water_dist));
+    else
+        P.out[slot] = make_uint4(__float_as_uint(color.x), __float_as_uint(color.y), __float_as_uint(color.z), id);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Primary rays: one wave per 8x8 tile, 4 tiles per 256-thread workgroup.
 // ------------------------------------------------------------------------------------------------
@@ -54,7 +65,8 @@ __global__ void __launch_bounds__(256) primary_tile_kernel(FrameParams P) {
             launch = R.hit && R.voxel != 0u && !is_liquid(s_liquid, R.voxel);
             if (launch) id |= VRT_ID_SHADOW_RAY;
         }
-        P.out[slot] = make_uint4(__float_as_uint(color.x), __float_as_uint(color.y), __float_as_uint(color.z), id);
+        if (SHADOW) P.out[slot] = make_uint4(__float_as_uint(color.x), __float_as_uint(color.y), __float_as_uint(color.z), id);
+        else store_pixel(P, slot, color, id, R);   // (the two-launch shadow kernel read-modify-writes texels: no compact form)
 
         if (SHADOW) {
             // Compaction of the solid hits into the workgroup's own 256-record slice of the hit buffer: ballot +
@@ -195,7 +207,7 @@ __global__ void __launch_bounds__(64 * WAVES) primary_shadow_wave_kernel(FramePa
                 id |= VRT_ID_SHADOWED;
             }
         }
-        P.out[slot] = make_uint4(__float_as_uint(color.x), __float_as_uint(color.y), __float_as_uint(color.z), id);
+        store_pixel(P, slot, color, id, R);
         if (STATS && P.steps) P.steps[slot] = R.iters | (S.iters << 16);
         const unsigned long long ballot = __ballot(launch);
         if (lane == 0) P.blk_counts[t_local] = (uint32_t)__popcll(ballot);  // per tile here: the launched-ray count of vrt_get_stats
@@ -287,6 +299,42 @@ __global__ void assemble_kernel(const Texel *gathered, Texel *dst, uint32_t widt
     dst[py * width + px] = gathered[rank * rank_stride + (uint64_t)t_local * 64u + p];
 }
 
+// Gather root, compact messages: the other ranks sent 8 bytes per pixel {id word | kIdNormYNeg, water_dist}; the root
+// re-creates the pixel's ray for the sky of a miss, runs the same shade() the sender would have run on the same
+// operands, applies the shadow factor and writes the texel at its row-major position.  Bit-identical to the texel the
+// sender would have stored (tests: the assembled frame equals the unsharded one).
+__global__ void assemble_shade_kernel(FrameParams P, const uint2 *gathered, Texel *dst, uint32_t root_weight, uint32_t period,
+                                      uint64_t rank_stride) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t tile = gid >> 6, p = gid & 63u;
+    if (tile >= P.tiles_total) return;
+    const uint32_t q = tile / period, r = tile % period;
+    if (r < root_weight) return;  // the root's own tiles are already in dst
+    const uint32_t rank = r - root_weight + 1u;
+    const uint2 rec = gathered[rank * rank_stride + (uint64_t)q * 64u + p];
+    const uint32_t px = (tile % P.tiles_x) * 8u + (p & 7u), py = (tile / P.tiles_x) * 8u + (p >> 3);
+
+    MarchResult R;
+    R.hit = (rec.x & VRT_ID_HIT) != 0u;
+    R.voxel = rec.x & VRT_ID_VOXEL_MASK;
+    R.norm = V3{(rec.x & VRT_ID_NX) ? 1.0f : 0.0f, (rec.x & VRT_ID_NY) ? ((rec.x & kIdNormYNeg) ? -1.0f : 1.0f) : 0.0f,
+                (rec.x & VRT_ID_NZ) ? 1.0f : 0.0f};  // shade() only asks norm.x != 0, norm.z != 0, norm.y == -1
+    R.water_dist = __uint_as_float(rec.y);
+    R.pos = V3{0.f, 0.f, 0.f};
+    R.iters = 0u;
+    R.visits = 0u;
+    V3 origin, dir, color;
+    create_ray(P, (int)px, (int)py, origin, dir);
+    uint32_t id = shade<false>(P, R, origin, dir, color);
+    id |= rec.x & (VRT_ID_SHADOW_RAY | VRT_ID_SHADOWED);
+    if (rec.x & VRT_ID_SHADOWED) {
+        color.x *= kShadowFactor;
+        color.y *= kShadowFactor;
+        color.z *= kShadowFactor;
+    }
+    dst[py * P.width + px] = make_uint4(__float_as_uint(color.x), __float_as_uint(color.y), __float_as_uint(color.z), id);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Launchers (called from vrt_backend.hip)
 // ------------------------------------------------------------------------------------------------
@@ -358,6 +406,13 @@ void launch_shadow(const FrameParams &P, uint32_t variant, bool stats, hipStream
 void launch_quantize(const Texel *out, uint8_t *rgba8, uint32_t n, hipStream_t st) {
     if (!n) return;
     hipLaunchKernelGGL(quantize_rgba8_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, out, rgba8, n);
+}
+
+void launch_assemble_shade(const FrameParams &P, const void *gathered, Texel *dst, uint32_t root_weight, uint32_t period,
+                           uint64_t rank_stride, hipStream_t st) {
+    if (!P.tiles_total) return;
+    hipLaunchKernelGGL(assemble_shade_kernel, dim3((P.tiles_total * 64u + 255u) / 256u), dim3(256), 0, st, P,
+                       (const uint2 *)gathered, dst, root_weight, period, rank_stride);
 }
 
 void launch_present(const Texel *out, uint32_t w, uint32_t h, uint32_t screen_w, uint32_t screen_h, const vrt_crosshair &ch,

@@ -66,10 +66,10 @@ class Gpu:
 
     def __init__(self, max_nodes: int, world_size: int, result_size, device: int = -1,
                  shard_rank: int = 0, shard_count: int = 1, tile_major: bool = False, root_weight: int = 1,
-                 row_major: bool = False):
+                 row_major: bool = False, compact: bool = False):
         self._lib = _ffi.vrt()
         cfg = _ffi.Config(max_nodes, world_size, result_size[0], result_size[1], device, shard_rank, shard_count,
-                          (1 if tile_major else 0) | (2 if row_major else 0), root_weight)
+                          (1 if tile_major else 0) | (2 if row_major else 0) | (4 if compact else 0), root_weight)
         h = C.c_void_p()
         rc = self._lib.vrt_create(C.byref(cfg), C.byref(h))
         if rc:
@@ -198,8 +198,9 @@ class Gpu:
         self._ck(self._lib.vrt_shard_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
-    def assemble(self, gathered_ptr: int, dst_ptr: int, rank_stride_bytes: int = 0):
-        self._ck(self._lib.vrt_assemble(self._h, C.c_void_p(gathered_ptr), rank_stride_bytes, C.c_void_p(dst_ptr)))
+    def assemble(self, gathered_ptr: int, dst_ptr: int, rank_stride_bytes: int = 0, compact: bool = False):
+        fn = self._lib.vrt_assemble_compact if compact else self._lib.vrt_assemble
+        self._ck(fn(self._h, C.c_void_p(gathered_ptr), rank_stride_bytes, C.c_void_p(dst_ptr)))
 
     # --- convenience: what join_game does (main.rs:211-223) ---
     def upload_world(self, world, materials=None):

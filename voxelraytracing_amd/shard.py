@@ -13,6 +13,7 @@ from __future__ import annotations
 import numpy as np
 
 TEXEL_BYTES = 16
+RECORD_BYTES = 8   # VRT_FLAG_COMPACT: {id word | norm.y sign, water_dist} — what the gather root needs to shade the pixel itself
 
 
 def tiles_of_rank(width: int, height: int, rank: int, count: int, root_weight: int = 1):
@@ -88,18 +89,26 @@ class FrameGather:
 
     in_place (needs a root context created with row_major=True): rank 0 renders its own tiles straight into the
     row-major frame and contributes nothing to the gather but an unused message-sized slot; with root_weight > 1
-    it also takes a larger share of the tiles than the ranks whose tiles have to cross a link."""
+    it also takes a larger share of the tiles than the ranks whose tiles have to cross a link.
+
+    compact (needs in_place; the other ranks' contexts created with compact=True): messages carry 8 bytes per pixel
+    instead of the 16-byte texel and the root shades them while de-interleaving (vrt_assemble_compact): half the bytes
+    over every link."""
 
     def __init__(self, torch, dist, rank: int, count: int, width: int, height: int, device, root_weight: int = 1,
-                 in_place: bool = False):
+                 in_place: bool = False, compact: bool = False):
         self.torch, self.dist, self.rank, self.count = torch, dist, rank, count
         self.width, self.height = width, height
         self.root_weight, self.in_place = root_weight, in_place
         assert in_place or root_weight == 1, "a weighted root renders in place"
+        assert in_place or not compact, "compact messages are shaded by an in-place root"
+        self.compact = compact
+        self.slot_bytes = RECORD_BYTES if compact else TEXEL_BYTES
+        words = self.slot_bytes // 4
         _, self.tiles_padded, _ = tiles_of_rank(width, height, rank, count, root_weight)
         self.slots = self.tiles_padded * 64
-        self.msgs = [torch.zeros(self.slots * 4, dtype=torch.int32, device=device) for _ in range(2)]
-        self.recv = [torch.zeros((count, self.slots * 4), dtype=torch.int32, device=device) if rank == 0 else None
+        self.msgs = [torch.zeros(self.slots * words, dtype=torch.int32, device=device) for _ in range(2)]
+        self.recv = [torch.zeros((count, self.slots * words), dtype=torch.int32, device=device) if rank == 0 else None
                      for _ in range(2)]
         n_frames = 2 if in_place else 1
         self.frames = [torch.zeros((height, width, 4), dtype=torch.int32, device=device) if rank == 0 else None
@@ -128,7 +137,7 @@ class FrameGather:
     def assemble(self, gpu, which: int = 0):
         """Rank 0: scatter the gathered tile buffers into the row-major texel frame on the device."""
         f = self._frame_of(which)
-        gpu.assemble(self.recv[which].data_ptr(), f.data_ptr(), self.slots * TEXEL_BYTES)
+        gpu.assemble(self.recv[which].data_ptr(), f.data_ptr(), self.slots * self.slot_bytes, **({"compact": True} if self.compact else {}))
         self.frame = f
 
     # ---- pipelined frames ----
