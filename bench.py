@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--root-weight", type=int, default=0,
                     help="N > 1: tiles per period dealt to the gather root (vrt_config.shard_root_weight); 0 = measure "
                          "a few candidates off the clock and keep the fastest")
+    ap.add_argument("--gather-batch", type=int, default=0,
+                    help="N > 1: frames per gather (FrameGather.batch); 0 = measure {1, 2, 4, 8} off the clock and keep the fastest")
     ap.add_argument("--force-gather", action="store_true",
                     help="development only: with --gpus 1, still run the pipelined RCCL gather + assemble path (one-rank group)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -120,7 +122,7 @@ def main():
         torch.cuda.set_stream(side)
         assert side.cuda_stream != 0
 
-    def make_pipeline(root_weight):
+    def make_pipeline(root_weight, batch=1):
         """(backend context, FrameGather) for this rank.  N > 1: the root renders its own tiles straight into the
         row-major frame (VRT_FLAG_ROW_MAJOR) and takes root_weight tiles of every root_weight + N - 1."""
         in_place = world > 1
@@ -136,9 +138,9 @@ def main():
         if sharded:
             g.set_stream(side.cuda_stream)
             f = FrameGather(torch, dist, rank, world, args.width, args.height, torch.device("cuda", local_rank),
-                            root_weight=root_weight, in_place=in_place, compact=compact)
+                            root_weight=root_weight, in_place=in_place, compact=compact, batch=batch)
             if args.rehearse_on_one_gpu:
-                def staged_gather(which=0, async_op=False, f=f):
+                def staged_gather(which=0, async_op=False, nframes=None, f=f):
                     torch.cuda.synchronize()
                     parts = [torch.empty(f.msg.numel(), dtype=torch.int32) for _ in range(world)] if rank == 0 else None
                     dist.gather(f.msgs[which].cpu(), parts, dst=0)
@@ -148,42 +150,50 @@ def main():
         return g, f
 
     def run_frames(g, f, n):
-        for _ in range(n):
+        for _ in range(n if (f is None or args.rehearse_on_one_gpu) else 0):
             if f is None:
                 g.render(MODE, **rkw)
-            elif args.rehearse_on_one_gpu:
+            else:
                 f.bind(g, 0)
                 g.render(MODE, **rkw)
                 f.gather()
                 if rank == 0:
                     f.assemble(g, 0)
-            else:
-                f.submit(g, lambda: g.render(MODE, **rkw))   # gather of this frame overlaps the next render
         if f is not None and not args.rehearse_on_one_gpu:
+            left = n
+            while left > 0:   # the gather of a batch overlaps the render of the next
+                f.submit(g, lambda: g.render(MODE, **rkw), min(left, f.batch))
+                left -= f.batch
             f.drain(g)
 
     # ---- N > 1: how much of the frame the gather root should trace itself (off the clock) ----
-    root_weight, tuning = 1, None
+    root_weight, batch, tuning, batch_tuning = 1, 1, None, None
     if world > 1:
+        def trial(w0, b):
+            g, f = make_pipeline(w0, b)
+            run_frames(g, f, 8)
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_frames(g, f, 48)
+            dist.barrier()
+            torch.cuda.synchronize()
+            dt = all_reduce(torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda"), dist.ReduceOp.MAX)
+            g.close()
+            return float(dt[0]) / 48 * 1e3      # the all-reduced times are identical on every rank
+        rehearsal = args.rehearse_on_one_gpu   # (its staged gather moves whole message buffers: one frame per gather)
+        batch = args.gather_batch if args.gather_batch > 0 else (1 if rehearsal else 4)
         if args.root_weight > 0:
             root_weight = args.root_weight
         else:
-            tuning = {}
-            for w0 in (1, 2, 3, 4, 6, 8, 12, 16):
-                g, f = make_pipeline(w0)
-                run_frames(g, f, 5)
-                dist.barrier()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                run_frames(g, f, 40)
-                dist.barrier()
-                torch.cuda.synchronize()
-                dt = all_reduce(torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda"), dist.ReduceOp.MAX)
-                tuning[w0] = float(dt[0]) / 40 * 1e3
-                g.close()
-                del g, f
-            root_weight = min(tuning, key=lambda k: (tuning[k], k))   # the all-reduced times are identical on every rank
-    gpu, fg = make_pipeline(root_weight)
+            tuning = {w0: trial(w0, batch) for w0 in (1, 2, 3, 4, 6, 8, 12, 16)}
+            root_weight = min(tuning, key=lambda k: (tuning[k], k))
+        if args.gather_batch == 0 and not rehearsal:
+            batch_tuning = {b: trial(root_weight, b) for b in (1, 2, 4, 8)}
+            batch = min(batch_tuning, key=lambda k: (batch_tuning[k], k))
+    elif sharded and args.gather_batch > 0:
+        batch = args.gather_batch   # --force-gather: the one-rank pipeline with batched gathers
+    gpu, fg = make_pipeline(root_weight, batch)
 
     # exact ray / step / node-visit counts of this frame (deterministic; a stats frame is never timed)
     if fg is not None:
@@ -272,6 +282,7 @@ def main():
                                f"which renders them in place) + RCCL gather of the other ranks' tile buffers "
                                f"({'8-byte records shaded at the root' if MODE != MODE_PATH and args.variant == 0 else '16-byte texels'}) to rank 0",
                    "root_weight": root_weight, "root_weight_tuning_ms_per_frame": tuning,
+                   "frames_per_gather": batch, "frames_per_gather_tuning_ms_per_frame": batch_tuning,
                    "kernel_variant": args.variant, "derived_tables": derived},
         "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "launches_in_flight": in_flight,

@@ -257,6 +257,44 @@ def test_weighted_in_place_root_gather_and_assemble(c2_small, n, w0, compact):
         c.close()
 
 
+def test_batched_gather_frames_stay_apart(c2_small, orc):
+    """FrameGather with 3 frames per gather: three different cameras rendered by 4 shard contexts (weighted, in-place
+    root, compact records) into the three slices of one message set; every assembled frame equals its unsharded render."""
+    import torch
+    from voxelraytracing_amd.shard import FrameGather, texels_to_frame
+    w, h = c2_small.size
+    n, w0, batch = 4, 3, 3
+    cams = [g.cam_data_create((18.0 + 9 * k, 30.0 + 40 * k, 0.0), (c2_small.eye[0] + 2 * k, c2_small.eye[1] + k, c2_small.eye[2]), 70.0,
+                              (float(w), float(h))) for k in range(batch)]
+    full = gpu_for_scene(c2_small)
+    want = []
+    for cam in cams:
+        full.write_cam_data(cam)
+        full.render(MODE_PRIMARY_SHADOW)
+        want.append(full.read_output()[:2])
+    fg0 = FrameGather(torch, None, 0, n, w, h, torch.device("cuda", 0), root_weight=w0, in_place=True, compact=True, batch=batch)
+    ctxs = [gpu_for_scene(c2_small, shard_rank=r, shard_count=n, root_weight=w0, row_major=(r == 0), compact=(r != 0)) for r in range(n)]
+    which = 1
+    for j, cam in enumerate(cams):
+        for r, sh in enumerate(ctxs):
+            sh.write_cam_data(cam)
+            if r == 0:
+                fg0.bind(sh, which, j)
+            else:   # what RCCL's gather would have put into rank r's row of the receive buffer
+                sh.bind_output(fg0.recv[which][r].data_ptr() + j * fg0.frame_words * 4)
+            sh.render(MODE_PRIMARY_SHADOW)
+    for sh in ctxs:
+        sh.synchronize()
+    for j, cam in enumerate(cams):
+        ctxs[0].write_cam_data(cam)          # the root shades with the uniforms of the frame it assembles
+        fg0.assemble(ctxs[0], which, j)
+        ctxs[0].synchronize()
+        a_rgb, a_ids = texels_to_frame(fg0.frame.cpu().numpy().view(np.uint32))
+        assert np.array_equal(a_ids, want[j][1]) and np.array_equal(a_rgb, want[j][0]), f"frame {j}"
+    for c in ctxs + [full]:
+        c.close()
+
+
 def test_full_size_properties():
     """At BASELINE's full size (1920x1080, 8^3 world) check size-independent properties instead of the oracle:
     determinism, shadow pass only darkens launched pixels by exactly the factor, stats add up."""

@@ -71,13 +71,13 @@ for t in tiles:
 fgw = shard.FrameGather(torch, dist, rank, world, w, h, torch.device("cpu"), root_weight=W0, in_place=True)
 assert fgw.tiles_padded == padded and (rank == 0 or len(tiles) <= padded)
 if rank == 0:
-    fgw.frames[0].copy_(torch.from_numpy(frame.view(np.int32)))    # what the in-place root's render leaves in the frame
+    fgw.frames[0][0].copy_(torch.from_numpy(frame.view(np.int32)))    # what the in-place root's render leaves in the frame
 else:
     fgw.msgs[0].copy_(torch.from_numpy(shard.pack_tiles_numpy(frame, rank, world, W0).view(np.int32)[:fgw.msgs[0].numel()]))
 fgw.gather(0)
 dist.barrier()
 if rank == 0:
-    got = shard.assemble_numpy(fgw.recv[0].numpy().view(np.uint32), w, h, world, W0, frame=fgw.frames[0].numpy().view(np.uint32).copy())
+    got = shard.assemble_numpy(fgw.recv[0].numpy().view(np.uint32), w, h, world, W0, frame=fgw.frames[0][0].numpy().view(np.uint32).copy())
     rgb, ids = shard.texels_to_frame(got)
     assert np.array_equal(ids, f_ids) and np.array_equal(rgb, f_rgb), "weighted in-place frame differs from the unsharded one"
     print("GLOO_WEIGHTED_OK", world)
@@ -91,6 +91,35 @@ if rank == 0:
     for r in range(1, world):
         assert torch.equal(fgc.recv[1][r], torch.arange(fgc.msgs[1].numel(), dtype=torch.int32) * (r + 1))
     print("GLOO_COMPACT_OK", world)
+# ---- several frames per gather: 3 + 2 frames through submit/drain, each assembled from its own slice ----
+fgb = shard.FrameGather(torch, dist, rank, world, w, h, torch.device("cpu"), root_weight=W0, in_place=True, compact=True, batch=3)
+class BatchGpu:
+    def __init__(self): self.bound, self.assembled = [], []
+    def bind_output(self, ptr): self.bound.append(ptr)
+    def assemble(self, gathered_ptr, dst_ptr, stride, compact=False): self.assembled.append((gathered_ptr, dst_ptr, stride, compact))
+bg = BatchGpu()
+frame_no = [0]
+def fake_render():
+    k = fgb.k & 1   # the message set being filled; bg.bound[-1] is the slice just bound
+    if rank != 0:
+        off = (bg.bound[-1] - fgb.msgs[k].data_ptr()) // 4
+        fgb.msgs[k][off:off + fgb.frame_words] = 1000 * frame_no[0] + rank
+    frame_no[0] += 1
+fgb.submit(bg, fake_render, 3)
+fgb.submit(bg, fake_render, 2)
+fgb.drain(bg)
+assert frame_no[0] == 5 and len(bg.bound) == 5
+if rank == 0:
+    fw = fgb.frame_words
+    assert [a[0] for a in bg.assembled] == [fgb.recv[0].data_ptr() + j * fw * 4 for j in range(3)] + [fgb.recv[1].data_ptr() + j * fw * 4 for j in range(2)]
+    assert all(a[2] == 3 * fw * 4 and a[3] for a in bg.assembled)
+    assert [a[1] for a in bg.assembled] == [fgb.frames[0][j].data_ptr() for j in range(3)] + [fgb.frames[1][j].data_ptr() for j in range(2)]
+    for r in range(1, world):
+        for j in range(3):
+            assert (fgb.recv[0][r][j * fw:(j + 1) * fw] == 1000 * j + r).all()
+        for j in range(2):
+            assert (fgb.recv[1][r][j * fw:(j + 1) * fw] == 1000 * (3 + j) + r).all()
+    print("GLOO_BATCH_OK", world)
 dist.destroy_process_group()
 '''
 
@@ -200,7 +229,7 @@ def test_tile_shard_gather_over_gloo(world, tmp_path):
         outs.append(out.decode())
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{out[-2000:]}"
-    assert f"GLOO_SHARD_OK {world}" in outs[0] and f"GLOO_WEIGHTED_OK {world}" in outs[0] and f"GLOO_COMPACT_OK {world}" in outs[0]
+    assert f"GLOO_SHARD_OK {world}" in outs[0] and f"GLOO_WEIGHTED_OK {world}" in outs[0] and f"GLOO_COMPACT_OK {world}" in outs[0] and f"GLOO_BATCH_OK {world}" in outs[0]
 
 
 def test_layout_helpers_round_trip():

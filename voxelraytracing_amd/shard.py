@@ -84,8 +84,12 @@ class FrameGather:
     """One process per GPU: owns the message tensors, binds the backend's output to them and gathers.
 
     `dist` is torch.distributed with an initialised process group (nccl = RCCL on the GPU box, gloo on CPU).
-    Two message / receive / frame buffers ping-pong so that the gather of frame k (on the collective's own stream)
-    overlaps the render of frame k+1 and the de-interleave of frame k-1 (`submit` / `drain`).
+    Two message / receive / frame buffer sets ping-pong so that the gather of batch k (on the collective's own stream)
+    overlaps the render of batch k+1 and the de-interleave of batch k-1 (`submit` / `drain`).
+
+    batch: frames per gather.  A rank's share of a 1080p frame is a few tens of microseconds of GPU work, less than
+    what one collective call costs the host; `batch` frames are rendered into consecutive slices of one message and
+    travel in one gather (fewer, larger collectives), each still assembled into its own frame buffer.
 
     in_place (needs a root context created with row_major=True): rank 0 renders its own tiles straight into the
     row-major frame and contributes nothing to the gather but an unused message-sized slot; with root_weight > 1
@@ -96,73 +100,81 @@ class FrameGather:
     over every link."""
 
     def __init__(self, torch, dist, rank: int, count: int, width: int, height: int, device, root_weight: int = 1,
-                 in_place: bool = False, compact: bool = False):
+                 in_place: bool = False, compact: bool = False, batch: int = 1):
         self.torch, self.dist, self.rank, self.count = torch, dist, rank, count
         self.width, self.height = width, height
-        self.root_weight, self.in_place = root_weight, in_place
+        self.root_weight, self.in_place, self.batch = root_weight, in_place, batch
         assert in_place or root_weight == 1, "a weighted root renders in place"
         assert in_place or not compact, "compact messages are shaded by an in-place root"
+        assert batch >= 1
         self.compact = compact
         self.slot_bytes = RECORD_BYTES if compact else TEXEL_BYTES
         words = self.slot_bytes // 4
         _, self.tiles_padded, _ = tiles_of_rank(width, height, rank, count, root_weight)
         self.slots = self.tiles_padded * 64
-        self.msgs = [torch.zeros(self.slots * words, dtype=torch.int32, device=device) for _ in range(2)]
-        self.recv = [torch.zeros((count, self.slots * words), dtype=torch.int32, device=device) if rank == 0 else None
+        self.frame_words = self.slots * words          # int32 words of one frame's message
+        self.msgs = [torch.zeros(batch * self.frame_words, dtype=torch.int32, device=device) for _ in range(2)]
+        self.recv = [torch.zeros((count, batch * self.frame_words), dtype=torch.int32, device=device) if rank == 0 else None
                      for _ in range(2)]
-        n_frames = 2 if in_place else 1
-        self.frames = [torch.zeros((height, width, 4), dtype=torch.int32, device=device) if rank == 0 else None
-                       for _ in range(n_frames)]
-        self.frame = self.frames[0]   # the last completed frame (rank 0)
-        self.k = 0            # frames submitted
-        self.pending = None   # (work, buffer index) of the gather still in flight
+        n_sets = 2 if (in_place or batch > 1) else 1
+        self.frames = [[torch.zeros((height, width, 4), dtype=torch.int32, device=device) if rank == 0 else None
+                        for _ in range(batch)] for _ in range(n_sets)]
+        self.frame = self.frames[0][0]   # the last completed frame (rank 0)
+        self.k = 0            # batches submitted
+        self.pending = None   # (work, buffer set, frames in it) of the gather still in flight
         # single-buffer aliases (tests, simple callers)
         self.msg, self.gathered = self.msgs[0], self.recv[0]
 
-    def _frame_of(self, which: int):
-        return self.frames[which % len(self.frames)]
+    def _frame_of(self, which: int, j: int = 0):
+        return self.frames[which % len(self.frames)][j]
 
-    def bind(self, gpu, which: int = 0):
-        """Make the backend render straight into message buffer `which` (the in-place root: into frame `which`)."""
+    def bind(self, gpu, which: int = 0, j: int = 0):
+        """Make the backend render straight into slice j of message buffer `which` (the in-place root: into frame j of set `which`)."""
         if self.in_place and self.rank == 0:
-            gpu.bind_output(self._frame_of(which).data_ptr())
+            gpu.bind_output(self._frame_of(which, j).data_ptr())
         else:
-            gpu.bind_output(self.msgs[which].data_ptr())
+            gpu.bind_output(self.msgs[which].data_ptr() + j * self.frame_words * 4)
 
-    def gather(self, which: int = 0, async_op: bool = False):
+    def gather(self, which: int = 0, async_op: bool = False, nframes: int | None = None):
         """One gather of equal-sized messages to rank 0 (RCCL: N-1 direct sends to the root)."""
-        return self.dist.gather(self.msgs[which], list(self.recv[which].unbind(0)) if self.rank == 0 else None, dst=0,
-                                async_op=async_op)
+        n = (self.batch if nframes is None else nframes) * self.frame_words
+        return self.dist.gather(self.msgs[which][:n], [row[:n] for row in self.recv[which].unbind(0)] if self.rank == 0 else None,
+                                dst=0, async_op=async_op)
 
-    def assemble(self, gpu, which: int = 0):
-        """Rank 0: scatter the gathered tile buffers into the row-major texel frame on the device."""
-        f = self._frame_of(which)
-        gpu.assemble(self.recv[which].data_ptr(), f.data_ptr(), self.slots * self.slot_bytes, **({"compact": True} if self.compact else {}))
+    def assemble(self, gpu, which: int = 0, j: int = 0):
+        """Rank 0: scatter frame j of the gathered tile buffers into its row-major texel frame on the device."""
+        f = self._frame_of(which, j)
+        gpu.assemble(self.recv[which].data_ptr() + j * self.frame_words * 4, f.data_ptr(), self.batch * self.frame_words * 4,
+                     **({"compact": True} if self.compact else {}))
         self.frame = f
 
     # ---- pipelined frames ----
-    def submit(self, gpu, render):
-        """Render frame k into message k&1, start its gather, then finish frame k-1 (wait + assemble on rank 0).
-        Waiting for gather k-1 here also guarantees message (k+1)&1 is free before the next render overwrites it."""
+    def submit(self, gpu, render, nframes: int = 1):
+        """Render `nframes` (<= batch) frames into message set k&1, start their gather, then finish the batch before
+        (wait + assemble on rank 0).  Waiting for that gather here also guarantees message set (k+1)&1 is free before
+        the next batch overwrites it."""
+        assert 1 <= nframes <= self.batch
         w = self.k & 1
-        self.bind(gpu, w)
-        render()
-        work = self.gather(w, async_op=True)
+        for j in range(nframes):
+            self.bind(gpu, w, j)
+            render()
+        work = self.gather(w, async_op=True, nframes=nframes)
         self._finish_pending(gpu)
-        self.pending = (work, w)
+        self.pending = (work, w, nframes)
         self.k += 1
 
     def _finish_pending(self, gpu):
         if self.pending is None:
             return
-        work, w = self.pending
+        work, w, nframes = self.pending
         work.wait()   # stream-ordered for RCCL (the current stream waits), host-blocking for gloo
         if self.rank == 0:
-            self.assemble(gpu, w)
+            for j in range(nframes):
+                self.assemble(gpu, w, j)
         self.pending = None
 
     def drain(self, gpu):
-        """Finish the last submitted frame."""
+        """Finish the last submitted batch."""
         self._finish_pending(gpu)
 
 
