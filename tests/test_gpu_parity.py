@@ -340,6 +340,25 @@ def test_path_trace_matches_oracle(orc, bounces, spp, seed):
     assert np.array_equal(ids2, ids) and np.array_equal(rgb2, rgb)
 
 
+@pytest.mark.parametrize("in_flight", [1, 2, 3])
+def test_path_trace_frames_in_flight(orc, in_flight):
+    """Path-trace frames enqueued back to back with different seeds (each on its own stream, path buffers and segment
+    cursors when more than one is in flight): the read-back is the last one, bit for bit what a lone frame gives."""
+    sc = scenes.c4((160, 96), bounces=3)
+    gpu = gpu_for_scene(sc)
+    gpu.set_frames_in_flight(in_flight)
+    for seed in (11, 12, 13, 14):
+        gpu.render(MODE_PATH, spp=2, seed=seed)
+    rgb, ids, _ = gpu.read_output()
+    r_rgb, r_ids, _, _ = orc.from_package_scene(sc).render(orc.MODE_PATH, *sc.size, spp=2, seed=14)
+    assert_frame_parity(rgb, ids, r_rgb, r_ids, f"path, {in_flight} in flight")
+    gpu.render(MODE_PATH, spp=2, seed=12)
+    gpu.render(MODE_PRIMARY_SHADOW)                 # a different kind of frame right behind a path frame
+    gpu.render(MODE_PATH, spp=2, seed=14)
+    rgb2, ids2, _ = gpu.read_output()
+    assert np.array_equal(ids2, ids) and np.array_equal(rgb2, rgb)
+
+
 def test_path_trace_mirror_materials_and_sharding(orc):
     """scatter = 0 (what Material::construct produces, graphics/mod.rs:44) makes every voxel a mirror; and a
     sharded path-traced frame is the union of its shards."""

@@ -57,6 +57,8 @@ struct vrt_ctx {
     hipStream_t extra_stream[kMaxInFlight - 1] = {nullptr, nullptr, nullptr};
     vrt::Texel *extra_out[kMaxInFlight - 1] = {nullptr, nullptr, nullptr};
     uint32_t *extra_blk[kMaxInFlight - 1] = {nullptr, nullptr, nullptr};
+    uint4 *extra_path[kMaxInFlight - 1] = {nullptr, nullptr, nullptr};                   // path mode: its own path buffers
+    unsigned long long *extra_counters[kMaxInFlight - 1] = {nullptr, nullptr, nullptr};  // ... and segment cursors
     uint32_t in_flight = 2;        // vrt_set_frames_in_flight
     bool alt_pending = false;      // frames may still be running on the extra streams
     uint32_t flip = 0;             // which (stream, output, counts) set the next pipelined frame takes
@@ -196,6 +198,7 @@ static int alloc_output(vrt_ctx *c) {
     c->own_out = nullptr; c->d_hits = nullptr; c->d_steps = nullptr; c->d_rgba8 = nullptr; c->d_path = nullptr; c->d_blk_counts = nullptr;
     for (auto &p : c->extra_out) { (void)hipFree(p); p = nullptr; }
     for (auto &p : c->extra_blk) { (void)hipFree(p); p = nullptr; }
+    for (auto &p : c->extra_path) { (void)hipFree(p); p = nullptr; }
     layout_tiles(c);
     const size_t n = c->slots ? c->slots : 1;
     HIP_TRY(c, hipMalloc(&c->own_out, n * sizeof(vrt::Texel)));
@@ -390,6 +393,8 @@ void vrt_destroy(vrt_ctx *c) {
         if (st) (void)hipStreamSynchronize(st);
     for (auto p : c->extra_out) (void)hipFree(p);
     for (auto p : c->extra_blk) (void)hipFree(p);
+    for (auto p : c->extra_path) (void)hipFree(p);
+    for (auto p : c->extra_counters) (void)hipFree(p);
     (void)hipFree(c->d_nodes); (void)hipFree(c->d_roots); (void)hipFree(c->d_mats); (void)hipFree(c->own_out);
     (void)hipFree(c->d_hits); (void)hipFree(c->d_counters); (void)hipFree(c->d_steps); (void)hipFree(c->d_rgba8); (void)hipFree(c->d_path);
     (void)hipFree(c->d_blk_counts);
@@ -648,14 +653,22 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     // two frames in flight: plain frames into the context's own buffers alternate between the two (stream, output, counts)
     // sets; anything else (stats, path trace, two-launch variants, a caller's stream or buffer) runs alone on c->stream
     const bool kstats_early = o.stats != 0 || c->settings.show_step_count == 1u;
-    const bool one_launch = o.mode == VRT_MODE_PRIMARY || (o.mode == VRT_MODE_PRIMARY_SHADOW && variant == 0u);
+    // (the path trace qualifies too: its launches depend on each other, so the other frame fills every tail between them)
+    const bool one_launch = o.mode == VRT_MODE_PRIMARY || (o.mode == VRT_MODE_PRIMARY_SHADOW && variant == 0u) || o.mode == VRT_MODE_PATH;
     const bool pipelined = c->in_flight > 1u && one_launch && !kstats_early && c->stream == c->own_stream && c->d_out == c->own_out;
     hipStream_t st = c->stream;
     vrt::Texel *out = c->d_out;
     uint32_t *blk = c->d_blk_counts;
+    uint4 **path_buf = &c->d_path;
+    unsigned long long *counters = c->d_counters;
     if (pipelined) {
         if (c->flip) {
             const uint32_t k = c->flip - 1u;
+            if (o.mode == VRT_MODE_PATH) {
+                if (!c->extra_counters[k]) HIP_TRY(c, hipMalloc(&c->extra_counters[k], kCounterBytes));
+                counters = c->extra_counters[k];
+                path_buf = &c->extra_path[k];
+            }
             if (!c->extra_stream[k]) HIP_TRY(c, hipStreamCreateWithFlags(&c->extra_stream[k], hipStreamNonBlocking));
             if (!c->extra_out[k]) HIP_TRY(c, hipMalloc(&c->extra_out[k], (size_t)(c->slots ? c->slots : 1) * sizeof(vrt::Texel)));
             if (!c->extra_blk[k]) HIP_TRY(c, hipMalloc(&c->extra_blk[k], (size_t)(c->tiles_local ? c->tiles_local : 1) * sizeof(uint32_t)));
@@ -671,8 +684,8 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     P.out = out;
     P.hits = c->d_hits;
     P.blk_counts = blk;
-    P.counters = c->d_counters;
-    P.seg_counts = reinterpret_cast<uint32_t *>(c->d_counters + vrt::kCtrCount);
+    P.counters = counters;
+    P.seg_counts = reinterpret_cast<uint32_t *>(counters + vrt::kCtrCount);
     P.hit_seg_cap = c->hit_seg_cap;
     P.steps = o.stats ? c->d_steps : nullptr;
     fill_uniforms(c, P);
@@ -696,41 +709,41 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     ev_kind = kEvNone;
     auto &ev = c->ev_pool[c->ev_used++];
     // the counters feed stats frames and the path trace's segment cursors; a plain primary(+shadow) frame reads none
-    if (kstats || o.mode == VRT_MODE_PATH) HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, kCounterBytes, c->stream));
+    if (kstats || o.mode == VRT_MODE_PATH) HIP_TRY(c, hipMemsetAsync(counters, 0, kCounterBytes, st));
     if (o.mode == VRT_MODE_PATH) {
         // wavefront path trace: per sample one launch per bounce over the compacted live-path buffer
         const uint32_t spp = o.spp ? o.spp : 1u, bounces = c->settings.max_ray_bounces;
         const size_t cap = (size_t)vrt::kHitSegments * c->hit_seg_cap;
-        if (!c->d_path) HIP_TRY(c, hipMalloc(&c->d_path, 2 * 3 * cap * sizeof(uint4)));
+        if (!*path_buf) HIP_TRY(c, hipMalloc(path_buf, 2 * 3 * cap * sizeof(uint4)));
         uint32_t *seg[2] = {P.seg_counts, P.seg_counts + vrt::kHitSegments * vrt::kSegStride};
-        uint4 *buf[2] = {c->d_path, c->d_path + 3 * cap};
+        uint4 *buf[2] = {*path_buf, *path_buf + 3 * cap};
         P.path_cap = (uint32_t)cap;
         P.spp = spp;
         P.seed = o.seed;
-        HIP_TRY(c, hipEventRecord(ev[0], c->stream));
-        if (bounces == 0) HIP_TRY(c, hipMemsetAsync(c->d_out, 0, (size_t)c->slots * sizeof(vrt::Texel), c->stream));
+        HIP_TRY(c, hipEventRecord(ev[0], st));
+        if (bounces == 0) HIP_TRY(c, hipMemsetAsync(out, 0, (size_t)c->slots * sizeof(vrt::Texel), st));
         bool first = true;
         for (uint32_t smp = 0; smp < spp && bounces > 0; smp++) {
             P.sample = smp;
             for (uint32_t b = 0; b < bounces; b++) {
-                if (!(smp == 0 && b == 0)) HIP_TRY(c, hipMemsetAsync(seg[b & 1], 0, kSegBytes, c->stream));
+                if (!(smp == 0 && b == 0)) HIP_TRY(c, hipMemsetAsync(seg[b & 1], 0, kSegBytes, st));
                 P.seg_counts = seg[b & 1];
                 P.path_out = buf[b & 1];
                 P.seg_in = seg[(b + 1) & 1];
                 P.path_in = buf[(b + 1) & 1];
                 P.last_bounce = b + 1 == bounces;
-                if (b == 0) vrt::launch_path_primary(P, kstats, c->stream);
-                else vrt::launch_path_bounce(P, kstats, c->stream);
+                if (b == 0) vrt::launch_path_primary(P, kstats, st);
+                else vrt::launch_path_bounce(P, kstats, st);
                 HIP_TRY(c, hipGetLastError());
-                if (first) { HIP_TRY(c, hipEventRecord(ev[1], c->stream)); first = false; }
+                if (first) { HIP_TRY(c, hipEventRecord(ev[1], st)); first = false; }
             }
         }
-        if (first) HIP_TRY(c, hipEventRecord(ev[1], c->stream));
+        if (first) HIP_TRY(c, hipEventRecord(ev[1], st));
         if (bounces > 0) {
-            vrt::launch_path_finish(c->d_out, c->slots, spp, c->stream);
+            vrt::launch_path_finish(out, c->slots, spp, st);
             HIP_TRY(c, hipGetLastError());
         }
-        HIP_TRY(c, hipEventRecord(ev[3], c->stream));
+        HIP_TRY(c, hipEventRecord(ev[3], st));
         ev_kind = kEvRecorded;
         c->last_spp = spp;
     } else {
