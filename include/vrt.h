@@ -195,9 +195,9 @@ int vrt_resize_output(vrt_ctx *ctx, uint32_t width, uint32_t height);
 int vrt_render(vrt_ctx *ctx, const vrt_render_opts *opts);
 
 /* How many frames the context keeps in flight (1..4, default 2 — a swapchain gives the reference's wgpu path the same):
- * consecutive vrt_render calls of plain single-launch frames (no stats, not the path trace, the context's own stream and
- * output buffers) alternate between that many internal streams, each with its own output buffer, so one frame's tail
- * overlaps the next one's ramp-up.  Every other call waits for all of them first; vrt_read_output / vrt_present /
+ * consecutive vrt_render calls of plain frames (default march, no stats, the context's own stream and output buffers;
+ * also path-trace frames) alternate between that many internal streams, each with its own output (and path) buffers, so
+ * one frame's tail overlaps the next one's ramp-up.  Every other call waits for all of them first; vrt_read_output / vrt_present /
  * vrt_device_output refer to the most recent frame.  1 = strictly one frame at a time. */
 int vrt_set_frames_in_flight(vrt_ctx *ctx, uint32_t n);
 
