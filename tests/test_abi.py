@@ -60,3 +60,23 @@ def test_create_validates_arguments_without_touching_the_gpu():
         assert lib.vrt_create(C.byref(cfg), C.byref(h)) == -1
         assert lib.vrt_last_error(None)
     assert lib.vrt_create(None, C.byref(h)) == -1
+
+
+def test_rust_sys_crate_declares_the_same_abi():
+    """bindings/rust/vrt-sys (not compilable here: no cargo) must name every function of include/vrt.h with the same
+    number of parameters, and its struct sizes (asserted in its own #[test]) must be the ctypes ones."""
+    src = open(os.path.join(ROOT, "bindings", "rust", "vrt-sys", "src", "lib.rs")).read()
+    rust = {m.group(1): m.group(2) for m in re.finditer(r"pub fn (vrt_\w+)\(([^)]*)\)", src)}
+    hdr = open(os.path.join(ROOT, "include", "vrt.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    c_fns = {m.group(1): m.group(2) for m in re.finditer(r"\b(vrt_\w+)\s*\(([^)]*)\)\s*;", hdr)}
+    assert sorted(rust) == sorted(c_fns) == sorted(_ffi.VRT_SYMBOLS)
+    for name, params in c_fns.items():
+        assert len([p for p in params.split(",") if p.strip()]) == len([p for p in rust[name].split(",") if p.strip()]), name
+    sizes = {m.group(1): int(m.group(2)) for m in re.finditer(r"size_of::<(\w+)>\(\), (\d+)\)", src)}
+    want = {"vrt_material": _ffi.Material, "vrt_cam_data": _ffi.CamData, "vrt_world_data": _ffi.WorldData, "vrt_settings": _ffi.Settings,
+            "vrt_crosshair": _ffi.Crosshair, "vrt_config": _ffi.Config, "vrt_render_opts": _ffi.RenderOpts, "vrt_stats": _ffi.Stats,
+            "vrt_accel_info": _ffi.AccelInfo}
+    assert sizes == {k: C.sizeof(v) for k, v in want.items()}
+    for flag, val in (("VRT_FLAG_TILE_MAJOR", 1), ("VRT_FLAG_ROW_MAJOR", 2), ("VRT_FLAG_COMPACT", 4)):
+        assert re.search(rf"#define {flag} {val}u", hdr) and re.search(rf"pub const {flag}: u32 = {val};", src)
