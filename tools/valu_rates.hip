@@ -14,7 +14,7 @@
         float e = a + 1.0f, f = a + 2.0f, g = a + 3.0f, h = a + 4.0f;             \
         int i0 = threadIdx.x, i1 = 7, i2 = 3, i3 = 11;                            \
         for (int it = 0; it < iters; it++) {                                      \
-            asm volatile(REP4(body) : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3) : : "vcc", "s10", "s11", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29"); \
+            asm volatile(REP4(body) : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3) : : "vcc", "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29"); \
         }                                                                         \
         out[blockIdx.x * blockDim.x + threadIdx.x] = a + b + c + d + e + f + g + h + (float)(i0 + i1 + i2 + i3); \
     }
@@ -26,6 +26,10 @@ KERNEL(k_fma_f32, "v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %2, %2, %1, %3\n v_fma_f
 KERNEL(k_min3_f32, "v_min3_f32 %0, %0, %1, %2\n v_min3_f32 %2, %2, %1, %3\n v_min3_f32 %3, %3, %1, %4\n v_min3_f32 %4, %4, %1, %5\n v_min3_f32 %5, %5, %1, %6\n v_min3_f32 %6, %6, %1, %7\n v_min3_f32 %7, %7, %1, %0\n v_min3_f32 %0, %0, %2, %3\n")
 KERNEL(k_cndmask_vcc, "v_cndmask_b32 %0, %2, %1, vcc\n v_cndmask_b32 %2, %3, %1, vcc\n v_cndmask_b32 %3, %4, %1, vcc\n v_cndmask_b32 %4, %5, %1, vcc\n v_cndmask_b32 %5, %6, %1, vcc\n v_cndmask_b32 %6, %7, %1, vcc\n v_cndmask_b32 %7, %0, %1, vcc\n v_cndmask_b32 %0, %3, %2, vcc\n")
 KERNEL(k_cndmask_e64, "v_cndmask_b32 %0, %2, %1, s[10:11]\n v_cndmask_b32 %2, %3, %1, s[10:11]\n v_cndmask_b32 %3, %4, %1, s[10:11]\n v_cndmask_b32 %4, %5, %1, s[10:11]\n v_cndmask_b32 %5, %6, %1, s[10:11]\n v_cndmask_b32 %6, %7, %1, s[10:11]\n v_cndmask_b32 %7, %0, %1, s[10:11]\n v_cndmask_b32 %0, %3, %2, s[10:11]\n")
+// the real pattern: a compare writes the mask, a select reads it (4 pairs per body)
+KERNEL(k_cmp_cnd_vcc, "v_cmp_eq_f32 vcc, %0, %1\n v_cndmask_b32 %2, %3, %4, vcc\n v_cmp_eq_f32 vcc, %5, %1\n v_cndmask_b32 %3, %4, %6, vcc\n v_cmp_eq_f32 vcc, %6, %1\n v_cndmask_b32 %4, %5, %7, vcc\n v_cmp_eq_f32 vcc, %7, %1\n v_cndmask_b32 %5, %6, %0, vcc\n")
+KERNEL(k_cmp_cnd_sgpr, "v_cmp_eq_f32 s[10:11], %0, %1\n v_cndmask_b32 %2, %3, %4, s[10:11]\n v_cmp_eq_f32 s[10:11], %5, %1\n v_cndmask_b32 %3, %4, %6, s[10:11]\n v_cmp_eq_f32 s[10:11], %6, %1\n v_cndmask_b32 %4, %5, %7, s[10:11]\n v_cmp_eq_f32 s[10:11], %7, %1\n v_cndmask_b32 %5, %6, %0, s[10:11]\n")
+KERNEL(k_cmp_cnd_2sgpr, "v_cmp_eq_f32 s[10:11], %0, %1\n v_cmp_eq_f32 s[12:13], %5, %1\n v_cmp_eq_f32 s[14:15], %6, %1\n v_cmp_eq_f32 s[16:17], %7, %1\n v_cndmask_b32 %2, %3, %4, s[10:11]\n v_cndmask_b32 %3, %4, %6, s[12:13]\n v_cndmask_b32 %4, %5, %7, s[14:15]\n v_cndmask_b32 %5, %6, %0, s[16:17]\n")
 KERNEL(k_min_f32, "v_min_f32 %0, %0, %1\n v_min_f32 %2, %2, %1\n v_min_f32 %3, %3, %1\n v_min_f32 %4, %4, %1\n v_min_f32 %5, %5, %1\n v_min_f32 %6, %6, %1\n v_min_f32 %7, %7, %1\n v_min_f32 %0, %0, %2\n")
 KERNEL(k_lshl_or, "v_lshl_or_b32 %8, %8, 2, %9\n v_lshl_or_b32 %9, %9, 2, %10\n v_lshl_or_b32 %10, %10, 2, %11\n v_lshl_or_b32 %11, %11, 2, %8\n v_lshl_or_b32 %8, %8, 1, %10\n v_lshl_or_b32 %9, %9, 1, %11\n v_lshl_or_b32 %10, %10, 1, %8\n v_lshl_or_b32 %11, %11, 1, %9\n")
 KERNEL(k_add3_u32, "v_add3_u32 %8, %8, %9, %10\n v_add3_u32 %9, %9, %10, %11\n v_add3_u32 %10, %10, %11, %8\n v_add3_u32 %11, %11, %8, %9\n v_add3_u32 %8, %8, %10, %11\n v_add3_u32 %9, %9, %11, %8\n v_add3_u32 %10, %10, %8, %9\n v_add3_u32 %11, %11, %9, %10\n")
@@ -73,7 +77,7 @@ int main() {
     float *d; hipMalloc(&d, (size_t)p.multiProcessorCount * 8 * 256 * 4);
     printf("%s, %d CUs, %.2f GHz\n", p.name, p.multiProcessorCount, ghz);
 #define RUN(k) run(#k, k, d, ghz, p.multiProcessorCount)
-    RUN(k_add_f32); RUN(k_mul_f32); RUN(k_fma_f32); RUN(k_min3_f32); RUN(k_cndmask_vcc); RUN(k_cndmask_e64); RUN(k_min_f32); RUN(k_lshl_or); RUN(k_add3_u32); RUN(k_cvt_flr); RUN(k_cmp_u32); RUN(k_pk_add_f32); RUN(k_sqrt_f32); RUN(k_div_fixup); RUN(k_cmp_f32);
+    RUN(k_add_f32); RUN(k_mul_f32); RUN(k_fma_f32); RUN(k_min3_f32); RUN(k_cndmask_vcc); RUN(k_cmp_cnd_vcc); RUN(k_cmp_cnd_sgpr); RUN(k_cmp_cnd_2sgpr); RUN(k_cndmask_e64); RUN(k_min_f32); RUN(k_lshl_or); RUN(k_add3_u32); RUN(k_cvt_flr); RUN(k_cmp_u32); RUN(k_pk_add_f32); RUN(k_sqrt_f32); RUN(k_div_fixup); RUN(k_cmp_f32);
     RUN(k_cvt_i32_f32); RUN(k_cvt_f32_i32); RUN(k_and_b32); RUN(k_add_u32); RUN(k_lshr_b32); RUN(k_bfi_b32); RUN(k_mad_u24);
     RUN(k_max3_u32); RUN(k_floor_f32); RUN(k_rcp_f32); RUN(k_mov_b32);
     return 0;
