@@ -320,6 +320,24 @@ def test_full_size_properties():
     assert np.array_equal(i2, s_ids) and np.array_equal(r2, s_rgb)
 
 
+def test_full_size_c2_matches_oracle(orc):
+    """The bench's own frame — 1920x1080, 8^3 world, primary + shadow — against the oracle, every pixel: the oracle's
+    OpenMP build finishes it in a fraction of a second on the GPU box's cores."""
+    sc = scenes.c2()
+    gpu = gpu_for_scene(sc)
+    gpu.render(MODE_PRIMARY_SHADOW, stats=True)
+    rgb, ids, _ = gpu.read_output()
+    r_rgb, r_ids, r_steps, st = orc.from_package_scene(sc).render(MODE_PRIMARY_SHADOW, 1920, 1080, want_steps=True)
+    assert_frame_parity(rgb, ids, r_rgb, r_ids, "C2 at full size")
+    assert np.array_equal(gpu.read_steps(), r_steps)
+    s = gpu.stats()
+    assert (s.steps, s.node_visits, s.secondary_rays, s.hits) == (st.steps, st.node_visits, st.secondary_rays, st.hits)
+    gpu.render(MODE_PRIMARY_SHADOW)          # the timed (stats-free, two-in-flight) kernels give the same frame
+    gpu.render(MODE_PRIMARY_SHADOW)
+    rgb2, ids2, _ = gpu.read_output()
+    assert np.array_equal(ids2, ids) and np.array_equal(rgb2, rgb)
+
+
 @pytest.mark.parametrize("bounces,spp,seed", [(1, 1, 0), (2, 1, 0), (4, 1, 7), (4, 3, 0), (3, 2, 123)])
 def test_path_trace_matches_oracle(orc, bounces, spp, seed):
     """Config C4's kernel family at a size the oracle finishes quickly: wavefront path trace, ids bit-exact,
