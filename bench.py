@@ -198,7 +198,7 @@ def main():
     # exact ray / step / node-visit counts of this frame (deterministic; a stats frame is never timed)
     if fg is not None:
         fg.bind(gpu, 0)
-    gpu.render(MODE, stats=True, **rkw)
+    gpu.render(MODE, stats=True, **(dict(rkw, variant=0) if rkw.get("variant") == 4 else rkw))   # (the persistent grid has no stats form)
     st = gpu.stats()
     counts = all_reduce(torch.tensor([st.primary_rays, st.secondary_rays], dtype=torch.int64, device="cuda"))
     rays_per_frame = int(counts[0] + counts[1])
@@ -245,7 +245,7 @@ def main():
     b_primary, b_shadow, b_fused = algorithmic_bytes(st, args.width, args.height)  # rank 0's own launches (its shard when N > 1)
     ms_p = kst.sum_ms_primary / max(kst.frames, 1)
     ms_s = kst.sum_ms_secondary / max(kst.frames, 1)
-    fused = args.mode == "shadow" and args.variant == 0 and ms_s == 0.0  # one launch: no second kernel was timed
+    fused = args.mode == "shadow" and args.variant in (0, 4) and ms_s == 0.0  # one launch: no second kernel was timed
     if fused:
         dom_name, dom_bytes, dom_ms = "primary_shadow_march", b_fused, ms_p
     else:

@@ -122,7 +122,8 @@ typedef struct {
     uint32_t mode;     /* vrt_mode */
     uint32_t variant;  /* kernel variant: 0 = default (grid march over the derived cell grid / brick pool; primary +
                         * shadow fused into one launch), 1 = literal octree walk (the shader's text), 2 = ancestor-cache
-                        * octree walk, 3 = grid march with the shadow rays as a second launch; DESIGN.md §Kernels */
+                        * octree walk, 3 = grid march with the shadow rays as a second launch, 4 = variant 0's work as a persistent grid
+                        * pulling tiles from per-XCD queues (primary + shadow frames only); DESIGN.md §Kernels */
     uint32_t stats;    /* 1: also count steps / node visits this frame (slower; not for timing) */
     uint32_t spp;      /* VRT_MODE_PATH only */
     uint32_t seed;     /* VRT_MODE_PATH only */

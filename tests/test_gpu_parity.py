@@ -295,6 +295,31 @@ def test_batched_gather_frames_stay_apart(c2_small, orc):
         c.close()
 
 
+def test_persistent_grid_variant_gives_the_same_frames(c1, c2_small):
+    """Variant 4 — the default kernel's work pulled from per-XCD tile queues by a grid that just fills the chip — against
+    variant 0, whole and sharded (tile-major), several frames in a row (the queue heads are reset per frame)."""
+    for sc in (c1, c2_small):
+        gpu = gpu_for_scene(sc)
+        gpu.render(MODE_PRIMARY_SHADOW)
+        rgb, ids, _ = gpu.read_output()
+        n0 = gpu.stats().secondary_rays
+        for _ in range(3):
+            gpu.render(MODE_PRIMARY_SHADOW, variant=4)
+        rgb4, ids4, _ = gpu.read_output()
+        assert np.array_equal(ids4, ids) and np.array_equal(rgb4, rgb) and gpu.stats().secondary_rays == n0
+        with pytest.raises(g.VrtError):
+            gpu.render(MODE_PRIMARY, variant=4)
+        with pytest.raises(g.VrtError):
+            gpu.render(MODE_PRIMARY_SHADOW, variant=4, stats=True)
+    acc = np.zeros_like(ids)
+    for r in range(3):
+        sh = gpu_for_scene(c2_small, shard_rank=r, shard_count=3, root_weight=2)
+        sh.render(MODE_PRIMARY_SHADOW, variant=4)
+        acc |= sh.read_output()[1]
+        sh.close()
+    assert np.array_equal(acc, ids)
+
+
 def test_full_size_properties():
     """At BASELINE's full size (1920x1080, 8^3 world) check size-independent properties instead of the oracle:
     determinism, shadow pass only darkens launched pixels by exactly the factor, stats add up."""

@@ -24,6 +24,7 @@ bool variant_supported(uint32_t variant);
 void launch_primary(const FrameParams &P, uint32_t variant, bool stats, bool shadow, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
 void launch_shadow(const FrameParams &P, uint32_t variant, bool stats, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
 void launch_primary_shadow_fused(const FrameParams &P, bool stats, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
+void launch_primary_shadow_persistent(const FrameParams &P, uint32_t *heads, uint32_t n_cus, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
 void launch_path_primary(const FrameParams &P, bool stats, hipStream_t st);
 void launch_path_bounce(const FrameParams &P, bool stats, hipStream_t st);
 void launch_path_finish(Texel *out, uint32_t n, uint32_t spp, hipStream_t st);
@@ -92,6 +93,8 @@ struct vrt_ctx {
     uint32_t *last_blk = nullptr;
     uint4 *d_hits = nullptr;
     uint32_t *d_blk_counts = nullptr;  // hit records per primary workgroup
+    uint32_t *d_heads = nullptr;   // variant 4: the per-XCD queue heads (8 x 64 B)
+    uint32_t n_cus = 0;
     uint32_t n_blocks = 0;
     uint32_t n_counts = 0;          // entries of blk_counts the last primary + shadow frame wrote
     uint4 *d_path = nullptr;  // path mode: 2 buffers x 3 planes x (kHitSegments * hit_seg_cap) records, lazily allocated
@@ -399,7 +402,7 @@ void vrt_destroy(vrt_ctx *c) {
     (void)hipFree(c->d_hits); (void)hipFree(c->d_counters); (void)hipFree(c->d_steps); (void)hipFree(c->d_rgba8); (void)hipFree(c->d_path);
     (void)hipFree(c->d_blk_counts);
     (void)hipFree(c->d_grid); (void)hipFree(c->d_bricks); (void)hipFree(c->d_chunk_bricks); (void)hipFree(c->d_chunk_offsets);
-    (void)hipFree(c->d_brick_total); (void)hipFree(c->d_ndc); (void)hipFree(c->d_screen);
+    (void)hipFree(c->d_brick_total); (void)hipFree(c->d_ndc); (void)hipFree(c->d_screen); (void)hipFree(c->d_heads);
     for (auto &t : c->ev_pool)
         for (auto &ev : t)
             if (ev) (void)hipEventDestroy(ev);
@@ -620,6 +623,8 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     if (opts) o = *opts;
     if (o.mode > VRT_MODE_PATH) return fail(c, VRT_ERR_INVALID_ARG, "vrt_render: mode %u not supported", o.mode);
     if (o.mode == VRT_MODE_PATH && o.variant != 0) return fail(c, VRT_ERR_INVALID_ARG, "vrt_render: the path trace has one kernel variant");
+    if (o.variant == 4u && (o.mode != VRT_MODE_PRIMARY_SHADOW || o.stats))
+        return fail(c, VRT_ERR_INVALID_ARG, "vrt_render: variant 4 (persistent grid) renders plain primary + shadow frames only");
     if (!vrt::variant_supported(o.variant)) return fail(c, VRT_ERR_INVALID_ARG, "vrt_render: unknown kernel variant %u", o.variant);
     int rc = validate_frame(c);
     if (rc) return rc;
@@ -632,10 +637,10 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     rc = ensure_ndc(c);
     if (rc) return rc;
     uint32_t variant = o.variant;
-    if (variant == 0u || variant == 3u || o.mode == VRT_MODE_PATH) {
+    if (variant == 0u || variant == 3u || variant == 4u || o.mode == VRT_MODE_PATH) {
         rc = ensure_accel(c);
         if (rc) return rc;
-        if (!c->accel_ok && (variant == 0u || variant == 3u)) variant = 2u;  // world too large for the tables: walk the octree
+        if (!c->accel_ok && (variant == 0u || variant == 3u || variant == 4u)) variant = 2u;  // world too large for the tables: walk the octree
     }
 
     vrt::FrameParams P;
@@ -747,8 +752,20 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
         ev_kind = kEvRecorded;
         c->last_spp = spp;
     } else {
-        const bool fused = shadow && variant == 0u;  // primary + shadow in one launch, hit records in LDS
-        if (c->tiles_local) {
+        const bool fused = shadow && variant == 0u;  // primary + shadow in one launch
+        if (c->tiles_local && variant == 4u) {
+            if (!c->d_heads) {
+                HIP_TRY(c, hipMalloc(&c->d_heads, 8 * 64));
+                hipDeviceProp_t prop;
+                HIP_TRY(c, hipGetDeviceProperties(&prop, c->device));
+                c->n_cus = (uint32_t)prop.multiProcessorCount;
+            }
+            HIP_TRY(c, hipMemsetAsync(c->d_heads, 0, 8 * 64, st));
+            c->n_counts = c->tiles_local;
+            vrt::launch_primary_shadow_persistent(P, c->d_heads, c->n_cus, st, ev[0], ev[1]);
+            HIP_TRY(c, hipGetLastError());
+            ev_kind = kEvOneKernel;
+        } else if (c->tiles_local) {
             c->n_counts = fused ? c->tiles_local : c->n_blocks;
             if (fused) vrt::launch_primary_shadow_fused(P, kstats, st, ev[0], ev[1]);
             else vrt::launch_primary(P, variant == 3u ? 0u : variant, kstats, shadow, st, ev[0], ev[1]);

@@ -166,6 +166,42 @@ __global__ void __launch_bounds__(256) shadow_kernel(FrameParams P) {
 // the terrain tiles that make up most of a frame).  (A workgroup-phase form — compact the four tiles' hits into an LDS
 // hit buffer, lane = record, flags back through LDS — ran in exactly the same time and was dropped: DESIGN.md §5.)
 // ------------------------------------------------------------------------------------------------
+// One tile = one wave: primary march, shading, the shadow march of the lanes that hit, one store per lane.
+template <int MARCH, bool LDS_ROOTS, bool STATS>
+__device__ __forceinline__ void trace_tile(const FrameParams &P, const uint32_t *s_roots, const uint32_t *s_liquid, uint32_t t_local,
+                                           uint32_t lane, MarchResult &R, MarchResult &S) {
+    const uint32_t tile = shard_tile(t_local, P.shard_first, P.shard_run, P.shard_period);
+    const uint32_t px = (tile % P.tiles_x) * 8u + (lane & 7u);
+    const uint32_t py = (tile / P.tiles_x) * 8u + (lane >> 3);
+    const uint32_t slot = P.tile_major ? t_local * 64u + lane : py * P.width + px;
+
+    V3 origin, dir;
+    create_ray(P, (int)px, (int)py, origin, dir);
+    R = march<MARCH, LDS_ROOTS, STATS>(P, s_roots, s_liquid, origin, dir);
+    V3 color;
+    uint32_t id = shade<MARCH == 1>(P, R, origin, dir, color);
+
+    const bool launch = R.hit && R.voxel != 0u && !is_liquid(s_liquid, R.voxel);
+    if (launch) {
+        id |= VRT_ID_SHADOW_RAY;
+        const V3 so{R.pos.x + R.norm.x * kShadowBias, R.pos.y + R.norm.y * kShadowBias, R.pos.z + R.norm.z * kShadowBias};
+        const V3 sd = vnormalize(V3{P.settings.sun_pos[0] - (float)P.world.min[0] - so.x,
+                                    P.settings.sun_pos[1] - (float)P.world.min[1] - so.y,
+                                    P.settings.sun_pos[2] - (float)P.world.min[2] - so.z});
+        S = march<MARCH, LDS_ROOTS, STATS>(P, s_roots, s_liquid, so, sd);
+        if (S.hit) {
+            color.x *= kShadowFactor;
+            color.y *= kShadowFactor;
+            color.z *= kShadowFactor;
+            id |= VRT_ID_SHADOWED;
+        }
+    }
+    store_pixel(P, slot, color, id, R);
+    if (STATS && P.steps) P.steps[slot] = R.iters | (S.iters << 16);
+    const unsigned long long ballot = __ballot(launch);
+    if (lane == 0) P.blk_counts[t_local] = (uint32_t)__popcll(ballot);  // per tile: the launched-ray count of vrt_get_stats
+}
+
 template <int MARCH, bool LDS_ROOTS, bool STATS, int WAVES>
 __global__ void __launch_bounds__(64 * WAVES) primary_shadow_wave_kernel(FrameParams P) {
     extern __shared__ uint32_t smem[];  // [0,8) liquid mask, [8,24) stats scratch, [24, ...) chunk roots
@@ -176,42 +212,10 @@ __global__ void __launch_bounds__(64 * WAVES) primary_shadow_wave_kernel(FramePa
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t t_local = blockIdx.x * (uint32_t)WAVES + (threadIdx.x >> 6);
-    const bool live = t_local < P.tiles_local;
     MarchResult R, S;
     R.iters = 0; R.visits = 0; R.hit = false;
     S.iters = 0; S.visits = 0; S.hit = false;
-    if (live) {
-        const uint32_t tile = shard_tile(t_local, P.shard_first, P.shard_run, P.shard_period);
-        const uint32_t px = (tile % P.tiles_x) * 8u + (lane & 7u);
-        const uint32_t py = (tile / P.tiles_x) * 8u + (lane >> 3);
-        const uint32_t slot = P.tile_major ? t_local * 64u + lane : py * P.width + px;
-
-        V3 origin, dir;
-        create_ray(P, (int)px, (int)py, origin, dir);
-        R = march<MARCH, LDS_ROOTS, STATS>(P, s_roots, s_liquid, origin, dir);
-        V3 color;
-        uint32_t id = shade<MARCH == 1>(P, R, origin, dir, color);
-
-        const bool launch = R.hit && R.voxel != 0u && !is_liquid(s_liquid, R.voxel);
-        if (launch) {
-            id |= VRT_ID_SHADOW_RAY;
-            const V3 so{R.pos.x + R.norm.x * kShadowBias, R.pos.y + R.norm.y * kShadowBias, R.pos.z + R.norm.z * kShadowBias};
-            const V3 sd = vnormalize(V3{P.settings.sun_pos[0] - (float)P.world.min[0] - so.x,
-                                        P.settings.sun_pos[1] - (float)P.world.min[1] - so.y,
-                                        P.settings.sun_pos[2] - (float)P.world.min[2] - so.z});
-            S = march<MARCH, LDS_ROOTS, STATS>(P, s_roots, s_liquid, so, sd);
-            if (S.hit) {
-                color.x *= kShadowFactor;
-                color.y *= kShadowFactor;
-                color.z *= kShadowFactor;
-                id |= VRT_ID_SHADOWED;
-            }
-        }
-        store_pixel(P, slot, color, id, R);
-        if (STATS && P.steps) P.steps[slot] = R.iters | (S.iters << 16);
-        const unsigned long long ballot = __ballot(launch);
-        if (lane == 0) P.blk_counts[t_local] = (uint32_t)__popcll(ballot);  // per tile here: the launched-ray count of vrt_get_stats
-    }
+    if (t_local < P.tiles_local) trace_tile<MARCH, LDS_ROOTS, STATS>(P, s_roots, s_liquid, t_local, lane, R, S);
     if (STATS) {
         block_add(s_acc, 0, R.iters);
         block_add(s_acc, 1, R.visits);
@@ -226,6 +230,40 @@ __global__ void __launch_bounds__(64 * WAVES) primary_shadow_wave_kernel(FramePa
             atomicAdd(&P.counters[kCtrPrimaryVisits], s_acc[1]);
             atomicAdd(&P.counters[kCtrHits], s_acc[2]);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same work as a persistent grid (variant 4; north_star's "persistent-threads kernel", kept for the measurement):
+// exactly as many workgroups as the chip holds (8 per CU), every wave pulls tiles from the queue of the XCD it runs on
+// until that is empty.  Eight queue heads, one per XCD on its own 64-byte line: a single head saturates at ~88 returning
+// atomics per microsecond (MI355X_MICROARCH.md "dequeue"), which 32 400 tiles per 0.1 ms frame would exceed.  Tile i of
+// XCD x is this context's tile x + 8 i, so neighbouring tiles still spread over the XCDs as the plain launch spreads them.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u; }  // HW_REG_XCC_ID[3:0]
+
+// Next tile of this XCD's queue (wave-uniform): lane 0 takes a ticket, everybody reads it.
+__device__ __forceinline__ uint32_t pop_tile(uint32_t *heads, uint32_t xcc, uint32_t lane) {
+    uint32_t i = 0;
+    if (lane == 0) i = __hip_atomic_fetch_add(&heads[xcc * 16u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return xcc + 8u * (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
+}
+
+template <int MARCH, bool LDS_ROOTS>
+__global__ void __launch_bounds__(256) primary_shadow_persistent_kernel(FrameParams P, uint32_t *heads, uint32_t max_tiles_per_wave) {
+    extern __shared__ uint32_t smem[];
+    uint32_t *s_liquid = smem, *s_roots = smem + 24;
+    stage_lds(P, s_roots, s_liquid, LDS_ROOTS);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t xcc = xcc_id();
+    // the trip count is bounded by the host (no wave can be handed more tiles than its XCD's queue holds): whatever
+    // the queue does, every wave leaves the loop and the grid drains
+    uint32_t t_local = pop_tile(heads, xcc, lane);
+    for (uint32_t k = 0; k < max_tiles_per_wave && t_local < P.tiles_local; k++) {
+        MarchResult R, S;
+        S.iters = 0; S.visits = 0; S.hit = false;
+        trace_tile<MARCH, LDS_ROOTS, false>(P, s_roots, s_liquid, t_local, lane, R, S);
+        t_local = pop_tile(heads, xcc, lane);  // (taking the next ticket before tracing this tile was slower still: 183 us)
     }
 }
 
@@ -364,8 +402,15 @@ static void launch_shadow_t(const FrameParams &P, bool stats, hipStream_t st, hi
 
 // variant 0: grid march over the derived cell grid / brick pool (needs P.grid), primary + shadow fused into one launch;
 // 1: literal octree walk; 2: ancestor-cache octree walk; 3: grid march, shadow rays as a second launch from a hit buffer
-// in HBM (the wavefront form the path trace is built from)
-bool variant_supported(uint32_t variant) { return variant <= 3u; }
+// in HBM (the wavefront form the path trace is built from); 4: variant 0's work as a persistent grid pulling tiles from
+// per-XCD queues (primary + shadow frames only)
+bool variant_supported(uint32_t variant) { return variant <= 4u; }
+
+// Variant 4: `heads` = 8 queue heads 64 bytes apart, zeroed by the caller on the same stream.
+void launch_primary_shadow_persistent(const FrameParams &P, uint32_t *heads, uint32_t n_cus, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+    hipExtLaunchKernelGGL((primary_shadow_persistent_kernel<0, false>), dim3(n_cus * 8u), dim3(256), 24u * 4u, st, e0, e1, 0, P, heads,
+                          (P.tiles_local + 7u) / 8u + 1u);
+}
 
 // One launch for primary + shadow (variant 0 only); blk_counts gets one launched-ray count per tile.
 void launch_primary_shadow_fused(const FrameParams &P, bool stats, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
