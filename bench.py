@@ -206,7 +206,12 @@ def main():
     # set-up, off the clock like the scene build and the share tuning: let the clocks settle (a cold chip runs the first
     # ~hundred frames ~4 % slower), then the W warm-up frames the caller asked for
     if not args.rehearse_on_one_gpu:
-        run_frames(gpu, fg, 300)
+        torch.cuda.synchronize()
+        t_probe = time.perf_counter()
+        run_frames(gpu, fg, 2)
+        torch.cuda.synchronize()
+        per_frame = (time.perf_counter() - t_probe) / 2
+        run_frames(gpu, fg, int(min(300, max(2, 0.05 / max(per_frame, 1e-6)))))   # ~50 ms, at most 300 frames
     run_frames(gpu, fg, args.warmup)
     gpu.stats()  # drop the warm-up frames' kernel timings
     if sharded:
