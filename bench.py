@@ -268,6 +268,19 @@ def main():
         except Exception:
             traffic = None
 
+    # what actually binds the kernel: VALU issue.  SIMD cycles available per VALU wave-instruction at the
+    # measured frame period (1 024 SIMDs at the nominal 2.4 GHz); the simple class issues in ~2.5 cycles, the half-rate
+    # class in ~4.2 (tools/valu_rates.hip), so a value between the two means the SIMDs issue VALU back to back
+    valu = None
+    try:
+        n_valu = json.load(open(tpath)).get("valu_wave_instructions", {}).get(dom_name)
+        if n_valu and world == 1 and not sharded:
+            valu = {"wave_instructions_per_launch": n_valu, "simds": 1024, "clock_ghz": 2.4,
+                    "simd_cycles_per_instruction": dt / args.steps * 2.4e9 * 1024 / n_valu,
+                    "issue_cost_cycles": {"simple": 2.5, "half_rate": 4.2, "transcendental": 8.1}}
+    except Exception:
+        valu = None
+
     out = {
         "metric": "Mrays/s at 1920x1080, 1 primary + 1 shadow ray",
         "value": rays_per_frame * args.steps / dt / 1e6,
@@ -296,6 +309,8 @@ def main():
                      "kernels_ms": ({"primary_shadow_march": ms_p} if fused else {"primary_march": ms_p, "shadow_march": ms_s}),
                      "frames_timed": kst.frames},
     }
+    if valu is not None:
+        out["valu_issue"] = valu
     if args.mode != "shadow":
         out["metric"] = f"Mrays/s at {args.width}x{args.height}, mode {args.mode}" + (f" {args.bounces} bounces {args.spp} spp" if args.mode == "path" else "")
         out["config"]["workload"] = out["config"]["workload"].replace("C2:", "non-headline:").replace("1 primary + 1 shadow ray per solid hit", f"mode {args.mode}")

@@ -18,6 +18,7 @@ for line in open(summary):
 pick = {"primary_shadow_march": "primary_shadow_wave_kernel<0, false, false, 4>",
         "primary_march": "primary_tile_kernel<0, false, false, true>", "shadow_march": "shadow_kernel<0, false, false>"}
 res = {k: (vals[v]["FETCH_SIZE"] * 2 + vals[v]["WRITE_SIZE"]) * 1024.0 for k, v in pick.items() if v in vals and "FETCH_SIZE" in vals[v]}
+res["valu_wave_instructions"] = {k: vals[v]["SQ_INSTS_VALU"] for k, v in pick.items() if v in vals and "SQ_INSTS_VALU" in vals[v]}
 res["_source"] = f"{summary} (FETCH_SIZE*2 + WRITE_SIZE, KB -> bytes per launch; separate --pmc passes, tools/pmc.sh)"
 json.dump(res, open(out, "w"), indent=1)
 print(res)
