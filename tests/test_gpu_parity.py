@@ -547,3 +547,23 @@ def test_fuzz_all_marches_agree_on_many_cameras():
             assert np.array_equal(rgb, frames[1][0], equal_nan=True), what
         n_checked += 1
     assert n_checked == 400
+
+
+def test_c5_world_32_cubed_matches_oracle(orc):
+    """Config C5's world (32^3 chunks = 1024^3 voxels, 64 MiB cell grid) at a small frame: primary + shadow and one
+    path-traced sample against the oracle, ids / step counts bit-exact; the table sizes are what DESIGN.md states."""
+    sc = scenes.c5((256, 144), bounces=3)
+    gpu = gpu_for_scene(sc)
+    o = orc.from_package_scene(sc)
+    for mode, kw in ((MODE_PRIMARY_SHADOW, {}), (MODE_PATH, dict(spp=1, seed=5))):
+        gpu.render(mode, stats=True, **kw)
+        rgb, ids, _ = gpu.read_output()
+        r_rgb, r_ids, r_steps, st = o.render(mode, *sc.size, want_steps=True, **kw)
+        assert_frame_parity(rgb, ids, r_rgb, r_ids, f"32^3 mode {mode}")
+        assert np.array_equal(gpu.read_steps(), r_steps) and gpu.stats().node_visits == st.node_visits
+    a = gpu.accel_info()
+    assert a.available == 1 and a.cells == 256 ** 3 and a.bytes == a.cells * 4 + a.bricks * 128
+    gpu.render(MODE_PRIMARY_SHADOW, variant=2)      # the octree walk on the same world (chunk table in global memory: 32 768 roots)
+    _, ids2, _ = gpu.read_output()
+    gpu.render(MODE_PRIMARY_SHADOW)
+    assert np.array_equal(gpu.read_output()[1], ids2)
