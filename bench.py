@@ -160,9 +160,11 @@ def main():
                 if rank == 0:
                     f.assemble(g, 0)
         if f is not None and not args.rehearse_on_one_gpu:
+            # the in-place root's own tiles never feed the collective: they run on the backend's in-flight streams
+            own = dict(own_streams=True) if (f.in_place and rank == 0 and MODE != MODE_PATH) else {}
             left = n
             while left > 0:   # the gather of a batch overlaps the render of the next
-                f.submit(g, lambda: g.render(MODE, **rkw), min(left, f.batch))
+                f.submit(g, lambda: g.render(MODE, **rkw, **own), min(left, f.batch))
                 left -= f.batch
             f.drain(g)
 

@@ -92,6 +92,8 @@ pub const VRT_MODE_PRIMARY: u32 = 0;
 pub const VRT_MODE_PRIMARY_SHADOW: u32 = 1;
 pub const VRT_MODE_PATH: u32 = 2;
 
+pub const VRT_RENDER_OWN_STREAMS: u32 = 1;
+
 #[repr(C)]
 #[derive(Clone, Copy, Default)]
 pub struct vrt_render_opts {
@@ -100,7 +102,8 @@ pub struct vrt_render_opts {
     pub stats: u32,
     pub spp: u32,
     pub seed: u32,
-    pub _reserved: [u32; 3],
+    pub flags: u32,
+    pub _reserved: [u32; 2],
 }
 
 #[repr(C)]

@@ -127,8 +127,15 @@ typedef struct {
     uint32_t stats;    /* 1: also count steps / node visits this frame (slower; not for timing) */
     uint32_t spp;      /* VRT_MODE_PATH only */
     uint32_t seed;     /* VRT_MODE_PATH only */
-    uint32_t _reserved[3];
+    uint32_t flags;    /* VRT_RENDER_* */
+    uint32_t _reserved[2];
 } vrt_render_opts;
+
+/* Run this frame on the context's own in-flight streams although the caller has set a stream (vrt_set_stream) and / or
+ * bound an output (vrt_bind_output).  The caller promises that nothing it enqueues on its stream reads this frame's
+ * output before vrt_synchronize (or a device-wide synchronise), and that frames in flight are bound to different
+ * buffers.  For a gather root that renders its own tiles in place: they never feed the collective. */
+#define VRT_RENDER_OWN_STREAMS 1u
 
 /* New relative to the reference (it presents to a swapchain and never reads back). */
 typedef struct {
@@ -275,7 +282,8 @@ int vrt_assemble(vrt_ctx *ctx, const void *gathered, uint64_t rank_stride_bytes,
 
 /* The same for VRT_FLAG_COMPACT messages (8 bytes per pixel slot; stride 0 = tiles_padded*64*8 bytes apart): the root —
  * a VRT_FLAG_ROW_MAJOR shard context holding the same camera / settings / world / materials as the senders — shades
- * every gathered pixel with the code the sender would have run and writes the texel into dst. */
+ * every gathered pixel with the code the sender would have run, under the uniforms current at this call, and writes the
+ * texel into dst. */
 int vrt_assemble_compact(vrt_ctx *ctx, const void *gathered, uint64_t rank_stride_bytes, void *dst);
 
 #ifdef __cplusplus

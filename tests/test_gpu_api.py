@@ -169,3 +169,34 @@ def test_frames_in_flight_keep_frames_apart(orc, in_flight):
     assert_frame_parity(rgb, ids, r_rgb, r_ids, "after an edit")
     with pytest.raises(VrtError):
         gpu.set_frames_in_flight(5)
+
+
+def test_render_on_own_streams_with_a_caller_stream_and_bound_outputs(orc):
+    """VRT_RENDER_OWN_STREAMS — what the in-place gather root does with its own tiles: the caller has set its stream and
+    binds a different buffer per frame, the frames still overlap on the context's streams; after a device-wide
+    synchronise every buffer holds its own frame."""
+    import torch
+    from voxelraytracing_amd.shard import texels_to_frame
+    sc = scenes.c2((160, 96))
+    gpu = gpu_for_scene(sc)
+    side = torch.cuda.Stream()
+    gpu.set_stream(side.cuda_stream)
+    o = orc.from_package_scene(sc)
+    cams = [g.cam_data_create((20.0 + 5 * k, 35.0 + 60 * k, 0.0), (sc.eye[0] + k, sc.eye[1] + 2 * k, sc.eye[2]), 70.0, (160.0, 96.0)) for k in range(6)]
+    bufs = [torch.zeros((96, 160, 4), dtype=torch.int32, device="cuda") for _ in cams]
+    torch.cuda.synchronize()
+    for cam, buf in zip(cams, bufs):
+        gpu.write_cam_data(cam)
+        gpu.bind_output(buf.data_ptr())
+        gpu.render(MODE_PRIMARY_SHADOW, own_streams=True)
+    torch.cuda.synchronize()
+    for k, (cam, buf) in enumerate(zip(cams, bufs)):
+        o.set_cam(cam)
+        r_rgb, r_ids, _, _ = o.render(orc.MODE_PRIMARY_SHADOW, 160, 96)
+        rgb, ids = texels_to_frame(buf.cpu().numpy().view(np.uint32))
+        assert_frame_parity(rgb, ids, r_rgb, r_ids, f"frame {k}")
+    assert gpu.stats().frames == 6
+    gpu.bind_output(0)
+    gpu.render(MODE_PRIMARY_SHADOW)          # back to the context's own buffer and the caller's stream
+    rgb, ids, _ = gpu.read_output()
+    assert_frame_parity(rgb, ids, r_rgb, r_ids, "own buffer again")

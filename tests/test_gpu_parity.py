@@ -567,3 +567,83 @@ def test_c5_world_32_cubed_matches_oracle(orc):
     _, ids2, _ = gpu.read_output()
     gpu.render(MODE_PRIMARY_SHADOW)
     assert np.array_equal(gpu.read_output()[1], ids2)
+
+
+def test_pipelined_in_place_root_with_a_stand_in_collective(c2_small):
+    """bench.py's N > 1 frame loop on the root, on one GPU: FrameGather.submit / drain with batched gathers, compact
+    records, a weighted in-place root that renders on the backend's own in-flight streams (VRT_RENDER_OWN_STREAMS) — and
+    a stand-in for RCCL's gather that copies the other ranks' (pre-rendered) messages into the receive buffer on the
+    current stream.  Every frame of every batch must equal the unsharded render of its camera."""
+    import torch
+    from voxelraytracing_amd.shard import FrameGather, texels_to_frame
+    w, h = c2_small.size
+    n, w0, batch, n_batches = 3, 2, 2, 3
+    cams = [g.cam_data_create((15.0 + 6 * k, 20.0 + 55 * k, 0.0), (c2_small.eye[0] + k, c2_small.eye[1] + 0.5 * k, c2_small.eye[2] - k),
+                              70.0, (float(w), float(h))) for k in range(batch * n_batches)]
+    full = gpu_for_scene(c2_small)
+    want = []
+    for cam in cams:
+        full.write_cam_data(cam)
+        full.render(MODE_PRIMARY_SHADOW)
+        want.append(full.read_output()[:2])
+    dev = torch.device("cuda", 0)
+    # what ranks 1..n-1 would send for every frame: rendered up front by their shard contexts
+    others = [gpu_for_scene(c2_small, shard_rank=r, shard_count=n, root_weight=w0, compact=True) for r in range(1, n)]
+    probe = FrameGather(torch, None, 1, n, w, h, dev, root_weight=w0, in_place=True, compact=True, batch=batch)
+    sent = []   # sent[k][r-1] = rank r's message for frame k
+    for cam in cams:
+        row = []
+        for sh in others:
+            msg = torch.zeros(probe.frame_words, dtype=torch.int32, device=dev)
+            sh.write_cam_data(cam)
+            sh.bind_output(msg.data_ptr())
+            sh.render(MODE_PRIMARY_SHADOW)
+            sh.synchronize()
+            row.append(msg)
+        sent.append(row)
+
+    class Work:
+        def wait(self):
+            pass
+
+    class StandInDist:
+        def __init__(self):
+            self.calls = 0
+        def gather(self, msg, gather_list, dst=0, async_op=False):
+            first = self.calls * batch          # the frames of this call's batch
+            nframes = msg.numel() // probe.frame_words
+            for j in range(nframes):
+                for r in range(1, n):
+                    gather_list[r][j * probe.frame_words:(j + 1) * probe.frame_words].copy_(sent[first + j][r - 1], non_blocking=True)
+            self.calls += 1
+            return Work()
+
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        root = gpu_for_scene(c2_small, shard_rank=0, shard_count=n, root_weight=w0, row_major=True)
+        root.set_stream(side.cuda_stream)
+        fg = FrameGather(torch, StandInDist(), 0, n, w, h, dev, root_weight=w0, in_place=True, compact=True, batch=batch)
+        k = [0]
+        def render():
+            root.write_cam_data(cams[k[0]])     # the uniforms of the frame being rendered ...
+            root.render(MODE_PRIMARY_SHADOW, own_streams=True)
+            k[0] += 1
+        done = []
+        orig_assemble = fg.assemble
+        def assemble(gpu, which=0, j=0):
+            frame_no = (len(done) // batch) * batch + j
+            gpu.write_cam_data(cams[frame_no])  # ... and of the frame being shaded at assembly (bench.py's camera never changes)
+            orig_assemble(gpu, which, j)
+            gpu.synchronize()
+            torch.cuda.synchronize()
+            a_rgb, a_ids = texels_to_frame(fg.frame.cpu().numpy().view(np.uint32))
+            assert np.array_equal(a_ids, want[frame_no][1]) and np.array_equal(a_rgb, want[frame_no][0]), f"frame {frame_no}"
+            done.append(frame_no)
+        fg.assemble = assemble
+        for _ in range(n_batches):
+            fg.submit(root, render, batch)
+        fg.drain(root)
+    torch.cuda.synchronize()
+    assert done == list(range(batch * n_batches))
+    for c in others + [root, full]:
+        c.close()

@@ -48,7 +48,7 @@ class Config(C.Structure):
 
 class RenderOpts(C.Structure):
     _fields_ = [("mode", C.c_uint32), ("variant", C.c_uint32), ("stats", C.c_uint32), ("spp", C.c_uint32),
-                ("seed", C.c_uint32), ("_reserved", C.c_uint32 * 3)]
+                ("seed", C.c_uint32), ("flags", C.c_uint32), ("_reserved", C.c_uint32 * 2)]
 
 
 class Stats(C.Structure):

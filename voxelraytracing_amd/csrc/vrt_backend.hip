@@ -62,6 +62,7 @@ struct vrt_ctx {
     unsigned long long *extra_counters[kMaxInFlight - 1] = {nullptr, nullptr, nullptr};  // ... and segment cursors
     uint32_t in_flight = 2;        // vrt_set_frames_in_flight
     bool alt_pending = false;      // frames may still be running on the extra streams
+    bool own_pending = false;      // ... or on own_stream while the caller's stream is the context's stream (VRT_RENDER_OWN_STREAMS)
     uint32_t flip = 0;             // which (stream, output, counts) set the next pipelined frame takes
     hipStream_t stream = nullptr;
     // four hipEvents per frame rendered since the last vrt_get_stats.  Primary(+shadow) frames: {begin, end} of the first
@@ -171,6 +172,10 @@ static int quiesce(vrt_ctx *c) {
         for (hipStream_t st : c->extra_stream)
             if (st) HIP_TRY(c, hipStreamSynchronize(st));
         c->alt_pending = false;
+    }
+    if (c->own_pending) {
+        HIP_TRY(c, hipStreamSynchronize(c->own_stream));
+        c->own_pending = false;
     }
     return VRT_OK;
 }
@@ -660,7 +665,13 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     const bool kstats_early = o.stats != 0 || c->settings.show_step_count == 1u;
     // (the path trace qualifies too: its launches depend on each other, so the other frame fills every tail between them)
     const bool one_launch = o.mode == VRT_MODE_PRIMARY || (o.mode == VRT_MODE_PRIMARY_SHADOW && variant == 0u) || o.mode == VRT_MODE_PATH;
-    const bool pipelined = c->in_flight > 1u && one_launch && !kstats_early && c->stream == c->own_stream && c->d_out == c->own_out;
+    // VRT_RENDER_OWN_STREAMS: the caller set a stream and / or bound an output but lets this frame run on the context's
+    // own streams (nothing on the caller's stream consumes it before a synchronise; frames in flight are bound to
+    // different buffers) — the gather root's own tiles in bench.py
+    const bool own_streams = (o.flags & VRT_RENDER_OWN_STREAMS) != 0u;
+    const bool pipelined = c->in_flight > 1u && one_launch && !kstats_early &&
+                           (own_streams || (c->stream == c->own_stream && c->d_out == c->own_out));
+    const bool bound = c->d_out != c->own_out;
     hipStream_t st = c->stream;
     vrt::Texel *out = c->d_out;
     uint32_t *blk = c->d_blk_counts;
@@ -675,10 +686,14 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
                 path_buf = &c->extra_path[k];
             }
             if (!c->extra_stream[k]) HIP_TRY(c, hipStreamCreateWithFlags(&c->extra_stream[k], hipStreamNonBlocking));
-            if (!c->extra_out[k]) HIP_TRY(c, hipMalloc(&c->extra_out[k], (size_t)(c->slots ? c->slots : 1) * sizeof(vrt::Texel)));
+            if (!bound && !c->extra_out[k]) HIP_TRY(c, hipMalloc(&c->extra_out[k], (size_t)(c->slots ? c->slots : 1) * sizeof(vrt::Texel)));
             if (!c->extra_blk[k]) HIP_TRY(c, hipMalloc(&c->extra_blk[k], (size_t)(c->tiles_local ? c->tiles_local : 1) * sizeof(uint32_t)));
-            st = c->extra_stream[k]; out = c->extra_out[k]; blk = c->extra_blk[k];
+            st = c->extra_stream[k]; blk = c->extra_blk[k];
+            if (!bound) out = c->extra_out[k];   // a bound output is the caller's buffer for this very frame
             c->alt_pending = true;
+        } else if (c->stream != c->own_stream) {
+            st = c->own_stream;
+            c->own_pending = true;
         }
         c->flip = (c->flip + 1u) % c->in_flight;
     } else {
@@ -962,7 +977,6 @@ int vrt_bind_output(vrt_ctx *c, void *texels) {
     if (texels && ((uintptr_t)texels % 16u)) return fail(c, VRT_ERR_INVALID_ARG, "vrt_bind_output: texels must be 16-byte aligned");
     // stream-ordered: launches capture the pointer, so frames already enqueued keep writing where they were
     // told to and the next vrt_render uses the new buffer (lets a host ping-pong two gather messages)
-    QUIESCE(c);
     c->d_out = texels ? (vrt::Texel *)texels : c->own_out;
     c->last_out = c->d_out;
     c->rendered = false;

@@ -120,9 +120,11 @@ class Gpu:
         self.result_size = (new_size[0], new_size[1])
 
     # --- PixelShader (shader.rs:295-380) ---
-    def encode_pass(self, mode: int = MODE_PRIMARY, variant: int = 0, stats: bool = False, spp: int = 1, seed: int = 0):
-        """PixelShader::encode_pass + queue.submit (shader.rs:371-379, main.rs:453,565). Asynchronous."""
-        o = RenderOpts(mode, variant, 1 if stats else 0, spp, seed)
+    def encode_pass(self, mode: int = MODE_PRIMARY, variant: int = 0, stats: bool = False, spp: int = 1, seed: int = 0,
+                    own_streams: bool = False):
+        """PixelShader::encode_pass + queue.submit (shader.rs:371-379, main.rs:453,565). Asynchronous.
+        own_streams: VRT_RENDER_OWN_STREAMS (include/vrt.h)."""
+        o = RenderOpts(mode, variant, 1 if stats else 0, spp, seed, 1 if own_streams else 0)
         self._ck(self._lib.vrt_render(self._h, C.byref(o)))
 
     render = encode_pass
