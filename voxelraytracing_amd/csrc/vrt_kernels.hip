@@ -5,14 +5,14 @@
 // ray_world :182-316, find_node/find_chunk_node :76-125, ray_color :131-142, ray_sky :144-157).
 // How they compute it is not — see DESIGN.md §Kernels.  In short:
 //   * one wave64 per 8x8 screen tile (the reference's @workgroup_size(8,8,1) is exactly one CDNA wave);
-//   * the in-chunk descent runs on the integer voxel coordinate (every centre the shader compares against
-//     is an integer, so `pos >= center` is one bit of floor(pos)) — no float centres, no min/max vectors;
-//   * the descent is not restarted from the chunk root every step: each lane keeps the child-block base of
-//     every split ancestor of its current leaf in registers and resumes below the deepest ancestor the new
-//     position shares with the old one (the found leaf is the same, the node loads are not);
-//   * the step arithmetic is branch-free and algebraically reduced where the reduction is bit-exact;
-//   * chunk roots and the 256-bit liquid mask are staged in LDS; secondary rays are launched from a
-//     wave-compacted hit buffer; one 16-byte texel {r,g,b,id} per pixel so a wave stores 1 KiB contiguously.
+//   * the default march (variant 0, vrt_march.h march_grid) does not walk the octree: the leaf under a position comes from
+//     a cell grid + brick pool that vrt_accel.hip derives from the node pool on the device (at most two loads, no loop);
+//     variants 1 (the shader's text) and 2 (walk resumed below the deepest shared ancestor) read the octree itself;
+//   * the step arithmetic is branch-free and algebraically reduced where the reduction is bit-exact (DESIGN.md §3);
+//   * primary + shadow is one launch with no cooperation between waves: a lane marches its pixel's shadow ray right
+//     after its primary ray and stores one 16-byte texel {r,g,b,id} (a wave stores 1 KiB contiguously); the two-launch
+//     form with a workgroup-compacted hit buffer in HBM is variant 3, a persistent grid over per-XCD tile queues variant 4;
+//   * the 256-bit liquid mask (and, for variants 1-2, the chunk-root table) is staged in LDS.
 #include <hip/hip_ext.h>
 
 #include "vrt_march.h"
