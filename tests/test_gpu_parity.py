@@ -647,3 +647,75 @@ def test_pipelined_in_place_root_with_a_stand_in_collective(c2_small):
     assert done == list(range(batch * n_batches))
     for c in others + [root, full]:
         c.close()
+
+
+@pytest.mark.parametrize("which", ["sun_intensity_inf", "sky_nan", "sun_pos_inf", "liquid_everything", "materials_shifted"])
+def test_non_finite_settings_and_odd_materials(orc, which):
+    """Settings the host would never send on purpose — an infinite sun, a NaN sky colour, a sun at infinity — make
+    `vox*f32(hit) + sky*f32(!hit)` (:135) produce NaNs that the one-sided shortcut (§3 g) would hide, so the kernels must
+    fall back to the blend; and material tables that flip which voxels are liquid.  All four marches against the oracle,
+    NaN for NaN, and the compact-record path of the gather root as well."""
+    import torch
+    from voxelraytracing_amd.shard import FrameGather, texels_to_frame
+    sc = scenes.c2((160, 96))
+    if which == "sun_intensity_inf":
+        sc.settings.sun_intensity = float("inf")
+    elif which == "sky_nan":
+        sc.settings.sky_color[1] = float("nan")
+    elif which == "sun_pos_inf":
+        sc.settings.sun_pos[0] = float("inf")
+    elif which == "liquid_everything":
+        for i in range(256):
+            sc.materials[i].is_liquid = 1       # every ray runs to the world's edge or 500 steps through "water"
+    elif which == "materials_shifted":
+        for i in range(256):
+            sc.materials[i].is_liquid = 1 if i in (40, 47) else 0   # grass and sand are liquid, water (3) is solid
+    gpu = gpu_for_scene(sc)
+    o = orc.from_package_scene(sc)
+    r_rgb, r_ids, r_steps, _ = o.render(MODE_PRIMARY_SHADOW, 160, 96, want_steps=True)
+
+    def same(rgb, ids, what):
+        assert np.array_equal(ids, r_ids), what
+        assert np.array_equal(np.isnan(rgb), np.isnan(r_rgb)), what
+        both = np.isfinite(rgb) & np.isfinite(r_rgb)
+        assert np.array_equal(np.isinf(rgb), np.isinf(r_rgb)) and float(np.abs(rgb[both] - r_rgb[both]).max(initial=0.0)) <= 1e-4, what
+
+    for variant in VARIANTS:
+        gpu.render(MODE_PRIMARY_SHADOW, variant=variant, stats=True)
+        rgb, ids, _ = gpu.read_output()
+        same(rgb, ids, f"{which} variant {variant}")
+        assert np.array_equal(gpu.read_steps(), r_steps), f"{which} variant {variant}"
+    if which == "liquid_everything":   # air flagged liquid: the backend hands the frame to the literal march; compact shards refuse it
+        sh = gpu_for_scene(sc, shard_rank=1, shard_count=2, compact=True)
+        with pytest.raises(g.VrtError):
+            sh.render(MODE_PRIMARY_SHADOW)
+        sh.close()
+        scp = scenes.c4((160, 96), bounces=3)
+        for i in range(256):
+            scp.materials[i].is_liquid = 1
+        gp = gpu_for_scene(scp)
+        gp.render(MODE_PATH, spp=1, seed=2, stats=True)
+        p_rgb, p_ids, _ = gp.read_output()
+        q_rgb, q_ids, q_steps, _ = orc.from_package_scene(scp).render(MODE_PATH, 160, 96, want_steps=True, spp=1, seed=2)
+        assert_frame_parity(p_rgb, p_ids, q_rgb, q_ids, "path trace with every material liquid")
+        assert np.array_equal(gp.read_steps(), q_steps)
+        return
+    # the gather root shading compact records must reproduce the same NaNs
+    n, w0 = 3, 2
+    fg0 = FrameGather(torch, None, 0, n, 160, 96, torch.device("cuda", 0), root_weight=w0, in_place=True, compact=True)
+    ctxs = []
+    for r in range(n):
+        sh = gpu_for_scene(sc, shard_rank=r, shard_count=n, root_weight=w0, row_major=(r == 0), compact=(r != 0))
+        if r == 0:
+            fg0.bind(sh, 0)
+        else:
+            sh.bind_output(fg0.recv[0][r].data_ptr())
+        sh.render(MODE_PRIMARY_SHADOW)
+        sh.synchronize()
+        ctxs.append(sh)
+    fg0.assemble(ctxs[0], 0)
+    ctxs[0].synchronize()
+    a_rgb, a_ids = texels_to_frame(fg0.frame.cpu().numpy().view(np.uint32))
+    same(a_rgb, a_ids, f"{which} compact gather")
+    for c in ctxs:
+        c.close()

@@ -25,8 +25,8 @@ void launch_primary(const FrameParams &P, uint32_t variant, bool stats, bool sha
 void launch_shadow(const FrameParams &P, uint32_t variant, bool stats, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
 void launch_primary_shadow_fused(const FrameParams &P, bool stats, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
 void launch_primary_shadow_persistent(const FrameParams &P, uint32_t *heads, uint32_t n_cus, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
-void launch_path_primary(const FrameParams &P, bool stats, hipStream_t st);
-void launch_path_bounce(const FrameParams &P, bool stats, hipStream_t st);
+void launch_path_primary(const FrameParams &P, bool stats, bool literal, hipStream_t st);
+void launch_path_bounce(const FrameParams &P, bool stats, bool literal, hipStream_t st);
 void launch_path_finish(Texel *out, uint32_t n, uint32_t spp, hipStream_t st);
 void launch_quantize(const Texel *out, uint8_t *rgba8, uint32_t n, hipStream_t st);
 void launch_assemble(const Texel *gathered, Texel *dst, uint32_t width, uint32_t tiles_x, uint32_t tiles_total,
@@ -642,7 +642,15 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     rc = ensure_ndc(c);
     if (rc) return rc;
     uint32_t variant = o.variant;
-    if (variant == 0u || variant == 3u || variant == 4u || o.mode == VRT_MODE_PATH) {
+    // The fast marches never ask whether *air* is liquid (ray_tracer.wgsl:226 asks for every voxel, voxel 0 included): a
+    // material table that flags voxel 0 as liquid — nothing the reference's data packs do — is traced by the literal march.
+    const bool air_liquid = c->h_mats[0].is_liquid == 1u;
+    if (air_liquid) {
+        if (c->compact || o.variant == 4u)
+            return fail(c, VRT_ERR_STATE, "vrt_render: materials[0].is_liquid == 1 (air flagged liquid) is traced by the literal march only");
+        variant = 1u;
+    }
+    if (variant == 0u || variant == 3u || variant == 4u || (o.mode == VRT_MODE_PATH && !air_liquid)) {
         rc = ensure_accel(c);
         if (rc) return rc;
         if (!c->accel_ok && (variant == 0u || variant == 3u || variant == 4u)) variant = 2u;  // world too large for the tables: walk the octree
@@ -653,7 +661,7 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     P.nodes = c->d_nodes;
     P.roots = c->d_roots;
     P.mats = c->d_mats;
-    if (c->accel_ok && c->accel_S == c->world.size_in_chunks && !c->accel_dirty) {
+    if (c->accel_ok && c->accel_S == c->world.size_in_chunks && !c->accel_dirty && !air_liquid) {
         P.grid = c->d_grid;
         P.bricks = c->d_bricks;
         P.grid_dim = c->accel_S * 8u;
@@ -752,8 +760,8 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
                 P.seg_in = seg[(b + 1) & 1];
                 P.path_in = buf[(b + 1) & 1];
                 P.last_bounce = b + 1 == bounces;
-                if (b == 0) vrt::launch_path_primary(P, kstats, st);
-                else vrt::launch_path_bounce(P, kstats, st);
+                if (b == 0) vrt::launch_path_primary(P, kstats, air_liquid, st);
+                else vrt::launch_path_bounce(P, kstats, air_liquid, st);
                 HIP_TRY(c, hipGetLastError());
                 if (first) { HIP_TRY(c, hipEventRecord(ev[1], st)); first = false; }
             }

@@ -257,40 +257,39 @@ __global__ void path_finish_kernel(Texel *out, uint32_t n, float spp) {
 
 static size_t lds_bytes_path(const FrameParams &P, bool lds_roots) { return (24u + (lds_roots ? P.n_roots : 0u)) * 4u; }
 
-// The path trace marches with the grid march when the derived tables exist (P.grid), else with the ancestor-cache walk.
-void launch_path_primary(const FrameParams &P, bool stats, hipStream_t st) {
+// The path trace marches with the grid march when the derived tables exist (P.grid), else with the ancestor-cache walk;
+// `literal` (air flagged liquid, vrt_backend.hip) with the shader's text.
+#define VRT_PATH_LAUNCH(kernel)                                                                                           \
+    do {                                                                                                                  \
+        const bool lds = (!P.grid || literal) && P.n_roots <= kLdsRootsMax;                                               \
+        const size_t sh = lds_bytes_path(P, lds);                                                                         \
+        if (literal) {                                                                                                    \
+            if (lds) { if (stats) hipLaunchKernelGGL((kernel<1, true, true>), grid, block, sh, st, P); else hipLaunchKernelGGL((kernel<1, true, false>), grid, block, sh, st, P); } \
+            else { if (stats) hipLaunchKernelGGL((kernel<1, false, true>), grid, block, sh, st, P); else hipLaunchKernelGGL((kernel<1, false, false>), grid, block, sh, st, P); } \
+        } else if (P.grid) {                                                                                              \
+            if (stats) hipLaunchKernelGGL((kernel<0, false, true>), grid, block, sh, st, P);                              \
+            else hipLaunchKernelGGL((kernel<0, false, false>), grid, block, sh, st, P);                                   \
+        } else if (lds) {                                                                                                 \
+            if (stats) hipLaunchKernelGGL((kernel<2, true, true>), grid, block, sh, st, P);                               \
+            else hipLaunchKernelGGL((kernel<2, true, false>), grid, block, sh, st, P);                                    \
+        } else {                                                                                                          \
+            if (stats) hipLaunchKernelGGL((kernel<2, false, true>), grid, block, sh, st, P);                              \
+            else hipLaunchKernelGGL((kernel<2, false, false>), grid, block, sh, st, P);                                   \
+        }                                                                                                                 \
+    } while (0)
+
+void launch_path_primary(const FrameParams &P, bool stats, bool literal, hipStream_t st) {
     if (P.tiles_local == 0) return;
     const dim3 grid((P.tiles_local + 3u) / 4u), block(256);
-    const bool lds = !P.grid && P.n_roots <= kLdsRootsMax;
-    const size_t sh = lds_bytes_path(P, lds);
-    if (P.grid) {
-        if (stats) hipLaunchKernelGGL((path_primary_kernel<0, false, true>), grid, block, sh, st, P);
-        else hipLaunchKernelGGL((path_primary_kernel<0, false, false>), grid, block, sh, st, P);
-    } else if (lds) {
-        if (stats) hipLaunchKernelGGL((path_primary_kernel<2, true, true>), grid, block, sh, st, P);
-        else hipLaunchKernelGGL((path_primary_kernel<2, true, false>), grid, block, sh, st, P);
-    } else {
-        if (stats) hipLaunchKernelGGL((path_primary_kernel<2, false, true>), grid, block, sh, st, P);
-        else hipLaunchKernelGGL((path_primary_kernel<2, false, false>), grid, block, sh, st, P);
-    }
+    VRT_PATH_LAUNCH(path_primary_kernel);
 }
 
-void launch_path_bounce(const FrameParams &P, bool stats, hipStream_t st) {
+void launch_path_bounce(const FrameParams &P, bool stats, bool literal, hipStream_t st) {
     if (P.tiles_local == 0) return;
     const dim3 grid(kHitSegments * (P.hit_seg_cap / 256u)), block(256);
-    const bool lds = !P.grid && P.n_roots <= kLdsRootsMax;
-    const size_t sh = lds_bytes_path(P, lds);
-    if (P.grid) {
-        if (stats) hipLaunchKernelGGL((path_bounce_kernel<0, false, true>), grid, block, sh, st, P);
-        else hipLaunchKernelGGL((path_bounce_kernel<0, false, false>), grid, block, sh, st, P);
-    } else if (lds) {
-        if (stats) hipLaunchKernelGGL((path_bounce_kernel<2, true, true>), grid, block, sh, st, P);
-        else hipLaunchKernelGGL((path_bounce_kernel<2, true, false>), grid, block, sh, st, P);
-    } else {
-        if (stats) hipLaunchKernelGGL((path_bounce_kernel<2, false, true>), grid, block, sh, st, P);
-        else hipLaunchKernelGGL((path_bounce_kernel<2, false, false>), grid, block, sh, st, P);
-    }
+    VRT_PATH_LAUNCH(path_bounce_kernel);
 }
+#undef VRT_PATH_LAUNCH
 
 void launch_path_finish(Texel *out, uint32_t n, uint32_t spp, hipStream_t st) {
     if (!n) return;
