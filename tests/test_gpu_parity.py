@@ -719,3 +719,44 @@ def test_non_finite_settings_and_odd_materials(orc, which):
     same(a_rgb, a_ids, f"{which} compact gather")
     for c in ctxs:
         c.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_garbage_node_pools_and_roots(orc, seed):
+    """Node pools the host would never build — random words (random split bits, child indices pointing anywhere, past
+    the end of the pool included) under random chunk roots (inside the pool, past it, zero) — are still a well-defined
+    input of the shader: a walk is at most six reads, a read past the end is 0.  The derived tables must agree with the
+    walks on them (every voxel), and all four marches with the oracle."""
+    from voxelraytracing_amd import Gpu
+    from test_gpu_accel import lookup_tables, walk_octree
+    rng = np.random.default_rng(seed)
+    S, n_nodes = 2, 4096
+    nodes = rng.integers(0, 1 << 16, n_nodes, dtype=np.uint16)
+    nodes[rng.random(n_nodes) < 0.5] &= 0x00FF        # half of them leaves with small voxel ids
+    nodes[rng.random(n_nodes) < 0.3] = 0              # plenty of air
+    nodes[0] = 0
+    roots = rng.integers(0, n_nodes + 300, S ** 3).astype(np.uint32)   # some past the end
+    roots[rng.integers(0, S ** 3)] = 0
+    sc = scenes.c1_flat((96, 64))                      # for the camera, settings and materials of a 2^3 world
+    gpu = Gpu(n_nodes, S, (96, 64))
+    gpu.write_nodes(nodes, 0, n_nodes)
+    gpu.write_chunk_roots(roots)
+    gpu.write_world_data(sc.world.world_data())
+    gpu.write_materials(sc.materials)
+    gpu.write_settings(sc.settings)
+    o = orc.OracleScene(nodes, roots, sc.materials, sc.cam, sc.settings, sc.world.world_data())
+    for k, (rot, eye) in enumerate([((15.0, 0.0, 0.0), (32.5, 20.5, 60.5)), ((-30.0, 140.0, 0.0), (10.5, 50.5, 12.25)),
+                                    ((80.0, 45.0, 10.0), (40.0, 63.5, 33.0))]):
+        cam = g.cam_data_create(rot, eye, 80.0, (96.0, 64.0))
+        gpu.write_cam_data(cam)
+        o.set_cam(cam)
+        r_rgb, r_ids, r_steps, st = o.render(MODE_PRIMARY_SHADOW, 96, 64, want_steps=True)
+        for variant in VARIANTS:
+            gpu.render(MODE_PRIMARY_SHADOW, variant=variant, stats=True)
+            rgb, ids, _ = gpu.read_output()
+            assert_frame_parity(rgb, ids, r_rgb, r_ids, f"seed {seed} camera {k} variant {variant}")
+            assert np.array_equal(gpu.read_steps(), r_steps) and gpu.stats().node_visits == st.node_visits
+    grid, bricks = gpu.read_accel()
+    v_ref, d_ref = walk_octree(nodes, roots, S)
+    v, size = lookup_tables(grid, bricks, S)
+    assert np.array_equal(v, v_ref) and np.array_equal(size, 32 >> d_ref)
