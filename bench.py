@@ -255,6 +255,8 @@ def main():
     fused = args.mode == "shadow" and args.variant in (0, 4) and ms_s == 0.0  # one launch: no second kernel was timed
     if fused:
         dom_name, dom_bytes, dom_ms = "primary_shadow_march", b_fused, ms_p
+    elif args.mode == "path":   # not the headline: first launch vs all bounce launches + finish; bytes as for shadow rays
+        dom_name, dom_bytes, dom_ms = ("path_primary_march", b_primary, ms_p) if ms_p >= ms_s else ("path_bounce_marches", b_shadow, ms_s)
     else:
         dom_name, dom_bytes, dom_ms = ("primary_march", b_primary, ms_p) if ms_p >= ms_s else ("shadow_march", b_shadow, ms_s)
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
@@ -308,7 +310,9 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "launches_in_flight": in_flight,
                      "achieved_aggregate": achieved * in_flight, "frame_period_ms": dt / args.steps * 1e3, "traffic": traffic,
                      "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
-                     "kernels_ms": ({"primary_shadow_march": ms_p} if fused else {"primary_march": ms_p, "shadow_march": ms_s}),
+                     "kernels_ms": ({"primary_shadow_march": ms_p} if fused else
+                                    {"path_primary_march": ms_p, "path_bounce_marches": ms_s} if args.mode == "path" else
+                                    {"primary_march": ms_p, "shadow_march": ms_s}),
                      "frames_timed": kst.frames},
     }
     if valu is not None:
