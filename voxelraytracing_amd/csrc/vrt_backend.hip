@@ -621,6 +621,146 @@ static void fill_uniforms(const vrt_ctx *c, vrt::FrameParams &P) {
 
 }
 
+// Where one frame runs and what it writes: the caller's stream and the current output, or — frames in flight — one of
+// the context's own (stream, output, launched-ray counts, path buffers, cursors) sets.
+struct FrameSet {
+    hipStream_t st;
+    vrt::Texel *out;
+    uint32_t *blk;
+    uint4 **path_buf;
+    unsigned long long *counters;
+};
+
+// Two (or more) frames in flight: plain frames — one launch, or the path trace's chain of launches — alternate between
+// the context's sets; anything else (stats, the two-launch variants, a caller's stream or bound buffer without
+// VRT_RENDER_OWN_STREAMS) waits for them and runs alone on c->stream.
+static int pick_frame_set(vrt_ctx *c, const vrt_render_opts &o, uint32_t variant, bool kstats, FrameSet &f) {
+    const bool chain = o.mode == VRT_MODE_PRIMARY || (o.mode == VRT_MODE_PRIMARY_SHADOW && variant == 0u) || o.mode == VRT_MODE_PATH;
+    // VRT_RENDER_OWN_STREAMS: the caller set a stream and / or bound an output but lets this frame run on the context's own
+    // streams (nothing on the caller's stream consumes it before a synchronise; frames in flight are bound to different
+    // buffers) — the gather root's own tiles in bench.py
+    const bool own_streams = (o.flags & VRT_RENDER_OWN_STREAMS) != 0u;
+    const bool pipelined = c->in_flight > 1u && chain && !kstats && (own_streams || (c->stream == c->own_stream && c->d_out == c->own_out));
+    const bool bound = c->d_out != c->own_out;
+    f = FrameSet{c->stream, c->d_out, c->d_blk_counts, &c->d_path, c->d_counters};
+    if (!pipelined) {
+        QUIESCE(c);
+        return VRT_OK;
+    }
+    if (c->flip) {
+        const uint32_t k = c->flip - 1u;
+        if (o.mode == VRT_MODE_PATH) {
+            if (!c->extra_counters[k]) HIP_TRY(c, hipMalloc(&c->extra_counters[k], kCounterBytes));
+            f.counters = c->extra_counters[k];
+            f.path_buf = &c->extra_path[k];
+        }
+        if (!c->extra_stream[k]) HIP_TRY(c, hipStreamCreateWithFlags(&c->extra_stream[k], hipStreamNonBlocking));
+        if (!bound && !c->extra_out[k]) HIP_TRY(c, hipMalloc(&c->extra_out[k], (size_t)(c->slots ? c->slots : 1) * sizeof(vrt::Texel)));
+        if (!c->extra_blk[k]) HIP_TRY(c, hipMalloc(&c->extra_blk[k], (size_t)(c->tiles_local ? c->tiles_local : 1) * sizeof(uint32_t)));
+        f.st = c->extra_stream[k];
+        f.blk = c->extra_blk[k];
+        if (!bound) f.out = c->extra_out[k];  // a bound output is the caller's buffer for this very frame
+        c->alt_pending = true;
+    } else if (c->stream != c->own_stream) {
+        f.st = c->own_stream;
+        c->own_pending = true;
+    }
+    c->flip = (c->flip + 1u) % c->in_flight;
+    return VRT_OK;
+}
+
+// The next free event quadruple of the pool (folding the pool into the accumulated times when it is full).
+static int next_events(vrt_ctx *c, std::array<hipEvent_t, 4> **ev, uint8_t **kind) {
+    if (c->ev_used == c->ev_pool.size()) {
+        if (c->ev_pool.size() >= 1024) {
+            const int rc = fold_events(c, nullptr);
+            if (rc) return rc;
+        } else {
+            std::array<hipEvent_t, 4> t{nullptr, nullptr, nullptr, nullptr};
+            for (auto &e : t) HIP_TRY(c, hipEventCreate(&e));
+            c->ev_pool.push_back(t);
+            c->ev_kind.push_back(kEvNone);
+        }
+    }
+    *kind = &c->ev_kind[c->ev_used];
+    **kind = kEvNone;
+    *ev = &c->ev_pool[c->ev_used++];
+    return VRT_OK;
+}
+
+// Wavefront path trace: per sample one launch per bounce over the compacted live-path buffer.
+static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f, const vrt_render_opts &o, bool kstats, bool literal,
+                             std::array<hipEvent_t, 4> &ev, uint8_t &ev_kind) {
+    const uint32_t spp = o.spp ? o.spp : 1u, bounces = c->settings.max_ray_bounces;
+    const size_t cap = (size_t)vrt::kHitSegments * c->hit_seg_cap;
+    if (!*f.path_buf) HIP_TRY(c, hipMalloc(f.path_buf, 2 * 3 * cap * sizeof(uint4)));
+    uint32_t *seg[2] = {P.seg_counts, P.seg_counts + vrt::kHitSegments * vrt::kSegStride};
+    uint4 *buf[2] = {*f.path_buf, *f.path_buf + 3 * cap};
+    P.path_cap = (uint32_t)cap;
+    P.spp = spp;
+    P.seed = o.seed;
+    HIP_TRY(c, hipEventRecord(ev[0], f.st));
+    if (bounces == 0) HIP_TRY(c, hipMemsetAsync(f.out, 0, (size_t)c->slots * sizeof(vrt::Texel), f.st));
+    bool first = true;
+    for (uint32_t smp = 0; smp < spp && bounces > 0; smp++) {
+        P.sample = smp;
+        for (uint32_t b = 0; b < bounces; b++) {
+            if (!(smp == 0 && b == 0)) HIP_TRY(c, hipMemsetAsync(seg[b & 1], 0, kSegBytes, f.st));
+            P.seg_counts = seg[b & 1];
+            P.path_out = buf[b & 1];
+            P.seg_in = seg[(b + 1) & 1];
+            P.path_in = buf[(b + 1) & 1];
+            P.last_bounce = b + 1 == bounces;
+            if (b == 0) vrt::launch_path_primary(P, kstats, literal, f.st);
+            else vrt::launch_path_bounce(P, kstats, literal, f.st);
+            HIP_TRY(c, hipGetLastError());
+            if (first) { HIP_TRY(c, hipEventRecord(ev[1], f.st)); first = false; }
+        }
+    }
+    if (first) HIP_TRY(c, hipEventRecord(ev[1], f.st));
+    if (bounces > 0) {
+        vrt::launch_path_finish(f.out, c->slots, spp, f.st);
+        HIP_TRY(c, hipGetLastError());
+    }
+    HIP_TRY(c, hipEventRecord(ev[3], f.st));
+    ev_kind = kEvRecorded;
+    c->last_spp = spp;
+    return VRT_OK;
+}
+
+// Primary (+ shadow) rays: one launch (variant 0, 4; primary only) or two (variants 1-3).
+static int launch_march_frame(vrt_ctx *c, const vrt::FrameParams &P, const FrameSet &f, bool shadow, uint32_t variant, bool kstats,
+                              std::array<hipEvent_t, 4> &ev, uint8_t &ev_kind) {
+    if (!c->tiles_local) return VRT_OK;  // an empty shard
+    const uint32_t march = variant == 3u ? 0u : variant;  // variant 3 = the grid march in two launches
+    if (variant == 4u) {
+        if (!c->d_heads) {
+            HIP_TRY(c, hipMalloc(&c->d_heads, 8 * 64));
+            hipDeviceProp_t prop;
+            HIP_TRY(c, hipGetDeviceProperties(&prop, c->device));
+            c->n_cus = (uint32_t)prop.multiProcessorCount;
+        }
+        HIP_TRY(c, hipMemsetAsync(c->d_heads, 0, 8 * 64, f.st));
+        c->n_counts = c->tiles_local;
+        vrt::launch_primary_shadow_persistent(P, c->d_heads, c->n_cus, f.st, ev[0], ev[1]);
+        HIP_TRY(c, hipGetLastError());
+        ev_kind = kEvOneKernel;
+        return VRT_OK;
+    }
+    const bool fused = shadow && variant == 0u;  // primary + shadow in one launch
+    c->n_counts = fused ? c->tiles_local : c->n_blocks;
+    if (fused) vrt::launch_primary_shadow_fused(P, kstats, f.st, ev[0], ev[1]);
+    else vrt::launch_primary(P, march, kstats, shadow, f.st, ev[0], ev[1]);
+    HIP_TRY(c, hipGetLastError());
+    ev_kind = kEvOneKernel;
+    if (shadow && !fused) {
+        vrt::launch_shadow(P, march, kstats, f.st, ev[2], ev[3]);
+        HIP_TRY(c, hipGetLastError());
+        ev_kind = kEvTwoKernels;
+    }
+    return VRT_OK;
+}
+
 int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     if (!c) return VRT_ERR_INVALID_ARG;
     vrt_render_opts o;
@@ -655,6 +795,15 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
         if (rc) return rc;
         if (!c->accel_ok && (variant == 0u || variant == 3u || variant == 4u)) variant = 2u;  // world too large for the tables: walk the octree
     }
+    // per-lane iteration counts exist in the STATS kernels only; the step-count debug view (F2 in the reference,
+    // main.rs:368-370) needs them, so it runs those kernels too
+    const bool kstats = o.stats != 0 || c->settings.show_step_count == 1u;
+
+    FrameSet f;
+    rc = pick_frame_set(c, o, variant, kstats, f);
+    if (rc) return rc;
+    c->last_out = f.out;
+    c->last_blk = f.blk;
 
     vrt::FrameParams P;
     memset(&P, 0, sizeof P);
@@ -668,139 +817,24 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
         P.grid_bytes = (uint32_t)((size_t)c->accel_S * c->accel_S * c->accel_S * 512u * sizeof(uint32_t));
         P.brick_bytes = (uint32_t)((size_t)c->brick_cap * 64u * sizeof(uint16_t));
     }
-    // two frames in flight: plain frames into the context's own buffers alternate between the two (stream, output, counts)
-    // sets; anything else (stats, path trace, two-launch variants, a caller's stream or buffer) runs alone on c->stream
-    const bool kstats_early = o.stats != 0 || c->settings.show_step_count == 1u;
-    // (the path trace qualifies too: its launches depend on each other, so the other frame fills every tail between them)
-    const bool one_launch = o.mode == VRT_MODE_PRIMARY || (o.mode == VRT_MODE_PRIMARY_SHADOW && variant == 0u) || o.mode == VRT_MODE_PATH;
-    // VRT_RENDER_OWN_STREAMS: the caller set a stream and / or bound an output but lets this frame run on the context's
-    // own streams (nothing on the caller's stream consumes it before a synchronise; frames in flight are bound to
-    // different buffers) — the gather root's own tiles in bench.py
-    const bool own_streams = (o.flags & VRT_RENDER_OWN_STREAMS) != 0u;
-    const bool pipelined = c->in_flight > 1u && one_launch && !kstats_early &&
-                           (own_streams || (c->stream == c->own_stream && c->d_out == c->own_out));
-    const bool bound = c->d_out != c->own_out;
-    hipStream_t st = c->stream;
-    vrt::Texel *out = c->d_out;
-    uint32_t *blk = c->d_blk_counts;
-    uint4 **path_buf = &c->d_path;
-    unsigned long long *counters = c->d_counters;
-    if (pipelined) {
-        if (c->flip) {
-            const uint32_t k = c->flip - 1u;
-            if (o.mode == VRT_MODE_PATH) {
-                if (!c->extra_counters[k]) HIP_TRY(c, hipMalloc(&c->extra_counters[k], kCounterBytes));
-                counters = c->extra_counters[k];
-                path_buf = &c->extra_path[k];
-            }
-            if (!c->extra_stream[k]) HIP_TRY(c, hipStreamCreateWithFlags(&c->extra_stream[k], hipStreamNonBlocking));
-            if (!bound && !c->extra_out[k]) HIP_TRY(c, hipMalloc(&c->extra_out[k], (size_t)(c->slots ? c->slots : 1) * sizeof(vrt::Texel)));
-            if (!c->extra_blk[k]) HIP_TRY(c, hipMalloc(&c->extra_blk[k], (size_t)(c->tiles_local ? c->tiles_local : 1) * sizeof(uint32_t)));
-            st = c->extra_stream[k]; blk = c->extra_blk[k];
-            if (!bound) out = c->extra_out[k];   // a bound output is the caller's buffer for this very frame
-            c->alt_pending = true;
-        } else if (c->stream != c->own_stream) {
-            st = c->own_stream;
-            c->own_pending = true;
-        }
-        c->flip = (c->flip + 1u) % c->in_flight;
-    } else {
-        QUIESCE(c);
-    }
-    c->last_out = out;
-    c->last_blk = blk;
-    P.out = out;
+    P.out = f.out;
     P.hits = c->d_hits;
-    P.blk_counts = blk;
-    P.counters = counters;
-    P.seg_counts = reinterpret_cast<uint32_t *>(counters + vrt::kCtrCount);
+    P.blk_counts = f.blk;
+    P.counters = f.counters;
+    P.seg_counts = reinterpret_cast<uint32_t *>(f.counters + vrt::kCtrCount);
     P.hit_seg_cap = c->hit_seg_cap;
     P.steps = o.stats ? c->d_steps : nullptr;
     fill_uniforms(c, P);
 
-    const bool shadow = o.mode == VRT_MODE_PRIMARY_SHADOW;
-    // per-lane iteration counts exist in the STATS kernels only; the step-count debug view (F2 in the reference,
-    // main.rs:368-370) needs them, so it runs those kernels too
-    const bool kstats = o.stats != 0 || c->settings.show_step_count == 1u;
-    if (c->ev_used == c->ev_pool.size()) {
-        if (c->ev_pool.size() >= 1024) {
-            rc = fold_events(c, nullptr);
-            if (rc) return rc;
-        } else {
-            std::array<hipEvent_t, 4> t{nullptr, nullptr, nullptr, nullptr};
-            for (auto &ev : t) HIP_TRY(c, hipEventCreate(&ev));
-            c->ev_pool.push_back(t);
-            c->ev_kind.push_back(kEvNone);
-        }
-    }
-    uint8_t &ev_kind = c->ev_kind[c->ev_used];
-    ev_kind = kEvNone;
-    auto &ev = c->ev_pool[c->ev_used++];
+    std::array<hipEvent_t, 4> *ev = nullptr;
+    uint8_t *ev_kind = nullptr;
+    rc = next_events(c, &ev, &ev_kind);
+    if (rc) return rc;
     // the counters feed stats frames and the path trace's segment cursors; a plain primary(+shadow) frame reads none
-    if (kstats || o.mode == VRT_MODE_PATH) HIP_TRY(c, hipMemsetAsync(counters, 0, kCounterBytes, st));
-    if (o.mode == VRT_MODE_PATH) {
-        // wavefront path trace: per sample one launch per bounce over the compacted live-path buffer
-        const uint32_t spp = o.spp ? o.spp : 1u, bounces = c->settings.max_ray_bounces;
-        const size_t cap = (size_t)vrt::kHitSegments * c->hit_seg_cap;
-        if (!*path_buf) HIP_TRY(c, hipMalloc(path_buf, 2 * 3 * cap * sizeof(uint4)));
-        uint32_t *seg[2] = {P.seg_counts, P.seg_counts + vrt::kHitSegments * vrt::kSegStride};
-        uint4 *buf[2] = {*path_buf, *path_buf + 3 * cap};
-        P.path_cap = (uint32_t)cap;
-        P.spp = spp;
-        P.seed = o.seed;
-        HIP_TRY(c, hipEventRecord(ev[0], st));
-        if (bounces == 0) HIP_TRY(c, hipMemsetAsync(out, 0, (size_t)c->slots * sizeof(vrt::Texel), st));
-        bool first = true;
-        for (uint32_t smp = 0; smp < spp && bounces > 0; smp++) {
-            P.sample = smp;
-            for (uint32_t b = 0; b < bounces; b++) {
-                if (!(smp == 0 && b == 0)) HIP_TRY(c, hipMemsetAsync(seg[b & 1], 0, kSegBytes, st));
-                P.seg_counts = seg[b & 1];
-                P.path_out = buf[b & 1];
-                P.seg_in = seg[(b + 1) & 1];
-                P.path_in = buf[(b + 1) & 1];
-                P.last_bounce = b + 1 == bounces;
-                if (b == 0) vrt::launch_path_primary(P, kstats, air_liquid, st);
-                else vrt::launch_path_bounce(P, kstats, air_liquid, st);
-                HIP_TRY(c, hipGetLastError());
-                if (first) { HIP_TRY(c, hipEventRecord(ev[1], st)); first = false; }
-            }
-        }
-        if (first) HIP_TRY(c, hipEventRecord(ev[1], st));
-        if (bounces > 0) {
-            vrt::launch_path_finish(out, c->slots, spp, st);
-            HIP_TRY(c, hipGetLastError());
-        }
-        HIP_TRY(c, hipEventRecord(ev[3], st));
-        ev_kind = kEvRecorded;
-        c->last_spp = spp;
-    } else {
-        const bool fused = shadow && variant == 0u;  // primary + shadow in one launch
-        if (c->tiles_local && variant == 4u) {
-            if (!c->d_heads) {
-                HIP_TRY(c, hipMalloc(&c->d_heads, 8 * 64));
-                hipDeviceProp_t prop;
-                HIP_TRY(c, hipGetDeviceProperties(&prop, c->device));
-                c->n_cus = (uint32_t)prop.multiProcessorCount;
-            }
-            HIP_TRY(c, hipMemsetAsync(c->d_heads, 0, 8 * 64, st));
-            c->n_counts = c->tiles_local;
-            vrt::launch_primary_shadow_persistent(P, c->d_heads, c->n_cus, st, ev[0], ev[1]);
-            HIP_TRY(c, hipGetLastError());
-            ev_kind = kEvOneKernel;
-        } else if (c->tiles_local) {
-            c->n_counts = fused ? c->tiles_local : c->n_blocks;
-            if (fused) vrt::launch_primary_shadow_fused(P, kstats, st, ev[0], ev[1]);
-            else vrt::launch_primary(P, variant == 3u ? 0u : variant, kstats, shadow, st, ev[0], ev[1]);
-            HIP_TRY(c, hipGetLastError());
-            ev_kind = kEvOneKernel;
-            if (shadow && !fused) {
-                vrt::launch_shadow(P, variant == 3u ? 0u : variant, kstats, c->stream, ev[2], ev[3]);
-                HIP_TRY(c, hipGetLastError());
-                ev_kind = kEvTwoKernels;
-            }
-        }
-    }
+    if (kstats || o.mode == VRT_MODE_PATH) HIP_TRY(c, hipMemsetAsync(f.counters, 0, kCounterBytes, f.st));
+    if (o.mode == VRT_MODE_PATH) rc = launch_path_frame(c, P, f, o, kstats, air_liquid, *ev, *ev_kind);
+    else rc = launch_march_frame(c, P, f, o.mode == VRT_MODE_PRIMARY_SHADOW, variant, kstats, *ev, *ev_kind);
+    if (rc) return rc;
     c->rendered = true;
     c->last_stats = o.stats != 0;
     c->last_mode = o.mode;
