@@ -359,7 +359,10 @@ def cpu_baseline(sc, args, rays_per_frame):
     rays = cst.primary_rays + cst.secondary_rays
     assert rays == rays_per_frame, "oracle and GPU disagree on the number of rays launched"
     dt = sorted(times)[len(times) // 2]
-    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+    t0 = time.perf_counter()   # SURVEY.md §8d also asks for a 1-thread figure: one frame
+    o.render(orc.MODE_PRIMARY_SHADOW, args.width, args.height, threads=1)
+    dt1 = time.perf_counter() - t0
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port", "value_1_thread": rays / dt1 / 1e6,
             "sample": f"{len(times)} full {args.width}x{args.height} frames of the same scene (median {dt:.3f} s/frame, "
                       f"{sum(times):.1f} s total), OpenMP dynamic over 8-row bands"}
 
