@@ -9,7 +9,8 @@
  * plus the build's deterministic world generator (no reference counterpart can be
  * reproduced: server/src/world/gen.rs uses an unseeded global RNG).
  * No GPU is needed for anything here.  Error codes are SetVoxelErr (common/src/world/mod.rs:129-135):
- * 0 ok, 1 PosOutOfBounds, 2 OutOfMemory, 3 NoChunk, 4 NoChange.
+ * 0 ok, 1 PosOutOfBounds, 2 OutOfMemory, 3 NoChunk, 4 NoChange; 5 BadChunkData (build-defined): a chunk payload whose
+ * child indices leave its own node array (untrusted network / file input) is refused by create_chunk.
  */
 #ifndef VRT_HOST_H
 #define VRT_HOST_H
@@ -34,7 +35,8 @@ int vrth_world_create_chunk(vrth_world *w, const int32_t chunk_pos[3], const uin
 
 /* GameState::set_voxel / ClientWorld::set_voxel — client/src/lib.rs:67-76, world.rs:344-350.
  * On success range_start/len is the edited chunk's whole pool range, which the caller re-uploads
- * (main.rs:352,356-362). NoChange when the voxel already has that value. */
+ * (main.rs:352,356-362). NoChange when the voxel already has that value.  OutOfMemory (2) also fills the range: the
+ * reference's set_node returns mid-way (mod.rs:414-415), leaving the splits it had made — same voxels, other nodes. */
 int vrth_world_set_voxel(vrth_world *w, const int32_t voxel_pos[3], uint16_t voxel, uint32_t *range_start, uint32_t *range_len);
 int vrth_world_get_voxel(const vrth_world *w, const int32_t voxel_pos[3], uint16_t *voxel_out);
 

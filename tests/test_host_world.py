@@ -214,3 +214,40 @@ def test_world_generator_is_deterministic_and_consistent():
     w1 = ClientWorld((4, 4, 4), 1 << 23, 8)
     w1.generate(0, 1, threads=1)
     assert np.array_equal(w1.nodes(), w.nodes()) and np.array_equal(w1.chunk_roots(), w.chunk_roots())
+
+
+def test_untrusted_chunk_payloads_are_refused():
+    """create_chunk walks a payload with its own child indices: a split node pointing outside the payload, or an empty
+    payload, is BadChunkData (the reference would panic on the slice bound when the chunk is first walked) — through
+    create_chunk itself, a GiveChunkData message and a region file alike; the world is left untouched."""
+    from voxelraytracing_amd.world import ClientWorld as CW
+    w = CW((0, 0, 0), 1 << 16, 1)
+    good = np.array([0x8001] + [5] * 8, dtype=np.uint16)            # root split at 1, eight leaves
+    assert w.create_chunk((0, 0, 0), good) == 1
+    before = w.nodes().copy()
+    for bad in (np.array([0x8002] + [5] * 8, dtype=np.uint16),      # children 2..9 of a 9-node payload
+                np.array([0x8001] + [5] * 7 + [0xFFF0], dtype=np.uint16),   # a grandchild block far outside
+                np.array([0xFFFF], dtype=np.uint16),
+                np.zeros(0, dtype=np.uint16)):
+        with pytest.raises(SetVoxelErr) as e:
+            w.create_chunk((0, 0, 0), bad)
+        assert e.value.kind == "BadChunkData"
+    assert np.array_equal(w.nodes(), before) and w.get_voxel((3, 3, 3)) == 5
+    # the same payload as a wire message (common/src/net.rs:46-55) ...
+    src = CW((0, 0, 0), 1 << 16, 1)
+    src.create_chunk((0, 0, 0), good)
+    msg = bytearray(src.encode_chunk_msg((0, 0, 0)))
+    assert w.ingest_chunk_msg(bytes(msg))[2:] == (1, 9)
+    i = bytes(msg).index(bytes([251, 0x01, 0x80]))                  # varint of the root word 0x8001: marker 251 + u16 LE
+    msg[i + 1] = 0x40                                               # -> 0x8040: children at 64..71
+    with pytest.raises(SetVoxelErr) as e:
+        w.ingest_chunk_msg(bytes(msg))
+    assert e.value.kind == "BadChunkData"
+    # ... and as a region file (servercli/src/main.rs:25-73)
+    img = bytearray(src.save_region((0, 0, 0)))
+    j = bytes(img).rindex(bytes([0x01, 0x80]))                      # the raw LE node words follow the header
+    img[j] = 0x40
+    with pytest.raises(SetVoxelErr) as e:
+        w.load_region(bytes(img), (0, 0, 0))
+    assert e.value.kind == "BadChunkData"
+    assert np.array_equal(w.nodes(), before)

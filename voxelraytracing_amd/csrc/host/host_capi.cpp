@@ -46,7 +46,7 @@ int vrth_world_set_voxel(vrth_world *w, const int32_t p[3], uint16_t voxel, uint
     if (cur == Voxel(voxel)) return (int)SetVoxelErr::NoChange;
     const Chunk *c = nullptr;
     const SetVoxelErr e = w->w.set_voxel(cp3(p), Voxel(voxel), &c);
-    if (e == SetVoxelErr::Ok && c) {
+    if ((e == SetVoxelErr::Ok || e == SetVoxelErr::OutOfMemory) && c) {  // OutOfMemory: the partial split is in the pool
         if (range_start) *range_start = c->range.start;
         if (range_len) *range_len = c->range.len();
     }

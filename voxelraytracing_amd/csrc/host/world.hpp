@@ -43,7 +43,9 @@ using ChunkPos = IVec3;  // GlobalPos<CHUNK_SIZE>
 
 inline int32_t div_euclid(int32_t a, int32_t b) { int32_t q = a / b; return (a % b < 0) ? q - 1 : q; }
 
-enum class SetVoxelErr : int { Ok = 0, PosOutOfBounds = 1, OutOfMemory = 2, NoChunk = 3, NoChange = 4 };  // mod.rs:129-135
+// mod.rs:129-135, plus BadChunkData (build-defined): a chunk payload whose child indices leave its own node array — the
+// reference panics on the slice bound when such a chunk is walked; here it is refused when it arrives (create_chunk)
+enum class SetVoxelErr : int { Ok = 0, PosOutOfBounds = 1, OutOfMemory = 2, NoChunk = 3, NoChange = 4, BadChunkData = 5 };
 
 // Voxel, mod.rs:137-148
 struct Voxel {
@@ -172,10 +174,13 @@ struct Svo {
 
         uint32_t sh = log2u(size) - node.depth;
         while (node.depth < target_depth) {
+            // `alloc.next().ok_or(OutOfMemory)?` (:414-415): running out of blocks returns mid-way, leaving the splits made
+            // so far (a split node whose 8 children repeat its voxel: the same voxels).  The reference then asserts
+            // first_child < Voxel::MAX_VALUE (:416; a chunk addresses < 32767 nodes) — a panic there, an error here, and
+            // checked before the block is taken so that nothing leaks.
+            const auto peeked = alloc.peek();
+            if (!peeked || *peeked >= Voxel::MAX_VALUE) return SetVoxelErr::OutOfMemory;
             const auto first = alloc.next();
-            if (!first) return SetVoxelErr::OutOfMemory;
-            // the reference asserts first_child < Voxel::MAX_VALUE (:416); a chunk addresses < 32767 nodes
-            if (*first >= Voxel::MAX_VALUE) return SetVoxelErr::OutOfMemory;
             for (int i = 0; i < 8; i++) nodes[*first + i] = Node::make(parent_voxel);
             nodes[node.idx] = Node::new_split((uint16_t)*first);
             sh -= 1;
@@ -371,10 +376,21 @@ public:
         shift_chunks(off, removed);
     }
 
+    // A chunk payload is walked with its own child indices (Svo::find_node / set_node index nodes[child_idx + octant]):
+    // every split node must point at 8 nodes inside the payload, and a payload is at least its root.  Payloads come
+    // from the network (GiveChunkData) and from region files, i.e. they are untrusted.
+    static bool chunk_payload_ok(const Node *src, uint32_t n) {
+        if (n == 0 || n > (uint32_t)Node::DATA_MASK + 8u) return false;
+        for (uint32_t i = 0; i < n; i++)
+            if (src[i].is_split() && (uint32_t)src[i].child_idx() + 8u > n) return false;
+        return true;
+    }
+
     // :310-335. Returns the absolute root; err set on failure.
     NodeAddr create_chunk(ChunkPos pos, const Node *src, uint32_t n, SetVoxelErr &err) {
         err = SetVoxelErr::Ok;
         if (!local_pos_for(pos)) { err = SetVoxelErr::PosOutOfBounds; return 0; }
+        if (!chunk_payload_ok(src, n)) { err = SetVoxelErr::BadChunkData; return 0; }
         if (Chunk *c = get_chunk_mut(pos)) {
             if (c->range.len() >= n) {
                 std::memcpy(nodes_.data() + c->range.start, src, (size_t)n * sizeof(Node));
@@ -400,15 +416,15 @@ public:
         const ChunkPos cp{div_euclid(p.x, c), div_euclid(p.y, c), div_euclid(p.z, c)};
         return {cp, {(uint32_t)(p.x - cp.x * c), (uint32_t)(p.y - cp.y * c), (uint32_t)(p.z - cp.z * c)}};
     }
-    // :344-350; on success *chunk_out is the edited chunk (its whole range is what the caller re-uploads)
+    // :344-350; *chunk_out is the chunk the edit went to (its whole range is what the caller re-uploads) — also when the
+    // edit ran out of memory half-way: the splits made until then are in the pool (Svo::set_node)
     SetVoxelErr set_voxel(VoxelPos p, Voxel v, const Chunk **chunk_out = nullptr) {
         if (auto e = check_bounds(p); e != SetVoxelErr::Ok) return e;
         auto [cp, lp] = split_pos(p);
         Chunk *c = get_chunk_mut(cp);
         if (!c) return SetVoxelErr::NoChunk;
-        if (auto e = c->set_voxel(nodes_.data(), lp, v); e != SetVoxelErr::Ok) return e;
         if (chunk_out) *chunk_out = c;
-        return SetVoxelErr::Ok;
+        return c->set_voxel(nodes_.data(), lp, v);
     }
     SetVoxelErr get_voxel(VoxelPos p, Voxel &out) const {  // :352-357
         if (auto e = check_bounds(p); e != SetVoxelErr::Ok) return e;

@@ -23,7 +23,7 @@ namespace vrt {
 bool variant_supported(uint32_t variant);
 void launch_primary(const FrameParams &P, uint32_t variant, bool stats, bool shadow, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
 void launch_shadow(const FrameParams &P, uint32_t variant, bool stats, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
-void launch_primary_shadow_fused(const FrameParams &P, bool stats, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
+void launch_primary_shadow_fused(const FrameParams &P, uint32_t march, bool stats, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
 void launch_primary_shadow_persistent(const FrameParams &P, uint32_t *heads, uint32_t n_cus, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
 void launch_path_primary(const FrameParams &P, bool stats, bool literal, hipStream_t st);
 void launch_path_bounce(const FrameParams &P, bool stats, bool literal, hipStream_t st);
@@ -635,7 +635,8 @@ struct FrameSet {
 // the context's sets; anything else (stats, the two-launch variants, a caller's stream or bound buffer without
 // VRT_RENDER_OWN_STREAMS) waits for them and runs alone on c->stream.
 static int pick_frame_set(vrt_ctx *c, const vrt_render_opts &o, uint32_t variant, bool kstats, FrameSet &f) {
-    const bool chain = o.mode == VRT_MODE_PRIMARY || (o.mode == VRT_MODE_PRIMARY_SHADOW && variant == 0u) || o.mode == VRT_MODE_PATH;
+    const bool chain = o.mode == VRT_MODE_PRIMARY || (o.mode == VRT_MODE_PRIMARY_SHADOW && (variant == 0u || (variant == 2u && c->compact))) ||
+                       o.mode == VRT_MODE_PATH;
     // VRT_RENDER_OWN_STREAMS: the caller set a stream and / or bound an output but lets this frame run on the context's own
     // streams (nothing on the caller's stream consumes it before a synchronise; frames in flight are bound to different
     // buffers) — the gather root's own tiles in bench.py
@@ -747,9 +748,12 @@ static int launch_march_frame(vrt_ctx *c, const vrt::FrameParams &P, const Frame
         ev_kind = kEvOneKernel;
         return VRT_OK;
     }
-    const bool fused = shadow && variant == 0u;  // primary + shadow in one launch
+    // primary + shadow in one launch: the default march, and — on a context whose pixel slots are 8-byte records — the
+    // octree walk it falls back to when the world is too large for the derived tables (the two-launch kernels store and
+    // re-read 16-byte texels, which such a buffer has no room for)
+    const bool fused = shadow && (variant == 0u || (variant == 2u && c->compact));
     c->n_counts = fused ? c->tiles_local : c->n_blocks;
-    if (fused) vrt::launch_primary_shadow_fused(P, kstats, f.st, ev[0], ev[1]);
+    if (fused) vrt::launch_primary_shadow_fused(P, march, kstats, f.st, ev[0], ev[1]);
     else vrt::launch_primary(P, march, kstats, shadow, f.st, ev[0], ev[1]);
     HIP_TRY(c, hipGetLastError());
     ev_kind = kEvOneKernel;

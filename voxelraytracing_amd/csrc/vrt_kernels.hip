@@ -256,14 +256,19 @@ __global__ void __launch_bounds__(256) primary_shadow_persistent_kernel(FramePar
     stage_lds(P, s_roots, s_liquid, LDS_ROOTS);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t xcc = xcc_id();
-    // the trip count is bounded by the host (no wave can be handed more tiles than its XCD's queue holds): whatever
-    // the queue does, every wave leaves the loop and the grid drains
-    uint32_t t_local = pop_tile(heads, xcc, lane);
-    for (uint32_t k = 0; k < max_tiles_per_wave && t_local < P.tiles_local; k++) {
-        MarchResult R, S;
-        S.iters = 0; S.visits = 0; S.hit = false;
-        trace_tile<MARCH, LDS_ROOTS, false>(P, s_roots, s_liquid, t_local, lane, R, S);
-        t_local = pop_tile(heads, xcc, lane);  // (taking the next ticket before tracing this tile was slower still: 183 us)
+    // Own queue first; once it is empty the wave goes round the other seven, so the frame is complete whatever set of
+    // XCDs the grid landed on (a partitioned device or a CU-masked stream shows fewer than eight XCC ids).  Every trip
+    // count is bounded by the host (no queue holds more than max_tiles_per_wave - 1 tiles): whatever the queues do, every
+    // wave leaves the loops and the grid drains.
+    for (uint32_t q = 0; q < 8u; q++) {
+        const uint32_t queue = (xcc + q) & 7u;
+        uint32_t t_local = pop_tile(heads, queue, lane);
+        for (uint32_t k = 0; k < max_tiles_per_wave && t_local < P.tiles_local; k++) {
+            MarchResult R, S;
+            S.iters = 0; S.visits = 0; S.hit = false;
+            trace_tile<MARCH, LDS_ROOTS, false>(P, s_roots, s_liquid, t_local, lane, R, S);
+            t_local = pop_tile(heads, queue, lane);  // (taking the next ticket before tracing this tile was slower still: 183 us)
+        }
     }
 }
 
@@ -412,13 +417,25 @@ void launch_primary_shadow_persistent(const FrameParams &P, uint32_t *heads, uin
                           (P.tiles_local + 7u) / 8u + 1u);
 }
 
-// One launch for primary + shadow (variant 0 only); blk_counts gets one launched-ray count per tile.
-void launch_primary_shadow_fused(const FrameParams &P, bool stats, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+// One launch for primary + shadow; blk_counts gets one launched-ray count per tile.  march 0 = the grid march (variant 0);
+// march 2 = the ancestor-cache octree walk, for contexts whose pixels are 8-byte records (VRT_FLAG_COMPACT: the
+// two-launch kernels store and re-read whole texels) when the world is too large for the derived tables.
+template <int MARCH, bool LDS_ROOTS>
+static void launch_fused_t(const FrameParams &P, bool stats, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
     constexpr int WAVES = 4;
     const dim3 grid((P.tiles_local + WAVES - 1u) / WAVES), block(64 * WAVES);
-    const uint32_t lds = 24u * 4u;
-    if (stats) hipExtLaunchKernelGGL((primary_shadow_wave_kernel<0, false, true, WAVES>), grid, block, lds, st, e0, e1, 0, P);
-    else hipExtLaunchKernelGGL((primary_shadow_wave_kernel<0, false, false, WAVES>), grid, block, lds, st, e0, e1, 0, P);
+    const uint32_t lds = (uint32_t)lds_bytes(P, LDS_ROOTS);
+    if (stats) hipExtLaunchKernelGGL((primary_shadow_wave_kernel<MARCH, LDS_ROOTS, true, WAVES>), grid, block, lds, st, e0, e1, 0, P);
+    else hipExtLaunchKernelGGL((primary_shadow_wave_kernel<MARCH, LDS_ROOTS, false, WAVES>), grid, block, lds, st, e0, e1, 0, P);
+}
+
+void launch_primary_shadow_fused(const FrameParams &P, uint32_t march, bool stats, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+    if (march == 2u) {
+        if (P.n_roots <= kLdsRootsMax) launch_fused_t<2, true>(P, stats, st, e0, e1);
+        else launch_fused_t<2, false>(P, stats, st, e0, e1);
+    } else {
+        launch_fused_t<0, false>(P, stats, st, e0, e1);
+    }
 }
 
 // e0 / e1: events the dispatch itself stamps with the kernel's begin and end (no separate marker packets on the stream)

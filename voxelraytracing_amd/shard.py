@@ -253,6 +253,9 @@ class ReplicatedWorld:
         try:
             start, n = self.world.set_voxel((v[0], v[1], v[2]), v[3])
         except Exception as e:
+            if getattr(e, "kind", "") == "OutOfMemory" and getattr(e, "range", None):
+                self._upload(*e.range)   # the edit stopped half-way: the pool changed (same voxels, deeper tree), keep the GPU copy in step
+                return None
             if getattr(e, "kind", "") in ("NoChange", "NoChunk", "PosOutOfBounds", "OutOfMemory"):
                 return None
             raise

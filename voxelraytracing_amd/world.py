@@ -20,7 +20,7 @@ CHUNK_INIT_FREE_MEM = 2048    # :23
 
 class SetVoxelErr(Exception):
     """common/src/world/mod.rs:129-135"""
-    NAMES = {1: "PosOutOfBounds", 2: "OutOfMemory", 3: "NoChunk", 4: "NoChange"}
+    NAMES = {1: "PosOutOfBounds", 2: "OutOfMemory", 3: "NoChunk", 4: "NoChange", 5: "BadChunkData"}
 
     def __init__(self, code: int):
         super().__init__(self.NAMES.get(code, str(code)))
@@ -96,7 +96,10 @@ class ClientWorld:
         s, n = C.c_uint32(), C.c_uint32()
         rc = self._lib.vrth_world_set_voxel(self._h, _i3(pos), voxel, C.byref(s), C.byref(n))
         if rc:
-            raise SetVoxelErr(rc)
+            e = SetVoxelErr(rc)
+            if e.kind == "OutOfMemory":      # Svo::set_node returned mid-way: the splits made so far are in the pool
+                e.range = (s.value, n.value)
+            raise e
         return s.value, n.value
 
     def get_voxel(self, pos) -> int:
