@@ -135,6 +135,8 @@ pub struct vrt_accel_info {
     pub bytes: u64,
     pub builds: u32,
     pub last_build_ms: f32,
+    pub chunk_builds: u32,
+    pub _reserved: u32,
 }
 
 pub const VRT_ID_VOXEL_MASK: u32 = 0x7FFF;
@@ -189,6 +191,6 @@ mod layout {
         assert_eq!(size_of::<vrt_config>(), 36);
         assert_eq!(size_of::<vrt_render_opts>(), 32);
         assert_eq!(size_of::<vrt_stats>(), 96);
-        assert_eq!(size_of::<vrt_accel_info>(), 40);
+        assert_eq!(size_of::<vrt_accel_info>(), 48);
     }
 }

@@ -227,23 +227,29 @@ int vrt_present(vrt_ctx *ctx, const vrt_crosshair *crosshair, uint32_t screen_w,
 int vrt_get_stats(vrt_ctx *ctx, vrt_stats *out);
 
 /* New relative to the reference: the lookup tables the default march derives on the device from the node pool
- * and chunk_roots (rebuilt before the next frame after any vrt_write_nodes / changed vrt_write_chunk_roots /
- * world resize; DESIGN.md §HBM layout).  `available` = 0 while a rebuild is pending or when the world is too
- * large for them (variant 0 then runs as variant 2). */
+ * and chunk_roots (brought up to date before the next frame: only the chunks a vrt_write_nodes range or a changed
+ * vrt_write_chunk_roots slot touched, the whole world after a resize or a write that touches many chunks; DESIGN.md §HBM
+ * layout).  `available` = 0 while a rebuild is pending or when the world is too large for them (variant 0 then runs
+ * as variant 2). */
 typedef struct {
     uint32_t available;
     uint32_t world_size_chunks;
-    uint64_t cells;        /* depth-3 cells in the grid: (8S)^3, 4 B each */
-    uint64_t bricks;       /* split cells: 64 x 2 B each */
+    uint64_t cells;        /* depth-3 cells in the grid: (8S)^3, 4 B each (+ a zero border on the device) */
+    uint64_t bricks;       /* bricks of the pool in use (64 x 2 B each): every chunk's region — its split cells plus slack
+                            * for edits — and the regions of chunks that outgrew theirs */
     uint64_t bytes;
-    uint32_t builds;       /* rebuilds since vrt_create */
-    float last_build_ms;   /* hipEvent time of the last rebuild */
+    uint32_t builds;       /* whole-world builds since vrt_create (first frame, resized / recentred grid) */
+    float last_build_ms;   /* hipEvent time of the last whole-world build */
+    uint32_t chunk_builds; /* chunks rebuilt alone since vrt_create: a vrt_write_nodes range or a changed chunk_roots slot
+                            * rebuilds only the chunks it touches, stream-ordered, with no host round trip */
+    uint32_t _reserved;
 } vrt_accel_info;
 int vrt_get_accel_info(vrt_ctx *ctx, vrt_accel_info *out);
 
 /* Copy the tables to host memory for inspection (synchronises): grid[cells] entries, x-major over the whole world
- * (leaf: voxel | leaf_size << 15; split depth-3 cell: 0x80000000 | brick * 64), bricks[bricks * 64] entries
- * ((x&3) | (y&3) << 2 | (z&3) << 4 inside the cell; voxel | 0x8000 for a size-2 leaf).  Either pointer may be NULL. */
+ * (lo = leaf size - 1; air leaf: lo; other leaf: voxel << 16 | lo; split depth-3 cell: 0x80000000 | brick * 64),
+ * bricks[bricks * 64] entries ((x&3) | (y&3) << 2 | (z&3) << 4 inside the cell; voxel << 1 | lo, lo = 1 for a size-2
+ * leaf).  Either pointer may be NULL. */
 int vrt_read_accel(vrt_ctx *ctx, uint32_t *grid, uint16_t *bricks);
 
 /* Per-pixel march-loop iteration counts of the last frame (primary | shadow << 16); the frame must

@@ -40,15 +40,17 @@ def lookup_tables(grid: np.ndarray, bricks: np.ndarray, S: int):
     z, y, x = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
     e = grid[z >> 2, y >> 2, x >> 2]
     is_brick = (e & 0x80000000) != 0
-    voxel = e & 0x7FFF
-    size = (e >> 15) & 0xFFFF
+    assert (e != 0).all()                    # 0 is the border's "outside the world"
+    voxel = (e >> 16) & 0x7FFF               # air leaves are their own lo: the voxel bits are zero
+    size = (e & 0xFFFF) + 1
+    assert np.isin(size[~is_brick], (4, 8, 16, 32)).all()
     if is_brick.any():
         assert ((e[is_brick] & 0x3F) == 0).all()
         b = (e[is_brick] & 0x7FFFFFFF) >> 6
         assert b.max() < len(bricks)
         w = bricks[b, (x[is_brick] & 3) | ((y[is_brick] & 3) << 2) | ((z[is_brick] & 3) << 4)].astype(np.uint32)
-        voxel[is_brick] = w & 0x7FFF
-        size[is_brick] = 1 + (w >> 15)
+        voxel[is_brick] = w >> 1
+        size[is_brick] = 1 + (w & 1)
     return voxel, size
 
 
@@ -67,17 +69,21 @@ def test_tables_equal_the_octree_walk_for_every_voxel():
     gpu = gpu_for_scene(sc)
     gpu.render(MODE_PRIMARY_SHADOW)
     a = gpu.accel_info()
-    assert (a.available, a.world_size_chunks, a.cells, a.builds) == (1, 2, 16 ** 3, 1)
-    assert a.bytes == a.cells * 4 + a.bricks * 128 and a.bricks > 0
+    assert (a.available, a.world_size_chunks, a.cells, a.builds, a.chunk_builds) == (1, 2, 16 ** 3, 1, 0)
+    assert a.bytes == 16 * 17 * 17 * 4 + a.bricks * 128 and a.bricks > 0     # the device grid has a zero border row / entry
     grid, bricks = check_tables(gpu, sc.world)
     assert len(bricks) == a.bricks
-    # bricks are laid out per chunk, cells in x-major order: the pool positions are 0, 64, 128, ... in that order
-    order = []
+    # bricks are laid out per chunk, cells in x-major order, each chunk's region followed by slack for edits: inside a
+    # chunk the pool positions are consecutive, and the regions follow each other in chunk order without overlapping
+    end = 0
     for chunk in range(8):
         cx, cy, cz = chunk % 2, (chunk // 2) % 2, chunk // 4
         sub = grid[cz * 8:(cz + 1) * 8, cy * 8:(cy + 1) * 8, cx * 8:(cx + 1) * 8].reshape(-1)
-        order += [int(e & 0x7FFFFFFF) for e in sub if e & 0x80000000]
-    assert order == [64 * i for i in range(len(order))]
+        at = [int(e & 0x7FFFFFFF) // 64 for e in sub if e & 0x80000000]
+        if at:
+            assert at == list(range(at[0], at[0] + len(at))) and at[0] >= end
+            end = at[-1] + 1 + 8 + len(at) // 8          # brick_slack() of vrt_accel.hip
+    assert end <= a.bricks
 
 
 def test_tables_follow_edits_and_skip_identical_root_rewrites(orc):
@@ -89,14 +95,15 @@ def test_tables_follow_edits_and_skip_identical_root_rewrites(orc):
     gpu.write_chunk_roots(sc.world.chunk_roots())
     gpu.render(MODE_PRIMARY_SHADOW)
     assert gpu.accel_info().builds == 1
-    # a voxel edit re-uploads the chunk's range: the tables are stale until the next frame, then rebuilt once
+    # a voxel edit re-uploads the chunk's range (main.rs:352-362): the tables are stale until the next frame, which rebuilds
+    # the chunks that were written — two here — and nothing else
     for pos, v in [((32, 12, 40), 0), ((30, 13, 44), 4), ((34, 13, 44), 3), ((33, 14, 41), 62)]:
         start, n = sc.world.set_voxel(pos, v)
         gpu.write_nodes(sc.world.nodes_ptr(), start, start + n)
     assert gpu.accel_info().available == 0
     gpu.render(MODE_PRIMARY_SHADOW)
     a = gpu.accel_info()
-    assert (a.available, a.builds) == (1, 2)
+    assert (a.available, a.builds, a.chunk_builds) == (1, 1, 2)
     check_tables(gpu, sc.world)
     rgb, ids, _ = gpu.read_output()
     r_rgb, r_ids, _, _ = orc.from_package_scene(sc).render(MODE_PRIMARY_SHADOW, 128, 128)
@@ -106,15 +113,72 @@ def test_tables_follow_edits_and_skip_identical_root_rewrites(orc):
         gpu.render(MODE_PRIMARY_SHADOW, variant=variant)
         _, ids_v, _ = gpu.read_output()
         assert np.array_equal(ids_v, ids)
-    assert gpu.accel_info().builds == 2
-    # moving a chunk root (here: dropping one chunk) is a real change
+    a = gpu.accel_info()
+    assert (a.builds, a.chunk_builds) == (1, 2)
+    # moving a chunk root (here: dropping one chunk) is a real change — of that chunk
     roots = sc.world.chunk_roots().copy()
     roots[0] = 0
     gpu.write_chunk_roots(roots)
     gpu.render(MODE_PRIMARY_SHADOW)
-    assert gpu.accel_info().builds == 3
+    a = gpu.accel_info()
+    assert (a.builds, a.chunk_builds) == (1, 3)
     grid, _ = gpu.read_accel()
-    assert (grid[:8, :8, :8] == (32 << 15)).all()   # the dropped chunk is one 32^3 air leaf
+    assert (grid[:8, :8, :8] == 31).all()   # the dropped chunk is one 32^3 air leaf: lo = 31
+
+
+def test_chunks_that_outgrow_their_brick_region_move_and_many_dirty_chunks_rebuild_the_world(orc):
+    """An edit burst splits more cells than a chunk's region has slack for: the chunk moves to a 512-brick region at the
+    tail of the pool (once); the tables stay exactly the octree's.  Touching more chunks than the tail has regions for
+    turns into one whole-world build, which packs everything again."""
+    sc = scenes.procedural(8, (160, 96), MODE_PRIMARY_SHADOW)
+    gpu = gpu_for_scene(sc)
+    gpu.render(MODE_PRIMARY_SHADOW)
+    a0 = gpu.accel_info()
+    rng = np.random.default_rng(5)
+    S = 8
+    # 1. forty scattered holes in one all-stone chunk at the bottom (a single node): every one splits another depth-3 cell
+    cx, cy, cz = 3, 0, 4
+    for _ in range(40):       # (40 x at most 40 nodes stays inside the chunk's 2048-node slack)
+        p = (cx * 32 + int(rng.integers(32)), cy * 32 + int(rng.integers(32)), cz * 32 + int(rng.integers(32)))
+        try:
+            start, n = sc.world.set_voxel(p, 0)
+        except Exception as e:
+            if getattr(e, "kind", "") == "NoChange":
+                continue
+            if getattr(e, "kind", "") != "OutOfMemory":
+                raise
+            start, n = e.range       # the chunk's 2048-node slack ran out mid-edit: the splits made so far are in the pool
+        gpu.write_nodes(sc.world.nodes_ptr(), start, start + n)
+    gpu.render(MODE_PRIMARY_SHADOW)
+    a1 = gpu.accel_info()
+    assert (a1.builds, a1.chunk_builds) == (1, 1) and a1.bricks == a0.bricks + 512     # moved to the tail
+    check_tables(gpu, sc.world)
+    # ... and further edits of it stay in that region
+    start, n = sc.world.set_voxel((cx * 32 + 1, cy * 32 + 1, cz * 32 + 1), 40)
+    gpu.write_nodes(sc.world.nodes_ptr(), start, start + n)
+    gpu.render(MODE_PRIMARY_SHADOW)
+    a2 = gpu.accel_info()
+    assert (a2.builds, a2.chunk_builds, a2.bricks) == (1, 2, a1.bricks)
+    # 2. one edit in each of 200 chunks, a frame after every 20: up to 128 chunks are rebuilt alone, then the world once
+    have = sc.world.chunk_roots().reshape(S, S, S) != 0        # all-air chunks are missing chunks (root 0)
+    chunks = [(x, y, z) for z in range(S) for y in range(S) for x in range(S) if have[z, y, x]]
+    assert len(chunks) >= 200
+    rng.shuffle(chunks)
+    for i, (x, y, z) in enumerate(chunks[:200]):
+        try:
+            start, n = sc.world.set_voxel((x * 32 + 5, y * 32 + 6, z * 32 + 7), 47)
+            gpu.write_nodes(sc.world.nodes_ptr(), start, start + n)
+        except Exception as e:
+            if getattr(e, "kind", "") != "NoChange":
+                raise
+        if i % 20 == 19:
+            gpu.render(MODE_PRIMARY_SHADOW)
+    a3 = gpu.accel_info()
+    assert a3.builds == 2 and a3.available
+    check_tables(gpu, sc.world)
+    rgb, ids, _ = gpu.read_output()
+    r_rgb, r_ids, _, _ = orc.from_package_scene(sc).render(MODE_PRIMARY_SHADOW, *sc.size)
+    assert_frame_parity(rgb, ids, r_rgb, r_ids, "after the edit bursts")
 
 
 def test_procedural_world_tables_and_shrinking_world(orc):

@@ -562,7 +562,7 @@ def test_c5_world_32_cubed_matches_oracle(orc):
         assert_frame_parity(rgb, ids, r_rgb, r_ids, f"32^3 mode {mode}")
         assert np.array_equal(gpu.read_steps(), r_steps) and gpu.stats().node_visits == st.node_visits
     a = gpu.accel_info()
-    assert a.available == 1 and a.cells == 256 ** 3 and a.bytes == a.cells * 4 + a.bricks * 128
+    assert a.available == 1 and a.cells == 256 ** 3 and a.bytes == 256 * 257 * 257 * 4 + a.bricks * 128   # (zero border)
     gpu.render(MODE_PRIMARY_SHADOW, variant=2)      # the octree walk on the same world (chunk table in global memory: 32 768 roots)
     _, ids2, _ = gpu.read_output()
     gpu.render(MODE_PRIMARY_SHADOW)

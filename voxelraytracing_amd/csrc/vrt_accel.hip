@@ -6,11 +6,16 @@
 // pool byte-identical to the host's (uploads stay range writes) and *derives* from it, on the GPU, a two-level
 // table that answers the same question in at most two loads and no loop:
 //
-//   cell grid   u32[(8S)^3], x-major over the whole world: one entry per depth-3 octree cell (4^3 voxels).
-//               leaf at depth d <= 3 covering the cell ->  voxel | (32 >> d) << 15      (bit 31 clear)
-//               split at depth 3                        ->  0x80000000 | brick * 64
+//   cell grid   u32[8S][8S+1][8S+1] = [z][y][x]: one entry per depth-3 octree cell (4^3 voxels); the last row of
+//               every z slab and the last entry of every row are a border that stays 0.  The entry *is* the march's
+//               next decision (lo = leaf size - 1):
+//               air leaf at depth d <= 3     ->  lo                       (3, 7, 15 or 31: "step through, nothing to do")
+//               other leaf at depth d <= 3   ->  voxel << 16 | lo
+//               cell split at depth 3        ->  0x80000000 | brick * 64
+//               border / beyond the grid     ->  0                        (a raw buffer load past the end returns 0 too:
+//                                                                          "the ray has left the world")
 //   brick pool  u16[bricks][64], index (x&3) | (y&3) << 2 | (z&3) << 4 inside the cell:
-//               leaf at depth 4 -> voxel | 0x8000 (size 2), leaf at depth 5 -> voxel (size 1)
+//               air leaf -> lo (1 at depth 4, 0 at depth 5); other leaf -> voxel << 1 | lo
 //
 // Every entry is exactly what find_node would return for any position inside it (same node word, same depth;
 // a node read past the end of the pool is 0, a missing chunk is root 0), so the march visits the same leaves
@@ -27,6 +32,16 @@ __device__ __forceinline__ uint32_t pool_node(const uint16_t *nodes, uint32_t n_
     return idx < n_nodes ? (uint32_t)nodes[idx] : 0u;  // past the end: an air leaf (what the march's buffer loads return)
 }
 
+// Position of a chunk's cell (cx, cy, cz) in the bordered grid [8S][8S+1][8S+1].
+__device__ __forceinline__ size_t cell_index(uint32_t S, uint32_t chunk, uint32_t cx, uint32_t cy, uint32_t cz) {
+    const uint32_t G = S * 8u, G1 = G + 1u;
+    const uint32_t chx = chunk % S, chy = (chunk / S) % S, chz = chunk / (S * S);
+    return ((size_t)(chz * 8u + cz) * G1 + (chy * 8u + cy)) * G1 + (chx * 8u + cx);
+}
+
+// A leaf's grid entry: air -> lo, anything else -> voxel << 16 | lo  (lo = leaf size - 1).
+__device__ __forceinline__ uint32_t leaf_entry(uint32_t node, uint32_t lo) { return ((node & 0x7FFFu) << 16) | lo; }
+
 // Walks the three levels above a cell. Returns the node word at the stop depth (<= 3) and that depth.
 __device__ __forceinline__ uint32_t descend3(const uint16_t *nodes, uint32_t n_nodes, uint32_t root, uint32_t cx, uint32_t cy,
                                              uint32_t cz, uint32_t &depth) {
@@ -41,8 +56,38 @@ __device__ __forceinline__ uint32_t descend3(const uint16_t *nodes, uint32_t n_n
     return node;
 }
 
-// One workgroup per chunk slot, one thread per depth-3 cell. Writes leaf entries, ranks the split cells
-// inside the chunk (their bricks are laid out contiguously per chunk, cells in x-major order) and the
+// In-chunk rank of this thread's cell among the chunk's split cells (x-major order) and the chunk's split-cell count.
+__device__ __forceinline__ uint32_t rank_split_cells(bool split, uint32_t *s_wave, uint32_t &total) {
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const unsigned long long ballot = __ballot(split);
+    if (lane == 0) s_wave[wave] = (uint32_t)__popcll(ballot);
+    __syncthreads();
+    uint32_t before = 0;
+    total = 0;
+    for (uint32_t w = 0; w < 8u; w++) {
+        if (w < wave) before += s_wave[w];
+        total += s_wave[w];
+    }
+    return before + (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
+}
+
+// The 64 entries of one split cell's brick: 8 depth-4 children x 8 depth-5 grandchildren.
+__device__ __forceinline__ void fill_brick(const uint16_t *nodes, uint32_t n_nodes, uint32_t root, uint32_t n3, uint16_t *b) {
+    for (uint32_t c = 0; c < 8u; c++) {
+        const uint32_t n4 = pool_node(nodes, n_nodes, root + (n3 & 0x7FFFu) + c);
+        const uint32_t x1 = (c & 1u) * 2u, y1 = ((c >> 1) & 1u) * 2u, z1 = ((c >> 2) & 1u) * 2u;
+        for (uint32_t g = 0; g < 8u; g++) {
+            const uint32_t x = x1 + (g & 1u), y = y1 + ((g >> 1) & 1u), z = z1 + ((g >> 2) & 1u);
+            uint32_t word;
+            if (n4 & 0x8000u) word = (pool_node(nodes, n_nodes, root + (n4 & 0x7FFFu) + g) & 0x7FFFu) << 1;  // depth 5: the walk stops here, size 1
+            else word = ((n4 & 0x7FFFu) << 1) | 1u;                                                          // depth-4 leaf, size 2
+            b[x | (y << 2) | (z << 4)] = (uint16_t)word;
+        }
+    }
+}
+
+// Whole-world build, pass 1.  One workgroup per chunk slot, one thread per depth-3 cell: writes leaf entries, ranks the
+// split cells inside the chunk (their bricks are laid out contiguously per chunk, cells in x-major order) and the
 // chunk's brick count.
 __global__ void __launch_bounds__(512) accel_cells_kernel(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots,
                                                           uint32_t S, uint32_t *grid, uint32_t *chunk_bricks) {
@@ -53,33 +98,27 @@ __global__ void __launch_bounds__(512) accel_cells_kernel(const uint16_t *nodes,
     uint32_t depth;
     const uint32_t node = descend3(nodes, n_nodes, root, cx, cy, cz, depth);
     const bool split = (node & 0x8000u) != 0u;  // only possible at depth 3
-
-    const unsigned long long ballot = __ballot(split);
-    const uint32_t lane = t & 63u, wave = t >> 6;
-    if (lane == 0) s_wave[wave] = (uint32_t)__popcll(ballot);
-    __syncthreads();
-    uint32_t before = 0, total = 0;
-    for (uint32_t w = 0; w < 8u; w++) {
-        if (w < wave) before += s_wave[w];
-        total += s_wave[w];
-    }
-    const uint32_t rank = before + (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
-
-    const uint32_t G = S * 8u;
-    const uint32_t chx = chunk % S, chy = (chunk / S) % S, chz = chunk / (S * S);
-    const size_t cell = ((size_t)(chz * 8u + cz) * G + (chy * 8u + cy)) * G + (chx * 8u + cx);
-    grid[cell] = split ? (0x80000000u | rank) : ((node & 0x7FFFu) | ((32u >> depth) << 15));
+    uint32_t total;
+    const uint32_t rank = rank_split_cells(split, s_wave, total);
+    grid[cell_index(S, chunk, cx, cy, cz)] = split ? (0x80000000u | rank) : leaf_entry(node, (32u >> depth) - 1u);
     if (t == 0) chunk_bricks[chunk] = total;
 }
 
-// Exclusive scan of the per-chunk brick counts (one workgroup; S^3 <= 10^6 entries, off the frame path).
-__global__ void __launch_bounds__(1024) accel_scan_kernel(const uint32_t *counts, uint32_t *offsets, uint32_t n, uint32_t *total) {
+// How many bricks a chunk's region of the pool holds beyond what it needs now: room for the cells an edit splits, so
+// that a chunk can be rebuilt in place (accel_chunks_kernel).
+// (A chunk without split cells — uniform, or missing — gets none: its first brick moves it to the tail.)
+__host__ __device__ __forceinline__ uint32_t brick_slack(uint32_t count) { return count ? 8u + count / 8u : 0u; }
+
+// Pass 2: exclusive scan of the per-chunk region sizes (count + slack) — one workgroup; S^3 <= 10^6 entries, off the
+// frame path.  `total` = bricks in all regions = where the relocation tail starts.
+__global__ void __launch_bounds__(1024) accel_scan_kernel(const uint32_t *counts, uint32_t *bases, uint32_t *caps, uint32_t n,
+                                                          uint32_t *total, uint32_t *tail) {
     __shared__ uint32_t s_part[1024];
     const uint32_t t = threadIdx.x;
     const uint32_t per = (n + 1023u) / 1024u;
     const uint32_t lo = min(t * per, n), hi = min(lo + per, n);
     uint32_t sum = 0;
-    for (uint32_t i = lo; i < hi; i++) sum += counts[i];
+    for (uint32_t i = lo; i < hi; i++) sum += min(512u, counts[i] + brick_slack(counts[i]));
     s_part[t] = sum;
     __syncthreads();
     for (uint32_t o = 1; o < 1024u; o <<= 1) {  // Hillis-Steele inclusive scan of the partials
@@ -90,56 +129,101 @@ __global__ void __launch_bounds__(1024) accel_scan_kernel(const uint32_t *counts
     }
     uint32_t run = s_part[t] - sum;
     for (uint32_t i = lo; i < hi; i++) {
-        offsets[i] = run;
-        run += counts[i];
+        const uint32_t cap = min(512u, counts[i] + brick_slack(counts[i]));  // a chunk has 512 cells: never more bricks
+        bases[i] = run;
+        caps[i] = cap;
+        run += cap;
     }
-    if (t == 1023u) *total = s_part[1023];
+    if (t == 1023u) { *total = s_part[1023]; *tail = s_part[1023]; }
 }
 
-// Fills the bricks of the split cells and replaces their in-chunk rank by the pool position.
+// Pass 3: fills the bricks of the split cells and replaces their in-chunk rank by the pool position.
 __global__ void __launch_bounds__(512) accel_bricks_kernel(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots,
-                                                           uint32_t S, uint32_t *grid, const uint32_t *chunk_offsets,
+                                                           uint32_t S, uint32_t *grid, const uint32_t *chunk_bases,
                                                            uint16_t *bricks, uint32_t brick_cap) {
     const uint32_t chunk = blockIdx.x;
     const uint32_t t = threadIdx.x, cx = t & 7u, cy = (t >> 3) & 7u, cz = t >> 6;
-    const uint32_t G = S * 8u;
-    const uint32_t chx = chunk % S, chy = (chunk / S) % S, chz = chunk / (S * S);
-    const size_t cell = ((size_t)(chz * 8u + cz) * G + (chy * 8u + cy)) * G + (chx * 8u + cx);
+    const size_t cell = cell_index(S, chunk, cx, cy, cz);
     const uint32_t e = grid[cell];
     if (!(e & 0x80000000u)) return;
-    const uint32_t brick = chunk_offsets[chunk] + (e & 0x7FFFFFFFu);
+    const uint32_t brick = chunk_bases[chunk] + (e & 0x7FFFFFFFu);
     if (brick >= brick_cap) return;  // cannot happen: the pool was sized from the scan's total
     const uint32_t root = roots[chunk];
     uint32_t depth;
     const uint32_t n3 = descend3(nodes, n_nodes, root, cx, cy, cz, depth);
-    uint16_t *b = bricks + (size_t)brick * 64u;
-    for (uint32_t c = 0; c < 8u; c++) {
-        const uint32_t n4 = pool_node(nodes, n_nodes, root + (n3 & 0x7FFFu) + c);
-        const uint32_t x1 = (c & 1u) * 2u, y1 = ((c >> 1) & 1u) * 2u, z1 = ((c >> 2) & 1u) * 2u;
-        for (uint32_t g = 0; g < 8u; g++) {
-            const uint32_t x = x1 + (g & 1u), y = y1 + ((g >> 1) & 1u), z = z1 + ((g >> 2) & 1u);
-            uint32_t word;
-            if (n4 & 0x8000u) word = pool_node(nodes, n_nodes, root + (n4 & 0x7FFFu) + g) & 0x7FFFu;  // depth 5: the walk stops here
-            else word = (n4 & 0x7FFFu) | 0x8000u;                                                      // depth-4 leaf, size 2
-            b[x | (y << 2) | (z << 4)] = (uint16_t)word;
+    fill_brick(nodes, n_nodes, root, n3, bricks + (size_t)brick * 64u);
+    grid[cell] = 0x80000000u | (brick * 64u);
+}
+
+// Rebuild of single chunks (a voxel edit, a chunk that arrived): one workgroup per listed chunk does all three passes
+// for it.  The bricks go back into the chunk's own region when they fit (they do, unless an edit burst outgrew the
+// slack); otherwise the chunk moves to a fresh 512-brick region — the most a chunk can ever need — taken from the tail of
+// the pool with one atomic.  The host keeps the tail from overflowing: it counts the chunks that may have moved since
+// the last whole-world build and asks for one of those instead when the tail could run out (vrt_backend.hip).
+struct ChunkList { uint32_t chunk[64]; };
+
+__global__ void __launch_bounds__(512) accel_chunks_kernel(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S,
+                                                           uint32_t *grid, uint32_t *chunk_bricks, uint32_t *chunk_bases,
+                                                           uint32_t *chunk_caps, uint32_t *tail, uint16_t *bricks, uint32_t brick_cap,
+                                                           ChunkList list) {
+    __shared__ uint32_t s_wave[8];
+    __shared__ uint32_t s_base;
+    const uint32_t chunk = list.chunk[blockIdx.x];
+    const uint32_t t = threadIdx.x, cx = t & 7u, cy = (t >> 3) & 7u, cz = t >> 6;
+    const uint32_t root = roots[chunk];
+    uint32_t depth;
+    const uint32_t node = descend3(nodes, n_nodes, root, cx, cy, cz, depth);
+    const bool split = (node & 0x8000u) != 0u;
+    uint32_t total;
+    const uint32_t rank = rank_split_cells(split, s_wave, total);
+    if (t == 0) {
+        uint32_t base = chunk_bases[chunk];
+        if (total > chunk_caps[chunk]) {
+            base = atomicAdd(tail, 512u);
+            chunk_bases[chunk] = base;
+            chunk_caps[chunk] = 512u;
         }
+        chunk_bricks[chunk] = total;
+        s_base = base;
     }
+    __syncthreads();
+    const size_t cell = cell_index(S, chunk, cx, cy, cz);
+    if (!split) {
+        grid[cell] = leaf_entry(node, (32u >> depth) - 1u);
+        return;
+    }
+    const uint32_t brick = s_base + rank;
+    if (brick >= brick_cap) return;  // cannot happen: the host accounts for every possible move
+    fill_brick(nodes, n_nodes, root, node, bricks + (size_t)brick * 64u);
     grid[cell] = 0x80000000u | (brick * 64u);
 }
 
 }  // namespace
 
 void launch_accel_cells(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S, uint32_t *grid,
-                        uint32_t *chunk_bricks, uint32_t *chunk_offsets, uint32_t *total, hipStream_t st) {
+                        uint32_t *chunk_bricks, uint32_t *chunk_bases, uint32_t *chunk_caps, uint32_t *total, uint32_t *tail,
+                        hipStream_t st) {
     const uint32_t n = S * S * S;
     hipLaunchKernelGGL(accel_cells_kernel, dim3(n), dim3(512), 0, st, nodes, n_nodes, roots, S, grid, chunk_bricks);
-    hipLaunchKernelGGL(accel_scan_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t *)chunk_bricks, chunk_offsets, n, total);
+    hipLaunchKernelGGL(accel_scan_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t *)chunk_bricks, chunk_bases, chunk_caps, n, total, tail);
 }
 
 void launch_accel_bricks(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S, uint32_t *grid,
-                         const uint32_t *chunk_offsets, uint16_t *bricks, uint32_t brick_cap, hipStream_t st) {
-    hipLaunchKernelGGL(accel_bricks_kernel, dim3(S * S * S), dim3(512), 0, st, nodes, n_nodes, roots, S, grid, chunk_offsets, bricks,
+                         const uint32_t *chunk_bases, uint16_t *bricks, uint32_t brick_cap, hipStream_t st) {
+    hipLaunchKernelGGL(accel_bricks_kernel, dim3(S * S * S), dim3(512), 0, st, nodes, n_nodes, roots, S, grid, chunk_bases, bricks,
                        brick_cap);
+}
+
+void launch_accel_chunks(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S, uint32_t *grid,
+                         uint32_t *chunk_bricks, uint32_t *chunk_bases, uint32_t *chunk_caps, uint32_t *tail, uint16_t *bricks,
+                         uint32_t brick_cap, const uint32_t *chunks, uint32_t n, hipStream_t st) {
+    for (uint32_t i = 0; i < n; i += 64u) {
+        ChunkList list;
+        const uint32_t m = n - i < 64u ? n - i : 64u;
+        for (uint32_t k = 0; k < m; k++) list.chunk[k] = chunks[i + k];
+        hipLaunchKernelGGL(accel_chunks_kernel, dim3(m), dim3(512), 0, st, nodes, n_nodes, roots, S, grid, chunk_bricks, chunk_bases,
+                           chunk_caps, tail, bricks, brick_cap, list);
+    }
 }
 
 }  // namespace vrt

@@ -7,6 +7,7 @@
 // 16-byte texel {r,g,b f32, id u32} per pixel slot, hit buffer 16 B per local pixel.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <array>
 #include <cmath>
 #include <cstdarg>
@@ -36,9 +37,13 @@ void launch_present(const Texel *out, uint32_t w, uint32_t h, uint32_t screen_w,
 void launch_assemble_shade(const FrameParams &P, const void *gathered, Texel *dst, uint32_t root_weight, uint32_t period,
                            uint64_t rank_stride, hipStream_t st);
 void launch_accel_cells(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S, uint32_t *grid,
-                        uint32_t *chunk_bricks, uint32_t *chunk_offsets, uint32_t *total, hipStream_t st);
+                        uint32_t *chunk_bricks, uint32_t *chunk_bases, uint32_t *chunk_caps, uint32_t *total, uint32_t *tail,
+                        hipStream_t st);
 void launch_accel_bricks(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S, uint32_t *grid,
-                         const uint32_t *chunk_offsets, uint16_t *bricks, uint32_t brick_cap, hipStream_t st);
+                         const uint32_t *chunk_bases, uint16_t *bricks, uint32_t brick_cap, hipStream_t st);
+void launch_accel_chunks(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S, uint32_t *grid,
+                         uint32_t *chunk_bricks, uint32_t *chunk_bases, uint32_t *chunk_caps, uint32_t *tail, uint16_t *bricks,
+                         uint32_t brick_cap, const uint32_t *chunks, uint32_t n, hipStream_t st);
 }  // namespace vrt
 
 static_assert(sizeof(vrt_material) == 32, "Material layout (mod.rs:20-28)");
@@ -106,20 +111,40 @@ struct vrt_ctx {
     uint8_t *d_screen = nullptr;   // vrt_present's target
     size_t screen_cap = 0;
 
-    // derived lookup tables of the grid march (vrt_accel.hip), rebuilt lazily when their inputs changed
+    // derived lookup tables of the grid march (vrt_accel.hip), rebuilt lazily when their inputs changed: the whole world
+    // (accel_dirty) or only the chunks a write touched (dirty_chunks)
     uint32_t *d_grid = nullptr;
-    size_t grid_cap = 0;          // cells allocated
+    size_t grid_cap = 0;          // entries allocated ([8S][8S+1][8S+1] with the zero border)
     uint16_t *d_bricks = nullptr;
-    uint32_t brick_cap = 0, n_bricks = 0;
-    uint32_t *d_chunk_bricks = nullptr, *d_chunk_offsets = nullptr, *d_brick_total = nullptr;
+    uint32_t brick_cap = 0, n_bricks = 0;   // n_bricks: bricks inside the chunks' regions after the last whole-world build
+    uint32_t *d_chunk_bricks = nullptr, *d_chunk_bases = nullptr, *d_chunk_caps = nullptr, *d_brick_total = nullptr, *d_brick_tail = nullptr;
     uint32_t chunk_cap = 0;
     uint32_t accel_S = 0;         // world size the tables were built for
     bool accel_dirty = true;
     bool accel_ok = false;        // false: world too large for the tables, variant 0 runs as variant 2
     uint32_t accel_max_s = 0;     // kAccelMaxS, or less through VRT_ACCEL_MAX_S (tests of the fallback)
-    uint32_t accel_builds = 0;
+    uint32_t accel_builds = 0, accel_chunk_builds = 0;
     float accel_last_ms = 0.f;
+    std::vector<uint32_t> dirty_chunks;     // chunk slots whose nodes or root changed since the tables were last brought up to date
+    std::vector<uint8_t> chunk_is_dirty;    // ... as flags, [n_roots]
+    std::vector<uint8_t> chunk_may_have_moved;  // rebuilt alone since the last whole-world build: may sit in the pool's tail
+    uint32_t chunks_moved = 0;
     std::vector<uint32_t> h_roots;  // what chunk_roots holds, to recognise the reference's per-frame rewrite of the same table
+    std::vector<std::pair<uint32_t, uint32_t>> roots_index;  // (root, chunk slot) sorted by root, roots != 0: which chunk owns a node
+    bool roots_index_stale = true;
+
+    // uploads are staged through pinned memory (copy-at-call semantics without waiting for the device) and ordered with
+    // the frames in flight by events, not by draining them
+    uint8_t *h_ring = nullptr;
+    static constexpr size_t kRingSegBytes = 1u << 20, kRingSegs = 8;
+    hipEvent_t ring_ev[kRingSegs] = {};
+    bool ring_ev_used[kRingSegs] = {};
+    uint32_t ring_seg = 0;
+    size_t ring_off = 0;
+    hipEvent_t ev_frames = nullptr;   // scratch: "everything enqueued on that frame stream so far"
+    hipEvent_t ev_upload = nullptr;   // the last upload / table rebuild on c->stream
+    uint64_t upload_gen = 0;          // bumped by every upload; a frame stream waits for ev_upload when it has not seen it
+    uint64_t seen_gen[kMaxInFlight] = {0, 0, 0, 0};  // [0] own_stream, [k] extra_stream[k - 1]
 
     float *d_ndc = nullptr;       // ndc_x[width] then ndc_y[height] (FrameParams), rebuilt when proj_size or the output size change
     uint32_t ndc_w = 0, ndc_h = 0;
@@ -240,61 +265,212 @@ static int alloc_roots(vrt_ctx *c, uint32_t world_size) {
     c->world_size = world_size;
     c->n_roots = (uint32_t)n;
     c->h_roots.assign((size_t)n, 0u);
+    c->dirty_chunks.clear();
+    c->chunk_is_dirty.assign((size_t)n, 0);
+    c->chunk_may_have_moved.assign((size_t)n, 0);
+    c->chunks_moved = 0;
+    c->roots_index_stale = true;
     c->accel_dirty = true;
     return VRT_OK;
 }
 
-// Largest world the grid march's tables cover: the cell grid is addressed by a 32-bit byte offset built with
-// 24-bit multiplies ((8S)^3 * 4 B < 2^32, (8S)^2 * 4 < 2^24), bricks by brick * 128 B < 2^32.
+// Largest world the grid march's tables cover: the cell grid is addressed by a 32-bit byte offset built with signed
+// 24-bit multiplies (8S (8S+1)^2 * 4 B < 2^31, (8S+1)^2 * 4 < 2^23), bricks by brick * 128 B < 2^32.
 static constexpr uint32_t kAccelMaxS = 100;
 static constexpr uint32_t kAccelMaxBricks = (1u << 25) - 1u;
+// Chunks that can be rebuilt alone between two whole-world builds: each may move, once, into a 512-brick region
+// (64 KiB) at the tail of the brick pool.
+static constexpr uint32_t kTailChunks = 128;
+// A write that touches more chunks than this is cheaper as a whole-world build.
+static constexpr uint32_t kMaxDirtyChunks = 256;
 
-// (Re)build the cell grid and brick pool from the node pool and chunk_roots when they changed (vrt_accel.hip).
+// ---- ordering without draining -------------------------------------------------------------------------------------
+// Frames in flight run on the context's own streams; uploads and table rebuilds run on c->stream.  An upload must come
+// after every frame enqueued before it (they read what it overwrites) and before every frame enqueued after it: both are
+// stream waits on events, the host never blocks on the device here.
+
+// c->stream waits for everything enqueued so far on the other frame streams.
+static int order_after_frames(vrt_ctx *c) {
+    auto wait_for = [&](hipStream_t st) -> int {
+        if (!st || st == c->stream) return VRT_OK;
+        if (!c->ev_frames) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_frames, hipEventDisableTiming));
+        HIP_TRY(c, hipEventRecord(c->ev_frames, st));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_frames, 0));
+        return VRT_OK;
+    };
+    if (c->alt_pending)
+        for (hipStream_t st : c->extra_stream) { const int rc = wait_for(st); if (rc) return rc; }
+    if (c->own_pending) { const int rc = wait_for(c->own_stream); if (rc) return rc; }
+    return VRT_OK;
+}
+
+// Everything enqueued on c->stream so far (an upload, a table rebuild) happens before later frames on other streams.
+static int publish_upload(vrt_ctx *c) {
+    if (!c->ev_upload) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(c->ev_upload, c->stream));
+    c->upload_gen += 1;
+    return VRT_OK;
+}
+
+// Called before a frame is enqueued on frame stream `st` (slot 0 = own_stream, k = extra_stream[k - 1]).
+static int frame_waits_for_uploads(vrt_ctx *c, hipStream_t st, uint32_t slot) {
+    if (st == c->stream || c->seen_gen[slot] == c->upload_gen) return VRT_OK;
+    HIP_TRY(c, hipStreamWaitEvent(st, c->ev_upload, 0));
+    c->seen_gen[slot] = c->upload_gen;
+    return VRT_OK;
+}
+
+// Copy `bytes` of host memory to the device with wgpu's write_buffer semantics — the caller may reuse `src` as soon as
+// this returns, the data is visible to the next frame — without waiting for the device: the bytes are copied into a
+// pinned ring now, the ring feeds an asynchronous copy on c->stream ordered after the frames in flight.  Transfers larger
+// than a ring segment (the initial pool upload) take the synchronous route.
+static int stage_upload(vrt_ctx *c, void *dst, const void *src, size_t bytes) {
+    if (bytes == 0) return VRT_OK;
+    int rc = order_after_frames(c);
+    if (rc) return rc;
+    if (bytes > vrt_ctx::kRingSegBytes) {
+        HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return publish_upload(c);
+    }
+    if (!c->h_ring) HIP_TRY(c, hipHostMalloc((void **)&c->h_ring, vrt_ctx::kRingSegBytes * vrt_ctx::kRingSegs, hipHostMallocDefault));
+    const size_t need = (bytes + 63u) & ~(size_t)63u;
+    if (c->ring_off + need > vrt_ctx::kRingSegBytes) {
+        c->ring_seg = (c->ring_seg + 1u) % vrt_ctx::kRingSegs;
+        c->ring_off = 0;
+        // the segment's previous copies must have left it (seven segments ago: practically always long done)
+        if (c->ring_ev_used[c->ring_seg]) HIP_TRY(c, hipEventSynchronize(c->ring_ev[c->ring_seg]));
+    }
+    uint8_t *slot = c->h_ring + (size_t)c->ring_seg * vrt_ctx::kRingSegBytes + c->ring_off;
+    memcpy(slot, src, bytes);
+    c->ring_off += need;
+    HIP_TRY(c, hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, c->stream));
+    if (!c->ring_ev[c->ring_seg]) HIP_TRY(c, hipEventCreateWithFlags(&c->ring_ev[c->ring_seg], hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(c->ring_ev[c->ring_seg], c->stream));
+    c->ring_ev_used[c->ring_seg] = true;
+    return publish_upload(c);
+}
+
+// ---- which chunks a write touched ----------------------------------------------------------------------------------
+static void mark_all_dirty(vrt_ctx *c) {
+    c->accel_dirty = true;
+    for (uint32_t ch : c->dirty_chunks) c->chunk_is_dirty[ch] = 0;
+    c->dirty_chunks.clear();
+}
+
+static void mark_chunk_dirty(vrt_ctx *c, uint32_t chunk) {
+    if (c->accel_dirty || c->chunk_is_dirty[chunk]) return;
+    if (c->dirty_chunks.size() >= kMaxDirtyChunks) { mark_all_dirty(c); return; }
+    c->chunk_is_dirty[chunk] = 1;
+    c->dirty_chunks.push_back(chunk);
+}
+
+// Nodes [start, end) were overwritten: the chunks whose octrees may have changed are the ones whose root lies in the range
+// and the one whose root precedes it (a chunk's nodes follow its root up to the next chunk's root: ChunkAlloc hands out
+// disjoint ranges, client/src/world.rs:239-256).  Node 0 is the root of every missing chunk: a write to it is everything.
+static void mark_node_range_dirty(vrt_ctx *c, uint32_t start, uint32_t end) {
+    if (c->accel_dirty) return;
+    if (start == 0u) { mark_all_dirty(c); return; }
+    if (c->roots_index_stale) {
+        c->roots_index.clear();
+        for (uint32_t i = 0; i < c->n_roots; i++)
+            if (c->h_roots[i]) c->roots_index.emplace_back(c->h_roots[i], i);
+        std::sort(c->roots_index.begin(), c->roots_index.end());
+        c->roots_index_stale = false;
+    }
+    auto it = std::upper_bound(c->roots_index.begin(), c->roots_index.end(), std::make_pair(start, 0xFFFFFFFFu));
+    // chunks sharing the root that precedes the range (normally one), then every chunk rooted inside it
+    if (it != c->roots_index.begin()) {
+        const uint32_t r = std::prev(it)->first;
+        for (auto k = std::prev(it);; --k) {
+            if (k->first != r) break;
+            mark_chunk_dirty(c, k->second);
+            if (c->accel_dirty || k == c->roots_index.begin()) break;
+        }
+    }
+    for (; it != c->roots_index.end() && it->first < end && !c->accel_dirty; ++it) mark_chunk_dirty(c, it->second);
+}
+
+// (Re)build the cell grid and brick pool from the node pool and chunk_roots when they changed (vrt_accel.hip): the whole
+// world, or — after a voxel edit or a chunk's arrival — only the chunks that were written, with no host round trip.
 static int ensure_accel(vrt_ctx *c) {
     const uint32_t S = c->world.size_in_chunks;
-    if (!c->accel_dirty && c->accel_S == S) return VRT_OK;
-    QUIESCE(c);  // a frame on the second stream may still be reading the old tables
+    if (!c->accel_dirty && c->accel_S == S && c->dirty_chunks.empty()) return VRT_OK;
+    if (S > c->accel_max_s) {  // too large for the tables: nothing to keep up to date, the octree walk reads the pool itself
+        mark_all_dirty(c);
+        c->accel_ok = false;
+        c->accel_S = S;
+        c->accel_dirty = false;
+        return VRT_OK;
+    }
+    if (!c->accel_dirty && c->accel_S == S && c->accel_ok) {
+        // single chunks; a chunk that outgrew its region moves to the tail once — make sure the tail has room for all of them
+        uint32_t fresh = 0;
+        for (uint32_t ch : c->dirty_chunks) fresh += c->chunk_may_have_moved[ch] ? 0u : 1u;
+        if (c->chunks_moved + fresh <= kTailChunks) {
+            int rc = order_after_frames(c);
+            if (rc) return rc;
+            vrt::launch_accel_chunks(c->d_nodes, c->max_nodes, c->d_roots, S, c->d_grid, c->d_chunk_bricks, c->d_chunk_bases,
+                                     c->d_chunk_caps, c->d_brick_tail, c->d_bricks, c->brick_cap, c->dirty_chunks.data(),
+                                     (uint32_t)c->dirty_chunks.size(), c->stream);
+            HIP_TRY(c, hipGetLastError());
+            for (uint32_t ch : c->dirty_chunks) {
+                if (!c->chunk_may_have_moved[ch]) { c->chunk_may_have_moved[ch] = 1; c->chunks_moved += 1; }
+                c->chunk_is_dirty[ch] = 0;
+            }
+            c->accel_chunk_builds += (uint32_t)c->dirty_chunks.size();
+            c->dirty_chunks.clear();
+            return publish_upload(c);
+        }
+    }
+    mark_all_dirty(c);   // (clears the chunk list: a whole-world build covers it)
+    QUIESCE(c);  // frames on the other streams may still be reading the old tables; this path reads a count back anyway
     c->accel_ok = false;
     c->accel_S = S;
     c->accel_dirty = false;
-    if (S > c->accel_max_s) return VRT_OK;
     const uint32_t n_chunks = S * S * S;
-    const size_t cells = (size_t)n_chunks * 512u;
-    if (cells > c->grid_cap) {
+    const size_t G = (size_t)S * 8u;
+    const size_t entries = G * (G + 1u) * (G + 1u);
+    if (entries > c->grid_cap) {
         (void)hipFree(c->d_grid);
         c->d_grid = nullptr; c->grid_cap = 0;
-        HIP_TRY(c, hipMalloc(&c->d_grid, cells * sizeof(uint32_t)));
-        c->grid_cap = cells;
+        HIP_TRY(c, hipMalloc(&c->d_grid, entries * sizeof(uint32_t)));
+        c->grid_cap = entries;
     }
+    // the border rows / entries are never written by the kernels: zero = "outside the world"
+    HIP_TRY(c, hipMemsetAsync(c->d_grid, 0, entries * sizeof(uint32_t), c->stream));
     if (n_chunks > c->chunk_cap) {
-        (void)hipFree(c->d_chunk_bricks); (void)hipFree(c->d_chunk_offsets);
-        c->d_chunk_bricks = c->d_chunk_offsets = nullptr; c->chunk_cap = 0;
+        (void)hipFree(c->d_chunk_bricks); (void)hipFree(c->d_chunk_bases); (void)hipFree(c->d_chunk_caps);
+        c->d_chunk_bricks = c->d_chunk_bases = c->d_chunk_caps = nullptr; c->chunk_cap = 0;
         HIP_TRY(c, hipMalloc(&c->d_chunk_bricks, (size_t)n_chunks * sizeof(uint32_t)));
-        HIP_TRY(c, hipMalloc(&c->d_chunk_offsets, (size_t)n_chunks * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc(&c->d_chunk_bases, (size_t)n_chunks * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc(&c->d_chunk_caps, (size_t)n_chunks * sizeof(uint32_t)));
         c->chunk_cap = n_chunks;
     }
     if (!c->d_brick_total) HIP_TRY(c, hipMalloc(&c->d_brick_total, sizeof(uint32_t)));
+    if (!c->d_brick_tail) HIP_TRY(c, hipMalloc(&c->d_brick_tail, sizeof(uint32_t)));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     HIP_TRY(c, hipEventCreate(&e0));
     HIP_TRY(c, hipEventCreate(&e1));
     auto body = [&]() -> int {
         HIP_TRY(c, hipEventRecord(e0, c->stream));
-        vrt::launch_accel_cells(c->d_nodes, c->max_nodes, c->d_roots, S, c->d_grid, c->d_chunk_bricks, c->d_chunk_offsets,
-                                c->d_brick_total, c->stream);
+        vrt::launch_accel_cells(c->d_nodes, c->max_nodes, c->d_roots, S, c->d_grid, c->d_chunk_bricks, c->d_chunk_bases, c->d_chunk_caps,
+                                c->d_brick_total, c->d_brick_tail, c->stream);
         HIP_TRY(c, hipGetLastError());
-        uint32_t total = 0;
+        uint32_t total = 0;  // bricks in all chunk regions (counts + slack)
         HIP_TRY(c, hipMemcpyAsync(&total, c->d_brick_total, sizeof total, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (total > kAccelMaxBricks) return VRT_OK;  // accel_ok stays false
-        if (total > c->brick_cap || !c->d_bricks) {
+        const uint64_t want = (uint64_t)total + (uint64_t)kTailChunks * 512u;
+        if (want > kAccelMaxBricks) return VRT_OK;  // accel_ok stays false
+        if (want > c->brick_cap || !c->d_bricks) {
             (void)hipFree(c->d_bricks);
             c->d_bricks = nullptr; c->brick_cap = 0;
-            uint64_t cap = (uint64_t)total + total / 4u + 1024u;  // slack: voxel edits split a few more cells
+            uint64_t cap = want + total / 4u;  // room to grow before the next reallocation
             if (cap > kAccelMaxBricks) cap = kAccelMaxBricks;
             HIP_TRY(c, hipMalloc(&c->d_bricks, (size_t)cap * 64u * sizeof(uint16_t)));
             c->brick_cap = (uint32_t)cap;
         }
-        vrt::launch_accel_bricks(c->d_nodes, c->max_nodes, c->d_roots, S, c->d_grid, c->d_chunk_offsets, c->d_bricks, c->brick_cap,
+        vrt::launch_accel_bricks(c->d_nodes, c->max_nodes, c->d_roots, S, c->d_grid, c->d_chunk_bases, c->d_bricks, c->brick_cap,
                                  c->stream);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipEventRecord(e1, c->stream));
@@ -303,7 +479,9 @@ static int ensure_accel(vrt_ctx *c) {
         c->n_bricks = total;
         c->accel_builds += 1;
         c->accel_ok = true;
-        return VRT_OK;
+        std::fill(c->chunk_may_have_moved.begin(), c->chunk_may_have_moved.end(), (uint8_t)0);
+        c->chunks_moved = 0;
+        return publish_upload(c);
     };
     const int rc = body();
     (void)hipEventDestroy(e0);
@@ -406,8 +584,13 @@ void vrt_destroy(vrt_ctx *c) {
     (void)hipFree(c->d_nodes); (void)hipFree(c->d_roots); (void)hipFree(c->d_mats); (void)hipFree(c->own_out);
     (void)hipFree(c->d_hits); (void)hipFree(c->d_counters); (void)hipFree(c->d_steps); (void)hipFree(c->d_rgba8); (void)hipFree(c->d_path);
     (void)hipFree(c->d_blk_counts);
-    (void)hipFree(c->d_grid); (void)hipFree(c->d_bricks); (void)hipFree(c->d_chunk_bricks); (void)hipFree(c->d_chunk_offsets);
-    (void)hipFree(c->d_brick_total); (void)hipFree(c->d_ndc); (void)hipFree(c->d_screen); (void)hipFree(c->d_heads);
+    (void)hipFree(c->d_grid); (void)hipFree(c->d_bricks); (void)hipFree(c->d_chunk_bricks); (void)hipFree(c->d_chunk_bases);
+    (void)hipFree(c->d_chunk_caps); (void)hipFree(c->d_brick_tail); (void)hipFree(c->d_brick_total);
+    if (c->h_ring) (void)hipHostFree(c->h_ring);
+    for (auto ev : c->ring_ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (c->ev_frames) (void)hipEventDestroy(c->ev_frames);
+    if (c->ev_upload) (void)hipEventDestroy(c->ev_upload); (void)hipFree(c->d_ndc); (void)hipFree(c->d_screen); (void)hipFree(c->d_heads);
     for (auto &t : c->ev_pool)
         for (auto &ev : t)
             if (ev) (void)hipEventDestroy(ev);
@@ -430,12 +613,11 @@ int vrt_write_nodes(vrt_ctx *c, const uint16_t *pool, uint32_t start, uint32_t e
     if ((uint64_t)root + count > c->max_nodes)
         return fail(c, VRT_ERR_OUT_OF_RANGE, "vrt_write_nodes: [%u,%u) exceeds the %u-node buffer", start, end, c->max_nodes);
     HIP_TRY(c, hipSetDevice(c->device));
-    QUIESCE(c);
-    // stream-ordered after earlier renders; the sync makes it copy-at-call-time (write_buffer
-    // semantics: the caller may reuse `pool` as soon as this returns)
-    HIP_TRY(c, hipMemcpyAsync(c->d_nodes + root, pool + root, (size_t)count * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->accel_dirty = true;
+    // copy-at-call-time (write_buffer semantics: the caller may reuse `pool` as soon as this returns) through the pinned
+    // ring, ordered after the frames in flight without waiting for them
+    const int rc = stage_upload(c, c->d_nodes + root, pool + root, (size_t)count * sizeof(uint16_t));
+    if (rc) return rc;
+    mark_node_range_dirty(c, start, end);   // (the widening repeats a neighbour's node: nothing of its octree changes)
     return VRT_OK;
 }
 
@@ -448,11 +630,14 @@ int vrt_write_chunk_roots(vrt_ctx *c, uint32_t offset, const uint32_t *roots, ui
     // the reference rewrites the whole table every frame (main.rs:446); an identical rewrite changes nothing
     if (memcmp(c->h_roots.data() + offset, roots, (size_t)cut * sizeof(uint32_t)) == 0) return VRT_OK;
     HIP_TRY(c, hipSetDevice(c->device));
-    QUIESCE(c);
-    HIP_TRY(c, hipMemcpyAsync(c->d_roots + offset, roots, (size_t)cut * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const int rc = stage_upload(c, c->d_roots + offset, roots, (size_t)cut * sizeof(uint32_t));
+    if (rc) return rc;
+    // the slots whose root changed are the chunks to rebuild (a chunk arrived or was dropped); a recentred grid changes
+    // nearly all of them and becomes a whole-world build
+    for (uint32_t i = 0; i < cut && !c->accel_dirty; i++)
+        if (c->h_roots[offset + i] != roots[i]) mark_chunk_dirty(c, offset + i);
     memcpy(c->h_roots.data() + offset, roots, (size_t)cut * sizeof(uint32_t));
-    c->accel_dirty = true;
+    c->roots_index_stale = true;
     return VRT_OK;
 }
 
@@ -470,10 +655,7 @@ int vrt_write_materials(vrt_ctx *c, uint32_t first, const vrt_material *mats, ui
     if (n == 0) return VRT_OK;
     memcpy(c->h_mats + first, mats, (size_t)n * sizeof(vrt_material));
     HIP_TRY(c, hipSetDevice(c->device));
-    QUIESCE(c);
-    HIP_TRY(c, hipMemcpyAsync(c->d_mats + first, mats, (size_t)n * sizeof(vrt_material), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return VRT_OK;
+    return stage_upload(c, c->d_mats + first, mats, (size_t)n * sizeof(vrt_material));
 }
 
 int vrt_set_camera(vrt_ctx *c, const vrt_cam_data *cam) {
@@ -522,8 +704,8 @@ static int ensure_ndc(vrt_ctx *c) {
     if (c->d_ndc && c->ndc_w == c->width && c->ndc_h == c->height &&
         memcmp(c->ndc_proj, c->cam.proj_size, sizeof c->ndc_proj) == 0)
         return VRT_OK;
-    QUIESCE(c);
     if (!c->d_ndc || c->ndc_w + c->ndc_h < c->width + c->height) {
+        QUIESCE(c);
         (void)hipFree(c->d_ndc);
         c->d_ndc = nullptr;
         HIP_TRY(c, hipMalloc(&c->d_ndc, (size_t)(c->width + c->height) * sizeof(float)));
@@ -532,8 +714,8 @@ static int ensure_ndc(vrt_ctx *c) {
     volatile float px = c->cam.proj_size[0], py = c->cam.proj_size[1];
     for (uint32_t i = 0; i < c->width; i++) { volatile float q = ((float)(int)i * 2.0f) / px; t[i] = q - 1.0f; }
     for (uint32_t i = 0; i < c->height; i++) { volatile float q = ((float)(int)i * 2.0f) / py; t[c->width + i] = q - 1.0f; }
-    HIP_TRY(c, hipMemcpyAsync(c->d_ndc, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const int rc = stage_upload(c, c->d_ndc, t.data(), t.size() * sizeof(float));
+    if (rc) return rc;
     c->ndc_w = c->width;
     c->ndc_h = c->height;
     memcpy(c->ndc_proj, c->cam.proj_size, sizeof c->ndc_proj);
@@ -662,9 +844,13 @@ static int pick_frame_set(vrt_ctx *c, const vrt_render_opts &o, uint32_t variant
         f.blk = c->extra_blk[k];
         if (!bound) f.out = c->extra_out[k];  // a bound output is the caller's buffer for this very frame
         c->alt_pending = true;
+        const int rc = frame_waits_for_uploads(c, f.st, k + 1u);
+        if (rc) return rc;
     } else if (c->stream != c->own_stream) {
         f.st = c->own_stream;
         c->own_pending = true;
+        const int rc = frame_waits_for_uploads(c, f.st, 0u);
+        if (rc) return rc;
     }
     c->flip = (c->flip + 1u) % c->in_flight;
     return VRT_OK;
@@ -814,11 +1000,12 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     P.nodes = c->d_nodes;
     P.roots = c->d_roots;
     P.mats = c->d_mats;
-    if (c->accel_ok && c->accel_S == c->world.size_in_chunks && !c->accel_dirty && !air_liquid) {
+    if (c->accel_ok && c->accel_S == c->world.size_in_chunks && !c->accel_dirty && c->dirty_chunks.empty() && !air_liquid) {
         P.grid = c->d_grid;
         P.bricks = c->d_bricks;
         P.grid_dim = c->accel_S * 8u;
-        P.grid_bytes = (uint32_t)((size_t)c->accel_S * c->accel_S * c->accel_S * 512u * sizeof(uint32_t));
+        const size_t G = (size_t)c->accel_S * 8u;
+        P.grid_bytes = (uint32_t)(G * (G + 1u) * (G + 1u) * sizeof(uint32_t));  // [8S][8S+1][8S+1]: the zero border
         P.brick_bytes = (uint32_t)((size_t)c->brick_cap * 64u * sizeof(uint16_t));
     }
     P.out = f.out;
@@ -973,27 +1160,55 @@ int vrt_get_stats(vrt_ctx *c, vrt_stats *out) {
     return VRT_OK;
 }
 
+// Bricks of the pool in use: the chunks' regions plus the tail regions of chunks that moved.
+static int bricks_in_use(vrt_ctx *c, uint32_t *n) {
+    *n = 0;
+    if (!c->accel_ok || !c->d_brick_tail) return VRT_OK;
+    HIP_TRY(c, hipMemcpyAsync(n, c->d_brick_tail, sizeof *n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (*n > c->brick_cap) *n = c->brick_cap;
+    return VRT_OK;
+}
+
 int vrt_get_accel_info(vrt_ctx *c, vrt_accel_info *out) {
     if (!c || !out) return fail(c, VRT_ERR_INVALID_ARG, "vrt_get_accel_info: null argument");
     memset(out, 0, sizeof *out);
-    out->available = c->accel_ok && !c->accel_dirty ? 1u : 0u;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const bool up_to_date = c->accel_ok && !c->accel_dirty && c->dirty_chunks.empty();
+    out->available = up_to_date ? 1u : 0u;
     out->world_size_chunks = c->accel_S;
     out->cells = (uint64_t)c->accel_S * c->accel_S * c->accel_S * 512u;
-    out->bricks = c->n_bricks;
-    out->bytes = out->cells * sizeof(uint32_t) + (uint64_t)c->n_bricks * 64u * sizeof(uint16_t);
+    uint32_t used = 0;
+    const int rc = bricks_in_use(c, &used);
+    if (rc) return rc;
+    out->bricks = used;
+    const uint64_t G = (uint64_t)c->accel_S * 8u;
+    out->bytes = G * (G + 1u) * (G + 1u) * sizeof(uint32_t) + (uint64_t)used * 64u * sizeof(uint16_t);
     out->builds = c->accel_builds;
     out->last_build_ms = c->accel_last_ms;
+    out->chunk_builds = c->accel_chunk_builds;
     return VRT_OK;
 }
 
 int vrt_read_accel(vrt_ctx *c, uint32_t *grid, uint16_t *bricks) {
     if (!c) return VRT_ERR_INVALID_ARG;
-    if (!c->accel_ok || c->accel_dirty) return fail(c, VRT_ERR_STATE, "vrt_read_accel: the tables are not built (render a frame first)");
+    if (!c->accel_ok || c->accel_dirty || !c->dirty_chunks.empty())
+        return fail(c, VRT_ERR_STATE, "vrt_read_accel: the tables are not up to date (render a frame first)");
     HIP_TRY(c, hipSetDevice(c->device));
-    const size_t cells = (size_t)c->accel_S * c->accel_S * c->accel_S * 512u;
-    if (grid) HIP_TRY(c, hipMemcpyAsync(grid, c->d_grid, cells * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    if (bricks && c->n_bricks)
-        HIP_TRY(c, hipMemcpyAsync(bricks, c->d_bricks, (size_t)c->n_bricks * 64u * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream));
+    QUIESCE(c);
+    const size_t G = (size_t)c->accel_S * 8u, G1 = G + 1u;
+    if (grid) {  // the device layout carries a zero border row / entry ([G][G+1][G+1]); the caller gets the G^3 cells
+        std::vector<uint32_t> t(G * G1 * G1);
+        HIP_TRY(c, hipMemcpyAsync(t.data(), c->d_grid, t.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        for (size_t z = 0; z < G; z++)
+            for (size_t y = 0; y < G; y++) memcpy(grid + (z * G + y) * G, t.data() + (z * G1 + y) * G1, G * sizeof(uint32_t));
+    }
+    uint32_t used = 0;
+    const int rc = bricks_in_use(c, &used);
+    if (rc) return rc;
+    if (bricks && used)
+        HIP_TRY(c, hipMemcpyAsync(bricks, c->d_bricks, (size_t)used * 64u * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return VRT_OK;
 }

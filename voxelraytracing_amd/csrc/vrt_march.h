@@ -338,13 +338,20 @@ __device__ __forceinline__ MarchResult march_fast(const FrameParams &P, const ui
 // ------------------------------------------------------------------------------------------------
 // MARCH = 0 (default): the grid march.  Same positions, same leaves, same results as the two above, bit for
 // bit; the leaf under a position comes from the derived cell grid / brick pool of vrt_accel.hip (at most two
-// loads, no loop, nothing carried between steps) instead of a walk of the octree.  Reductions (b)-(e) as in
+// loads, no loop, nothing carried between steps) instead of a walk of the octree.  Reductions (b)-(d) as in
 // march_fast, plus:
-//   (b') (mask ? t : -t) * unit  ==  t * (mask ? unit : -unit)                   ((-a)*b and a*(-b) are the same bits)
-//   (h)  leaf bounds from the leaf size s (a power of two): low = v & ~(s-1), high = (v | (s-1)) + 1, chosen per
-//        axis by one bit-field insert with the direction mask
-//   (i)  the exit-axis flags and "left the world" are not carried through the loop: they are functions of the
-//        last step's operands, which each lane still holds when it leaves
+//   (b'') |t| * |unit|  ==  (mask ? t : -t) * unit up to the sign of a zero          (abs is a free operand modifier)
+//   (c')  the :247-270 branch tree on bit patterns: min3_u32(bits - 1) + 1
+//   (h)   leaf bounds from lo = leaf size - 1 (what the table stores): low = v & ~lo, high = (v | lo) + 1, chosen per
+//         axis by one bit-field insert with the direction mask
+//   (i)   the exit-axis flags and "left the world" are not carried through the loop: they are functions of the
+//         last step's operands, which each lane still holds when it leaves
+//   (l)   the table entry is the step's decision: an air leaf of the cell grid is its own lo (1..31), everything else
+//         (other leaf, split cell, beyond the world) is one unsigned compare away — and "beyond the world" is an
+//         entry like any other: the grid has a zero border and a load past its end returns 0, so the march has no
+//         bounds test of its own (e).  That holds for rays whose origin and direction are finite — every
+//         coordinate then stays within one voxel of the world, where the border is; a wave with a non-finite ray
+//         (`careful`, wave-uniform) runs the shader's own test (e) on every step instead.
 // ------------------------------------------------------------------------------------------------
 using TableBuf = __amdgpu_buffer_rsrc_t;
 __device__ __forceinline__ TableBuf table_buffer(const void *p, uint32_t bytes) {
@@ -356,9 +363,9 @@ __device__ __forceinline__ float min3_nan_ignoring(float a, float b, float c) {
     return r;
 }
 
-__device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t uniform_b, uint32_t c) {
-    uint32_t r;  // a * b + c on 24-bit operands, b wave-uniform
-    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(uniform_b), "v"(c));
+__device__ __forceinline__ uint32_t mad_i24(int a, uint32_t uniform_b, uint32_t c) {
+    uint32_t r;  // a * b + c on signed 24-bit factors, b wave-uniform
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(uniform_b), "v"(c));
     return r;
 }
 
@@ -368,22 +375,30 @@ __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {
     return r;
 }
 
-// f32 -> i32 rounding towards -inf (v_cvt_flr_i32_f32).  Used where only "is the coordinate inside [0, size)" and, if
-// so, its integer part matter: equal to trunc2i for every non-negative input, negative for every negative one.
+// |a| * b: the absolute value is an operand modifier, not an instruction
+__device__ __forceinline__ float abs_mul(float a, float b) {
+    float r;
+    asm("v_mul_f32_e64 %0, |%1|, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// f32 -> i32 rounding towards -inf (v_cvt_flr_i32_f32): the integer part of every coordinate inside the world, -1 for
+// the positions just beyond a low face (a step overshoots a face by 0.001 |dir|).
 __device__ __forceinline__ int flr2i(float x) {
     int r;
     asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
-    return r;
-}
-__device__ __forceinline__ uint32_t max3_u32(uint32_t a, uint32_t b, uint32_t c) {
-    uint32_t r;
-    asm("v_max3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
 __device__ __forceinline__ uint32_t min3_u32(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t r;
     asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
+}
+
+__device__ __forceinline__ bool finite3(V3 v) {
+    // exponent field all ones <=> inf or NaN
+    return ((__float_as_uint(v.x) & 0x7F800000u) != 0x7F800000u) && ((__float_as_uint(v.y) & 0x7F800000u) != 0x7F800000u) &&
+           ((__float_as_uint(v.z) & 0x7F800000u) != 0x7F800000u);
 }
 
 template <bool STATS>
@@ -398,6 +413,8 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
     R.visits = 0u;
 
     const bool mx = dir.x >= 0.0f, my = dir.y >= 0.0f, mz = dir.z >= 0.0f;
+    // (l): is any ray of this wave not finite?  (Wave-uniform; evaluated before lanes leave.)
+    const bool careful = __ballot(!(finite3(origin) && finite3(dir))) != 0ull;
 
     V3 pos = origin;
     if (pos.x - floorf(pos.x) < 0.001f || pos.y - floorf(pos.y) < 0.001f || pos.z - floorf(pos.z) < 0.001f) {
@@ -413,12 +430,14 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
         sqrtf(1.0f + (dir.y / dir.x) * (dir.y / dir.x) + (dir.z / dir.x) * (dir.z / dir.x)),
         sqrtf(1.0f + (dir.x / dir.y) * (dir.x / dir.y) + (dir.z / dir.y) * (dir.z / dir.y)),
         sqrtf(1.0f + (dir.x / dir.z) * (dir.x / dir.z) + (dir.y / dir.z) * (dir.y / dir.z))};
+    const float ux = fabsf(unit.x), uy = fabsf(unit.y), uz = fabsf(unit.z);
     const uint32_t mxm = mx ? ~0u : 0u, mym = my ? ~0u : 0u, mzm = mz ? ~0u : 0u;
     const uint32_t mx1 = mx ? 1u : 0u, my1 = my ? 1u : 0u, mz1 = mz ? 1u : 0u;
 
     const uint32_t wsize = P.world.size;
     const TableBuf gb = table_buffer(P.grid, P.grid_bytes), bb = table_buffer(P.bricks, P.brick_bytes);
-    const uint32_t row_bytes = P.grid_dim * 4u, slab_bytes = P.grid_dim * P.grid_dim * 4u;  // < 2^24: grid_dim <= 800
+    // rows and slabs carry one border entry / row: [8S][8S + 1][8S + 1]; both strides < 2^23 (grid_dim <= 800)
+    const uint32_t row_bytes = (P.grid_dim + 1u) * 4u, slab_bytes = (P.grid_dim + 1u) * row_bytes;
 
     int vx = trunc2i(pos.x), vy = trunc2i(pos.y), vz = trunc2i(pos.z);  // pos > 0 here (or NaN -> 0)
     uint32_t voxel = 0u;
@@ -429,19 +448,25 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
     uint32_t iter = 0u;
 
     for (;;) {
-        iter += 1u;
         // ---- find_node: cell, then brick ----
-        const uint32_t coff = mad_u24((uint32_t)vz >> 2, slab_bytes, mad_u24((uint32_t)vy >> 2, row_bytes, (uint32_t)vx & ~3u));
+        const uint32_t coff = mad_i24(vz >> 2, slab_bytes, mad_i24(vy >> 2, row_bytes, (uint32_t)vx & ~3u));
         const uint32_t e = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(gb, coff, 0, 0);
-        voxel = e & 0x7FFFu;
-        uint32_t sz = e >> 15;  // leaf size in voxels: 32 >> depth
-        if ((int)e < 0) {
-            const uint32_t u = ((uint32_t)vx & 3u) | (((uint32_t)vy & 3u) << 2) | (((uint32_t)vz & 3u) << 4);
-            const uint32_t b = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(bb, (e + u) << 1, 0, 0);  // the shift drops bit 31
-            voxel = b & 0x7FFFu;
-            sz = 1u + (b >> 15);
+        uint32_t lo = e;    // an air leaf of the cell grid: the entry is lo, nothing else to do
+        voxel = 0u;
+        if (e - 1u >= 31u) {
+            if (e == 0u) break;  // border, or past either end of the grid: the position is outside the world
+            if ((int)e < 0) {
+                const uint32_t u = ((uint32_t)vx & 3u) | (((uint32_t)vy & 3u) << 2) | (((uint32_t)vz & 3u) << 4);
+                const uint32_t b = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(bb, (e + u) << 1, 0, 0);  // the shift drops bit 31
+                lo = b & 1u;
+                voxel = b >> 1;
+            } else {
+                lo = e & 31u;
+                voxel = e >> 16;
+            }
         }
-        if (STATS) R.visits += (uint32_t)__clz((int)sz) - 25u;  // depth + 1 node words on the reference's walk
+        iter += 1u;  // a node was looked up (:221); the shader never looks one up outside the world
+        if (STATS) R.visits += (uint32_t)__clz((int)(lo + 1u)) - 25u;  // depth + 1 node words on the reference's walk
 
         if (voxel != 0u) {
             if (!is_liquid(s_liquid, voxel)) break;  // solid: the hit
@@ -452,14 +477,13 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
         }
 
         // ---- step to the leaf's exit face ----
-        const uint32_t lo = sz - 1u;
         const float tx = (float)(int)(bfi(lo, mxm, (uint32_t)vx) + mx1) - pos.x;
         const float ty = (float)(int)(bfi(lo, mym, (uint32_t)vy) + my1) - pos.y;
         const float tz = (float)(int)(bfi(lo, mzm, (uint32_t)vz) + mz1) - pos.z;
         // (b'') |t| * |unit| has the bits of (mask ? t : -t) * unit, except that a zero is always +0 (never observed)
-        adx = fabsf(tx) * fabsf(unit.x);
-        ady = fabsf(ty) * fabsf(unit.y);
-        adz = fabsf(tz) * fabsf(unit.z);
+        adx = abs_mul(tx, ux);
+        ady = abs_mul(ty, uy);
+        adz = abs_mul(tz, uz);
         // (c') the minimum over the non-zero distances, on bit patterns: non-negative floats order like unsigned integers,
         // NaNs above every number, and bits - 1 sends +0 to the very top, so one unsigned min3 replaces the shader's
         // branch tree (:247-270): the smallest non-zero number; a NaN only if nothing else is non-zero; +0 if all are zero
@@ -470,13 +494,13 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
         pos.y += dir.y * (step == ady ? sp : step);
         pos.z += dir.z * (step == adz ? sp : step);
 
-        // (e') floor instead of trunc: one unsigned compare sees both "pos < 0" (negative integer = huge) and "pos >= size".
-        // It is only a filter — whatever it flags (and whatever the instruction makes of a NaN) is re-examined with the
-        // exact test (e) — and for every position that stays inside, floor == trunc.
+        // the next lookup's coordinates.  Finite rays: floor — just beyond a face it is -1 or `size`, which the grid's
+        // border answers with 0.  A wave with a non-finite ray: i32(f32) as the shader has it (NaN -> 0) and its own
+        // test (:285) — those coordinates are then always inside the grid.
         vx = flr2i(pos.x);
         vy = flr2i(pos.y);
         vz = flr2i(pos.z);
-        if (max3_u32((uint32_t)vx, (uint32_t)vy, (uint32_t)vz) >= wsize) {
+        if (careful) {
             vx = trunc2i(pos.x);
             vy = trunc2i(pos.y);
             vz = trunc2i(pos.z);
@@ -488,8 +512,11 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
     // `iter` is one scalar loop counter per wave
     R.iters = STATS ? iter : 0u;
     if (dew != -1.0f) R.water_dist += total_len - dew;
-    // (i): a lane that left through a solid leaf or by exhaustion holds a position that passed this test
-    if (min3_nan_ignoring(pos.x, pos.y, pos.z) < 0.0f || max(max((uint32_t)vx, (uint32_t)vy), (uint32_t)vz) >= wsize) return R;
+    // (i): "left the world" (:285-290) from the position itself; a lane that left through a solid leaf or by exhaustion
+    // holds a position that passes this test
+    if (min3_nan_ignoring(pos.x, pos.y, pos.z) < 0.0f ||
+        max(max((uint32_t)trunc2i(pos.x), (uint32_t)trunc2i(pos.y)), (uint32_t)trunc2i(pos.z)) >= wsize)
+        return R;
     const bool stepped = step != -1.0f;
 
     R.hit = true;
