@@ -113,6 +113,8 @@ VRT_SYMBOLS = {
 
 def _load(name: str, symbols: dict) -> C.CDLL:
     path = os.path.join(_HERE, name)
+    if name == "libvrt.so" and os.environ.get("VRT_LIB"):   # development: A/B another build of the backend (tools/ab/)
+        path = os.environ["VRT_LIB"]
     if not os.path.exists(path):
         raise ImportError(
             f"{path} is missing — the native library is the product, there is no fallback. Build it with "

@@ -432,7 +432,6 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
         sqrtf(1.0f + (dir.x / dir.z) * (dir.x / dir.z) + (dir.y / dir.z) * (dir.y / dir.z))};
     const float ux = fabsf(unit.x), uy = fabsf(unit.y), uz = fabsf(unit.z);
     const uint32_t mxm = mx ? ~0u : 0u, mym = my ? ~0u : 0u, mzm = mz ? ~0u : 0u;
-    const uint32_t mx1 = mx ? 1u : 0u, my1 = my ? 1u : 0u, mz1 = mz ? 1u : 0u;
 
     const uint32_t wsize = P.world.size;
     const TableBuf gb = table_buffer(P.grid, P.grid_bytes), bb = table_buffer(P.bricks, P.brick_bytes);
@@ -440,46 +439,83 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
     const uint32_t row_bytes = (P.grid_dim + 1u) * 4u, slab_bytes = (P.grid_dim + 1u) * row_bytes;
 
     int vx = trunc2i(pos.x), vy = trunc2i(pos.y), vz = trunc2i(pos.z);  // pos > 0 here (or NaN -> 0)
+    // the voxel of the last lookup.  Only the slow path writes it; a lane on the fast path (a plain air leaf, not in water)
+    // always finds it 0: whatever sent it through the slow path before — an air or liquid brick entry, leaving water —
+    // left it 0 or left the lane in water, and a lane in water takes the slow path
     uint32_t voxel = 0u;
     // operands of the last step taken; a step is never negative, so -1 says "none yet" (the normal then stays zero, :272)
     float step = -1.0f, adx = 0.0f, ady = 0.0f, adz = 0.0f;
     float dew = -1.0f;  // dist_entered_water
+    // (l) lanes that have more to do than step through an air leaf carry a bit that pushes every entry out of the air-leaf
+    // range, so the fast path asks one question only: lanes inside water (dew != -1: bookkeeping even in air), and every
+    // lane of a `careful` wave (the shader's own bounds test, the lookup repeated at its i32(f32) coordinates)
+    uint32_t slow_bit = careful ? 0x80000000u : 0u;
     float total_len = 0.0f;
-    uint32_t iter = 0u;
+    uint32_t iter = 0u;      // wave-uniform trip count (loop control)
+    uint32_t looked_up = 0u; // STATS: node lookups of this lane (:221) — one less than its trips if it left through the border
+#ifdef VRT_EXP_VALU
+    uint32_t exp_acc = 0u;
+#endif
 
     for (;;) {
+        iter += 1u;
         // ---- find_node: cell, then brick ----
-        const uint32_t coff = mad_i24(vz >> 2, slab_bytes, mad_i24(vy >> 2, row_bytes, (uint32_t)vx & ~3u));
-        const uint32_t e = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(gb, coff, 0, 0);
+        uint32_t e = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(
+            gb, mad_i24(vz >> 2, slab_bytes, mad_i24(vy >> 2, row_bytes, (uint32_t)vx & ~3u)), 0, 0);
         uint32_t lo = e;    // an air leaf of the cell grid: the entry is lo, nothing else to do
-        voxel = 0u;
-        if (e - 1u >= 31u) {
-            if (e == 0u) break;  // border, or past either end of the grid: the position is outside the world
-            if ((int)e < 0) {
-                const uint32_t u = ((uint32_t)vx & 3u) | (((uint32_t)vy & 3u) << 2) | (((uint32_t)vz & 3u) << 4);
-                const uint32_t b = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(bb, (e + u) << 1, 0, 0);  // the shift drops bit 31
-                lo = b & 1u;
-                voxel = b >> 1;
-            } else {
-                lo = e & 31u;
-                voxel = e >> 16;
+        bool stop = false;
+        if ((e | slow_bit) - 1u >= 31u) {
+            if (careful) {  // wave-uniform: the shader's test (:285) on the shader's coordinates (i32(NaN) = 0), then its lookup
+                vx = trunc2i(pos.x);
+                vy = trunc2i(pos.y);
+                vz = trunc2i(pos.z);
+                e = 0u;
+                if (!(min3_nan_ignoring(pos.x, pos.y, pos.z) < 0.0f || max(max((uint32_t)vx, (uint32_t)vy), (uint32_t)vz) >= wsize))
+                    e = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(
+                        gb, mad_i24(vz >> 2, slab_bytes, mad_i24(vy >> 2, row_bytes, (uint32_t)vx & ~3u)), 0, 0);
+                lo = e;
             }
+            stop = e == 0u;  // border, or past either end of the grid: the position is outside the world
+            if (!stop) {
+                voxel = 0u;
+                if ((int)e < 0) {
+                    const uint32_t u = ((uint32_t)vx & 3u) | (((uint32_t)vy & 3u) << 2) | (((uint32_t)vz & 3u) << 4);
+                    const uint32_t b = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(bb, (e + u) << 1, 0, 0);  // the shift drops bit 31
+                    lo = b & 1u;
+                    voxel = b >> 1;
+                } else if (e > 31u) {
+                    lo = e & 31u;
+                    voxel = e >> 16;
+                }
+                if (STATS) { looked_up += 1u; R.visits += (uint32_t)__clz((int)(lo + 1u)) - 25u; }
+                if (voxel != 0u) {
+                    if (!is_liquid(s_liquid, voxel)) stop = true;                          // solid: the hit
+                    else if (dew == -1.0f) { dew = total_len; slow_bit = 0x80000000u; }    // liquid: water bookkeeping (:231-242)
+                } else if (dew != -1.0f) {
+                    R.water_dist += total_len - dew;
+                    dew = -1.0f;
+                    if (!careful) slow_bit = 0u;
+                }
+            }
+        } else if (STATS) {
+            looked_up += 1u;
+            R.visits += (uint32_t)__clz((int)(lo + 1u)) - 25u;  // depth + 1 node words on the reference's walk
         }
-        iter += 1u;  // a node was looked up (:221); the shader never looks one up outside the world
-        if (STATS) R.visits += (uint32_t)__clz((int)(lo + 1u)) - 25u;  // depth + 1 node words on the reference's walk
+        if (stop) break;
 
-        if (voxel != 0u) {
-            if (!is_liquid(s_liquid, voxel)) break;  // solid: the hit
-            if (dew == -1.0f) dew = total_len;       // liquid: water bookkeeping (:231-242)
-        } else if (dew != -1.0f) {
-            R.water_dist += total_len - dew;
-            dew = -1.0f;
-        }
-
+#ifdef VRT_EXP_VALU   // tools/ab experiments only: marginal cost of VRT_EXP_VALU extra simple VALU instructions per step
+#pragma unroll
+        for (int k_ = 0; k_ < VRT_EXP_VALU; k_++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(exp_acc) : "v"(lo));
+#endif
+#ifdef VRT_EXP_SALU   // ... of VRT_EXP_SALU extra scalar instructions per step
+#pragma unroll
+        for (int k_ = 0; k_ < VRT_EXP_SALU; k_++) asm volatile("s_mov_b32 vcc_lo, 0" ::: "vcc");
+#endif
         // ---- step to the leaf's exit face ----
-        const float tx = (float)(int)(bfi(lo, mxm, (uint32_t)vx) + mx1) - pos.x;
-        const float ty = (float)(int)(bfi(lo, mym, (uint32_t)vy) + my1) - pos.y;
-        const float tz = (float)(int)(bfi(lo, mzm, (uint32_t)vz) + mz1) - pos.z;
+        // (h) the exit plane: low = v & ~lo, high = (v | lo) + 1; the direction mask is 0 or ~0 = -1, so "+ 1" is "- mask"
+        const float tx = (float)(int)(bfi(lo, mxm, (uint32_t)vx) - mxm) - pos.x;
+        const float ty = (float)(int)(bfi(lo, mym, (uint32_t)vy) - mym) - pos.y;
+        const float tz = (float)(int)(bfi(lo, mzm, (uint32_t)vz) - mzm) - pos.z;
         // (b'') |t| * |unit| has the bits of (mask ? t : -t) * unit, except that a zero is always +0 (never observed)
         adx = abs_mul(tx, ux);
         ady = abs_mul(ty, uy);
@@ -494,29 +530,24 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
         pos.y += dir.y * (step == ady ? sp : step);
         pos.z += dir.z * (step == adz ? sp : step);
 
-        // the next lookup's coordinates.  Finite rays: floor — just beyond a face it is -1 or `size`, which the grid's
-        // border answers with 0.  A wave with a non-finite ray: i32(f32) as the shader has it (NaN -> 0) and its own
-        // test (:285) — those coordinates are then always inside the grid.
+        // the next lookup's coordinates: floor — just beyond a face it is -1 or `size`, which the grid's border answers
+        // with 0 (a `careful` wave looks its coordinates up again, as the shader has them)
         vx = flr2i(pos.x);
         vy = flr2i(pos.y);
         vz = flr2i(pos.z);
-        if (careful) {
-            vx = trunc2i(pos.x);
-            vy = trunc2i(pos.y);
-            vz = trunc2i(pos.z);
-            if (min3_nan_ignoring(pos.x, pos.y, pos.z) < 0.0f || max(max((uint32_t)vx, (uint32_t)vy), (uint32_t)vz) >= wsize) break;
-        }
-        if (iter >= kMaxSteps) break;
+        if (iter >= kMaxSteps) break;  // at most kMaxSteps lookups (:220); every lane still here has looked up exactly `iter` nodes
     }
-    // per-lane iteration counts are kept by the STATS kernels only (counters, step-count debug view); without them
-    // `iter` is one scalar loop counter per wave
-    R.iters = STATS ? iter : 0u;
+    // per-lane lookup counts are kept by the STATS kernels only (counters, step-count debug view)
+    R.iters = STATS ? looked_up : 0u;
     if (dew != -1.0f) R.water_dist += total_len - dew;
     // (i): "left the world" (:285-290) from the position itself; a lane that left through a solid leaf or by exhaustion
     // holds a position that passes this test
     if (min3_nan_ignoring(pos.x, pos.y, pos.z) < 0.0f ||
         max(max((uint32_t)trunc2i(pos.x), (uint32_t)trunc2i(pos.y)), (uint32_t)trunc2i(pos.z)) >= wsize)
         return R;
+#ifdef VRT_EXP_VALU
+    if (exp_acc == 0x12345u) voxel ^= 1u;
+#endif
     const bool stepped = step != -1.0f;
 
     R.hit = true;
