@@ -5,48 +5,42 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" is one frame: 1920x1080, 8x8x8-chunk procedural SVO world, 1 primary ray per pixel + 1 shadow ray
-per solid hit (config C2; inputs resident in HBM before the timed region).  With N > 1 the frame is
-sharded by interleaved 8x8 screen tiles over N processes (one per GPU) and gathered to rank 0 with one RCCL
-gather per frame plus a de-interleave kernel — total work fixed, so scaling is "strong".
+A "step" is one frame: 1920x1080, 8x8x8-chunk procedural SVO world, 1 primary ray per pixel + 1 shadow ray per solid
+hit (config C2; scene, derived tables and ndc tables resident in HBM before the timed region).  A timed frame issues
+the reference frame loop's whole seam (clientdesktop/src/main.rs:426-453: settings, camera, chunk_roots, world data,
+dispatch) with a camera that orbits slowly, so the frames in flight are different frames; `value_fixed_camera` is the
+same loop with the camera standing still and `value_1_in_flight` with one launch at a time.
+
+N > 1: the frame is sharded by interleaved 8x8 screen tiles (total work fixed: "strong" scaling), one process per GPU
+over RCCL (under torch.distributed.run, or started by this script itself when WORLD_SIZE is not set), or — with
+--single-process — one process driving N devices through the C ABI's own multi-device context (vrt_config.device_ids).
 Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+N_SIMD = 1024               # 256 CUs x 4 SIMD-32
+NOMINAL_GHZ = 2.4
 
 
-def algorithmic_bytes(st, width, height):
-    """SURVEY.md §8d / DESIGN.md §Algorithmic bytes, per kernel, from exact step / node-visit counts.
-
-    march step: 4 B chunk_roots entry + 2 B x L node words + 4 B material is_liquid  = 8 + 2L
-    primary kernel: + 16 B output per pixel (f32x3 + id word) + 16 B hit record per secondary ray launched
-    shadow kernel:  + 16 B hit record read per ray (+ 32 B rgb/id read-modify-write per occluded ray, not
-                    counted: occlusion count is not part of vrt_stats)"""
-    p_steps, p_vis = st.primary_steps, st.primary_node_visits
-    s_steps, s_vis = st.steps - p_steps, st.node_visits - p_vis
-    primary = 8 * p_steps + 2 * p_vis + 16 * st.primary_rays + 16 * st.secondary_rays
-    shadow = 8 * s_steps + 2 * s_vis + 16 * st.secondary_rays
-    # the fused launch (default): both marches, one texel store per pixel; its hit records never leave LDS
-    fused = 8 * st.steps + 2 * st.node_visits + 16 * st.primary_rays
-    return primary, shadow, fused
-
-
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--chunks", type=int, default=8, help="world size in chunks (8 = config C2)")
+    ap.add_argument("--chunks", type=int, default=8, help="world size in chunks (8 = config C2, 16 = C3)")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--mode", choices=["shadow", "primary", "path"], default="shadow",
                     help="shadow = the headline metric (config C2); path = the C4/C5 kernel family (not the headline)")
@@ -54,28 +48,84 @@ def main():
     ap.add_argument("--bounces", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frames-in-flight", type=int, default=2,
-                    help="N = 1: frames the backend keeps in flight (vrt_set_frames_in_flight; 1 = one launch at a time)")
+                    help="frames the backend keeps in flight (vrt_set_frames_in_flight; 1 = one launch at a time)")
+    ap.add_argument("--fixed-camera", action="store_true", help="headline loop with a standing camera and no per-frame seam calls")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra legs (fixed camera, 1 in flight, clock probe)")
+    ap.add_argument("--settle-seconds", type=float, default=2.0, help="upper bound of the clock-settling frames before the warm-up (0 = none)")
     ap.add_argument("--root-weight", type=int, default=0,
                     help="N > 1: tiles per period dealt to the gather root (vrt_config.shard_root_weight); 0 = measure "
                          "a few candidates off the clock and keep the fastest")
     ap.add_argument("--gather-batch", type=int, default=0,
                     help="N > 1: frames per gather (FrameGather.batch); 0 = measure {1, 2, 4, 8} off the clock and keep the fastest")
+    ap.add_argument("--single-process", action="store_true",
+                    help="N > 1: one process, N devices behind one vrt context (vrt_config.device_ids; peer stores over xGMI)")
     ap.add_argument("--force-gather", action="store_true",
                     help="development only: with --gpus 1, still run the pipelined RCCL gather + assemble path (one-rank group)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
-                    help="development only: run the N > 1 code path with every rank on cuda:0 and a gloo gather staged "
-                         "through host memory (RCCL refuses two ranks on one device); never used for reported numbers")
-    args = ap.parse_args()
+                    help="development only: run the N > 1 code path with every rank / device on cuda:0 (multi-process: a gloo "
+                         "gather staged through host memory, RCCL refuses two ranks on one device); never for reported numbers")
+    return ap.parse_args()
 
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: start one process per GPU ourselves — before anything touches torch or the GPU
+# ---------------------------------------------------------------------------------------------------------------------
+def self_launch(args) -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # rank 0's stdout carries the JSON line; the other ranks' stdout joins stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode]
+    for p in procs[1:]:
+        try:
+            rcs.append(p.wait(timeout=600))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rcs.append(-9)
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print(f"bench.py: ranks failed: {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
+def algorithmic_bytes(st):
+    """SURVEY.md §8d / DESIGN.md §Algorithmic bytes, from exact step / node-visit counts: what the *reference algorithm*
+    moves.  march step: 4 B chunk_roots entry + 2 B x L node words + 4 B material is_liquid = 8 + 2L; + 16 B texel per
+    primary ray; two-launch variants: + 16 B hit record written and read per secondary ray."""
+    p_steps, p_vis = st.primary_steps, st.primary_node_visits
+    s_steps, s_vis = st.steps - p_steps, st.node_visits - p_vis
+    primary = 8 * p_steps + 2 * p_vis + 16 * st.primary_rays + 16 * st.secondary_rays
+    shadow = 8 * s_steps + 2 * s_vis + 16 * st.secondary_rays
+    fused = 8 * st.steps + 2 * st.node_visits + 16 * st.primary_rays
+    return primary, shadow, fused
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.single_process:
+        sys.exit(self_launch(args))
+
+    import numpy as np
     import torch
-    from voxelraytracing_amd import Gpu, MODE_PATH, MODE_PRIMARY, MODE_PRIMARY_SHADOW, scenes
+    from voxelraytracing_amd import Gpu, MODE_PATH, MODE_PRIMARY, MODE_PRIMARY_SHADOW, _ffi, scenes
+    from voxelraytracing_amd import graphics as g
     from voxelraytracing_amd.shard import FrameGather
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    world = 1 if args.single_process else int(os.environ.get("WORLD_SIZE", "1"))
+    if not args.single_process and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU path")
     if args.rehearse_on_one_gpu:
@@ -113,6 +163,15 @@ def main():
     if MODE == MODE_PATH:
         sc.settings.max_ray_bounces = args.bounces
         scenes._diffuse(sc.materials)
+    # the orbit: ORBIT camera positions on a 6-voxel circle around the scene's eye, the view swinging +-8 degrees
+    ORBIT = 48
+    cams = []
+    for k in range(ORBIT):
+        a = 2.0 * math.pi * k / ORBIT
+        eye = (sc.eye[0] + 6.0 * math.cos(a), sc.eye[1] + 1.5 * math.sin(2 * a), sc.eye[2] + 6.0 * math.sin(a))
+        rot = (sc.rot[0] + 3.0 * math.sin(a), sc.rot[1] + 8.0 * math.sin(a), sc.rot[2])
+        cams.append((rot, eye))
+    world_data = sc.world.world_data()
     side = None
     if sharded:
         # One non-default torch stream carries everything of this rank: the backend's kernels (vrt_set_stream), the
@@ -122,21 +181,26 @@ def main():
         torch.cuda.set_stream(side)
         assert side.cuda_stream != 0
 
-    def make_pipeline(root_weight, batch=1):
+    devices = None
+    if args.single_process and args.gpus > 1:
+        devices = [0] * args.gpus if args.rehearse_on_one_gpu else list(range(args.gpus))
+
+    def make_pipeline(root_weight, batch=1, in_flight=None):
         """(backend context, FrameGather) for this rank.  N > 1: the root renders its own tiles straight into the
         row-major frame (VRT_FLAG_ROW_MAJOR) and takes root_weight tiles of every root_weight + N - 1."""
         in_place = world > 1
         compact = in_place and MODE != MODE_PATH and args.variant == 0   # 8 B/pixel over the links, shaded at the root
-        g = Gpu(sc.world.max_nodes(), sc.world.size_in_chunks(), sc.size, device=local_rank, shard_rank=rank, shard_count=world,
-                tile_major=sharded and not (in_place and rank == 0), root_weight=root_weight, row_major=in_place and rank == 0,
-                compact=compact and rank != 0)
-        g.upload_world(sc.world, sc.materials)
-        g.write_cam_data(sc.cam)
-        g.write_settings(sc.settings)
-        g.set_frames_in_flight(args.frames_in_flight)
+        kw = dict(devices=devices, root_weight=root_weight) if devices else \
+            dict(shard_rank=rank, shard_count=world, tile_major=sharded and not (in_place and rank == 0), root_weight=root_weight,
+                 row_major=in_place and rank == 0, compact=compact and rank != 0)
+        gp = Gpu(sc.world.max_nodes(), sc.world.size_in_chunks(), sc.size, device=local_rank, **kw)
+        gp.upload_world(sc.world, sc.materials)
+        gp.write_cam_data(sc.cam)
+        gp.write_settings(sc.settings)
+        gp.set_frames_in_flight(args.frames_in_flight if in_flight is None else in_flight)
         f = None
         if sharded:
-            g.set_stream(side.cuda_stream)
+            gp.set_stream(side.cuda_stream)
             f = FrameGather(torch, dist, rank, world, args.width, args.height, torch.device("cuda", local_rank),
                             root_weight=root_weight, in_place=in_place, compact=compact, batch=batch)
             if args.rehearse_on_one_gpu:
@@ -147,42 +211,67 @@ def main():
                     if rank == 0:
                         f.recv[which].copy_(torch.stack(parts))
                 f.gather = staged_gather
-        return g, f
+        return gp, f
 
-    def run_frames(g, f, n):
+    frame_no = [0]
+
+    def seam(gp, fixed):
+        """What draw_frame does before the dispatch (main.rs:426-449): settings, camera, chunk_roots, world data."""
+        if fixed:
+            return
+        rot, eye = cams[frame_no[0] % ORBIT]
+        frame_no[0] += 1
+        gp.write_settings(sc.settings)
+        gp.write_cam_data(g.cam_data_create(rot, eye, 70.0, (float(args.width), float(args.height))))
+        gp.write_chunk_roots(sc.world.chunk_roots())     # a fresh S^3 table every frame, as the reference does (world.rs:154-159)
+        gp.write_world_data(world_data)
+
+    def run_frames(gp, f, n, fixed=False):
         for _ in range(n if (f is None or args.rehearse_on_one_gpu) else 0):
+            seam(gp, fixed)
             if f is None:
-                g.render(MODE, **rkw)
+                gp.render(MODE, **rkw)
             else:
-                f.bind(g, 0)
-                g.render(MODE, **rkw)
+                f.bind(gp, 0)
+                gp.render(MODE, **rkw)
                 f.gather()
                 if rank == 0:
-                    f.assemble(g, 0)
+                    f.assemble(gp, 0)
         if f is not None and not args.rehearse_on_one_gpu:
             # the in-place root's own tiles never feed the collective: they run on the backend's in-flight streams
             own = dict(own_streams=True) if (f.in_place and rank == 0 and MODE != MODE_PATH) else {}
+
+            def one():
+                seam(gp, fixed)
+                gp.render(MODE, **rkw, **own)
             left = n
             while left > 0:   # the gather of a batch overlaps the render of the next
-                f.submit(g, lambda: g.render(MODE, **rkw, **own), min(left, f.batch))
+                f.submit(gp, one, min(left, f.batch))
                 left -= f.batch
-            f.drain(g)
+            f.drain(gp)
 
-    # ---- N > 1: how much of the frame the gather root should trace itself (off the clock) ----
+    def sync():
+        if sharded:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(gp, f, n, fixed=False):
+        sync()
+        t0 = time.perf_counter()
+        run_frames(gp, f, n, fixed)
+        sync()
+        dt = time.perf_counter() - t0
+        return float(all_reduce(torch.tensor([dt], dtype=torch.float64, device="cuda"), dist.ReduceOp.MAX if world > 1 else None)[0])
+
+    # ---- N > 1 (one process per GPU): how much of the frame the gather root should trace itself (off the clock) ----
     root_weight, batch, tuning, batch_tuning = 1, 1, None, None
     if world > 1:
         def trial(w0, b):
-            g, f = make_pipeline(w0, b)
-            run_frames(g, f, 8)
-            dist.barrier()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            run_frames(g, f, 48)
-            dist.barrier()
-            torch.cuda.synchronize()
-            dt = all_reduce(torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda"), dist.ReduceOp.MAX)
-            g.close()
-            return float(dt[0]) / 48 * 1e3      # the all-reduced times are identical on every rank
+            gp, f = make_pipeline(w0, b)
+            run_frames(gp, f, 8, True)
+            dt = timed(gp, f, 48, True)
+            gp.close()
+            return dt / 48 * 1e3      # the all-reduced times are identical on every rank
         rehearsal = args.rehearse_on_one_gpu   # (its staged gather moves whole message buffers: one frame per gather)
         batch = args.gather_batch if args.gather_batch > 0 else (1 if rehearsal else 4)
         if args.root_weight > 0:
@@ -195,61 +284,117 @@ def main():
             batch = min(batch_tuning, key=lambda k: (batch_tuning[k], k))
     elif sharded and args.gather_batch > 0:
         batch = args.gather_batch   # --force-gather: the one-rank pipeline with batched gathers
+    elif devices:
+        root_weight = args.root_weight if args.root_weight > 0 else {2: 4, 4: 3, 8: 2}.get(args.gpus, 2)
     gpu, fg = make_pipeline(root_weight, batch)
 
-    # exact ray / step / node-visit counts of this frame (deterministic; a stats frame is never timed)
-    if fg is not None:
-        fg.bind(gpu, 0)
-    gpu.render(MODE, stats=True, **(dict(rkw, variant=0) if rkw.get("variant") == 4 else rkw))   # (the persistent grid has no stats form)
-    st = gpu.stats()
-    counts = all_reduce(torch.tensor([st.primary_rays, st.secondary_rays], dtype=torch.int64, device="cuda"))
-    rays_per_frame = int(counts[0] + counts[1])
+    # ---- exact ray / step / node-visit counts (deterministic; a stats frame is never timed): the scene's own camera,
+    # and the ray count of every camera of the orbit ----
+    def stats_frame(cam):
+        gpu.write_cam_data(cam)
+        if fg is not None:
+            fg.bind(gpu, 0)
+        gpu.render(MODE, stats=True, **(dict(rkw, variant=0) if rkw.get("variant") == 4 else rkw))   # (the persistent grid has no stats form)
+        return gpu.stats()
+    orbit_rays = []
+    for rot, eye in cams:
+        s_ = stats_frame(g.cam_data_create(rot, eye, 70.0, (float(args.width), float(args.height))))
+        orbit_rays.append([s_.primary_rays, s_.secondary_rays])
+    st = stats_frame(sc.cam)
+    steps_img = None
+    if not sharded and not devices and MODE != MODE_PATH:
+        steps_img = gpu.read_steps()    # per pixel: primary | shadow << 16 march steps of the fixed-camera frame
+    counts = all_reduce(torch.tensor(orbit_rays + [[st.primary_rays, st.secondary_rays]], dtype=torch.int64, device="cuda")).cpu().numpy()
+    orbit_rays = counts[:-1].sum(axis=1)
+    rays_fixed = int(counts[-1].sum())
 
-    # set-up, off the clock like the scene build and the share tuning: let the clocks settle (a cold chip runs the first
-    # ~hundred frames ~4 % slower), then the W warm-up frames the caller asked for
-    if not args.rehearse_on_one_gpu:
-        torch.cuda.synchronize()
-        t_probe = time.perf_counter()
-        run_frames(gpu, fg, 2)
-        torch.cuda.synchronize()
-        per_frame = (time.perf_counter() - t_probe) / 2
-        run_frames(gpu, fg, int(min(300, max(2, 0.05 / max(per_frame, 1e-6)))))   # ~50 ms, at most 300 frames
-    run_frames(gpu, fg, args.warmup)
+    # ---- set-up, off the clock like the scene build and the share tuning: let the clocks settle — consecutive 50-frame
+    # windows within 1 % of each other, at most 2 s — then the W warm-up frames the caller asked for ----
+    fixed = args.fixed_camera
+    settle = {"windows": 0, "ms_per_frame": None, "converged": False}
+    if not args.rehearse_on_one_gpu and args.settle_seconds > 0:
+        t_end = time.perf_counter() + args.settle_seconds
+        prev = None
+        while time.perf_counter() < t_end:
+            cur = timed(gpu, fg, 50, fixed) / 50
+            settle["windows"] += 1
+            settle["ms_per_frame"] = cur * 1e3
+            if prev is not None and abs(cur - prev) <= 0.01 * prev:
+                settle["converged"] = True
+                break
+            prev = cur
+    run_frames(gpu, fg, args.warmup, fixed)
     gpu.stats()  # drop the warm-up frames' kernel timings
-    if sharded:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run_frames(gpu, fg, args.steps)   # every timed frame is gathered and assembled on rank 0 before the clock stops
-    if sharded:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    dt = float(all_reduce(torch.tensor([dt], dtype=torch.float64, device="cuda"), dist.ReduceOp.MAX if world > 1 else None)[0])
+    frame_no[0] = 0
+    dt = timed(gpu, fg, args.steps, fixed)   # every timed frame is gathered and assembled on rank 0 before the clock stops
+    rays_total = rays_fixed * args.steps if fixed else int(sum(int(orbit_rays[i % ORBIT]) for i in range(args.steps)))
+    kst = gpu.stats()   # per-kernel durations over exactly the timed frames: HIP events on the streams the kernels ran on
 
-    # per-kernel durations over exactly the timed frames: HIP events on the stream the kernels ran on
-    kst = gpu.stats()
+    # ---- extra legs, off the headline clock (N = 1): standing camera, one launch at a time, the clock the march runs at ----
+    extras = {}
+    if world == 1 and not sharded and not devices and not args.no_extras:
+        if not fixed:
+            gpu.write_cam_data(sc.cam)
+            run_frames(gpu, fg, 50, True)
+            d2 = timed(gpu, fg, args.steps, True)
+            gpu.stats()
+            extras["value_fixed_camera"] = rays_fixed * args.steps / d2 / 1e6
+            extras["ms_per_step_fixed_camera"] = d2 / args.steps * 1e3
+        if args.frames_in_flight != 1:
+            gpu.set_frames_in_flight(1)
+            gpu.write_cam_data(sc.cam)
+            run_frames(gpu, fg, 50, True)
+            d1 = timed(gpu, fg, args.steps, True)
+            k1 = gpu.stats()
+            extras["value_1_in_flight"] = rays_fixed * args.steps / d1 / 1e6
+            extras["ms_per_step_1_in_flight"] = d1 / args.steps * 1e3
+            extras["avg_launch_ms_1_in_flight"] = k1.sum_ms_primary / max(k1.frames, 1)
+            gpu.set_frames_in_flight(args.frames_in_flight)
+        if MODE == MODE_PRIMARY_SHADOW and args.variant == 0:
+            # the clock: right behind the timed load, frames of the probe build (the same kernel + two stamps per wave)
+            run_frames(gpu, fg, 100, True)
+            gpu.stats()
+            for _ in range(200):
+                gpu.render(MODE, stats=2)
+            cs = gpu.stats()
+            if cs.clock_ref_ticks:
+                extras["shader_clock_ghz"] = cs.clock_shader_ticks / cs.clock_ref_ticks * 0.1   # x 100 MHz
+
     if sharded and rank == 0 and os.environ.get("VRT_BENCH_VERIFY", "1") == "1":
         # off the clock: the assembled frame must equal an unsharded render of the same frame on this GPU
+        last = cams[(frame_no[0] - 1) % ORBIT] if not fixed else None
+        cam = sc.cam if fixed else g.cam_data_create(last[0], last[1], 70.0, (float(args.width), float(args.height)))
         ref = Gpu(sc.world.max_nodes(), sc.world.size_in_chunks(), sc.size, device=local_rank)
         ref.upload_world(sc.world, sc.materials)
-        ref.write_cam_data(sc.cam)
+        ref.write_cam_data(cam)
         ref.write_settings(sc.settings)
         ref.render(MODE, **rkw)
         r_rgb, r_ids, _ = ref.read_output()
         from voxelraytracing_amd.shard import texels_to_frame
-        import numpy as np
         a_rgb, a_ids = texels_to_frame(fg.frame.cpu().numpy().view(np.uint32))
         if not (np.array_equal(a_ids, r_ids) and np.array_equal(a_rgb, r_rgb)):
             raise SystemExit("gathered frame differs from the unsharded render")
         ref.close()
+    if devices and os.environ.get("VRT_BENCH_VERIFY", "1") == "1":
+        ref = Gpu(sc.world.max_nodes(), sc.world.size_in_chunks(), sc.size, device=0)
+        ref.upload_world(sc.world, sc.materials)
+        last = cams[(frame_no[0] - 1) % ORBIT] if not fixed else None
+        ref.write_cam_data(sc.cam if fixed else g.cam_data_create(last[0], last[1], 70.0, (float(args.width), float(args.height))))
+        ref.write_settings(sc.settings)
+        ref.render(MODE, **rkw)
+        r_rgb, r_ids, _ = ref.read_output()
+        a_rgb, a_ids, _ = gpu.read_output()
+        if not (np.array_equal(a_ids, r_ids) and np.array_equal(a_rgb, r_rgb)):
+            raise SystemExit("the multi-device frame differs from the single-device render")
+        ref.close()
     if rank != 0:
         dist.destroy_process_group()
         return
+
     ai = gpu.accel_info()
     derived = {"available": bool(ai.available), "cells": int(ai.cells), "bricks": int(ai.bricks), "bytes": int(ai.bytes),
-               "builds": int(ai.builds), "last_build_ms": round(float(ai.last_build_ms), 4)}
-    b_primary, b_shadow, b_fused = algorithmic_bytes(st, args.width, args.height)  # rank 0's own launches (its shard when N > 1)
+               "builds": int(ai.builds), "chunk_builds": int(ai.chunk_builds), "last_build_ms": round(float(ai.last_build_ms), 4)}
+    b_primary, b_shadow, b_fused = algorithmic_bytes(st)  # rank 0's own launches (its shard when N > 1), fixed-camera frame
     ms_p = kst.sum_ms_primary / max(kst.frames, 1)
     ms_s = kst.sum_ms_secondary / max(kst.frames, 1)
     fused = args.mode == "shadow" and args.variant in (0, 4) and ms_s == 0.0  # one launch: no second kernel was timed
@@ -259,69 +404,110 @@ def main():
         dom_name, dom_bytes, dom_ms = ("path_primary_march", b_primary, ms_p) if ms_p >= ms_s else ("path_bounce_marches", b_shadow, ms_s)
     else:
         dom_name, dom_bytes, dom_ms = ("primary_march", b_primary, ms_p) if ms_p >= ms_s else ("shadow_march", b_shadow, ms_s)
-    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    # frames in flight: consecutive launches overlap on the chip, so a launch's own begin-to-end time (what the events
-    # and rocprofv3 report) is longer than the frame period; `achieved` stays bytes per launch / that duration,
-    # `achieved_aggregate` is what the in-flight launches deliver together
-    in_flight = args.frames_in_flight if (world == 1 and not sharded and (fused or args.mode == "primary")) else 1
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get(dom_name)
-        except Exception:
-            traffic = None
+    period_s = dt / args.steps
+    in_flight = args.frames_in_flight if (world == 1 and not sharded and not devices and (fused or args.mode == "primary")) else 1
 
-    # what actually binds the kernel: VALU issue.  SIMD cycles available per VALU wave-instruction at the
-    # measured frame period (1 024 SIMDs at the nominal 2.4 GHz); the simple class issues in ~2.5 cycles, the half-rate
-    # class in ~4.2 (tools/valu_rates.hip), so a value between the two means the SIMDs issue VALU back to back
-    valu = None
+    # ---- what bounds the dominant kernel: instruction issue.  Counters come from profiles/traffic_latest.json, which the
+    # PMC tool stamps with the code object and the workload it measured; they are printed only for that very build and workload
+    code = _ffi.code_object_sha256()
+    workload_key = f"{args.mode}:{args.chunks}:{args.width}x{args.height}:v{args.variant}"
+    pmc, pmc_note = None, None
     try:
-        n_valu = json.load(open(tpath)).get("valu_wave_instructions", {}).get(dom_name)
-        if n_valu and world == 1 and not sharded:
-            valu = {"wave_instructions_per_launch": n_valu, "simds": 1024, "clock_ghz": 2.4,
-                    "simd_cycles_per_instruction": dt / args.steps * 2.4e9 * 1024 / n_valu,
-                    "issue_cost_cycles": {"simple": 2.5, "half_rate": 4.2, "transcendental": 8.1}}
-    except Exception:
-        valu = None
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+        if tj.get("code_object_sha256") != code:
+            pmc_note = "profiles/traffic_latest.json was collected on another build of the kernels (code-object hash differs): not printed"
+        elif tj.get("workload") != workload_key:
+            pmc_note = f"profiles/traffic_latest.json holds workload {tj.get('workload')}, this run is {workload_key}: not printed"
+        else:
+            pmc = tj.get("kernels", {}).get(dom_name)
+    except Exception as e:
+        pmc_note = f"profiles/traffic_latest.json unreadable: {e}"
+    clock_ghz = extras.get("shader_clock_ghz")
+    peak_clock = clock_ghz or NOMINAL_GHZ
+    roof = {"bound": "valu_issue", "kernel": dom_name, "unit": "G wave-instructions/s",
+            # one VALU wave64 instruction holds a SIMD-32 for 2 cycles: 1024 SIMDs x clock / 2
+            "peak": N_SIMD * peak_clock / 2.0, "peak_clock_ghz": peak_clock,
+            "peak_clock_source": "measured in-kernel (s_memtime / s_memrealtime, probe build, right behind the timed frames)" if clock_ghz
+                                 else "nominal (no probe in this mode)",
+            "achieved": None, "frac": None, "traffic": None,
+            "frame_period_ms": period_s * 1e3, "launches_in_flight": in_flight, "avg_launch_ms": dom_ms,
+            "kernels_ms": ({"primary_shadow_march": ms_p} if fused else
+                           {"path_primary_march": ms_p, "path_bounce_marches": ms_s} if args.mode == "path" else
+                           {"primary_march": ms_p, "shadow_march": ms_s}),
+            "frames_timed": kst.frames, "code_object_sha256": code}
+    if pmc_note:
+        roof["pmc_note"] = pmc_note
+    if pmc and world == 1 and not sharded and not devices:
+        n_valu, n_salu = pmc["valu_wave_instructions"], pmc.get("salu_wave_instructions")
+        period_fixed = (extras.get("ms_per_step_fixed_camera", period_s * 1e3) if not fixed else period_s * 1e3) * 1e-3
+        roof["achieved"] = n_valu / period_fixed / 1e9          # the counters are of the fixed-camera frame: its period
+        roof["frac"] = roof["achieved"] / roof["peak"]
+        roof["traffic"] = pmc["hbm_bytes"]
+        roof["valu_wave_instructions_per_launch"] = n_valu
+        roof["salu_wave_instructions_per_launch"] = n_salu
+        roof["period_used_ms"] = period_fixed * 1e3
+        # the same with every class at its measured issue cost (tools/valu_rates.hip): SIMD cycles the launch's
+        # instructions need / SIMD cycles the frame period offers
+        cls = pmc.get("issue_cycles_by_class")
+        if cls:
+            need = sum(cls.values())
+            roof["class_weighted"] = {"issue_cycles_per_launch": cls, "simd_cycles_available": N_SIMD * peak_clock * 1e9 * period_fixed,
+                                      "frac": need / (N_SIMD * peak_clock * 1e9 * period_fixed)}
+    # §8(d)'s algorithmic bytes stay as a secondary object; a fraction above 1 says the kernel does not move those bytes
+    # (the derived tables answer from L1 / L2); `measured_hbm` is what the PMC passes saw
+    hbm = {"algorithmic_bytes_per_launch": dom_bytes, "algorithmic_gbs_at_frame_period": dom_bytes / period_s / 1e9,
+           "frac_of_hbm_peak": dom_bytes / period_s / 1e9 / HBM_PEAK_GBS, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "note": "bytes of the reference algorithm (SURVEY 8d); frac > 1 = not moved: the grid march reads derived tables that hit in L1/L2"}
+    if roof["traffic"]:
+        hbm["measured_hbm_bytes_per_launch"] = roof["traffic"]
+        hbm["measured_hbm_gbs"] = roof["traffic"] / period_s / 1e9
+        hbm["measured_frac_of_hbm_peak"] = hbm["measured_hbm_gbs"] / HBM_PEAK_GBS
+    # wave-level march trips of the fixed-camera frame, from the per-pixel step counts: a tile's wave runs max-over-lanes trips
+    if steps_img is not None:
+        t = steps_img.reshape(args.height // 8, 8, args.width // 8, 8)
+        prim = (t & 0xFFFF).max(axis=(1, 3)).astype(np.int64)
+        shad = (t >> 16).max(axis=(1, 3)).astype(np.int64)
+        lane_steps = int((steps_img & 0xFFFF).sum() + (steps_img >> 16).sum())
+        roof["wave_march_trips_per_launch"] = {"primary": int(prim.sum()), "shadow": int(shad.sum()),
+                                               "lane_steps": lane_steps, "lane_utilisation_of_trips": lane_steps / (64.0 * (prim.sum() + shad.sum()))}
 
     out = {
         "metric": "Mrays/s at 1920x1080, 1 primary + 1 shadow ray",
-        "value": rays_per_frame * args.steps / dt / 1e6,
+        "value": rays_total / dt / 1e6,
         "unit": "Mrays/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3,
+        "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": period_s * 1e3,
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"{'C2' if (args.chunks, args.width, args.height) == (8, 1920, 1080) else 'C2-family'}: {args.width}x{args.height} frame, {args.chunks}x{args.chunks}x{args.chunks}-chunk procedural SVO "
+        "config": {"workload": f"{'C2' if (args.chunks, args.width, args.height) == (8, 1920, 1080) else 'C3' if (args.chunks, args.width, args.height) == (16, 1920, 1080) else 'C2-family'}: "
+                               f"{args.width}x{args.height} frame, {args.chunks}x{args.chunks}x{args.chunks}-chunk procedural SVO "
                                f"world (seed 1), 1 primary + 1 shadow ray per solid hit",
-                   "rays_per_frame_actual": rays_per_frame, "rays_per_frame_nominal": 2 * args.width * args.height,
-                   "sharding": ("whole frame" if not sharded else "whole frame through the one-rank gather pipeline") if world == 1 else
-                               f"8x8 tiles interleaved over {world} ranks ({root_weight} of every {root_weight + world - 1} to the gather root, "
-                               f"which renders them in place) + RCCL gather of the other ranks' tile buffers "
-                               f"({'8-byte records shaded at the root' if MODE != MODE_PATH and args.variant == 0 else '16-byte texels'}) to rank 0",
+                   "camera": "standing" if fixed else f"orbit of {ORBIT} positions (6-voxel circle, +-8 degrees), the whole per-frame seam of main.rs:426-453 issued every frame",
+                   "rays_per_frame_actual": rays_fixed if fixed else float(np.mean(orbit_rays)), "rays_per_frame_nominal": 2 * args.width * args.height,
+                   "rays_per_frame_fixed_camera": rays_fixed,
+                   "sharding": ("whole frame" if not sharded else "whole frame through the one-rank gather pipeline") if (world == 1 and not devices) else
+                               (f"one process, {args.gpus} devices behind one vrt context (vrt_config.device_ids): 8x8 tiles interleaved, "
+                                f"{root_weight} of every {root_weight + args.gpus - 1} to device 0, the others store 8-byte records straight into device 0's memory over xGMI"
+                                if devices else
+                                f"8x8 tiles interleaved over {world} ranks ({root_weight} of every {root_weight + world - 1} to the gather root, "
+                                f"which renders them in place) + RCCL gather of the other ranks' tile buffers "
+                                f"({'8-byte records shaded at the root' if MODE != MODE_PATH and args.variant == 0 else '16-byte texels'}) to rank 0"),
                    "root_weight": root_weight, "root_weight_tuning_ms_per_frame": tuning,
                    "frames_per_gather": batch, "frames_per_gather_tuning_ms_per_frame": batch_tuning,
+                   "frames_in_flight": args.frames_in_flight, "clock_settle": settle,
                    "kernel_variant": args.variant, "derived_tables": derived},
-        "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "launches_in_flight": in_flight,
-                     "achieved_aggregate": achieved * in_flight, "frame_period_ms": dt / args.steps * 1e3, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
-                     "kernels_ms": ({"primary_shadow_march": ms_p} if fused else
-                                    {"path_primary_march": ms_p, "path_bounce_marches": ms_s} if args.mode == "path" else
-                                    {"primary_march": ms_p, "shadow_march": ms_s}),
-                     "frames_timed": kst.frames},
+        "roofline": roof,
+        "hbm": hbm,
     }
-    if valu is not None:
-        out["valu_issue"] = valu
+    out.update(extras)
     if args.mode != "shadow":
         out["metric"] = f"Mrays/s at {args.width}x{args.height}, mode {args.mode}" + (f" {args.bounces} bounces {args.spp} spp" if args.mode == "path" else "")
         out["config"]["workload"] = out["config"]["workload"].replace("C2:", "non-headline:").replace("1 primary + 1 shadow ray per solid hit", f"mode {args.mode}")
-    if world == 1 and not args.no_cpu_baseline and args.mode == "shadow":
-        out["cpu_baseline"] = cpu_baseline(sc, args, rays_per_frame)
+    if world == 1 and not devices and not args.no_cpu_baseline and args.mode == "shadow":
+        out["cpu_baseline"] = cpu_baseline(sc, args, rays_fixed)
     print(json.dumps(out), flush=True)
     if sharded:
         dist.destroy_process_group()
@@ -346,13 +532,13 @@ def usable_cores():
 def cpu_baseline(sc, args, rays_per_frame):
     """The oracle (a port, not the reference: the reference is WGSL on wgpu and has no CPU tracer) timed on
     this box's host cores over a bounded sample of the same workload: whole frames of the same scene and
-    camera, repeated for about 3 s of wall time (>= 2 frames)."""
+    standing camera, repeated for about 8 s of wall time (>= 2 frames), plus one frame on one thread."""
     from oracle import orc
     o = orc.from_package_scene(sc)
     cores = usable_cores()
     times = []
     t_all = time.perf_counter()
-    while len(times) < 2 or (time.perf_counter() - t_all < 3.0 and len(times) < 50):
+    while len(times) < 2 or (time.perf_counter() - t_all < 8.0 and len(times) < 60):
         t0 = time.perf_counter()
         _, _, _, cst = o.render(orc.MODE_PRIMARY_SHADOW, args.width, args.height, threads=cores)
         times.append(time.perf_counter() - t0)
@@ -363,8 +549,8 @@ def cpu_baseline(sc, args, rays_per_frame):
     o.render(orc.MODE_PRIMARY_SHADOW, args.width, args.height, threads=1)
     dt1 = time.perf_counter() - t0
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port", "value_1_thread": rays / dt1 / 1e6,
-            "sample": f"{len(times)} full {args.width}x{args.height} frames of the same scene (median {dt:.3f} s/frame, "
-                      f"{sum(times):.1f} s total), OpenMP dynamic over 8-row bands"}
+            "sample": f"{len(times)} full {args.width}x{args.height} frames of the same scene, standing camera (median {dt:.3f} s/frame, "
+                      f"{sum(times):.1f} s total), OpenMP dynamic over 8-row bands; + 1 frame on 1 thread ({dt1:.1f} s)"}
 
 
 if __name__ == "__main__":

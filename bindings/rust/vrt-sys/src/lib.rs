@@ -123,6 +123,8 @@ pub struct vrt_stats {
     pub sum_ms_primary: f64,
     pub sum_ms_secondary: f64,
     pub sum_ms_total: f64,
+    pub clock_shader_ticks: u64,
+    pub clock_ref_ticks: u64,
 }
 
 #[repr(C)]
@@ -190,7 +192,7 @@ mod layout {
         assert_eq!(size_of::<vrt_crosshair>(), 32);
         assert_eq!(size_of::<vrt_config>(), 36);
         assert_eq!(size_of::<vrt_render_opts>(), 32);
-        assert_eq!(size_of::<vrt_stats>(), 96);
+        assert_eq!(size_of::<vrt_stats>(), 112);
         assert_eq!(size_of::<vrt_accel_info>(), 48);
     }
 }

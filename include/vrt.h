@@ -124,7 +124,9 @@ typedef struct {
                         * shadow fused into one launch), 1 = literal octree walk (the shader's text), 2 = ancestor-cache
                         * octree walk, 3 = grid march with the shadow rays as a second launch, 4 = variant 0's work as a persistent grid
                         * pulling tiles from per-XCD queues (primary + shadow frames only); DESIGN.md §Kernels */
-    uint32_t stats;    /* 1: also count steps / node visits this frame (slower; not for timing) */
+    uint32_t stats;    /* 1: also count steps / node visits this frame (slower; not for timing); 2: clock probe — the default
+                        * primary + shadow kernel with s_memtime / s_memrealtime stamps around one wave in sixteen
+                        * (vrt_stats.clock_*; the frame itself is the normal one) */
     uint32_t spp;      /* VRT_MODE_PATH only */
     uint32_t seed;     /* VRT_MODE_PATH only */
     uint32_t flags;    /* VRT_RENDER_* */
@@ -153,6 +155,8 @@ typedef struct {
     double sum_ms_primary;        /* kernel times (one hipEvent triple per frame, recorded on the stream */
     double sum_ms_secondary;      /* the kernels run on) */
     double sum_ms_total;
+    uint64_t clock_shader_ticks;  /* clock-probe frames (opts.stats = 2) since the previous vrt_get_stats: summed s_memtime */
+    uint64_t clock_ref_ticks;     /* ... and s_memrealtime (100 MHz) differences: shader clock = 100 MHz x their ratio */
 } vrt_stats;
 
 /* Per-pixel id word written next to the f32 radiance (build-defined; bit-exact parity target):

@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""tools/isa_mix.py [--out profiles/rNN_isa_mix] — instruction mix of the default march kernel, from its ISA.
+
+Compiles csrc/vrt_kernels.hip to gfx950 assembly with the Makefile's flags (hipcc -S, device only), takes the kernel the
+bench times (primary_shadow_wave_kernel<0, false, false, 4>: grid march, primary + shadow in one launch), finds its two
+march loops (primary ray, shadow ray) and classifies every instruction of every basic block of each loop:
+
+    valu_simple   full-rate VALU (add / sub / mul / fma / and / or / xor / shifts / mov, incl. the VOP3 forms with modifiers)
+    valu_half     half-rate VALU: compares, v_cndmask, conversions, min / max, the three-operand integer ops
+                  (v_bfi, v_mad_*24, v_min3 / v_max3, v_lshl_or, v_add3, v_or3, v_and_or, v_add_lshl), v_div_fixup, v_*_co_*
+    valu_pk       packed f32 (v_pk_*: two floats per instruction)
+    valu_trans    transcendental (rcp / sqrt / rsq / exp / log / sin / cos)
+    salu          scalar ALU (incl. the exec-mask bookkeeping of divergent control flow)
+    branch        s_branch / s_cbranch_*
+    wait_nop      s_waitcnt / s_nop
+    vmem / lds / smem
+
+(the classes and their issue costs are measured by tools/valu_rates.hip -> profiles/rNN_valu_issue_rates.txt).  The *fast
+path* of a loop is what a wave executes on a march step in which every lane is in a plain air leaf of the cell grid: the
+header block, the block where the slow region rejoins, the step arithmetic and the latch.  Writes <out>.json (counts,
+code-object hash of the library in the tree) and <out>.txt (the listing of both loops, block by block).
+"""
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+KERNEL = "_ZN3vrt26primary_shadow_wave_kernelILi0ELb0ELb0ELi4ELb0EEEvNS_11FrameParamsE"
+HIPFLAGS = ("-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt "
+            "-fno-gpu-flush-denormals-to-zero -Wno-unused-value").split()
+
+TRANS = ("v_rcp", "v_sqrt", "v_rsq", "v_exp", "v_log", "v_sin", "v_cos")
+HALF = ("v_cmp", "v_cmpx", "v_cndmask", "v_cvt", "v_floor", "v_ceil", "v_trunc", "v_rndne", "v_fract", "v_min", "v_max", "v_med3", "v_bfi",
+        "v_bfe", "v_mad_u32_u24", "v_mad_i32_i24", "v_mul_u32_u24", "v_mul_i32_i24", "v_lshl_or", "v_lshl_add", "v_add3", "v_or3",
+        "v_and_or", "v_add_lshl", "v_xad", "v_div_fixup", "v_div_scale", "v_div_fmas", "v_perm", "v_alignbit", "v_sad", "v_mul_lo",
+        "v_mul_hi", "v_mad_u64", "v_ldexp", "v_frexp", "v_readlane", "v_readfirstlane", "v_writelane", "v_mbcnt", "v_bcnt", "v_ffb")
+
+
+def classify(op: str) -> str:
+    if op.startswith("v_pk_"):
+        return "valu_pk"
+    if op.startswith(TRANS):
+        return "valu_trans"
+    if op.startswith("v_") and ("_co_" in op or op.startswith(HALF)):
+        return "valu_half"
+    if op.startswith("v_"):
+        return "valu_simple"
+    if op in ("s_waitcnt", "s_nop") or op.startswith("s_waitcnt"):
+        return "wait_nop"
+    if op.startswith(("s_branch", "s_cbranch")):
+        return "branch"
+    if op.startswith(("s_load", "s_buffer_load")):
+        return "smem"
+    if op.startswith("s_"):
+        return "salu"
+    if op.startswith(("buffer_", "global_", "flat_", "scratch_")):
+        return "vmem"
+    if op.startswith("ds_"):
+        return "lds"
+    return "other"
+
+
+def kernel_text(asm: str) -> list:
+    lines = asm.splitlines()
+    start = next(i for i, l in enumerate(lines) if l.startswith(KERNEL + ":"))
+    end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
+    return lines[start + 1:end + 1]
+
+
+def blocks_of(lines):
+    """[(label, [instruction lines], is_loop_header, in_loop_of)] in layout order."""
+    out, cur, label = [], [], "entry"
+    hdr, inloop = False, None
+    for l in lines:
+        m = re.match(r"^(\.LBB\d+_\d+):\s*(;.*)?$", l) or re.match(r"^; %bb\.(\d+):\s*(;.*)?$", l)
+        if m:
+            out.append((label, cur, hdr, inloop))
+            label, cur = (m.group(1) if l.startswith(".") else "bb." + m.group(1)), []
+            c = m.group(2) or ""
+            hdr = "Loop Header" in c and "in Loop" not in c.split("Loop Header")[0][-12:] and "=>This" in c
+            mm = re.search(r"in Loop: Header=(BB\d+_\d+)", c)
+            inloop = ("." + "L" + mm.group(1)) if mm else (label if hdr else None)
+            continue
+        t = l.split(";")[0].strip()
+        if not t or t.startswith((".", ";")) or t.startswith(";;#"):
+            continue
+        cur.append(t)
+    out.append((label, cur, hdr, inloop))
+    return out
+
+
+def count(insts):
+    c = {}
+    for t in insts:
+        k = classify(t.split()[0])
+        c[k] = c.get(k, 0) + 1
+    return c
+
+
+def add(a, b):
+    return {k: a.get(k, 0) + b.get(k, 0) for k in set(a) | set(b)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_isa_mix"))
+    ap.add_argument("--asm", default=None, help="an existing .s instead of compiling")
+    args = ap.parse_args()
+    if args.asm:
+        asm = open(args.asm).read()
+    else:
+        with tempfile.TemporaryDirectory() as d:
+            s = os.path.join(d, "vrt_kernels.s")
+            subprocess.check_call(["/opt/rocm/bin/hipcc", *HIPFLAGS, "-S", "--cuda-device-only", "-o", s,
+                                   os.path.join(ROOT, "voxelraytracing_amd", "csrc", "vrt_kernels.hip")], stderr=subprocess.DEVNULL)
+            asm = open(s).read()
+    bl = blocks_of(kernel_text(asm))
+    headers = [b[0] for b in bl if b[2]]
+    assert len(headers) == 2, f"expected the primary and the shadow march loop, found {headers}"
+    res = {"kernel": "primary_shadow_wave_kernel<0, false, false, 4>", "loops": {}}
+    listing = []
+    total = {}
+    for b in bl:
+        total = add(total, count(b[1]))
+    res["whole_kernel_static"] = total
+    for name, h in zip(("primary", "shadow"), headers):
+        loop = [b for b in bl if b[3] == h]
+        # the latch is laid out just before the header: blocks "in Loop" that precede it
+        idx = {b[0]: i for i, b in enumerate(loop)}
+        per_block = {b[0]: count(b[1]) for b in loop}
+        # fast path: header -> (first s_cbranch_execz target = rejoin) -> fall through (step arithmetic) -> its s_branch target (latch) .. header
+        hb = next(b for b in loop if b[0] == h)
+        rejoin = next(t.split()[-1] for t in hb[1] if t.startswith("s_cbranch_execz"))
+        order = [b[0] for b in loop]
+        step = order[order.index(rejoin) + 1]
+        sb = next(b for b in loop if b[0] == step)
+        latch = next(t.split()[-1] for t in sb[1] if t.startswith("s_branch"))
+        fast = [h, rejoin, step, latch]
+        # blocks between the latch label and the header in layout order belong to the latch path too
+        li = order.index(latch)
+        hi = order.index(h)
+        if li < hi:
+            fast = [h, rejoin, step] + order[li:hi]
+        fp = {}
+        for lab in fast:
+            fp = add(fp, per_block[lab])
+        allc = {}
+        for lab in per_block:
+            allc = add(allc, per_block[lab])
+        res["loops"][name] = {"header": h, "fast_path_blocks": fast, "fast_path": fp, "all_blocks_static": allc,
+                              "per_block": per_block}
+        listing.append(f"==== {name} march loop (header {h}); fast path = {' -> '.join(fast)} ====")
+        for b in loop:
+            mark = " [fast path]" if b[0] in fast else ""
+            listing.append(f"{b[0]}:{mark}   {per_block[b[0]]}")
+            listing += ["    " + t for t in b[1]]
+    try:
+        from voxelraytracing_amd import _ffi
+        res["code_object_sha256"] = _ffi.code_object_sha256()
+    except Exception as e:   # the library is not built: the mix still stands for the source
+        res["code_object_sha256"] = None
+        res["note"] = f"libvrt.so not hashed: {e}"
+    json.dump(res, open(args.out + ".json", "w"), indent=1, sort_keys=True)
+    with open(args.out + ".txt", "w") as f:
+        f.write(f"# {res['kernel']}: ISA of the two march loops, block by block (tools/isa_mix.py; hipcc -S, gfx950)\n")
+        for name in ("primary", "shadow"):
+            f.write(f"# {name} fast path per step: {json.dumps(res['loops'][name]['fast_path'], sort_keys=True)}\n")
+        f.write("\n".join(listing) + "\n")
+    for name in ("primary", "shadow"):
+        print(name, "fast path per step:", json.dumps(res["loops"][name]["fast_path"], sort_keys=True))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,6 +1,7 @@
 #!/bin/bash
 # tools/pmc.sh <tag> [bench args...] — rocprofv3 PMC passes (one counter group per run; no tracing mixed in,
-# as the pool requires) over a short bench run. Output under gpurun_out/pmc_<tag>/.
+# as the pool requires) over a short bench run of one and the same frame (standing camera, no extra legs).
+# Output under gpurun_out/pmc_<tag>/; tools/traffic_from_pmc.py turns the summary into profiles/traffic_latest.json.
 TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
@@ -8,12 +9,13 @@ mkdir -p $OUT
 i=0
 for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SMEM" \
            "SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU" \
+           "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH" \
            "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" \
            "FETCH_SIZE" "WRITE_SIZE" \
            "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum" \
            "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --output-format csv -d $OUT/g$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $OUT/g$i.log 2>&1 || echo "group $i failed: $grp"
+  rocprofv3 --pmc $grp --output-format csv -d $OUT/g$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --fixed-camera --no-extras --settle-seconds 0 "$@" > $OUT/g$i.log 2>&1 || echo "group $i failed: $grp"
 done
 python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT > $OUT/summary.txt
 cat $OUT/summary.txt

@@ -1,11 +1,22 @@
 #!/usr/bin/env python3
-"""profiles/traffic_latest.json from a tools/pmc.sh summary: HBM bytes per launch of the two default march kernels =
-FETCH_SIZE x 2 (gfx950 tallies 128-B read requests at 64 B: MI355X_MICROARCH.md §HBM) + WRITE_SIZE, both in KB."""
+"""tools/traffic_from_pmc.py <pmc summary> <isa mix json> <valu issue rates txt> <out json> [workload key]
+
+profiles/traffic_latest.json from a tools/pmc.sh summary, for bench.py's `roofline` object — stamped with the code object
+(sha256 of libvrt.so's device code) and the workload the counters were collected on; bench.py prints them only for that
+very build and workload.  Per kernel:
+  hbm_bytes                 FETCH_SIZE x 2 (gfx950 tallies 128-B read requests at 64 B: MI355X_MICROARCH.md §HBM) + WRITE_SIZE,
+                            both in KB, separate --pmc passes
+  valu_ / salu_wave_instructions    SQ_INSTS_VALU, SQ_INSTS_SALU per launch
+  issue_cycles_by_class     SIMD cycles those instructions need at the issue costs tools/valu_rates.hip measured, the VALU
+                            split into classes in the proportions of the march loop's fast path (tools/isa_mix.py) — an
+                            estimate of the mix outside the loop, exact counts overall
+"""
 import json
 import re
 import sys
 
-summary, out = sys.argv[1], sys.argv[2]
+summary, mix_path, rates_path, out = sys.argv[1:5]
+workload = sys.argv[5] if len(sys.argv) > 5 else "shadow:8:1920x1080:v0"
 cur, vals = None, {}
 for line in open(summary):
     if line.startswith("== "):
@@ -15,10 +26,36 @@ for line in open(summary):
         m = re.match(r"\s+(\S+)\s+dispatches=\s*\d+ mean/dispatch=(\S+)", line)
         if m and cur:
             vals[cur][m.group(1)] = float(m.group(2))
-pick = {"primary_shadow_march": "primary_shadow_wave_kernel<0, false, false, 4>",
+mix = json.load(open(mix_path))
+rates = {}
+for line in open(rates_path):
+    m = re.match(r"(k_\w+)\s+\S+ ms\s+in-kernel clock (\S+) GHz\s+(\S+) cycles", line)
+    if m:
+        rates[m.group(1)] = float(m.group(3))
+mean = lambda ks: sum(rates[k] for k in ks) / len(ks)   # noqa: E731
+cost = {"valu_simple": mean(["k_add_f32", "k_mul_f32", "k_mul_abs", "k_fma_f32", "k_and_b32", "k_add_u32", "k_lshr_b32", "k_mov_b32"]),
+        "valu_half": mean(["k_min3_f32", "k_cndmask_e64", "k_cvt_flr", "k_cvt_i32_f32", "k_cvt_f32_i32", "k_cmp_u32", "k_cmp_f32", "k_bfi_b32",
+                           "k_mad_i24", "k_max3_u32"]),
+        "valu_pk": rates["k_pk_add_f32"], "valu_trans": mean(["k_sqrt_f32", "k_rcp_f32"]), "salu": rates["k_salu"]}
+fp = {}
+for lp in mix["loops"].values():
+    for k, v in lp["fast_path"].items():
+        fp[k] = fp.get(k, 0) + v
+n_v = sum(fp.get(k, 0) for k in ("valu_simple", "valu_half", "valu_pk", "valu_trans"))
+pick = {"primary_shadow_march": "primary_shadow_wave_kernel<0, false, false, 4, false>",
         "primary_march": "primary_tile_kernel<0, false, false, true>", "shadow_march": "shadow_kernel<0, false, false>"}
-res = {k: (vals[v]["FETCH_SIZE"] * 2 + vals[v]["WRITE_SIZE"]) * 1024.0 for k, v in pick.items() if v in vals and "FETCH_SIZE" in vals[v]}
-res["valu_wave_instructions"] = {k: vals[v]["SQ_INSTS_VALU"] for k, v in pick.items() if v in vals and "SQ_INSTS_VALU" in vals[v]}
-res["_source"] = f"{summary} (FETCH_SIZE*2 + WRITE_SIZE, KB -> bytes per launch; separate --pmc passes, tools/pmc.sh)"
-json.dump(res, open(out, "w"), indent=1)
-print(res)
+kernels = {}
+for k, v in pick.items():
+    if v not in vals or "SQ_INSTS_VALU" not in vals[v]:
+        continue
+    c = vals[v]
+    by = {cl: c["SQ_INSTS_VALU"] * fp.get(cl, 0) / n_v * cost[cl] for cl in ("valu_simple", "valu_half", "valu_pk", "valu_trans")}
+    by["salu"] = c.get("SQ_INSTS_SALU", 0.0) * cost["salu"]
+    kernels[k] = {"hbm_bytes": (c["FETCH_SIZE"] * 2 + c["WRITE_SIZE"]) * 1024.0 if "FETCH_SIZE" in c and "WRITE_SIZE" in c else None,
+                  "valu_wave_instructions": c["SQ_INSTS_VALU"], "salu_wave_instructions": c.get("SQ_INSTS_SALU"),
+                  "issue_cycles_by_class": by, "counters": c}
+res = {"code_object_sha256": mix.get("code_object_sha256"), "workload": workload, "kernels": kernels,
+       "issue_cost_cycles": cost, "fast_path_mix": fp,
+       "_source": f"{summary} (tools/pmc.sh: separate --pmc passes), {mix_path}, {rates_path}"}
+json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "counters"} for k, v in kernels.items()}, indent=1))

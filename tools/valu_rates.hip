@@ -1,6 +1,9 @@
-// tools/valu_rates.hip — issue rate of the VALU instruction classes the march uses, on a full chip at 8 waves / SIMD.
-// Each kernel is a loop of 32 copies of one instruction on independent registers; cycles per wave-instruction per SIMD
-// = elapsed * clock / (instructions per SIMD).  hipcc --offload-arch=gfx950 -O2 tools/valu_rates.hip -o tools/valu_rates
+// tools/valu_rates.hip — issue cost of the instruction classes the march uses, on a full chip at 8 waves / SIMD.
+// Each kernel is a loop of 32 copies of one instruction (or of a mix) on independent registers; cycles per
+// wave-instruction per SIMD = elapsed * clock / (instructions per SIMD), where the clock is the one the kernel itself
+// ran at: every workgroup stamps s_memtime (shader clock) and s_memrealtime (100 MHz) around its loop and the host takes
+// the median ratio (MI355X_MICROARCH.md, check 6) — a dense VALU loop does not hold the nominal 2.4 GHz.
+// hipcc --offload-arch=gfx950 -O2 tools/valu_rates.hip -o tools/valu_rates
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
@@ -9,14 +12,19 @@
 #define REP32(x) REP4(REP4(x)) REP4(REP4(x))
 
 #define KERNEL(name, body)                                                        \
-    __global__ void __launch_bounds__(256) name(float *out, int iters) {          \
+    __global__ void __launch_bounds__(256) name(float *out, int iters, unsigned long long *clk) { \
+        const unsigned long long t0_ = __builtin_amdgcn_s_memtime(), r0_ = __builtin_amdgcn_s_memrealtime(); \
         float a = threadIdx.x * 0.001f + 1.0f, b = 1.0001f, c = 0.5f, d = 2.0f;   \
         float e = a + 1.0f, f = a + 2.0f, g = a + 3.0f, h = a + 4.0f;             \
         int i0 = threadIdx.x, i1 = 7, i2 = 3, i3 = 11;                            \
         for (int it = 0; it < iters; it++) {                                      \
-            asm volatile(REP4(body) : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3) : : "vcc", "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29"); \
+            asm volatile(REP4(body) : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3) : : "vcc", "scc", "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29"); \
         }                                                                         \
         out[blockIdx.x * blockDim.x + threadIdx.x] = a + b + c + d + e + f + g + h + (float)(i0 + i1 + i2 + i3); \
+        if (threadIdx.x == 0) {                                                   \
+            clk[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0_;             \
+            clk[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r0_;     \
+        }                                                                         \
     }
 
 // 8 instructions per body (x4 = 32 per loop trip)
@@ -50,35 +58,59 @@ KERNEL(k_max3_u32, "v_max3_u32 %8, %8, %9, %10\n v_max3_u32 %9, %9, %10, %11\n v
 KERNEL(k_floor_f32, "v_floor_f32 %0, %0\n v_floor_f32 %2, %2\n v_floor_f32 %3, %3\n v_floor_f32 %4, %4\n v_floor_f32 %5, %5\n v_floor_f32 %6, %6\n v_floor_f32 %7, %7\n v_floor_f32 %1, %1\n")
 KERNEL(k_rcp_f32, "v_rcp_f32 %0, %0\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3\n v_rcp_f32 %4, %4\n v_rcp_f32 %5, %5\n v_rcp_f32 %6, %6\n v_rcp_f32 %7, %7\n v_rcp_f32 %1, %1\n")
 KERNEL(k_mov_b32, "v_mov_b32 %0, %1\n v_mov_b32 %2, %3\n v_mov_b32 %3, %4\n v_mov_b32 %4, %5\n v_mov_b32 %5, %6\n v_mov_b32 %6, %7\n v_mov_b32 %7, %0\n v_mov_b32 %1, %2\n")
+KERNEL(k_mad_i24, "v_mad_i32_i24 %8, %8, %9, %10\n v_mad_i32_i24 %9, %9, %10, %11\n v_mad_i32_i24 %10, %10, %11, %8\n v_mad_i32_i24 %11, %11, %8, %9\n v_mad_i32_i24 %8, %8, %10, %11\n v_mad_i32_i24 %9, %9, %11, %8\n v_mad_i32_i24 %10, %10, %8, %9\n v_mad_i32_i24 %11, %11, %9, %10\n")
+KERNEL(k_mul_abs, "v_mul_f32_e64 %0, |%0|, %1\n v_mul_f32_e64 %2, |%2|, %1\n v_mul_f32_e64 %3, |%3|, %1\n v_mul_f32_e64 %4, |%4|, %1\n v_mul_f32_e64 %5, |%5|, %1\n v_mul_f32_e64 %6, |%6|, %1\n v_mul_f32_e64 %7, |%7|, %1\n v_mul_f32_e64 %0, |%0|, %2\n")
+// scalar instructions: alone, and interleaved one to one with simple VALU (does the scalar stream ride along for free?)
+KERNEL(k_salu, "s_and_b64 s[10:11], s[10:11], s[12:13]\n s_or_b64 s[12:13], s[12:13], s[14:15]\n s_xor_b64 s[14:15], s[14:15], s[16:17]\n s_and_b64 s[16:17], s[16:17], s[10:11]\n s_or_b64 s[10:11], s[10:11], s[14:15]\n s_andn2_b64 s[12:13], s[12:13], s[16:17]\n s_xor_b64 s[14:15], s[14:15], s[10:11]\n s_and_b64 s[16:17], s[16:17], s[12:13]\n")
+KERNEL(k_salu_valu, "s_and_b64 s[10:11], s[10:11], s[12:13]\n v_add_f32 %0, %0, %1\n s_or_b64 s[12:13], s[12:13], s[14:15]\n v_add_f32 %2, %2, %1\n s_xor_b64 s[14:15], s[14:15], s[16:17]\n v_add_f32 %3, %3, %1\n s_and_b64 s[16:17], s[16:17], s[10:11]\n v_add_f32 %4, %4, %1\n")
+KERNEL(k_nop, "s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n")
+// a dependent chain of simple VALU (every instruction needs the one before)
+KERNEL(k_add_dep, "v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n")
+
+#include <algorithm>
 
 template <typename K>
-static void run(const char *name, K kernel, float *d_out, double ghz, int sms) {
+static void run(const char *name, K kernel, float *d_out, unsigned long long *d_clk, int sms) {
     const int iters = 4000, blocks = sms * 8;  // 8 workgroups of 4 waves per CU = 8 waves per SIMD
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, d_out, 100);
+    for (int w = 0; w < 40; w++) hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, d_out, iters, d_clk);  // ~50 ms of this load: the clock settles on it
     hipDeviceSynchronize();
     float best = 1e30f;
+    std::vector<unsigned long long> clk(2 * (size_t)blocks);
+    double ghz = 0;
     for (int r = 0; r < 5; r++) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, d_out, iters);
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, d_out, iters, d_clk);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
-        if (ms < best) best = ms;
+        if (ms < best) {
+            best = ms;
+            hipMemcpy(clk.data(), d_clk, clk.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            std::vector<double> ratio;
+            for (int b = 0; b < blocks; b++) if (clk[2 * b + 1]) ratio.push_back((double)clk[2 * b] / (double)clk[2 * b + 1]);
+            std::sort(ratio.begin(), ratio.end());
+            ghz = ratio.empty() ? 0.0 : ratio[ratio.size() / 2] * 0.1;   // x 100 MHz
+        }
     }
     const double insts_per_simd = 8.0 * iters * 32.0;  // 8 waves x iters x 32 instructions
-    printf("%-16s %.3f ms  %.2f cycles per wave-instruction per SIMD at %.2f GHz\n", name, best, best * 1e-3 * ghz * 1e9 / insts_per_simd, ghz);
+    printf("%-16s %.3f ms  in-kernel clock %.3f GHz  %.2f cycles per wave-instruction per SIMD\n", name, best, ghz,
+           best * 1e-3 * ghz * 1e9 / insts_per_simd);
 }
 
 int main() {
+    setvbuf(stdout, nullptr, _IOLBF, 0);
     hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
-    const double ghz = p.clockRate * 1e-6;
     float *d; hipMalloc(&d, (size_t)p.multiProcessorCount * 8 * 256 * 4);
-    printf("%s, %d CUs, %.2f GHz\n", p.name, p.multiProcessorCount, ghz);
-#define RUN(k) run(#k, k, d, ghz, p.multiProcessorCount)
-    RUN(k_add_f32); RUN(k_mul_f32); RUN(k_fma_f32); RUN(k_min3_f32); RUN(k_cndmask_vcc); RUN(k_cmp_cnd_vcc); RUN(k_cmp_cnd_sgpr); RUN(k_cmp_cnd_2sgpr); RUN(k_cndmask_e64); RUN(k_min_f32); RUN(k_lshl_or); RUN(k_add3_u32); RUN(k_cvt_flr); RUN(k_cmp_u32); RUN(k_pk_add_f32); RUN(k_sqrt_f32); RUN(k_div_fixup); RUN(k_cmp_f32);
-    RUN(k_cvt_i32_f32); RUN(k_cvt_f32_i32); RUN(k_and_b32); RUN(k_add_u32); RUN(k_lshr_b32); RUN(k_bfi_b32); RUN(k_mad_u24);
-    RUN(k_max3_u32); RUN(k_floor_f32); RUN(k_rcp_f32); RUN(k_mov_b32);
+    unsigned long long *dc; hipMalloc(&dc, (size_t)p.multiProcessorCount * 8 * 2 * sizeof(unsigned long long));
+    printf("%s, %d CUs, nominal %.2f GHz; 8 waves / SIMD, 32 instructions per loop trip\n", p.name, p.multiProcessorCount, p.clockRate * 1e-6);
+#define RUN(k) run(#k, k, d, dc, p.multiProcessorCount)
+    RUN(k_add_f32); RUN(k_mul_f32); RUN(k_mul_abs); RUN(k_fma_f32); RUN(k_and_b32); RUN(k_add_u32); RUN(k_lshr_b32); RUN(k_mov_b32); RUN(k_add_dep);
+    RUN(k_min3_f32); RUN(k_min_f32); RUN(k_cndmask_e64); RUN(k_cmp_cnd_sgpr); RUN(k_cmp_cnd_vcc); RUN(k_cmp_cnd_2sgpr); RUN(k_cndmask_vcc);
+    RUN(k_lshl_or); RUN(k_add3_u32); RUN(k_cvt_flr); RUN(k_cvt_i32_f32); RUN(k_cvt_f32_i32); RUN(k_floor_f32); RUN(k_cmp_u32); RUN(k_cmp_f32);
+    RUN(k_bfi_b32); RUN(k_mad_u24); RUN(k_mad_i24); RUN(k_max3_u32); RUN(k_div_fixup); RUN(k_pk_add_f32);
+    RUN(k_sqrt_f32); RUN(k_rcp_f32);
+    RUN(k_salu); RUN(k_salu_valu); RUN(k_nop);
     return 0;
 }

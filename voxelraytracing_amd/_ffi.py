@@ -56,7 +56,8 @@ class Stats(C.Structure):
                 ("steps", C.c_uint64), ("node_visits", C.c_uint64), ("primary_steps", C.c_uint64),
                 ("primary_node_visits", C.c_uint64), ("ms_total", C.c_float), ("ms_primary", C.c_float),
                 ("ms_secondary", C.c_float), ("frames", C.c_uint32), ("sum_ms_primary", C.c_double),
-                ("sum_ms_secondary", C.c_double), ("sum_ms_total", C.c_double)]
+                ("sum_ms_secondary", C.c_double), ("sum_ms_total", C.c_double),
+                ("clock_shader_ticks", C.c_uint64), ("clock_ref_ticks", C.c_uint64)]
 
 
 class Crosshair(C.Structure):
@@ -125,6 +126,26 @@ def _load(name: str, symbols: dict) -> C.CDLL:
         fn.restype = res
         fn.argtypes = args
     return lib
+
+
+def code_object_sha256(path: str | None = None) -> str:
+    """sha256 of the device code (the ELF section .hip_fatbin) of libvrt.so: names the kernels a measurement belongs to
+    (bench.py prints PMC-derived figures only next to the build they were collected on)."""
+    import hashlib
+    import struct
+    path = path or os.environ.get("VRT_LIB") or os.path.join(_HERE, "libvrt.so")
+    data = open(path, "rb").read()
+    if data[:4] != b"\x7fELF" or data[4] != 2:
+        return hashlib.sha256(data).hexdigest()
+    shoff, = struct.unpack_from("<Q", data, 0x28)
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", data, 0x3A)
+    sec = [struct.unpack_from("<IIQQQQIIQQ", data, shoff + i * shentsize) for i in range(shnum)]
+    names = sec[shstrndx]
+    for s in sec:
+        name = data[names[4] + s[0]:data.index(b"\0", names[4] + s[0])]
+        if name == b".hip_fatbin":
+            return hashlib.sha256(data[s[4]:s[4] + s[5]]).hexdigest()
+    return hashlib.sha256(data).hexdigest()
 
 
 _vrt = None

@@ -107,6 +107,7 @@ struct vrt_ctx {
     unsigned long long *d_counters = nullptr;  // [kCtrCount] stats, then the hit-segment counters
     uint32_t hit_seg_cap = 0;
     uint32_t *d_steps = nullptr;
+    unsigned long long *d_clock = nullptr;  // clock-probe frames: {s_memtime ticks, s_memrealtime ticks}, summed until vrt_get_stats
     uint8_t *d_rgba8 = nullptr;
     uint8_t *d_screen = nullptr;   // vrt_present's target
     size_t screen_cap = 0;
@@ -583,7 +584,7 @@ void vrt_destroy(vrt_ctx *c) {
     for (auto p : c->extra_counters) (void)hipFree(p);
     (void)hipFree(c->d_nodes); (void)hipFree(c->d_roots); (void)hipFree(c->d_mats); (void)hipFree(c->own_out);
     (void)hipFree(c->d_hits); (void)hipFree(c->d_counters); (void)hipFree(c->d_steps); (void)hipFree(c->d_rgba8); (void)hipFree(c->d_path);
-    (void)hipFree(c->d_blk_counts);
+    (void)hipFree(c->d_blk_counts); (void)hipFree(c->d_clock);
     (void)hipFree(c->d_grid); (void)hipFree(c->d_bricks); (void)hipFree(c->d_chunk_bricks); (void)hipFree(c->d_chunk_bases);
     (void)hipFree(c->d_chunk_caps); (void)hipFree(c->d_brick_tail); (void)hipFree(c->d_brick_total);
     if (c->h_ring) (void)hipHostFree(c->h_ring);
@@ -958,6 +959,9 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     if (opts) o = *opts;
     if (o.mode > VRT_MODE_PATH) return fail(c, VRT_ERR_INVALID_ARG, "vrt_render: mode %u not supported", o.mode);
     if (o.mode == VRT_MODE_PATH && o.variant != 0) return fail(c, VRT_ERR_INVALID_ARG, "vrt_render: the path trace has one kernel variant");
+    if (o.stats > 2u) return fail(c, VRT_ERR_INVALID_ARG, "vrt_render: stats %u (0, 1 = count steps, 2 = clock probe)", o.stats);
+    if (o.stats == 2u && (o.mode != VRT_MODE_PRIMARY_SHADOW || (o.variant != 0u)))
+        return fail(c, VRT_ERR_INVALID_ARG, "vrt_render: the clock probe (stats = 2) is a build of the default primary + shadow kernel");
     if (o.variant == 4u && (o.mode != VRT_MODE_PRIMARY_SHADOW || o.stats))
         return fail(c, VRT_ERR_INVALID_ARG, "vrt_render: variant 4 (persistent grid) renders plain primary + shadow frames only");
     if (!vrt::variant_supported(o.variant)) return fail(c, VRT_ERR_INVALID_ARG, "vrt_render: unknown kernel variant %u", o.variant);
@@ -968,7 +972,13 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     if (c->compact && (o.mode == VRT_MODE_PATH || (o.variant != 0u && o.variant != 2u) || c->settings.show_step_count == 1u))
         return fail(c, VRT_ERR_STATE, "vrt_render: a VRT_FLAG_COMPACT context renders primary(+shadow) frames with the default march "
                     "only (no path trace, step-count view, literal or two-launch variants)");
-    if (o.stats && !c->d_steps) HIP_TRY(c, hipMalloc(&c->d_steps, (size_t)(c->slots ? c->slots : 1) * sizeof(uint32_t)));
+    if (o.stats == 1u && !c->d_steps) HIP_TRY(c, hipMalloc(&c->d_steps, (size_t)(c->slots ? c->slots : 1) * sizeof(uint32_t)));
+    if (o.stats == 2u && !c->d_clock) {
+        HIP_TRY(c, hipMalloc(&c->d_clock, 2 * sizeof(unsigned long long)));
+        HIP_TRY(c, hipMemsetAsync(c->d_clock, 0, 2 * sizeof(unsigned long long), c->stream));
+        const int rc2 = publish_upload(c);
+        if (rc2) return rc2;
+    }
     rc = ensure_ndc(c);
     if (rc) return rc;
     uint32_t variant = o.variant;
@@ -987,7 +997,7 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     }
     // per-lane iteration counts exist in the STATS kernels only; the step-count debug view (F2 in the reference,
     // main.rs:368-370) needs them, so it runs those kernels too
-    const bool kstats = o.stats != 0 || c->settings.show_step_count == 1u;
+    const bool kstats = o.stats == 1u || c->settings.show_step_count == 1u;
 
     FrameSet f;
     rc = pick_frame_set(c, o, variant, kstats, f);
@@ -1014,7 +1024,8 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     P.counters = f.counters;
     P.seg_counts = reinterpret_cast<uint32_t *>(f.counters + vrt::kCtrCount);
     P.hit_seg_cap = c->hit_seg_cap;
-    P.steps = o.stats ? c->d_steps : nullptr;
+    P.steps = o.stats == 1u ? c->d_steps : nullptr;
+    P.clock = o.stats == 2u ? c->d_clock : nullptr;
     fill_uniforms(c, P);
 
     std::array<hipEvent_t, 4> *ev = nullptr;
@@ -1027,7 +1038,7 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     else rc = launch_march_frame(c, P, f, o.mode == VRT_MODE_PRIMARY_SHADOW, variant, kstats, *ev, *ev_kind);
     if (rc) return rc;
     c->rendered = true;
-    c->last_stats = o.stats != 0;
+    c->last_stats = o.stats == 1u;
     c->last_mode = o.mode;
     c->timing_pending = true;
     return VRT_OK;
@@ -1147,6 +1158,14 @@ int vrt_get_stats(vrt_ctx *c, vrt_stats *out) {
             s.node_visits = h[vrt::kCtrVisits];
             s.primary_steps = h[vrt::kCtrPrimarySteps];
             s.primary_node_visits = h[vrt::kCtrPrimaryVisits];
+        }
+        if (c->d_clock) {  // clock-probe frames since the last call
+            unsigned long long clk[2] = {0, 0};
+            HIP_TRY(c, hipMemcpyAsync(clk, c->d_clock, sizeof clk, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipMemsetAsync(c->d_clock, 0, sizeof clk, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            s.clock_shader_ticks = clk[0];
+            s.clock_ref_ticks = clk[1];
         }
         s.ms_primary = last[0]; s.ms_secondary = last[1]; s.ms_total = last[2];
         s.frames = c->acc_frames;

@@ -39,6 +39,7 @@ struct FrameParams {
     uint32_t *seg_counts;    // path mode: records in segment s of the path buffer at seg_counts[s * kSegStride]
     unsigned long long *counters;  // see Counter
     uint32_t *steps;         // optional per-slot step counts (stats frames only), may be null
+    unsigned long long *clock;  // clock-probe frames only (vrt_render_opts.stats = 2): {shader-clock ticks, 100 MHz reference ticks}
     // path-trace mode: wavefront of live paths, ping-pong between bounces. A record is three uint4 planes
     // {slot, origin.xyz} {dir.xyz, rng} {throughput.rgb, 0} of path_cap entries each, segmented like `hits`.
     const uint4 *path_in;

@@ -202,12 +202,20 @@ __device__ __forceinline__ void trace_tile(const FrameParams &P, const uint32_t 
     if (lane == 0) P.blk_counts[t_local] = (uint32_t)__popcll(ballot);  // per tile: the launched-ray count of vrt_get_stats
 }
 
-template <int MARCH, bool LDS_ROOTS, bool STATS, int WAVES>
+// PROBE (vrt_render_opts.stats = 2, a diagnostic build of the timed kernel — in the real one no stamp executes): one wave
+// in sixteen stamps the shader clock (s_memtime) and the 100 MHz reference (s_memrealtime) around its work and adds the
+// differences to P.clock[0], P.clock[1]; their ratio is the clock the march ran at (MI355X_MICROARCH.md, check 6).
+template <int MARCH, bool LDS_ROOTS, bool STATS, int WAVES, bool PROBE = false>
 __global__ void __launch_bounds__(64 * WAVES) primary_shadow_wave_kernel(FrameParams P) {
     extern __shared__ uint32_t smem[];  // [0,8) liquid mask, [8,24) stats scratch, [24, ...) chunk roots
     uint32_t *s_liquid = smem, *s_roots = smem + 24;
     unsigned long long *s_acc = reinterpret_cast<unsigned long long *>(smem + 8);
     if (STATS && threadIdx.x < 6) s_acc[threadIdx.x] = 0ull;
+    unsigned long long t0 = 0, r0 = 0;
+    if (PROBE) {
+        t0 = __builtin_amdgcn_s_memtime();
+        r0 = __builtin_amdgcn_s_memrealtime();
+    }
     stage_lds(P, s_roots, s_liquid, LDS_ROOTS);
 
     const uint32_t lane = threadIdx.x & 63u;
@@ -216,6 +224,13 @@ __global__ void __launch_bounds__(64 * WAVES) primary_shadow_wave_kernel(FramePa
     R.iters = 0; R.visits = 0; R.hit = false;
     S.iters = 0; S.visits = 0; S.hit = false;
     if (t_local < P.tiles_local) trace_tile<MARCH, LDS_ROOTS, STATS>(P, s_roots, s_liquid, t_local, lane, R, S);
+    if (PROBE) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if ((blockIdx.x & 3u) == 0u && threadIdx.x == 0 && P.clock) {
+            atomicAdd(&P.clock[0], t1 - t0);
+            atomicAdd(&P.clock[1], r1 - r0);
+        }
+    }
     if (STATS) {
         block_add(s_acc, 0, R.iters);
         block_add(s_acc, 1, R.visits);
@@ -425,7 +440,8 @@ static void launch_fused_t(const FrameParams &P, bool stats, hipStream_t st, hip
     constexpr int WAVES = 4;
     const dim3 grid((P.tiles_local + WAVES - 1u) / WAVES), block(64 * WAVES);
     const uint32_t lds = (uint32_t)lds_bytes(P, LDS_ROOTS);
-    if (stats) hipExtLaunchKernelGGL((primary_shadow_wave_kernel<MARCH, LDS_ROOTS, true, WAVES>), grid, block, lds, st, e0, e1, 0, P);
+    if (P.clock && !stats) hipExtLaunchKernelGGL((primary_shadow_wave_kernel<MARCH, LDS_ROOTS, false, WAVES, true>), grid, block, lds, st, e0, e1, 0, P);
+    else if (stats) hipExtLaunchKernelGGL((primary_shadow_wave_kernel<MARCH, LDS_ROOTS, true, WAVES>), grid, block, lds, st, e0, e1, 0, P);
     else hipExtLaunchKernelGGL((primary_shadow_wave_kernel<MARCH, LDS_ROOTS, false, WAVES>), grid, block, lds, st, e0, e1, 0, P);
 }
 

@@ -124,7 +124,7 @@ class Gpu:
                     own_streams: bool = False):
         """PixelShader::encode_pass + queue.submit (shader.rs:371-379, main.rs:453,565). Asynchronous.
         own_streams: VRT_RENDER_OWN_STREAMS (include/vrt.h)."""
-        o = RenderOpts(mode, variant, 1 if stats else 0, spp, seed, 1 if own_streams else 0)
+        o = RenderOpts(mode, variant, int(stats), spp, seed, 1 if own_streams else 0)   # stats: False/True, or 2 = clock probe
         self._ck(self._lib.vrt_render(self._h, C.byref(o)))
 
     render = encode_pass
