@@ -1,10 +1,13 @@
-"""Cost of a voxel edit between two frames: range upload + identical-table check + table rebuild + the frame."""
+"""Cost of a voxel edit between two frames (main.rs:352-362): range upload of the chunk (incl. its 2048-node slack), the
+per-frame chunk_roots rewrite, the table update of that chunk, the frame.  Three figures: a lone frame with a synchronise
+behind it, the same with an edit in front, and the frame period of a pipelined loop with an edit before every frame."""
 import os
 import sys
 import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from voxelraytracing_amd import Gpu, MODE_PRIMARY_SHADOW, scenes
-sc = scenes.c2()
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 8     # world size in chunks (8 = C2, 32 = C5's world)
+sc = scenes.procedural(S, (1920, 1080), MODE_PRIMARY_SHADOW)
 gpu = Gpu(sc.world.max_nodes(), sc.world.size_in_chunks(), sc.size)
 gpu.upload_world(sc.world, sc.materials); gpu.write_cam_data(sc.cam); gpu.write_settings(sc.settings)
 for _ in range(50): gpu.render(MODE_PRIMARY_SHADOW)
@@ -12,6 +15,10 @@ gpu.synchronize()
 t0=time.perf_counter()
 for _ in range(200): gpu.render(MODE_PRIMARY_SHADOW)
 gpu.synchronize(); base=(time.perf_counter()-t0)/200
+lone=[]
+for _ in range(30):
+    t0=time.perf_counter(); gpu.render(MODE_PRIMARY_SHADOW); gpu.synchronize(); lone.append(time.perf_counter()-t0)
+lone.sort()
 ex,ey,ez=(int(v) for v in sc.eye)
 ts=[]; bs=[]
 for k in range(40):
@@ -22,6 +29,32 @@ for k in range(40):
     gpu.write_nodes(sc.world.nodes_ptr(), start, start+n)
     gpu.write_chunk_roots(sc.world.chunk_roots())
     gpu.render(MODE_PRIMARY_SHADOW); gpu.synchronize()
-    ts.append(time.perf_counter()-t0); bs.append(gpu.accel_info().last_build_ms)
-ts.sort(); bs.sort()
-print("frame %.1f us; edit+upload+rebuild+frame median %.1f us; rebuild (events) median %.1f us, n=%d" % (base*1e6, ts[len(ts)//2]*1e6, bs[len(bs)//2]*1e3, len(ts)))
+    ts.append(time.perf_counter()-t0)
+ts.sort()
+edits=[]
+for k in range(200):
+    p=(ex+(k%7)-3, ey-8-(k%5), ez+(k%9)-4)
+    try: edits.append(sc.world.set_voxel(p, 5 if k%2 else 0) and p)
+    except Exception: pass
+gpu.synchronize()
+n_pipe=0; host=[0.0,0.0,0.0,0.0]
+t0=time.perf_counter()
+for k in range(200):   # an edit before every frame, nothing waits for the device
+    p=(ex+(k%7)-3, ey-8-(k%5), ez+(k%9)-4)
+    h0=time.perf_counter()
+    try: start,n=sc.world.set_voxel(p, 4 if k%2 else 0)
+    except Exception: continue
+    h1=time.perf_counter()
+    gpu.write_nodes(sc.world.nodes_ptr(), start, start+n)
+    h2=time.perf_counter()
+    gpu.write_chunk_roots(sc.world.chunk_roots())
+    h3=time.perf_counter()
+    gpu.render(MODE_PRIMARY_SHADOW); n_pipe+=1
+    h4=time.perf_counter()
+    for i,d in enumerate((h1-h0,h2-h1,h3-h2,h4-h3)): host[i]+=d
+gpu.synchronize(); pipe=(time.perf_counter()-t0)/max(n_pipe,1)
+print("host us per edit frame: set_voxel %.1f, write_nodes %.1f, chunk_roots + write_chunk_roots %.1f, render (incl. the table update's launch) %.1f" % tuple(h/max(n_pipe,1)*1e6 for h in host))
+a = gpu.accel_info()
+print("%d^3 world: pipelined frame period %.1f us, with an edit before every frame %.1f us (n=%d); lone frame + synchronise %.1f us, "
+      "edit + range upload + chunk_roots rewrite + table update + frame + synchronise %.1f us (n=%d); whole-world builds %d, chunks rebuilt alone %d" %
+      (S, base*1e6, pipe*1e6, n_pipe, lone[len(lone)//2]*1e6, ts[len(ts)//2]*1e6, len(ts), a.builds, a.chunk_builds))

@@ -156,23 +156,45 @@ __global__ void __launch_bounds__(512) accel_bricks_kernel(const uint16_t *nodes
 }
 
 // Rebuild of single chunks (a voxel edit, a chunk that arrived): one workgroup per listed chunk does all three passes
-// for it.  The bricks go back into the chunk's own region when they fit (they do, unless an edit burst outgrew the
+// for it.  One workgroup has nobody to hide its load latency behind, and a cell's walk is a chain of dependent 2-byte
+// reads (3 levels to the cell, then 72 more for a brick), so the chunk's nodes — at most 32 767 + 8 of them, 64 KiB, a
+// chunk addresses no more (common/src/world/mod.rs:416) — are first copied into LDS with coalesced reads and every walk
+// reads LDS.  The bricks go back into the chunk's own region when they fit (they do, unless an edit burst outgrew the
 // slack); otherwise the chunk moves to a fresh 512-brick region — the most a chunk can ever need — taken from the tail of
 // the pool with one atomic.  The host keeps the tail from overflowing: it counts the chunks that may have moved since
 // the last whole-world build and asks for one of those instead when the tail could run out (vrt_backend.hip).
 struct ChunkList { uint32_t chunk[64]; };
 
+constexpr uint32_t kChunkNodesMax = 0x7FFFu + 8u;  // child_idx <= 0x7FFF, + 8 children
+
+__device__ __forceinline__ uint32_t lds_node(const uint16_t *s_nodes, uint32_t idx) {
+    return idx < kChunkNodesMax ? (uint32_t)s_nodes[idx] : 0u;  // (garbage pools: an index the 15-bit child field cannot form)
+}
+
 __global__ void __launch_bounds__(512) accel_chunks_kernel(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S,
                                                            uint32_t *grid, uint32_t *chunk_bricks, uint32_t *chunk_bases,
                                                            uint32_t *chunk_caps, uint32_t *tail, uint16_t *bricks, uint32_t brick_cap,
                                                            ChunkList list) {
+    extern __shared__ uint16_t s_nodes[];  // kChunkNodesMax node words of this chunk, relative to its root (+ padding)
     __shared__ uint32_t s_wave[8];
     __shared__ uint32_t s_base;
     const uint32_t chunk = list.chunk[blockIdx.x];
     const uint32_t t = threadIdx.x, cx = t & 7u, cy = (t >> 3) & 7u, cz = t >> 6;
     const uint32_t root = roots[chunk];
-    uint32_t depth;
-    const uint32_t node = descend3(nodes, n_nodes, root, cx, cy, cz, depth);
+    // stage: pairs of nodes as one 32-bit load where the pair is aligned and inside the pool, else word by word
+    for (uint32_t i = t; i < kChunkNodesMax; i += 512u) {
+        const uint64_t g = (uint64_t)root + i;
+        s_nodes[i] = g < n_nodes ? nodes[g] : (uint16_t)0;   // past the end of the pool: an air leaf (what the march's buffer loads return)
+    }
+    __syncthreads();
+    // the three levels above this thread's cell
+    uint32_t node = lds_node(s_nodes, 0u), depth = 0u;
+    while ((node & 0x8000u) && depth < 3u) {
+        const uint32_t sh = 2u - depth;
+        const uint32_t sel = ((cx >> sh) & 1u) | (((cy >> sh) & 1u) << 1) | (((cz >> sh) & 1u) << 2);
+        node = lds_node(s_nodes, (node & 0x7FFFu) + sel);
+        depth += 1u;
+    }
     const bool split = (node & 0x8000u) != 0u;
     uint32_t total;
     const uint32_t rank = rank_split_cells(split, s_wave, total);
@@ -194,11 +216,46 @@ __global__ void __launch_bounds__(512) accel_chunks_kernel(const uint16_t *nodes
     }
     const uint32_t brick = s_base + rank;
     if (brick >= brick_cap) return;  // cannot happen: the host accounts for every possible move
-    fill_brick(nodes, n_nodes, root, node, bricks + (size_t)brick * 64u);
+    // the brick, assembled in registers (64 entries = 32 words) and stored as eight 16-byte vectors
+    uint32_t w[32];
+#pragma unroll
+    for (uint32_t k = 0; k < 32u; k++) w[k] = 0u;
+#pragma unroll
+    for (uint32_t c = 0; c < 8u; c++) {
+        const uint32_t n4 = lds_node(s_nodes, (node & 0x7FFFu) + c);
+        const uint32_t x1 = (c & 1u) * 2u, y1 = ((c >> 1) & 1u) * 2u, z1 = ((c >> 2) & 1u) * 2u;
+#pragma unroll
+        for (uint32_t g = 0; g < 8u; g++) {
+            const uint32_t x = x1 + (g & 1u), y = y1 + ((g >> 1) & 1u), z = z1 + ((g >> 2) & 1u);
+            uint32_t word;
+            if (n4 & 0x8000u) word = (lds_node(s_nodes, (n4 & 0x7FFFu) + g) & 0x7FFFu) << 1;  // depth 5: the walk stops here, size 1
+            else word = ((n4 & 0x7FFFu) << 1) | 1u;                                            // depth-4 leaf, size 2
+            const uint32_t e = x | (y << 2) | (z << 4);
+            w[e >> 1] |= word << ((e & 1u) * 16u);
+        }
+    }
+    uint4 *dst = reinterpret_cast<uint4 *>(bricks + (size_t)brick * 64u);   // 128-byte aligned: hipMalloc + brick * 128
+#pragma unroll
+    for (uint32_t k = 0; k < 8u; k++) dst[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+    __threadfence();
     grid[cell] = 0x80000000u | (brick * 64u);
 }
 
+// Upload of a staged range: the pinned ring is mapped into the device's address space, so a kernel reads it over PCIe and
+// writes the resident buffer — a launch like any other on the stream, where hipMemcpyAsync makes the host wait for the
+// work the stream still has queued (measured: vrt_write_nodes returned after the frames in flight, 235 us, instead of 15).
+__global__ void __launch_bounds__(256) upload_words_kernel(uint32_t *dst, const uint32_t *src, uint32_t n_words) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 }  // namespace
+
+void launch_upload_words(void *dst, const void *pinned_src, uint32_t n_words, hipStream_t st) {
+    if (!n_words) return;
+    const uint32_t blocks = (n_words + 255u) / 256u;
+    hipLaunchKernelGGL(upload_words_kernel, dim3(blocks < 1024u ? blocks : 1024u), dim3(256), 0, st, (uint32_t *)dst,
+                       (const uint32_t *)pinned_src, n_words);
+}
 
 void launch_accel_cells(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S, uint32_t *grid,
                         uint32_t *chunk_bricks, uint32_t *chunk_bases, uint32_t *chunk_caps, uint32_t *total, uint32_t *tail,
@@ -217,12 +274,18 @@ void launch_accel_bricks(const uint16_t *nodes, uint32_t n_nodes, const uint32_t
 void launch_accel_chunks(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S, uint32_t *grid,
                          uint32_t *chunk_bricks, uint32_t *chunk_bases, uint32_t *chunk_caps, uint32_t *tail, uint16_t *bricks,
                          uint32_t brick_cap, const uint32_t *chunks, uint32_t n, hipStream_t st) {
+    static bool lds_set = false;   // 64 KiB + of dynamic LDS needs opting in (the CU has 160 KiB)
+    if (!lds_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(accel_chunks_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)((kChunkNodesMax + 1u) * sizeof(uint16_t)));
+        lds_set = true;
+    }
     for (uint32_t i = 0; i < n; i += 64u) {
         ChunkList list;
         const uint32_t m = n - i < 64u ? n - i : 64u;
         for (uint32_t k = 0; k < m; k++) list.chunk[k] = chunks[i + k];
-        hipLaunchKernelGGL(accel_chunks_kernel, dim3(m), dim3(512), 0, st, nodes, n_nodes, roots, S, grid, chunk_bricks, chunk_bases,
-                           chunk_caps, tail, bricks, brick_cap, list);
+        hipLaunchKernelGGL(accel_chunks_kernel, dim3(m), dim3(512), (kChunkNodesMax + 1u) * sizeof(uint16_t), st, nodes, n_nodes, roots, S,
+                           grid, chunk_bricks, chunk_bases, chunk_caps, tail, bricks, brick_cap, list);
     }
 }
 

@@ -41,6 +41,7 @@ void launch_accel_cells(const uint16_t *nodes, uint32_t n_nodes, const uint32_t 
                         hipStream_t st);
 void launch_accel_bricks(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S, uint32_t *grid,
                          const uint32_t *chunk_bases, uint16_t *bricks, uint32_t brick_cap, hipStream_t st);
+void launch_upload_words(void *dst, const void *pinned_src, uint32_t n_words, hipStream_t st);
 void launch_accel_chunks(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S, uint32_t *grid,
                          uint32_t *chunk_bricks, uint32_t *chunk_bases, uint32_t *chunk_caps, uint32_t *tail, uint16_t *bricks,
                          uint32_t brick_cap, const uint32_t *chunks, uint32_t n, hipStream_t st);
@@ -136,7 +137,7 @@ struct vrt_ctx {
 
     // uploads are staged through pinned memory (copy-at-call semantics without waiting for the device) and ordered with
     // the frames in flight by events, not by draining them
-    uint8_t *h_ring = nullptr;
+    uint8_t *h_ring = nullptr, *d_ring = nullptr;   // the pinned ring, and where the device sees it
     static constexpr size_t kRingSegBytes = 1u << 20, kRingSegs = 8;
     hipEvent_t ring_ev[kRingSegs] = {};
     bool ring_ev_used[kRingSegs] = {};
@@ -329,12 +330,15 @@ static int stage_upload(vrt_ctx *c, void *dst, const void *src, size_t bytes) {
     if (bytes == 0) return VRT_OK;
     int rc = order_after_frames(c);
     if (rc) return rc;
-    if (bytes > vrt_ctx::kRingSegBytes) {
+    if (bytes > vrt_ctx::kRingSegBytes || (bytes & 3u) || ((uintptr_t)dst & 3u)) {
         HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         return publish_upload(c);
     }
-    if (!c->h_ring) HIP_TRY(c, hipHostMalloc((void **)&c->h_ring, vrt_ctx::kRingSegBytes * vrt_ctx::kRingSegs, hipHostMallocDefault));
+    if (!c->h_ring) {
+        HIP_TRY(c, hipHostMalloc((void **)&c->h_ring, vrt_ctx::kRingSegBytes * vrt_ctx::kRingSegs, hipHostMallocMapped));
+        HIP_TRY(c, hipHostGetDevicePointer((void **)&c->d_ring, c->h_ring, 0));
+    }
     const size_t need = (bytes + 63u) & ~(size_t)63u;
     if (c->ring_off + need > vrt_ctx::kRingSegBytes) {
         c->ring_seg = (c->ring_seg + 1u) % vrt_ctx::kRingSegs;
@@ -342,10 +346,11 @@ static int stage_upload(vrt_ctx *c, void *dst, const void *src, size_t bytes) {
         // the segment's previous copies must have left it (seven segments ago: practically always long done)
         if (c->ring_ev_used[c->ring_seg]) HIP_TRY(c, hipEventSynchronize(c->ring_ev[c->ring_seg]));
     }
-    uint8_t *slot = c->h_ring + (size_t)c->ring_seg * vrt_ctx::kRingSegBytes + c->ring_off;
-    memcpy(slot, src, bytes);
+    const size_t at = (size_t)c->ring_seg * vrt_ctx::kRingSegBytes + c->ring_off;
+    memcpy(c->h_ring + at, src, bytes);
     c->ring_off += need;
-    HIP_TRY(c, hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, c->stream));
+    vrt::launch_upload_words(dst, c->d_ring + at, (uint32_t)(bytes / 4u), c->stream);
+    HIP_TRY(c, hipGetLastError());
     if (!c->ring_ev[c->ring_seg]) HIP_TRY(c, hipEventCreateWithFlags(&c->ring_ev[c->ring_seg], hipEventDisableTiming));
     HIP_TRY(c, hipEventRecord(c->ring_ev[c->ring_seg], c->stream));
     c->ring_ev_used[c->ring_seg] = true;
