@@ -82,11 +82,15 @@ pub struct vrt_config {
     pub shard_count: u32,
     pub flags: u32,
     pub shard_root_weight: u32,
+    pub n_devices: u32,
+    pub device_ids: [i32; VRT_MAX_DEVICES],
 }
 
+pub const VRT_MAX_DEVICES: usize = 16;
 pub const VRT_FLAG_TILE_MAJOR: u32 = 1;
 pub const VRT_FLAG_ROW_MAJOR: u32 = 2;
 pub const VRT_FLAG_COMPACT: u32 = 4;
+pub const VRT_FLAG_TEXEL_MESSAGES: u32 = 8;
 
 pub const VRT_MODE_PRIMARY: u32 = 0;
 pub const VRT_MODE_PRIMARY_SHADOW: u32 = 1;
@@ -190,7 +194,7 @@ mod layout {
         assert_eq!(size_of::<vrt_world_data>(), 32);
         assert_eq!(size_of::<vrt_settings>(), 48);
         assert_eq!(size_of::<vrt_crosshair>(), 32);
-        assert_eq!(size_of::<vrt_config>(), 36);
+        assert_eq!(size_of::<vrt_config>(), 104);
         assert_eq!(size_of::<vrt_render_opts>(), 32);
         assert_eq!(size_of::<vrt_stats>(), 112);
         assert_eq!(size_of::<vrt_accel_info>(), 48);

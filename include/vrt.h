@@ -91,6 +91,7 @@ typedef struct {
  * next ones to ranks 1, 2, ... one each.  shard_root_weight 0 or 1 = equal shares (tile t belongs to rank t % N).
  * A weight > 1 lets the gather root, whose own tiles never cross a link, take more of the frame than the ranks
  * whose tiles all arrive over one xGMI link each. */
+#define VRT_MAX_DEVICES 16
 typedef struct {
     uint32_t max_nodes;          /* NodeBuffer capacity in nodes (shader.rs:9-16; forced even) */
     uint32_t world_size_chunks;  /* S: chunk_roots holds S^3 entries (shader.rs:59,67) */
@@ -98,7 +99,17 @@ typedef struct {
     int32_t device;              /* HIP device ordinal; -1 = current */
     uint32_t shard_rank, shard_count;
     uint32_t flags;              /* VRT_FLAG_* */
-    uint32_t shard_root_weight;  /* tiles per period dealt to rank 0; 0 = 1 */
+    uint32_t shard_root_weight;  /* tiles per period dealt to rank 0; 0 = 1 (a multi-device context: 0 = a default for n_devices) */
+    /* One context, one thread, N devices (the reference drives one GpuResources from the winit thread, main.rs:398-455):
+     * n_devices > 1 makes this a multi-device context over device_ids[0 .. n_devices) — the same ordinal may appear more
+     * than once (a one-GPU rehearsal).  Every write is replicated to all of them (the scene is read-only during a frame),
+     * vrt_render traces the frame's 8x8 tiles interleaved over the devices — device_ids[0] its share straight into the
+     * row-major frame, the others as 8-byte records stored over xGMI directly into device_ids[0]'s memory
+     * (hipDeviceEnablePeerAccess; no collective library, no second process) — and device_ids[0] shades those records into the
+     * frame.  The frame, read-backs, vrt_present and vrt_device_output are device_ids[0]'s.  shard_rank / shard_count must be
+     * 0 / 0-1; of the flags only VRT_FLAG_TEXEL_MESSAGES applies.  n_devices 0 or 1: `device` alone, as before. */
+    uint32_t n_devices;
+    int32_t device_ids[VRT_MAX_DEVICES];
 } vrt_config;
 
 /* Write the output in the tile-major shard layout even with shard_count = 1 (a one-rank gather pipeline). */
@@ -111,6 +122,11 @@ typedef struct {
  * uniforms it holds anyway, to shade the pixel itself bit for bit (vrt_assemble_compact).  Plain primary(+shadow)
  * frames with the default march only; vrt_read_output is not available on such a context. */
 #define VRT_FLAG_COMPACT 4u
+
+/* A multi-device context (vrt_config.n_devices > 1) whose other devices send whole 16-byte texels instead of 8-byte
+ * records: twice the bytes over every link, but every kind of frame — also the path trace and the non-default marches,
+ * whose pixels the root cannot re-shade from an id word. */
+#define VRT_FLAG_TEXEL_MESSAGES 8u
 
 typedef enum {
     VRT_MODE_PRIMARY = 0,        /* the reference's live shader (ray_tracer.wgsl) */

@@ -1,0 +1,151 @@
+"""One context over several devices (vrt_config.device_ids, include/vrt.h) — SURVEY.md §8(b)'s boundary for a multi-GPU
+node: the caller keeps the reference's shape (one thread, one GpuResources, main.rs:398-455) and the backend shards the
+frame behind vrt_render.  The pool has one GPU per box, so every device id here is 0: the same code path (N contexts,
+messages stored into device 0's receive buffer, event-ordered assembly) with the peer stores staying on one device.
+The frame must be, bit for bit, the single-device frame."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from voxelraytracing_amd import MODE_PATH, MODE_PRIMARY, MODE_PRIMARY_SHADOW, scenes
+from voxelraytracing_amd import graphics as g
+
+from util import gpu_for_scene
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def c2_small():
+    return scenes.c2((640, 360))
+
+
+def reference_frames(sc, cams, mode, **kw):
+    one = gpu_for_scene(sc)
+    out = []
+    for cam in cams:
+        one.write_cam_data(cam)
+        one.render(mode, **kw)
+        out.append(one.read_output()[:2])
+    st = None
+    one.render(mode, stats=True, **kw)
+    st = one.stats()
+    one.close()
+    return out, st
+
+
+@pytest.mark.parametrize("n", [2, 3, 8])
+def test_group_frames_equal_single_device_frames(c2_small, n):
+    w, h = c2_small.size
+    cams = [g.cam_data_create((18.0 + 7 * k, 30.0 + 33 * k, 0.0), (c2_small.eye[0] + k, c2_small.eye[1], c2_small.eye[2] - k), 70.0,
+                              (float(w), float(h))) for k in range(5)]
+    want, st1 = reference_frames(c2_small, cams, MODE_PRIMARY_SHADOW)
+    grp = gpu_for_scene(c2_small, devices=[0] * n)
+    assert grp.shard_info()[2] == (w // 8) * (h // 8)
+    # frames enqueued back to back (two in flight, alternating message slots): read-backs return the last one
+    for upto in (1, 2, 5):
+        for cam in cams[:upto]:
+            grp.write_cam_data(cam)
+            grp.render(MODE_PRIMARY_SHADOW)
+        rgb, ids, _ = grp.read_output()
+        assert np.array_equal(ids, want[upto - 1][1]) and np.array_equal(rgb, want[upto - 1][0]), f"{n} devices, after {upto} frames"
+    # primary-only frames, one at a time
+    grp.set_frames_in_flight(1)
+    one = gpu_for_scene(c2_small)
+    one.write_cam_data(cams[2])
+    one.render(MODE_PRIMARY)
+    grp.write_cam_data(cams[2])
+    grp.render(MODE_PRIMARY)
+    a, b = grp.read_output(), one.read_output()
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0])
+    # the counters of a stats frame are the sum over the devices = the single device's
+    grp.write_cam_data(cams[-1])
+    grp.render(MODE_PRIMARY_SHADOW, stats=True)
+    s = grp.stats()
+    assert (s.primary_rays, s.secondary_rays, s.hits, s.steps, s.node_visits) == \
+           (st1.primary_rays, st1.secondary_rays, st1.hits, st1.steps, st1.node_visits)
+    rgb, ids, _ = grp.read_output()
+    assert np.array_equal(ids, want[-1][1]) and np.array_equal(rgb, want[-1][0])
+    # presentation comes from device 0's frame
+    one.write_cam_data(cams[-1])
+    one.render(MODE_PRIMARY_SHADOW)
+    assert np.array_equal(grp.present(), one.present())
+    grp.close()
+    one.close()
+
+
+def test_group_follows_edits_uploads_and_resizes(orc):
+    sc = scenes.c1_flat((128, 128))
+    grp = gpu_for_scene(sc, devices=[0, 0, 0])
+    one = gpu_for_scene(sc)
+    for pos, v in [((32, 12, 40), 0), ((30, 13, 44), 4), ((34, 13, 44), 3)]:
+        start, n = sc.world.set_voxel(pos, v)
+        for gp in (grp, one):
+            gp.write_nodes(sc.world.nodes_ptr(), start, start + n)
+            gp.write_chunk_roots(sc.world.chunk_roots())
+            gp.render(MODE_PRIMARY_SHADOW)
+        a, b = grp.read_output(), one.read_output()
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0])
+    r_rgb, r_ids, _, _ = orc.from_package_scene(sc).render(orc.MODE_PRIMARY_SHADOW, 128, 128)
+    assert np.array_equal(a[1], r_ids)
+    ai = grp.accel_info()
+    assert ai.available and ai.chunk_builds > 0
+    for gp in (grp, one):
+        gp.resize_result_texture((192, 96))
+        gp.write_cam_data(g.cam_data_create(sc.rot, sc.eye, 70.0, (192.0, 96.0)))
+        gp.render(MODE_PRIMARY_SHADOW)
+    a, b = grp.read_output(), one.read_output()
+    assert a[1].shape == (96, 192) and np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0])
+    ptr, nbytes = grp.device_output()
+    assert ptr and nbytes == 192 * 96 * 16          # device 0's row-major frame: what a host with GPU interop presents
+    # what belongs to a caller that runs its own collective is refused here
+    for call in (lambda: grp.set_stream(0), lambda: grp.bind_output(0), lambda: grp.assemble(1, 1), lambda: grp.read_steps()):
+        with pytest.raises(g.VrtError):
+            call()
+    with pytest.raises(g.VrtError):
+        grp.render(MODE_PATH)                       # 8-byte records cannot carry a path-traced pixel
+    grp.close()
+    one.close()
+
+
+def test_group_with_texel_messages_runs_every_kind_of_frame(orc):
+    sc = scenes.c4((256, 144), bounces=3)
+    grp = gpu_for_scene(sc, devices=[0, 0, 0, 0], texel_messages=True)
+    one = gpu_for_scene(sc)
+    for mode, kw in ((MODE_PATH, dict(spp=2, seed=5)), (MODE_PRIMARY_SHADOW, dict(variant=1)), (MODE_PRIMARY_SHADOW, dict(variant=3)),
+                     (MODE_PRIMARY_SHADOW, {})):
+        for gp in (grp, one):
+            gp.render(mode, **kw)
+            gp.render(mode, **kw)
+        a, b = grp.read_output(), one.read_output()
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0]), f"mode {mode} {kw}"
+    grp.close()
+    one.close()
+
+
+def test_c3_frame_through_a_group_of_8(orc):
+    """Config C3 as a host of the C ABI sees it: one context, 8 devices, 1920x1080 over the 16^3-chunk world."""
+    sc = scenes.c3()
+    grp = gpu_for_scene(sc, devices=[0] * 8)
+    grp.render(MODE_PRIMARY_SHADOW)
+    grp.render(MODE_PRIMARY_SHADOW)
+    rgb, ids, _ = grp.read_output()
+    r_rgb, r_ids, _, _ = orc.from_package_scene(sc).render(orc.MODE_PRIMARY_SHADOW, 1920, 1080)
+    assert np.array_equal(ids, r_ids) and float(np.abs(rgb - r_rgb).max()) <= 1e-4
+    grp.close()
+
+
+def test_cpp_host_renders_through_a_multi_device_context(tmp_path):
+    """csrc/host/example_frame_loop.cpp — the reference's frame loop on the C++ mirror, vrt_* calls only — with its Gpu
+    created over three devices: the file it writes equals the single-device run's."""
+    exe = os.path.join(ROOT, "voxelraytracing_amd", "vrt_frame_loop")
+    outs = []
+    for extra in ([], ["0,0,0"]):
+        out = tmp_path / f"frame{len(extra)}.bin"
+        r = subprocess.run([exe, str(out), "256", "256"] + extra, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        outs.append(np.fromfile(out, dtype=np.uint32))
+    assert np.array_equal(outs[0], outs[1])

@@ -40,10 +40,14 @@ class Settings(C.Structure):
                 ("sun_pos", C.c_float * 3), ("_padding2", C.c_uint32)]
 
 
+MAX_DEVICES = 16
+
+
 class Config(C.Structure):
     _fields_ = [("max_nodes", C.c_uint32), ("world_size_chunks", C.c_uint32), ("width", C.c_uint32),
                 ("height", C.c_uint32), ("device", C.c_int32), ("shard_rank", C.c_uint32),
-                ("shard_count", C.c_uint32), ("flags", C.c_uint32), ("shard_root_weight", C.c_uint32)]
+                ("shard_count", C.c_uint32), ("flags", C.c_uint32), ("shard_root_weight", C.c_uint32),
+                ("n_devices", C.c_uint32), ("device_ids", C.c_int32 * MAX_DEVICES)]
 
 
 class RenderOpts(C.Structure):

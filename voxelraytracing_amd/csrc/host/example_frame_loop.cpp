@@ -1,13 +1,16 @@
 // example_frame_loop.cpp — the reference's join_game + frame loop (clientdesktop/src/main.rs:189-229,
 // 278-297, 398-455) written against the C++ host mirror, with the wgpu backend replaced by libvrt.so.
 //
-//   vrt_frame_loop <out.bin> [width height]
+//   vrt_frame_loop <out.bin> [width height [devices]]      devices = a comma-separated list of HIP ordinals: one context
+//                                                          over several devices (vrt_config.device_ids); "0,0,0" rehearses
+//                                                          the multi-device path on one GPU
 // builds the C1 world (2^3 chunks, Superflat rule via Svo::set_node), uploads it, renders one primary frame,
 // edits two voxels the way update_input does (re-uploading the chunk's range), renders a primary+shadow frame
 // and writes {w, h, ids[w*h], rgb[w*h*3]} of the second frame to out.bin.  tests/test_cpp_host.py compares
 // the file with the same sequence driven through the Python bindings.
 #include <cstdio>
 #include <cstdlib>
+#include <memory>
 #include <vector>
 
 #include "graphics.hpp"
@@ -37,7 +40,15 @@ int main(int argc, char **argv) {
                 }
 
         // GpuResources::new(gpu, fmt, result_size, max_nodes, world_size) — main.rs:211-217
-        Gpu gpu(max_nodes, world_size, {W, H});
+        std::vector<int> devices;
+        if (argc > 4)
+            for (const char *p = argv[4]; *p;) {
+                devices.push_back(std::atoi(p));
+                while (*p && *p != ',') p++;
+                if (*p == ',') p++;
+            }
+        std::unique_ptr<Gpu> gpu_holder(devices.size() > 1 ? new Gpu(max_nodes, world_size, {W, H}, devices) : new Gpu(max_nodes, world_size, {W, H}));
+        Gpu &gpu = *gpu_holder;
         GpuResources res({W, H}, max_nodes, world_size);
         res.buffers.nodes.write(gpu, world.nodes(), {0, res.buffers.nodes.size()});  // main.rs:218
         std::vector<Material> mats(256);

@@ -110,7 +110,13 @@ struct GpuError : std::runtime_error { using std::runtime_error::runtime_error; 
 class Gpu {
 public:
     Gpu(uint32_t max_nodes, uint32_t world_size, UVec2 result_size, int device = -1, uint32_t shard_rank = 0, uint32_t shard_count = 1) {
-        vrt_config cfg{max_nodes, world_size, result_size.x, result_size.y, device, shard_rank, shard_count, 0, 0};
+        vrt_config cfg{max_nodes, world_size, result_size.x, result_size.y, device, shard_rank, shard_count, 0, 0, 0, {0}};
+        if (vrt_create(&cfg, &ctx_) != VRT_OK) throw GpuError(vrt_last_error(nullptr));
+    }
+    // One context over several devices (vrt_config.device_ids): the frame is traced by all of them and lands on devices[0].
+    Gpu(uint32_t max_nodes, uint32_t world_size, UVec2 result_size, const std::vector<int> &devices) {
+        vrt_config cfg{max_nodes, world_size, result_size.x, result_size.y, -1, 0, 0, 0, 0, (uint32_t)devices.size(), {0}};
+        for (size_t i = 0; i < devices.size() && i < VRT_MAX_DEVICES; i++) cfg.device_ids[i] = devices[i];
         if (vrt_create(&cfg, &ctx_) != VRT_OK) throw GpuError(vrt_last_error(nullptr));
     }
     ~Gpu() { vrt_destroy(ctx_); }

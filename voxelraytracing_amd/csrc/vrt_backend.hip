@@ -54,7 +54,12 @@ static_assert(sizeof(vrt_settings) == 48, "Settings layout (mod.rs:132-143)");
 static_assert(sizeof(vrt_crosshair) == 32, "Crosshair layout (mod.rs:63-70)");
 static_assert(sizeof(vrt::Texel) == 16, "texel");
 
+struct vrt_group;
+
 struct vrt_ctx {
+    vrt_group *grp = nullptr;   // a multi-device context (vrt_config.n_devices > 1): everything else below is unused, see vrt_group
+    hipStream_t last_stream = nullptr;  // the stream the most recent frame was enqueued on
+    hipEvent_t wait_before_frame = nullptr;  // set by a multi-device context: the next frame's stream waits for it first (its message slot is free)
     int device = 0;
     hipStream_t own_stream = nullptr;
     // Two frames in flight (what a swapchain gives the reference): consecutive plain frames alternate between the
@@ -86,6 +91,7 @@ struct vrt_ctx {
     uint32_t width = 0, height = 0;
     uint32_t shard_rank = 0, shard_count = 1, shard_w0 = 1;
     uint32_t shard_first = 0, shard_run = 1, shard_period = 1;  // vrt_device.h shard_tile()
+    bool whole_frame_owner = false;  // device_ids[0] of a multi-device context: its row-major buffer holds the assembled frame
     bool compact = false;     // VRT_FLAG_COMPACT: 8-byte records instead of texels (a sharded, tile-major context whose tiles cross a link)
     bool tile_major = false;  // output layout [t_local][64]: always when sharded, on request (VRT_FLAG_TILE_MAJOR) otherwise
     uint32_t tiles_x = 0, tiles_total = 0, tiles_local = 0, tiles_padded = 0;
@@ -153,6 +159,7 @@ struct vrt_ctx {
     float ndc_proj[2] = {0.f, 0.f};
 
     vrt_material h_mats[256];
+    uint32_t liquid_mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // bit v <=> h_mats[v].is_liquid == 1 (kept by vrt_write_materials)
     vrt_cam_data cam;
     vrt_settings settings;
     vrt_world_data world;
@@ -496,11 +503,35 @@ static int ensure_accel(vrt_ctx *c) {
     return rc;
 }
 
+// ---- one context over several devices (vrt_config.n_devices > 1); defined behind the C ABI below ----
+static int grp_create(const vrt_config *cfg, vrt_ctx **out);
+static void grp_destroy(vrt_ctx *c);
+static int grp_render(vrt_ctx *c, const vrt_render_opts *opts);
+static int grp_synchronize(vrt_ctx *c);
+static int grp_get_stats(vrt_ctx *c, vrt_stats *out);
+static int grp_resize_output(vrt_ctx *c, uint32_t w, uint32_t h);
+static int grp_set_frames_in_flight(vrt_ctx *c, uint32_t n);
+static vrt_ctx *grp_root(vrt_ctx *c);
+template <typename F> static int grp_each(vrt_ctx *c, F f);
+#define GRP_EACH(c, call)                                                   \
+    do {                                                                    \
+        if ((c) && (c)->grp) return grp_each((c), [&](vrt_ctx *d) { return call; }); \
+    } while (0)
+#define GRP_ROOT(c, call)                                                   \
+    do {                                                                    \
+        if ((c) && (c)->grp) { vrt_ctx *d = grp_root(c); const int rc_ = call; if (rc_) (c)->err = d->err; return rc_; } \
+    } while (0)
+#define GRP_REFUSE(c, what)                                                 \
+    do {                                                                    \
+        if ((c) && (c)->grp) return fail((c), VRT_ERR_STATE, what ": not on a multi-device context (it owns its streams and message buffers)"); \
+    } while (0)
+
 extern "C" {
 
 int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     if (!cfg || !out) return fail(nullptr, VRT_ERR_INVALID_ARG, "vrt_create: null argument");
     *out = nullptr;
+    if (cfg->n_devices > 1u) return grp_create(cfg, out);
     if (cfg->max_nodes < 2 || cfg->max_nodes > 0x7FFFFFFEu)
         return fail(nullptr, VRT_ERR_INVALID_ARG, "max_nodes must be in [2, 2^31 - 2] (the pool is addressed through a 32-bit byte offset)");
     if (cfg->width == 0 || cfg->height == 0 || (cfg->width % 8u) || (cfg->height % 8u))
@@ -579,6 +610,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
 
 void vrt_destroy(vrt_ctx *c) {
     if (!c) return;
+    if (c->grp) { grp_destroy(c); return; }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (hipStream_t st : c->extra_stream)
@@ -609,6 +641,7 @@ void vrt_destroy(vrt_ctx *c) {
 const char *vrt_last_error(const vrt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
 int vrt_write_nodes(vrt_ctx *c, const uint16_t *pool, uint32_t start, uint32_t end) {
+    GRP_EACH(c, vrt_write_nodes(d, pool, start, end));
     if (!c || !pool) return fail(c, VRT_ERR_INVALID_ARG, "vrt_write_nodes: null argument");
     if (end < start) return fail(c, VRT_ERR_INVALID_ARG, "vrt_write_nodes: end %u < start %u", end, start);
     // NodeBuffer::write, shader.rs:24-33: widen to even bounds
@@ -628,6 +661,7 @@ int vrt_write_nodes(vrt_ctx *c, const uint16_t *pool, uint32_t start, uint32_t e
 }
 
 int vrt_write_chunk_roots(vrt_ctx *c, uint32_t offset, const uint32_t *roots, uint32_t n) {
+    GRP_EACH(c, vrt_write_chunk_roots(d, offset, roots, n));
     if (!c || (!roots && n)) return fail(c, VRT_ERR_INVALID_ARG, "vrt_write_chunk_roots: null argument");
     if (offset > c->n_roots) return fail(c, VRT_ERR_OUT_OF_RANGE, "vrt_write_chunk_roots: offset %u > %u", offset, c->n_roots);
     // ArrayBuffer::write truncates to capacity (shader.rs:134-135)
@@ -648,6 +682,7 @@ int vrt_write_chunk_roots(vrt_ctx *c, uint32_t offset, const uint32_t *roots, ui
 }
 
 int vrt_resize_world(vrt_ctx *c, uint32_t world_size_chunks) {
+    GRP_EACH(c, vrt_resize_world(d, world_size_chunks));
     if (!c) return VRT_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     QUIESCE(c);
@@ -656,33 +691,41 @@ int vrt_resize_world(vrt_ctx *c, uint32_t world_size_chunks) {
 }
 
 int vrt_write_materials(vrt_ctx *c, uint32_t first, const vrt_material *mats, uint32_t n) {
+    GRP_EACH(c, vrt_write_materials(d, first, mats, n));
     if (!c || (!mats && n)) return fail(c, VRT_ERR_INVALID_ARG, "vrt_write_materials: null argument");
     if ((uint64_t)first + n > 256) return fail(c, VRT_ERR_OUT_OF_RANGE, "vrt_write_materials: %u+%u > 256", first, n);
     if (n == 0) return VRT_OK;
     memcpy(c->h_mats + first, mats, (size_t)n * sizeof(vrt_material));
+    memset(c->liquid_mask, 0, sizeof c->liquid_mask);
+    for (int v = 0; v < 256; v++)
+        if (c->h_mats[v].is_liquid == 1u) c->liquid_mask[v >> 5] |= 1u << (v & 31);
     HIP_TRY(c, hipSetDevice(c->device));
     return stage_upload(c, c->d_mats + first, mats, (size_t)n * sizeof(vrt_material));
 }
 
 int vrt_set_camera(vrt_ctx *c, const vrt_cam_data *cam) {
+    GRP_EACH(c, vrt_set_camera(d, cam));
     if (!c || !cam) return fail(c, VRT_ERR_INVALID_ARG, "vrt_set_camera: null argument");
     c->cam = *cam;
     return VRT_OK;
 }
 
 int vrt_set_settings(vrt_ctx *c, const vrt_settings *s) {
+    GRP_EACH(c, vrt_set_settings(d, s));
     if (!c || !s) return fail(c, VRT_ERR_INVALID_ARG, "vrt_set_settings: null argument");
     c->settings = *s;
     return VRT_OK;
 }
 
 int vrt_set_world(vrt_ctx *c, const vrt_world_data *w) {
+    GRP_EACH(c, vrt_set_world(d, w));
     if (!c || !w) return fail(c, VRT_ERR_INVALID_ARG, "vrt_set_world: null argument");
     c->world = *w;
     return VRT_OK;
 }
 
 int vrt_resize_output(vrt_ctx *c, uint32_t width, uint32_t height) {
+    if (c && c->grp) return grp_resize_output(c, width, height);
     if (!c) return VRT_ERR_INVALID_ARG;
     if (width == 0 || height == 0 || (width % 8u) || (height % 8u) || (uint64_t)width * height > (1ull << 28))
         return fail(c, VRT_ERR_INVALID_ARG, "output %ux%u: dimensions must be non-zero multiples of 8", width, height);
@@ -800,8 +843,7 @@ static void fill_uniforms(const vrt_ctx *c, vrt::FrameParams &P) {
     P.finite_settings = std::isfinite(s.sun_intensity) && std::isfinite(s.sky_color[0]) && std::isfinite(s.sky_color[1]) &&
                         std::isfinite(s.sky_color[2]) && std::isfinite(s.sun_pos[0]) && std::isfinite(s.sun_pos[1]) &&
                         std::isfinite(s.sun_pos[2]);
-    for (int v = 0; v < 256; v++)
-        if (c->h_mats[v].is_liquid == 1u) P.liquid[v >> 5] |= 1u << (v & 31);
+    memcpy(P.liquid, c->liquid_mask, sizeof P.liquid);
 
     P.ndc_x = c->d_ndc;
     P.ndc_y = c->d_ndc + c->width;
@@ -958,6 +1000,7 @@ static int launch_march_frame(vrt_ctx *c, const vrt::FrameParams &P, const Frame
 }
 
 int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
+    if (c && c->grp) return grp_render(c, opts);
     if (!c) return VRT_ERR_INVALID_ARG;
     vrt_render_opts o;
     memset(&o, 0, sizeof o);
@@ -1009,6 +1052,11 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     if (rc) return rc;
     c->last_out = f.out;
     c->last_blk = f.blk;
+    c->last_stream = f.st;
+    if (c->wait_before_frame) {
+        HIP_TRY(c, hipStreamWaitEvent(f.st, c->wait_before_frame, 0));
+        c->wait_before_frame = nullptr;
+    }
 
     vrt::FrameParams P;
     memset(&P, 0, sizeof P);
@@ -1050,6 +1098,7 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
 }
 
 int vrt_synchronize(vrt_ctx *c) {
+    if (c && c->grp) return grp_synchronize(c);
     if (!c) return VRT_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     QUIESCE(c);
@@ -1058,6 +1107,8 @@ int vrt_synchronize(vrt_ctx *c) {
 }
 
 int vrt_read_output(vrt_ctx *c, float *rgb, uint32_t *ids, uint8_t *rgba8) {
+    if (c && c->grp) { const int rc_ = grp_synchronize(c); if (rc_) return rc_; }
+    GRP_ROOT(c, vrt_read_output(d, rgb, ids, rgba8));
     if (!c) return VRT_ERR_INVALID_ARG;
     if (!c->rendered) return fail(c, VRT_ERR_STATE, "vrt_read_output: nothing rendered yet");
     if (c->compact) return fail(c, VRT_ERR_STATE, "vrt_read_output: a VRT_FLAG_COMPACT context holds 8-byte records, not texels (vrt_assemble_compact shades them)");
@@ -1098,9 +1149,12 @@ int vrt_read_output(vrt_ctx *c, float *rgb, uint32_t *ids, uint8_t *rgba8) {
 }
 
 int vrt_present(vrt_ctx *c, const vrt_crosshair *crosshair, uint32_t screen_w, uint32_t screen_h, uint8_t *rgba8) {
+    if (c && c->grp) { const int rc_ = grp_synchronize(c); if (rc_) return rc_; }
+    GRP_ROOT(c, vrt_present(d, crosshair, screen_w, screen_h, rgba8));
     if (!c || !crosshair || !rgba8) return fail(c, VRT_ERR_INVALID_ARG, "vrt_present: null argument");
     if (!c->rendered) return fail(c, VRT_ERR_STATE, "vrt_present: nothing rendered yet");
-    if (c->tile_major || c->shard_count > 1u) return fail(c, VRT_ERR_STATE, "vrt_present: needs the whole row-major frame");
+    if (c->tile_major || (c->shard_count > 1u && !c->whole_frame_owner))
+        return fail(c, VRT_ERR_STATE, "vrt_present: needs the whole row-major frame");
     if (screen_w < c->width || screen_h < c->height || (uint64_t)screen_w * screen_h > (1ull << 28))
         return fail(c, VRT_ERR_INVALID_ARG, "vrt_present: screen %ux%u must be at least the %ux%u result texture (the sampler magnifies "
                     "with Nearest; its Linear minification is not implemented)", screen_w, screen_h, c->width, c->height);
@@ -1121,6 +1175,7 @@ int vrt_present(vrt_ctx *c, const vrt_crosshair *crosshair, uint32_t screen_w, u
 }
 
 int vrt_read_steps(vrt_ctx *c, uint32_t *steps) {
+    GRP_REFUSE(c, "vrt_read_steps");
     if (!c || !steps) return fail(c, VRT_ERR_INVALID_ARG, "vrt_read_steps: null argument");
     if (!c->rendered || !c->last_stats || !c->d_steps)
         return fail(c, VRT_ERR_STATE, "vrt_read_steps: the last frame was not rendered with opts.stats = 1");
@@ -1132,6 +1187,7 @@ int vrt_read_steps(vrt_ctx *c, uint32_t *steps) {
 }
 
 int vrt_get_stats(vrt_ctx *c, vrt_stats *out) {
+    if (c && c->grp) return grp_get_stats(c, out);
     if (!c || !out) return fail(c, VRT_ERR_INVALID_ARG, "vrt_get_stats: null argument");
     if (!c->rendered) return fail(c, VRT_ERR_STATE, "vrt_get_stats: nothing rendered yet");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1195,6 +1251,7 @@ static int bricks_in_use(vrt_ctx *c, uint32_t *n) {
 }
 
 int vrt_get_accel_info(vrt_ctx *c, vrt_accel_info *out) {
+    GRP_ROOT(c, vrt_get_accel_info(d, out));
     if (!c || !out) return fail(c, VRT_ERR_INVALID_ARG, "vrt_get_accel_info: null argument");
     memset(out, 0, sizeof *out);
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1215,6 +1272,7 @@ int vrt_get_accel_info(vrt_ctx *c, vrt_accel_info *out) {
 }
 
 int vrt_read_accel(vrt_ctx *c, uint32_t *grid, uint16_t *bricks) {
+    GRP_ROOT(c, vrt_read_accel(d, grid, bricks));
     if (!c) return VRT_ERR_INVALID_ARG;
     if (!c->accel_ok || c->accel_dirty || !c->dirty_chunks.empty())
         return fail(c, VRT_ERR_STATE, "vrt_read_accel: the tables are not up to date (render a frame first)");
@@ -1238,6 +1296,7 @@ int vrt_read_accel(vrt_ctx *c, uint32_t *grid, uint16_t *bricks) {
 }
 
 int vrt_set_frames_in_flight(vrt_ctx *c, uint32_t n) {
+    if (c && c->grp) return grp_set_frames_in_flight(c, n);
     if (!c) return VRT_ERR_INVALID_ARG;
     if (n < 1u || n > vrt_ctx::kMaxInFlight) return fail(c, VRT_ERR_INVALID_ARG, "vrt_set_frames_in_flight: 1..%u", vrt_ctx::kMaxInFlight);
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1249,6 +1308,7 @@ int vrt_set_frames_in_flight(vrt_ctx *c, uint32_t n) {
 }
 
 int vrt_set_stream(vrt_ctx *c, void *hip_stream) {
+    GRP_REFUSE(c, "vrt_set_stream");
     if (!c) return VRT_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     QUIESCE(c);
@@ -1258,6 +1318,7 @@ int vrt_set_stream(vrt_ctx *c, void *hip_stream) {
 }
 
 int vrt_bind_output(vrt_ctx *c, void *texels) {
+    GRP_REFUSE(c, "vrt_bind_output");
     if (!c) return VRT_ERR_INVALID_ARG;
     if (texels && ((uintptr_t)texels % 16u)) return fail(c, VRT_ERR_INVALID_ARG, "vrt_bind_output: texels must be 16-byte aligned");
     // stream-ordered: launches capture the pointer, so frames already enqueued keep writing where they were
@@ -1269,6 +1330,7 @@ int vrt_bind_output(vrt_ctx *c, void *texels) {
 }
 
 int vrt_device_output(vrt_ctx *c, void **texels, uint64_t *bytes) {
+    GRP_ROOT(c, vrt_device_output(d, texels, bytes));
     if (!c) return VRT_ERR_INVALID_ARG;
     if (texels) *texels = c->d_out == c->own_out ? c->last_out : c->d_out;  // own buffers: the one holding the last frame
     if (bytes) *bytes = (uint64_t)c->slots * (c->compact ? 8u : sizeof(vrt::Texel));
@@ -1276,6 +1338,7 @@ int vrt_device_output(vrt_ctx *c, void **texels, uint64_t *bytes) {
 }
 
 int vrt_shard_info(vrt_ctx *c, uint32_t *tiles_local, uint32_t *tiles_padded, uint32_t *tiles_total) {
+    GRP_ROOT(c, vrt_shard_info(d, tiles_local, tiles_padded, tiles_total));
     if (!c) return VRT_ERR_INVALID_ARG;
     if (tiles_local) *tiles_local = c->tiles_local;
     if (tiles_padded) *tiles_padded = c->tiles_padded;
@@ -1284,6 +1347,7 @@ int vrt_shard_info(vrt_ctx *c, uint32_t *tiles_local, uint32_t *tiles_padded, ui
 }
 
 int vrt_assemble(vrt_ctx *c, const void *gathered, uint64_t rank_stride_bytes, void *dst) {
+    GRP_REFUSE(c, "vrt_assemble");
     if (!c) return VRT_ERR_INVALID_ARG;
     if (!gathered || !dst) return fail(c, VRT_ERR_INVALID_ARG, "vrt_assemble: null argument");
     if (rank_stride_bytes % 16u) return fail(c, VRT_ERR_INVALID_ARG, "vrt_assemble: rank stride must be a multiple of 16 bytes");
@@ -1297,6 +1361,7 @@ int vrt_assemble(vrt_ctx *c, const void *gathered, uint64_t rank_stride_bytes, v
 }
 
 int vrt_assemble_compact(vrt_ctx *c, const void *gathered, uint64_t rank_stride_bytes, void *dst) {
+    GRP_REFUSE(c, "vrt_assemble_compact");
     if (!c) return VRT_ERR_INVALID_ARG;
     if (!gathered || !dst) return fail(c, VRT_ERR_INVALID_ARG, "vrt_assemble_compact: null argument");
     if (rank_stride_bytes % 8u) return fail(c, VRT_ERR_INVALID_ARG, "vrt_assemble_compact: rank stride must be a multiple of 8 bytes");
@@ -1319,3 +1384,227 @@ int vrt_assemble_compact(vrt_ctx *c, const void *gathered, uint64_t rank_stride_
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One context over several devices (vrt_config.n_devices > 1).
+//
+// The reference is one process on one thread driving one GpuResources (main.rs:398-455); this keeps that shape for a
+// node with several GPUs.  A group is N ordinary contexts, one per entry of device_ids: device 0's is a row-major shard
+// root, the others are tile-major shard contexts that write 8-byte records (or texels, VRT_FLAG_TEXEL_MESSAGES).  Every
+// upload is replicated (each context stages its own copy); a frame is
+//     for r >= 1:  [device r] wait until device 0 has consumed message slot k -> render into device 0's memory
+//                             (peer stores over xGMI, hipDeviceEnablePeerAccess) -> record done[r][k]
+//     device 0:    render its own tiles straight into frame buffer k (its in-flight stream X) -> on X: wait for every
+//                  done[r][k] -> shade / scatter the messages into the frame -> record consumed[k]
+// all enqueued from the calling thread without waiting for anything: two message slots and device 0's two frame buffers
+// give the same two frames in flight a single device has.  No collective library, no second process.
+// ---------------------------------------------------------------------------------------------------------------------
+struct vrt_group {
+    std::vector<vrt_ctx *> dev;      // dev[0] = the root
+    bool texels = false;             // VRT_FLAG_TEXEL_MESSAGES
+    static constexpr uint32_t kSlots = 2;
+    void *recv[kSlots] = {nullptr, nullptr};               // on device 0: [n_devices][tiles_padded * 64] records or texels
+    size_t rank_stride = 0;                                // bytes between two devices' messages
+    hipEvent_t consumed[kSlots] = {nullptr, nullptr};      // device 0 has assembled the frame of this slot
+    bool consumed_used[kSlots] = {false, false};
+    std::vector<std::array<hipEvent_t, kSlots>> done;      // [r][slot]: device r's message is complete
+    uint32_t slot = 0, in_flight = 2;
+    bool last_was_stats = false;
+};
+
+static vrt_ctx *grp_root(vrt_ctx *c) { return c->grp->dev[0]; }
+
+template <typename F>
+static int grp_each(vrt_ctx *c, F f) {
+    for (vrt_ctx *d : c->grp->dev) {
+        const int rc = f(d);
+        if (rc) { c->err = d->err; return rc; }
+    }
+    return VRT_OK;
+}
+
+static int grp_alloc_messages(vrt_ctx *c) {
+    vrt_group *g = c->grp;
+    vrt_ctx *root = g->dev[0];
+    HIP_TRY(c, hipSetDevice(root->device));
+    for (auto &p : g->recv) { (void)hipFree(p); p = nullptr; }
+    g->rank_stride = (size_t)root->tiles_padded * 64u * (g->texels ? 16u : 8u);
+    for (auto &p : g->recv) {
+        HIP_TRY(c, hipMalloc(&p, g->rank_stride * g->dev.size()));
+        HIP_TRY(c, hipMemset(p, 0, g->rank_stride * g->dev.size()));
+    }
+    g->slot = 0;
+    g->consumed_used[0] = g->consumed_used[1] = false;
+    return VRT_OK;
+}
+
+static int grp_create(const vrt_config *cfg, vrt_ctx **out) {
+    const uint32_t n = cfg->n_devices;
+    if (n > VRT_MAX_DEVICES) return fail(nullptr, VRT_ERR_INVALID_ARG, "n_devices %u > VRT_MAX_DEVICES", n);
+    if (cfg->shard_rank != 0u || cfg->shard_count > 1u)
+        return fail(nullptr, VRT_ERR_INVALID_ARG, "a multi-device context shards by itself: shard_rank / shard_count must be 0");
+    if (cfg->flags & ~VRT_FLAG_TEXEL_MESSAGES)
+        return fail(nullptr, VRT_ERR_INVALID_ARG, "a multi-device context takes VRT_FLAG_TEXEL_MESSAGES only");
+    vrt_ctx *c = new (std::nothrow) vrt_ctx();
+    vrt_group *g = new (std::nothrow) vrt_group();
+    if (!c || !g) { delete c; delete g; return fail(nullptr, VRT_ERR_OOM, "host allocation failed"); }
+    c->grp = g;
+    g->texels = (cfg->flags & VRT_FLAG_TEXEL_MESSAGES) != 0u;
+    // the root's own tiles never cross a link, so it takes more of the frame; measured defaults
+    const uint32_t w0 = cfg->shard_root_weight ? cfg->shard_root_weight : (n == 2u ? 4u : n <= 4u ? 3u : 2u);
+    auto body = [&]() -> int {
+        for (uint32_t r = 0; r < n; r++) {
+            vrt_config sub = *cfg;
+            sub.n_devices = 0;
+            sub.device = cfg->device_ids[r];
+            sub.shard_rank = r;
+            sub.shard_count = n;
+            sub.shard_root_weight = w0;
+            sub.flags = r == 0u ? VRT_FLAG_ROW_MAJOR : (g->texels ? 0u : VRT_FLAG_COMPACT);
+            vrt_ctx *d = nullptr;
+            const int rc = vrt_create(&sub, &d);
+            if (rc) { c->err = g_create_err; return rc; }
+            g->dev.push_back(d);
+        }
+        g->dev[0]->whole_frame_owner = true;
+        g->done.resize(n);
+        for (uint32_t r = 1; r < n; r++) {
+            HIP_TRY(c, hipSetDevice(g->dev[r]->device));
+            if (g->dev[r]->device != g->dev[0]->device) {
+                const hipError_t e = hipDeviceEnablePeerAccess(g->dev[0]->device, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+                    return fail(c, VRT_ERR_DEVICE, "device %d cannot store into device %d's memory (hipDeviceEnablePeerAccess: %s)",
+                                g->dev[r]->device, g->dev[0]->device, hipGetErrorString(e));
+                (void)hipGetLastError();
+            }
+            for (auto &ev : g->done[r]) HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        }
+        HIP_TRY(c, hipSetDevice(g->dev[0]->device));
+        for (auto &ev : g->consumed) HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        return grp_alloc_messages(c);
+    };
+    const int rc = body();
+    if (rc) {
+        g_create_err = c->err;
+        grp_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return VRT_OK;
+}
+
+static void grp_destroy(vrt_ctx *c) {
+    vrt_group *g = c->grp;
+    for (vrt_ctx *d : g->dev) {
+        (void)hipSetDevice(d->device);
+        (void)vrt_synchronize(d);
+    }
+    if (!g->dev.empty()) (void)hipSetDevice(g->dev[0]->device);
+    for (auto p : g->recv) (void)hipFree(p);
+    for (auto ev : g->consumed)
+        if (ev) (void)hipEventDestroy(ev);
+    for (auto &evs : g->done)
+        for (auto ev : evs)
+            if (ev) (void)hipEventDestroy(ev);
+    for (vrt_ctx *d : g->dev) vrt_destroy(d);
+    delete g;
+    delete c;
+}
+
+static int grp_synchronize(vrt_ctx *c) { return grp_each(c, [](vrt_ctx *d) { return vrt_synchronize(d); }); }
+
+static int grp_set_frames_in_flight(vrt_ctx *c, uint32_t n) {
+    if (n < 1u || n > vrt_group::kSlots) return fail(c, VRT_ERR_INVALID_ARG, "vrt_set_frames_in_flight: 1..%u on a multi-device context", vrt_group::kSlots);
+    int rc = grp_synchronize(c);
+    if (rc) return rc;
+    c->grp->in_flight = n;
+    return grp_each(c, [&](vrt_ctx *d) { return vrt_set_frames_in_flight(d, n); });
+}
+
+static int grp_resize_output(vrt_ctx *c, uint32_t w, uint32_t h) {
+    int rc = grp_synchronize(c);
+    if (rc) return rc;
+    rc = grp_each(c, [&](vrt_ctx *d) { return vrt_resize_output(d, w, h); });
+    if (rc) return rc;
+    return grp_alloc_messages(c);
+}
+
+static int grp_render(vrt_ctx *c, const vrt_render_opts *opts) {
+    vrt_group *g = c->grp;
+    vrt_ctx *root = g->dev[0];
+    vrt_render_opts o;
+    memset(&o, 0, sizeof o);
+    if (opts) o = *opts;
+    if (!g->texels && (o.mode == VRT_MODE_PATH || (o.variant != 0u && o.variant != 2u)))
+        return fail(c, VRT_ERR_STATE, "vrt_render: this multi-device context exchanges 8-byte records (primary(+shadow) frames of the default "
+                    "march); create it with VRT_FLAG_TEXEL_MESSAGES for the path trace and the other marches");
+    if (o.stats == 2u || o.variant == 4u) return fail(c, VRT_ERR_INVALID_ARG, "vrt_render: no clock probe / persistent grid on a multi-device context");
+    const uint32_t n = (uint32_t)g->dev.size();
+    const bool plain = o.stats == 0u && root->settings.show_step_count != 1u;
+    if (!plain || g->in_flight == 1u || g->last_was_stats) {   // a stats frame (counters are read back) stands alone
+        const int rc = grp_synchronize(c);
+        if (rc) return rc;
+    }
+    g->last_was_stats = !plain;
+    const uint32_t k = g->slot;
+    g->slot = (g->slot + 1u) % (g->in_flight > 1u ? vrt_group::kSlots : 1u);
+    o.flags |= VRT_RENDER_OWN_STREAMS;   // every device's frame runs on that context's in-flight streams, into the buffer bound here
+    for (uint32_t r = 1; r < n; r++) {
+        vrt_ctx *d = g->dev[r];
+        HIP_TRY(c, hipSetDevice(d->device));
+        int rc = vrt_bind_output(d, (uint8_t *)g->recv[k] + (size_t)r * g->rank_stride);
+        // the slot's previous message must have been consumed by device 0 before this frame overwrites it
+        d->wait_before_frame = g->consumed_used[k] ? g->consumed[k] : nullptr;
+        if (!rc) rc = vrt_render(d, &o);
+        d->wait_before_frame = nullptr;
+        if (rc) { c->err = d->err; return rc; }
+        if (d->tiles_local) HIP_TRY(c, hipEventRecord(g->done[r][k], d->last_stream));
+    }
+    HIP_TRY(c, hipSetDevice(root->device));
+    int rc = vrt_render(root, &o);
+    if (rc) { c->err = root->err; return rc; }
+    hipStream_t X = root->last_stream ? root->last_stream : root->stream;
+    for (uint32_t r = 1; r < n; r++)
+        if (g->dev[r]->tiles_local) HIP_TRY(c, hipStreamWaitEvent(X, g->done[r][k], 0));
+    // shade / scatter the other devices' messages into the frame the root has just rendered its own tiles into
+    vrt::Texel *frame = root->last_out;
+    if (g->texels) {
+        vrt::launch_assemble((const vrt::Texel *)g->recv[k], frame, root->width, root->tiles_x, root->tiles_total, root->shard_w0,
+                             root->shard_period, true, g->rank_stride / 16u, X);
+    } else {
+        vrt::FrameParams P;
+        memset(&P, 0, sizeof P);
+        P.mats = root->d_mats;
+        fill_uniforms(root, P);
+        vrt::launch_assemble_shade(P, g->recv[k], frame, root->shard_w0, root->shard_period, g->rank_stride / 8u, X);
+    }
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(g->consumed[k], X));
+    g->consumed_used[k] = true;
+    return VRT_OK;
+}
+
+static int grp_get_stats(vrt_ctx *c, vrt_stats *out) {
+    if (!out) return fail(c, VRT_ERR_INVALID_ARG, "vrt_get_stats: null argument");
+    int rc = grp_synchronize(c);
+    if (rc) return rc;
+    vrt_stats acc;
+    memset(&acc, 0, sizeof acc);
+    bool first = true;
+    for (vrt_ctx *d : c->grp->dev) {
+        vrt_stats s;
+        (void)hipSetDevice(d->device);
+        rc = vrt_get_stats(d, &s);
+        if (rc) { c->err = d->err; return rc; }
+        acc.primary_rays += s.primary_rays; acc.secondary_rays += s.secondary_rays; acc.hits += s.hits;
+        acc.steps += s.steps; acc.node_visits += s.node_visits; acc.primary_steps += s.primary_steps;
+        acc.primary_node_visits += s.primary_node_visits;
+        if (first) {   // kernel times: the root's own launches
+            acc.ms_total = s.ms_total; acc.ms_primary = s.ms_primary; acc.ms_secondary = s.ms_secondary; acc.frames = s.frames;
+            acc.sum_ms_primary = s.sum_ms_primary; acc.sum_ms_secondary = s.sum_ms_secondary; acc.sum_ms_total = s.sum_ms_total;
+            first = false;
+        }
+    }
+    *out = acc;
+    return VRT_OK;
+}

@@ -354,7 +354,12 @@ __global__ void assemble_kernel(const Texel *gathered, Texel *dst, uint32_t widt
         t_local = q;
     }
     const uint32_t px = (tile % tiles_x) * 8u + (p & 7u), py = (tile / tiles_x) * 8u + (p >> 3);
-    dst[py * width + px] = gathered[rank * rank_stride + (uint64_t)t_local * 64u + p];
+    // the messages may have been stored by another device (a multi-device context's peers write them over xGMI, RCCL's
+    // gather likewise): read them past this device's caches
+    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(gathered + rank * rank_stride + (uint64_t)t_local * 64u + p);
+    const unsigned long long lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    dst[py * width + px] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
 }
 
 // Gather root, compact messages: the other ranks sent 8 bytes per pixel {id word | kIdNormYNeg, water_dist}; the root
@@ -369,7 +374,10 @@ __global__ void assemble_shade_kernel(FrameParams P, const uint2 *gathered, Texe
     const uint32_t q = tile / period, r = tile % period;
     if (r < root_weight) return;  // the root's own tiles are already in dst
     const uint32_t rank = r - root_weight + 1u;
-    const uint2 rec = gathered[rank * rank_stride + (uint64_t)q * 64u + p];
+    // (read past this device's caches: another device may have stored the record, see assemble_kernel)
+    const unsigned long long rw = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(gathered + rank * rank_stride + (uint64_t)q * 64u + p),
+                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const uint2 rec = make_uint2((uint32_t)rw, (uint32_t)(rw >> 32));
     const uint32_t px = (tile % P.tiles_x) * 8u + (p & 7u), py = (tile / P.tiles_x) * 8u + (p >> 3);
 
     MarchResult R;
