@@ -800,3 +800,29 @@ def test_compact_shards_without_the_derived_tables_stay_inside_their_records(c2_
     assert np.array_equal(a_ids, ids) and np.array_equal(a_rgb, rgb)
     for c in ctxs + [full]:
         c.close()
+
+
+def test_persistent_path_kernel_gives_the_same_frames(orc, monkeypatch):
+    """VRT_PATH_PERSISTENT=1: the path trace as one launch of persistent waves whose lanes are refilled in batches (built
+    and measured, not the default) — bit for bit the frame of the launch-per-bounce kernels, whole and sharded."""
+    sc = scenes.c4((320, 184), bounces=4)
+    ref = gpu_for_scene(sc)
+    ref.render(MODE_PATH, spp=3, seed=11)
+    rgb, ids, _ = ref.read_output()
+    monkeypatch.setenv("VRT_PATH_PERSISTENT", "1")
+    gpu = gpu_for_scene(sc)
+    for _ in range(3):
+        gpu.render(MODE_PATH, spp=3, seed=11)
+    rgb2, ids2, _ = gpu.read_output()
+    assert np.array_equal(ids2, ids) and np.array_equal(rgb2, rgb)
+    r_rgb, r_ids, _, _ = orc.from_package_scene(sc).render(orc.MODE_PATH, *sc.size, spp=3, seed=11)
+    assert_frame_parity(rgb2, ids2, r_rgb, r_ids, "persistent path kernel")
+    acc_rgb, acc_ids = np.zeros_like(rgb), np.zeros_like(ids)
+    for r in range(3):
+        sh = gpu_for_scene(sc, shard_rank=r, shard_count=3, root_weight=2)
+        sh.render(MODE_PATH, spp=3, seed=11)
+        s_rgb, s_ids, _ = sh.read_output()
+        acc_rgb += s_rgb
+        acc_ids |= s_ids
+        sh.close()
+    assert np.array_equal(acc_ids, ids) and np.array_equal(acc_rgb, rgb)

@@ -29,6 +29,7 @@ void launch_primary_shadow_persistent(const FrameParams &P, uint32_t *heads, uin
 void launch_path_primary(const FrameParams &P, bool stats, bool literal, hipStream_t st);
 void launch_path_bounce(const FrameParams &P, bool stats, bool literal, hipStream_t st);
 void launch_path_finish(Texel *out, uint32_t n, uint32_t spp, hipStream_t st);
+void launch_path_persistent(const FrameParams &P, uint32_t *heads, uint32_t n_cus, hipStream_t st);
 void launch_quantize(const Texel *out, uint8_t *rgba8, uint32_t n, hipStream_t st);
 void launch_assemble(const Texel *gathered, Texel *dst, uint32_t width, uint32_t tiles_x, uint32_t tiles_total,
                      uint32_t root_weight, uint32_t period, bool skip_root, uint64_t rank_stride, hipStream_t st);
@@ -131,6 +132,7 @@ struct vrt_ctx {
     bool accel_dirty = true;
     bool accel_ok = false;        // false: world too large for the tables, variant 0 runs as variant 2
     uint32_t accel_max_s = 0;     // kAccelMaxS, or less through VRT_ACCEL_MAX_S (tests of the fallback)
+    bool path_persistent = false;  // VRT_PATH_PERSISTENT=1: plain path frames as one persistent launch instead of one launch per bounce
     uint32_t accel_builds = 0, accel_chunk_builds = 0;
     float accel_last_ms = 0.f;
     std::vector<uint32_t> dirty_chunks;     // chunk slots whose nodes or root changed since the tables were last brought up to date
@@ -574,6 +576,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         const long v = strtol(e, nullptr, 10);
         if (v >= 0 && v < (long)kAccelMaxS) c->accel_max_s = (uint32_t)v;
     }
+    if (const char *e = getenv("VRT_PATH_PERSISTENT")) c->path_persistent = e[0] == '1';
     memset(c->h_mats, 0, sizeof c->h_mats);
     memset(&c->cam, 0, sizeof c->cam);
     memset(&c->settings, 0, sizeof c->settings);
@@ -927,6 +930,27 @@ static int next_events(vrt_ctx *c, std::array<hipEvent_t, 4> **ev, uint8_t **kin
 static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f, const vrt_render_opts &o, bool kstats, bool literal,
                              std::array<hipEvent_t, 4> &ev, uint8_t &ev_kind) {
     const uint32_t spp = o.spp ? o.spp : 1u, bounces = c->settings.max_ray_bounces;
+    if (bounces > 0 && !kstats && !literal && P.grid && c->path_persistent) {
+        // VRT_PATH_PERSISTENT=1 (built and measured, not the default: 10.8 against 13.0 Grays/s on C4):
+        // persistent waves whose lanes own pixels and are refilled in batches (vrt_path.hip); one launch per frame
+        // whatever spp and the bounce count are, no path buffers.  The tile queues' eight heads live at the start of this
+        // frame set's segment-counter area (zeroed with the counters just before).
+        if (!c->n_cus) {
+            hipDeviceProp_t prop;
+            HIP_TRY(c, hipGetDeviceProperties(&prop, c->device));
+            c->n_cus = (uint32_t)prop.multiProcessorCount;
+        }
+        P.spp = spp;
+        P.seed = o.seed;
+        HIP_TRY(c, hipEventRecord(ev[0], f.st));
+        vrt::launch_path_persistent(P, P.seg_counts, c->n_cus, f.st);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipEventRecord(ev[1], f.st));
+        HIP_TRY(c, hipEventRecord(ev[3], f.st));
+        ev_kind = kEvRecorded;
+        c->last_spp = spp;
+        return VRT_OK;
+    }
     const size_t cap = (size_t)vrt::kHitSegments * c->hit_seg_cap;
     if (!*f.path_buf) HIP_TRY(c, hipMalloc(f.path_buf, 2 * 3 * cap * sizeof(uint4)));
     uint32_t *seg[2] = {P.seg_counts, P.seg_counts + vrt::kHitSegments * vrt::kSegStride};

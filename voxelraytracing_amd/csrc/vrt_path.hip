@@ -11,6 +11,8 @@
 // paths that are still alive (same per-segment ballot compaction as the shadow hit buffer), marches them and
 // appends the survivors to the other buffer.  A pixel's path has exactly one owner lane per bounce, so
 // radiance accumulates into the pixel's texel with plain read-modify-writes.
+#include <cstdlib>
+
 #include "vrt_march.h"
 
 namespace vrt {
@@ -242,6 +244,314 @@ __global__ void __launch_bounds__(256) path_bounce_kernel(FrameParams P) {
             atomicAdd(&P.counters[kCtrSecondary], s_acc[2]);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The path trace as ONE launch (VRT_PATH_PERSISTENT=1; built and measured, not the default): persistent waves, lanes
+// refilled in batches.
+//
+// The wavefront kernels above run one launch per bounce; a bounce launch marches rays whose directions were just
+// randomised, so a wave's lanes finish after very different numbers of steps and the wave runs as long as its slowest
+// lane (measured: 36-39 % lane utilisation).  Here a lane owns a *pixel* — all its samples, all their segments, in the
+// order the oracle traces them, the radiance summed in a register — and a wave keeps marching with the lanes it has:
+//   * the march loop is resumable (its state lives in the lane's registers across the phases below);
+//   * when kRefillAt lanes have finished their segment, the wave leaves the march loop once, and those lanes do what
+//     comes next together: shade, draw the bounce direction, or end the sample / the pixel and take the next pixel of
+//     the wave's tile queue — then all lanes re-enter the march loop;
+//   * tiles come from eight per-XCD ticket counters (one atomic per 64 pixels, any wave steals from any queue).
+// Every path executes exactly the instructions the wavefront kernels execute for it, so the frame is bit-identical to
+// theirs (tests) — scheduling is the only difference.  No path buffers in HBM, one launch per frame whatever spp is.
+// Measured on C4 (1080p, 4 bounces): 10.8 Grays/s at the best batch size (40 waiting lanes; 6.2 at 8, 8.1 at 64) against
+// 13.0 for the launch-per-bounce kernels: what a lane does between two segments — shading, six RNG draws with three
+// logarithms and cosines, two normalisations, the nine divides and four square roots of a ray's set-up, ~800 VALU
+// instructions — costs as much as marching the segment, and here it is issued for a batch of 16-40 lanes where the
+// launch-per-bounce kernels issue it for 64.  What the batches win in the march they lose between the segments.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kRefillAt = 40;   // lanes that must be waiting before the wave leaves the march loop for them (measured optimum)
+
+struct Segment {      // one ray being marched (march_grid's loop state, vrt_march.h)
+    V3 pos, dir;
+    float ux, uy, uz;
+    uint32_t mxm, mym, mzm;
+    int vx, vy, vz;
+    float step, adx, ady, adz, dew, total_len, water_dist;
+    uint32_t slow_bit, voxel, iter;
+    bool careful;
+};
+
+// march_grid's prologue.  false: the ray starts outside the world (a miss before any lookup).
+__device__ __forceinline__ bool segment_begin(const FrameParams &P, V3 origin, V3 dir, Segment &m) {
+    m.dir = dir;
+    m.careful = !(finite3(origin) && finite3(dir));
+    V3 pos = origin;
+    if (pos.x - floorf(pos.x) < 0.001f || pos.y - floorf(pos.y) < 0.001f || pos.z - floorf(pos.z) < 0.001f) {
+        pos.x += 0.001f * dir.x;
+        pos.y += 0.001f * dir.y;
+        pos.z += 0.001f * dir.z;
+    }
+    m.pos = pos;
+    m.water_dist = 0.0f;
+    m.voxel = 0u;
+    m.step = -1.0f;
+    m.adx = m.ady = m.adz = 0.0f;
+    m.dew = -1.0f;
+    m.total_len = 0.0f;
+    m.iter = 0u;
+    m.slow_bit = m.careful ? 0x80000000u : 0u;
+    const float world_max = 0.0f + (float)P.world.size;
+    if ((pos.x <= 0.0f || pos.y <= 0.0f || pos.z <= 0.0f) || (pos.x >= world_max || pos.y >= world_max || pos.z >= world_max)) return false;
+    const V3 unit{
+        sqrtf(1.0f + (dir.y / dir.x) * (dir.y / dir.x) + (dir.z / dir.x) * (dir.z / dir.x)),
+        sqrtf(1.0f + (dir.x / dir.y) * (dir.x / dir.y) + (dir.z / dir.y) * (dir.z / dir.y)),
+        sqrtf(1.0f + (dir.x / dir.z) * (dir.x / dir.z) + (dir.y / dir.z) * (dir.y / dir.z))};
+    m.ux = fabsf(unit.x); m.uy = fabsf(unit.y); m.uz = fabsf(unit.z);
+    m.mxm = dir.x >= 0.0f ? ~0u : 0u; m.mym = dir.y >= 0.0f ? ~0u : 0u; m.mzm = dir.z >= 0.0f ? ~0u : 0u;
+    m.vx = trunc2i(pos.x); m.vy = trunc2i(pos.y); m.vz = trunc2i(pos.z);
+    return true;
+}
+
+// One trip of march_grid's loop.  true: the segment is over (solid hit, left the world, or kMaxSteps lookups).
+__device__ __forceinline__ bool segment_trip(const FrameParams &P, const uint32_t *s_liquid, TableBuf gb, TableBuf bb, uint32_t row_bytes,
+                                             uint32_t slab_bytes, Segment &m) {
+    m.iter += 1u;
+    uint32_t e = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(
+        gb, mad_i24(m.vz >> 2, slab_bytes, mad_i24(m.vy >> 2, row_bytes, (uint32_t)m.vx & ~3u)), 0, 0);
+    uint32_t lo = e;
+    if ((e | m.slow_bit) - 1u >= 31u) {
+        if (m.careful) {
+            m.vx = trunc2i(m.pos.x);
+            m.vy = trunc2i(m.pos.y);
+            m.vz = trunc2i(m.pos.z);
+            e = 0u;
+            if (!(min3_nan_ignoring(m.pos.x, m.pos.y, m.pos.z) < 0.0f ||
+                  max(max((uint32_t)m.vx, (uint32_t)m.vy), (uint32_t)m.vz) >= P.world.size))
+                e = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(
+                    gb, mad_i24(m.vz >> 2, slab_bytes, mad_i24(m.vy >> 2, row_bytes, (uint32_t)m.vx & ~3u)), 0, 0);
+            lo = e;
+        }
+        if (e == 0u) return true;   // outside the world
+        m.voxel = 0u;
+        if ((int)e < 0) {
+            const uint32_t u = ((uint32_t)m.vx & 3u) | (((uint32_t)m.vy & 3u) << 2) | (((uint32_t)m.vz & 3u) << 4);
+            const uint32_t b = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(bb, (e + u) << 1, 0, 0);
+            lo = b & 1u;
+            m.voxel = b >> 1;
+        } else if (e > 31u) {
+            lo = e & 31u;
+            m.voxel = e >> 16;
+        }
+        if (m.voxel != 0u) {
+            if (!is_liquid(s_liquid, m.voxel)) return true;   // solid: the hit
+            if (m.dew == -1.0f) { m.dew = m.total_len; m.slow_bit = 0x80000000u; }
+        } else if (m.dew != -1.0f) {
+            m.water_dist += m.total_len - m.dew;
+            m.dew = -1.0f;
+            if (!m.careful) m.slow_bit = 0u;
+        }
+    }
+    const float tx = (float)(int)(bfi(lo, m.mxm, (uint32_t)m.vx) - m.mxm) - m.pos.x;
+    const float ty = (float)(int)(bfi(lo, m.mym, (uint32_t)m.vy) - m.mym) - m.pos.y;
+    const float tz = (float)(int)(bfi(lo, m.mzm, (uint32_t)m.vz) - m.mzm) - m.pos.z;
+    m.adx = abs_mul(tx, m.ux);
+    m.ady = abs_mul(ty, m.uy);
+    m.adz = abs_mul(tz, m.uz);
+    m.step = __uint_as_float(min3_u32(__float_as_uint(m.adx) - 1u, __float_as_uint(m.ady) - 1u, __float_as_uint(m.adz) - 1u) + 1u);
+    m.total_len += m.step;
+    const float sp = m.step + 0.001f;
+    m.pos.x += m.dir.x * (m.step == m.adx ? sp : m.step);
+    m.pos.y += m.dir.y * (m.step == m.ady ? sp : m.step);
+    m.pos.z += m.dir.z * (m.step == m.adz ? sp : m.step);
+    m.vx = flr2i(m.pos.x);
+    m.vy = flr2i(m.pos.y);
+    m.vz = flr2i(m.pos.z);
+    return m.iter >= kMaxSteps;
+}
+
+// march_grid's epilogue: the MarchResult of a finished segment (`started` false: segment_begin said miss).
+__device__ __forceinline__ MarchResult segment_end(const FrameParams &P, const Segment &m, bool started) {
+    MarchResult R;
+    R.hit = false;
+    R.pos = V3{0.f, 0.f, 0.f};
+    R.norm = V3{0.f, 0.f, 0.f};
+    R.water_dist = 0.0f;
+    R.voxel = 0u;
+    R.iters = 0u;
+    R.visits = 0u;
+    if (!started) return R;
+    R.water_dist = m.water_dist;
+    if (m.dew != -1.0f) R.water_dist += m.total_len - m.dew;
+    if (min3_nan_ignoring(m.pos.x, m.pos.y, m.pos.z) < 0.0f ||
+        max(max((uint32_t)trunc2i(m.pos.x), (uint32_t)trunc2i(m.pos.y)), (uint32_t)trunc2i(m.pos.z)) >= P.world.size)
+        return R;
+    R.hit = true;
+    R.pos = m.pos;
+    if (m.step != -1.0f)
+        R.norm = V3{(m.step == m.adx ? 1.0f : 0.0f) * -vsign(m.dir.x), (m.step == m.ady ? 1.0f : 0.0f) * -vsign(m.dir.y),
+                    (m.step == m.adz ? 1.0f : 0.0f) * -vsign(m.dir.z)};
+    R.voxel = m.voxel;
+    return R;
+}
+
+__device__ __forceinline__ uint32_t path_xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u; }
+
+// Next tile of the frame for this wave: its own XCD's queue first, then the others (tile i of queue x = x + 8 i).
+// ~0u: the frame has no tiles left.  Wave-uniform.
+__device__ __forceinline__ uint32_t next_tile(uint32_t *heads, uint32_t tiles, uint32_t &queue_round, uint32_t xcc, uint32_t lane) {
+    while (queue_round < 8u) {
+        const uint32_t q = (xcc + queue_round) & 7u;
+        uint32_t i = 0;   // (called by all 64 lanes: lane 0 takes the ticket, everybody reads it)
+        if (lane == 0) i = __hip_atomic_fetch_add(&heads[q * 16u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t t = q + 8u * (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
+        if (t < tiles) return t;
+        queue_round += 1u;   // that queue is empty for good
+    }
+    return ~0u;
+}
+
+__global__ void __launch_bounds__(256) path_persistent_kernel(FrameParams P, uint32_t *heads, uint32_t refill_at) {
+    extern __shared__ uint32_t smem[];
+    uint32_t *s_liquid = smem;
+    if (threadIdx.x < 8) s_liquid[threadIdx.x] = P.liquid[threadIdx.x];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t xcc = path_xcc_id();
+    const TableBuf gb = table_buffer(P.grid, P.grid_bytes), bb = table_buffer(P.bricks, P.brick_bytes);
+    const uint32_t row_bytes = (P.grid_dim + 1u) * 4u, slab_bytes = (P.grid_dim + 1u) * row_bytes;
+    const uint32_t bounces = P.settings.max_ray_bounces;
+    const float fspp = (float)P.spp;
+
+    // the wave's queue: pixels q_pos .. 63 of tile q_tile are still to be handed out
+    uint32_t queue_round = 0u;
+    uint32_t q_tile = next_tile(heads, P.tiles_local, queue_round, xcc, lane), q_pos = 0u;
+
+    enum : uint32_t { kMarching = 0u, kWaiting = 1u, kRetired = 2u };
+    uint32_t state = kWaiting;   // kWaiting: the segment is over (or there is none yet) — something has to be decided
+    bool have_pixel = false, started = false;
+    Segment m;
+    m.pos = m.dir = V3{0.f, 0.f, 0.f};
+    m.ux = m.uy = m.uz = 0.f; m.mxm = m.mym = m.mzm = 0u; m.vx = m.vy = m.vz = 0;
+    m.step = -1.f; m.adx = m.ady = m.adz = 0.f; m.dew = -1.f; m.total_len = 0.f; m.water_dist = 0.f;
+    m.slow_bit = 0u; m.voxel = 0u; m.iter = 0u; m.careful = false;
+    PathState st;
+    st.slot = 0u; st.rng = 0u;
+    st.origin = st.dir = st.thr = V3{0.f, 0.f, 0.f};
+    V3 sum{0.f, 0.f, 0.f};
+    uint32_t px = 0u, py = 0u, sample = 0u, bounce = 0u, id0 = 0u;
+
+    for (;;) {
+        // ---- 1. (waiting lanes) what comes after the segment this lane has just finished ----
+        bool new_segment = false;
+        if (state == kWaiting && have_pixel) {
+            const MarchResult R = segment_end(P, m, started);
+            if (sample == 0u && bounce == 0u) {   // the id word of the primary segment, composed as shade() does
+                id0 = R.voxel & VRT_ID_VOXEL_MASK;
+                if (R.hit) id0 |= VRT_ID_HIT;
+                if (R.norm.x != 0.0f) id0 |= VRT_ID_NX;
+                if (R.norm.y != 0.0f) id0 |= VRT_ID_NY;
+                if (R.norm.z != 0.0f) id0 |= VRT_ID_NZ;
+                if (R.water_dist != 0.0f) id0 |= VRT_ID_WATER;
+            }
+            bool path_over;
+            if (!R.hit) {   // path_segment(): a miss adds the sky's light and ends the path
+                const V3 sky = ray_sky(P, st.origin, st.dir);
+                sum.x += sky.x * st.thr.x;
+                sum.y += sky.y * st.thr.y;
+                sum.z += sky.z * st.thr.z;
+                path_over = true;
+            } else {
+                const V3 mc = hit_color(P, R);
+                const float d = vdot(R.norm, st.dir);
+                const V3 spec{st.dir.x - 2.0f * R.norm.x * d, st.dir.y - 2.0f * R.norm.y * d, st.dir.z - 2.0f * R.norm.z * d};
+                const V3 rd = rng_next_dir(st.rng);
+                const V3 sc = vnormalize(V3{R.norm.x + rd.x, R.norm.y + rd.y, R.norm.z + rd.z});
+                const float scatter = P.mats[min(R.voxel, 255u)].scatter;
+                const V3 nd = vnormalize(V3{vmix(spec.x, sc.x, scatter), vmix(spec.y, sc.y, scatter), vmix(spec.z, sc.z, scatter)});
+                st.thr = V3{st.thr.x * mc.x, st.thr.y * mc.y, st.thr.z * mc.z};
+                st.origin = V3{R.pos.x + R.norm.x * kShadowBias, R.pos.y + R.norm.y * kShadowBias, R.pos.z + R.norm.z * kShadowBias};
+                st.dir = nd;
+                bounce += 1u;
+                path_over = bounce >= bounces;
+                new_segment = !path_over;
+            }
+            if (path_over) {
+                sample += 1u;
+                if (sample < P.spp) {   // the pixel's next sample: its primary ray again, a fresh RNG stream
+                    create_ray(P, (int)px, (int)py, st.origin, st.dir);
+                    st.thr = V3{1.0f, 1.0f, 1.0f};
+                    st.rng = py * P.width + px + sample * (P.width * P.height) + P.seed * 0x9E3779B9u;
+                    bounce = 0u;
+                    new_segment = true;
+                } else {
+                    P.out[st.slot] = make_uint4(__float_as_uint(sum.x / fspp), __float_as_uint(sum.y / fspp), __float_as_uint(sum.z / fspp), id0);
+                    have_pixel = false;
+                }
+            }
+        }
+        // ---- 2. (the whole wave) lanes without a pixel take the next ones of the wave's queue.  The queue's position is
+        // wave state: it is advanced here, outside any divergent branch, with every lane of the wave present ----
+        for (uint32_t round = 0; round < 4u; round++) {   // (a hand-out spans at most two tiles; the bound is a belt)
+            const unsigned long long want = __ballot(state == kWaiting && !have_pixel);
+            if (want == 0ull || q_tile == ~0u) break;
+            if (q_pos == 64u) {
+                q_tile = next_tile(heads, P.tiles_local, queue_round, xcc, lane);
+                q_pos = 0u;
+                continue;
+            }
+            const uint32_t rank = (uint32_t)__popcll(want & ((1ull << lane) - 1ull));
+            const uint32_t avail = 64u - q_pos;
+            if (state == kWaiting && !have_pixel && rank < avail) {
+                const uint32_t i = q_pos + rank;
+                const uint32_t tile = shard_tile(q_tile, P.shard_first, P.shard_run, P.shard_period);
+                px = (tile % P.tiles_x) * 8u + (i & 7u);
+                py = (tile / P.tiles_x) * 8u + (i >> 3);
+                st.slot = P.tile_major ? q_tile * 64u + i : py * P.width + px;
+                create_ray(P, (int)px, (int)py, st.origin, st.dir);
+                st.thr = V3{1.0f, 1.0f, 1.0f};
+                st.rng = py * P.width + px + P.seed * 0x9E3779B9u;   // sample 0
+                sum = V3{0.f, 0.f, 0.f};
+                sample = 0u;
+                bounce = 0u;
+                have_pixel = true;
+                new_segment = true;
+            }
+            const uint32_t n = (uint32_t)__popcll(want);
+            q_pos += n < avail ? n : avail;
+        }
+        // ---- 3. (waiting lanes) the next segment's set-up, or retirement ----
+        if (state == kWaiting) {
+            if (new_segment) {
+                started = segment_begin(P, st.origin, st.dir, m);
+                if (started) state = kMarching;   // (a ray that starts outside the world is over at once: stays waiting)
+            } else if (!have_pixel && q_tile == ~0u) {
+                state = kRetired;   // nothing left to hand out: this lane is done for the frame
+            }
+        }
+        const unsigned long long marching = __ballot(state == kMarching);
+        if (marching == 0ull) {
+            if (__ballot(state == kWaiting) == 0ull) break;   // every lane retired: the wave is done
+            continue;
+        }
+        // ---- march: all lanes that have a ray, until enough of them are waiting again ----
+        for (;;) {
+            if (state == kMarching && segment_trip(P, s_liquid, gb, bb, row_bytes, slab_bytes, m)) state = kWaiting;
+            const uint32_t n_march = (uint32_t)__popcll(__ballot(state == kMarching));
+            const uint32_t n_wait = (uint32_t)__popcll(__ballot(state == kWaiting));
+            if (n_march == 0u || n_wait >= refill_at) break;
+        }
+    }
+}
+
+void launch_path_persistent(const FrameParams &P, uint32_t *heads, uint32_t n_cus, hipStream_t st) {
+    if (P.tiles_local == 0) return;
+    // as many waves as the chip holds at this kernel's register count, but no more than there are tiles
+    const uint32_t waves = min(n_cus * 4u * 8u, P.tiles_local);
+    static uint32_t refill_at = 0;
+    if (!refill_at) {
+        const char *e = getenv("VRT_PATH_REFILL");   // experiments: how many waiting lanes end a march phase
+        refill_at = e ? (uint32_t)atoi(e) : kRefillAt;
+        if (refill_at < 1u || refill_at > 64u) refill_at = kRefillAt;
+    }
+    hipLaunchKernelGGL(path_persistent_kernel, dim3((waves + 3u) / 4u), dim3(256), 8u * 4u, st, P, heads, refill_at);
 }
 
 // rgb /= spp after the last sample
