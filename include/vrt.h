@@ -239,10 +239,19 @@ int vrt_synchronize(vrt_ctx *ctx);
 int vrt_read_output(vrt_ctx *ctx, float *rgb, uint32_t *ids, uint8_t *rgba8);
 
 /* ScreenShader::encode_pass (shader.rs:273-293, main.rs:454) into host memory: for every pixel of a screen_w x
- * screen_h target, fs_main of screen_shader.wgsl:43-65 — the rgba8unorm result texture sampled at the pixel centre
- * (Nearest, the sampler's magnification filter: the screen must be at least the texture's size) blended with the
- * crosshair — written as unorm8 RGBA, screen_w*screen_h*4 bytes (synchronises).  Unsharded contexts only. */
+ * screen_h target — any size: the reference renders its 1080 rows into whatever the window is (main.rs:175,206-210) —
+ * fs_main of screen_shader.wgsl:43-65: the rgba8unorm result texture sampled at the pixel centre through the reference's
+ * sampler (texture.rs:31-44: ClampToEdge, mag Nearest / min Linear, lod clamped to [1, 1] — a level of detail of 1
+ * selects the minification filter, so the sample is bilinear at every window size and the texel itself at 1:1) blended
+ * with the crosshair, written as unorm8 RGBA, screen_w*screen_h*4 bytes (synchronises).  Whole-frame contexts only. */
 int vrt_present(vrt_ctx *ctx, const vrt_crosshair *crosshair, uint32_t screen_w, uint32_t screen_h, uint8_t *rgba8);
+
+/* The same, left on the device: *rgba8_device points at screen_w*screen_h*4 bytes of the context's own screen buffer,
+ * valid until the next vrt_present / vrt_present_device / vrt_destroy; the blit is enqueued on the context's stream
+ * (vrt_set_stream) and nothing is copied to the host — for a host that hands the image to its window system through GPU
+ * interop (a 1080p frame is 8 MB of PCIe traffic otherwise).  vrt_synchronize before reading it from another stream. */
+int vrt_present_device(vrt_ctx *ctx, const vrt_crosshair *crosshair, uint32_t screen_w, uint32_t screen_h, void **rgba8_device,
+                       uint64_t *bytes);
 
 int vrt_get_stats(vrt_ctx *ctx, vrt_stats *out);
 

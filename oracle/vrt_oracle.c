@@ -328,13 +328,36 @@ void orc_present(const float *rgb, uint32_t w, uint32_t h, uint32_t screen_w, ui
                 const float wd = ch->size * 0.25f;
                 mask = (((dx < ch->size && dy < wd) || (dy < ch->size && dx < wd)) ? 1.0f : 0.0f) * ch->color[3];
             }
-            /* textureSample, Nearest: the texel containing the sample point */
-            uint32_t tx = (uint32_t)floorf(u * (float)w), ty = (uint32_t)floorf(v * (float)h);
-            if (tx > w - 1u) tx = w - 1u;
-            if (ty > h - 1u) ty = h - 1u;
-            const float *t = rgb + ((size_t)ty * w + tx) * 3;
-            float texel[4] = {(float)orc_unorm8(t[0]) / 255.0f, (float)orc_unorm8(t[1]) / 255.0f,
-                              (float)orc_unorm8(t[2]) / 255.0f, 1.0f};
+            /* textureSample(tex, tex_s, tex_coord) (:61).  The sampler (texture.rs:31-44) is mag Nearest / min Linear with
+             * lod_min_clamp = lod_max_clamp = 1.0 over a single mip level: the level of detail is clamped to 1 for every
+             * sample, and a level of detail > 0 selects the *minification* filter (Vulkan 1.3 §16.5.7 "if lambda <= 0 the
+             * texture is magnified, otherwise minified"; the one level there is serves as level 1 clamped back to 0).  So
+             * the blit is bilinear at every window size — at 1:1 the sample points are the texel centres, the weights
+             * (1, 0), the result the texel itself.  Bilinear as the spec words it on unnormalised coordinates, f32:
+             * i0 = floor(u W - 1/2), a = frac(u W - 1/2), ClampToEdge on the indices,
+             * ((t00 (1-a) + t10 a) (1-b) + (t01 (1-a) + t11 a) b), texels decoded from rgba8unorm (k / 255, alpha 1). */
+            const float ut = u * (float)w - 0.5f, vt = v * (float)h - 0.5f;
+            const float fu = floorf(ut), fv = floorf(vt);
+            const float a = ut - fu, b = vt - fv;
+            int32_t x0 = (int32_t)fu, y0 = (int32_t)fv, x1 = x0 + 1, y1 = y0 + 1;
+            if (x0 < 0) x0 = 0;
+            if (y0 < 0) y0 = 0;
+            if (x1 < 0) x1 = 0;
+            if (y1 < 0) y1 = 0;
+            if (x0 > (int32_t)w - 1) x0 = (int32_t)w - 1;
+            if (y0 > (int32_t)h - 1) y0 = (int32_t)h - 1;
+            if (x1 > (int32_t)w - 1) x1 = (int32_t)w - 1;
+            if (y1 > (int32_t)h - 1) y1 = (int32_t)h - 1;
+            const float *t00 = rgb + ((size_t)y0 * w + (size_t)x0) * 3, *t10 = rgb + ((size_t)y0 * w + (size_t)x1) * 3;
+            const float *t01 = rgb + ((size_t)y1 * w + (size_t)x0) * 3, *t11 = rgb + ((size_t)y1 * w + (size_t)x1) * 3;
+            float texel[4];
+            for (int k = 0; k < 3; k++) {
+                const float c00 = (float)orc_unorm8(t00[k]) / 255.0f, c10 = (float)orc_unorm8(t10[k]) / 255.0f;
+                const float c01 = (float)orc_unorm8(t01[k]) / 255.0f, c11 = (float)orc_unorm8(t11[k]) / 255.0f;
+                const float top = c00 * (1.0f - a) + c10 * a, bot = c01 * (1.0f - a) + c11 * a;
+                texel[k] = top * (1.0f - b) + bot * b;
+            }
+            texel[3] = 1.0f * (1.0f - b) + 1.0f * b;   /* alpha 1 through the same expression (it is exactly 1 for b in [0,1)) */
             const float cc[4] = {ch->color[0], ch->color[1], ch->color[2], 1.0f};
             uint8_t *o = rgba8 + ((size_t)sy * screen_w + sx) * 4;
             for (int k = 0; k < 4; k++) o[k] = (uint8_t)orc_unorm8(texel[k] * (1.0f - mask) + cc[k] * mask);  /* :60-63 */

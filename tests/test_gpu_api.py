@@ -115,13 +115,14 @@ def test_two_contexts_are_independent():
 
 def test_present_quantise_and_crosshair_blit(orc):
     """vrt_present = textureStore to rgba8unorm + fs_main of screen_shader.wgsl, byte for byte what the oracle's
-    restatement gives from the same f32 frame: default cross, a dot, no crosshair, and a 2x magnified window."""
+    restatement gives from the same f32 frame: default cross, a dot, no crosshair; windows at 1:1, magnified, minified to
+    0.75x and 0.5x and squeezed on one axis only (the reference renders 1080 rows into whatever the window is)."""
     sc = scenes.c2((128, 72))
     gpu = gpu_for_scene(sc)
     gpu.render(MODE_PRIMARY_SHADOW)
     rgb, _, q = gpu.read_output(rgba8=True)
     for kw in (dict(), dict(style=1, size=9.5, color=(1.0, 0.2, 0.1, 0.75)), dict(style=0), dict(style=2, size=17.0, color=(0.0, 0.0, 0.0, 1.0))):
-        for screen in ((128, 72), (256, 144), (200, 100)):
+        for screen in ((128, 72), (256, 144), (200, 100), (96, 54), (64, 36), (150, 40), (33, 7)):
             got = gpu.present(screen, **kw)
             want = orc.present(rgb, screen, **kw)
             assert got.shape == (screen[1], screen[0], 4) and np.array_equal(got, want), (kw, screen)
@@ -130,8 +131,19 @@ def test_present_quantise_and_crosshair_blit(orc):
     cross = gpu.present()                                 # Crosshair::default(): white, alpha 0.33, size 5
     changed = np.argwhere((cross != q).any(axis=2))
     assert 0 < len(changed) <= 2 * (10 * 3) and np.abs(changed - np.array([36, 64])).max() <= 5
+    # the image can stay on the device (a host with GPU interop): same bytes, nothing copied by the library
+    import ctypes
+    from voxelraytracing_amd import _ffi
+    ptr, nbytes = gpu.present_device((96, 54))
+    assert ptr and nbytes == 96 * 54 * 4
+    gpu.synchronize()
+    host = np.empty(nbytes, dtype=np.uint8)
+    hip_memcpy = _ffi.vrt().hipMemcpy                      # the HIP runtime libvrt.so itself is linked against
+    hip_memcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    assert hip_memcpy(host.ctypes.data, ptr, nbytes, 2) == 0    # hipMemcpyDeviceToHost
+    assert np.array_equal(host.reshape(54, 96, 4), gpu.present((96, 54)))
     with pytest.raises(VrtError):
-        gpu.present((64, 36))                             # minification (the sampler's Linear filter) is not offered
+        gpu.present((0, 36))
 
 
 @pytest.mark.parametrize("in_flight", [1, 2, 3, 4])

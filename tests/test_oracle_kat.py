@@ -277,7 +277,7 @@ def test_shadow_ray_definition(orc):
 
 def test_present_known_answers(orc):
     """screen_shader.wgsl:43-65 over the rgba8unorm texture: quantisation (clamp, x255, ties to even), the default
-    cross (size 5, arm half-width 1.25, alpha 0.33 white), a dot, and Nearest magnification."""
+    cross (size 5, arm half-width 1.25, alpha 0.33 white), a dot, and the sampler's bilinear rule."""
     rgb = np.zeros((8, 16, 3), dtype=np.float32)
     rgb[..., 0], rgb[..., 1], rgb[..., 2] = 0.5, 2.0, -1.0
     plain = orc.present(rgb, (16, 8), style=0)
@@ -290,7 +290,18 @@ def test_present_known_answers(orc):
     assert (cross[on] == np.array([170, 255, 84, 255], dtype=np.uint8)).all()
     dot = orc.present(rgb, (16, 8), style=1, size=1.0, color=(0.0, 0.0, 0.0, 1.0))
     assert (dot[3:5, 7:9] == np.array([0, 0, 0, 255], dtype=np.uint8)).all() and (dot != plain).any(axis=2).sum() == 4   # distance sqrt(0.5) < 1
-    ramp = np.zeros((2, 2, 3), dtype=np.float32)
-    ramp[0, 1, 0] = ramp[1, 0, 1] = 1.0
-    big = orc.present(ramp, (6, 4), style=0)                                    # 3x / 2x magnification, Nearest
-    assert (big[:2, 3:, 0] == 255).all() and (big[:2, :3, 0] == 0).all() and (big[2:, :3, 1] == 255).all() and (big[2:, 3:, 1] == 0).all()
+    # textureSample through the reference's sampler: its lod clamp [1, 1] (texture.rs:39-40) selects the min filter, Linear,
+    # at every size.  A 2 x 1 texture {0, 1} on a 4-pixel row: the sample points sit at texel coordinates u W - 1/2 =
+    # -0.25, 0.25, 0.75, 1.25 -> ClampToEdge gives 0, a blend of 0.25, of 0.75, and 1: 0, 63.75 -> 64, 191.25 -> 191, 255
+    ramp = np.zeros((1, 2, 3), dtype=np.float32)
+    ramp[0, 1, 0] = 1.0
+    row = orc.present(ramp, (4, 1), style=0)
+    assert row[0, :, 0].tolist() == [0, 64, 191, 255] and (row[..., 3] == 255).all()
+    # minified 2:1 the sample point falls on the corner shared by four texels: their mean (here 0, 1, 0, 0 -> 63.75 -> 64)
+    quad = np.zeros((2, 2, 3), dtype=np.float32)
+    quad[0, 1, 1] = 1.0
+    assert orc.present(quad, (1, 1), style=0)[0, 0].tolist() == [0, 64, 0, 255]
+    # at 1:1 the weights are (1, 0): the texture itself
+    chk = np.zeros((4, 4, 3), dtype=np.float32)
+    chk[::2, 1::2, 2] = 1.0
+    assert np.array_equal(orc.present(chk, (4, 4), style=0)[..., 2], (chk[..., 2] * 255).astype(np.uint8))

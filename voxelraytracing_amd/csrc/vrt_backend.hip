@@ -1172,20 +1172,18 @@ int vrt_read_output(vrt_ctx *c, float *rgb, uint32_t *ids, uint8_t *rgba8) {
     return VRT_OK;
 }
 
-int vrt_present(vrt_ctx *c, const vrt_crosshair *crosshair, uint32_t screen_w, uint32_t screen_h, uint8_t *rgba8) {
-    if (c && c->grp) { const int rc_ = grp_synchronize(c); if (rc_) return rc_; }
-    GRP_ROOT(c, vrt_present(d, crosshair, screen_w, screen_h, rgba8));
-    if (!c || !crosshair || !rgba8) return fail(c, VRT_ERR_INVALID_ARG, "vrt_present: null argument");
-    if (!c->rendered) return fail(c, VRT_ERR_STATE, "vrt_present: nothing rendered yet");
+// ScreenShader::encode_pass into the context's screen buffer on the device; asynchronous on c->stream.
+static int present_on_device(vrt_ctx *c, const vrt_crosshair *crosshair, uint32_t screen_w, uint32_t screen_h, const char *who) {
+    if (!c->rendered) return fail(c, VRT_ERR_STATE, "%s: nothing rendered yet", who);
     if (c->tile_major || (c->shard_count > 1u && !c->whole_frame_owner))
-        return fail(c, VRT_ERR_STATE, "vrt_present: needs the whole row-major frame");
-    if (screen_w < c->width || screen_h < c->height || (uint64_t)screen_w * screen_h > (1ull << 28))
-        return fail(c, VRT_ERR_INVALID_ARG, "vrt_present: screen %ux%u must be at least the %ux%u result texture (the sampler magnifies "
-                    "with Nearest; its Linear minification is not implemented)", screen_w, screen_h, c->width, c->height);
+        return fail(c, VRT_ERR_STATE, "%s: needs the whole row-major frame", who);
+    if (screen_w == 0u || screen_h == 0u || (uint64_t)screen_w * screen_h > (1ull << 28))
+        return fail(c, VRT_ERR_INVALID_ARG, "%s: screen %ux%u out of range", who, screen_w, screen_h);
     HIP_TRY(c, hipSetDevice(c->device));
     QUIESCE(c);
     const size_t bytes = (size_t)screen_w * screen_h * 4u;
     if (bytes > c->screen_cap) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));   // an earlier present may still be writing the old buffer
         (void)hipFree(c->d_screen);
         c->d_screen = nullptr; c->screen_cap = 0;
         HIP_TRY(c, hipMalloc(&c->d_screen, bytes));
@@ -1193,8 +1191,28 @@ int vrt_present(vrt_ctx *c, const vrt_crosshair *crosshair, uint32_t screen_w, u
     }
     vrt::launch_present(c->last_out, c->width, c->height, screen_w, screen_h, *crosshair, c->d_screen, c->stream);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(rgba8, c->d_screen, bytes, hipMemcpyDeviceToHost, c->stream));
+    return VRT_OK;
+}
+
+int vrt_present(vrt_ctx *c, const vrt_crosshair *crosshair, uint32_t screen_w, uint32_t screen_h, uint8_t *rgba8) {
+    if (c && c->grp) { const int rc_ = grp_synchronize(c); if (rc_) return rc_; }
+    GRP_ROOT(c, vrt_present(d, crosshair, screen_w, screen_h, rgba8));
+    if (!c || !crosshair || !rgba8) return fail(c, VRT_ERR_INVALID_ARG, "vrt_present: null argument");
+    const int rc = present_on_device(c, crosshair, screen_w, screen_h, "vrt_present");
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(rgba8, c->d_screen, (size_t)screen_w * screen_h * 4u, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VRT_OK;
+}
+
+int vrt_present_device(vrt_ctx *c, const vrt_crosshair *crosshair, uint32_t screen_w, uint32_t screen_h, void **rgba8_device, uint64_t *bytes) {
+    if (c && c->grp) { const int rc_ = grp_synchronize(c); if (rc_) return rc_; }
+    GRP_ROOT(c, vrt_present_device(d, crosshair, screen_w, screen_h, rgba8_device, bytes));
+    if (!c || !crosshair || !rgba8_device) return fail(c, VRT_ERR_INVALID_ARG, "vrt_present_device: null argument");
+    const int rc = present_on_device(c, crosshair, screen_w, screen_h, "vrt_present_device");
+    if (rc) return rc;
+    *rgba8_device = c->d_screen;
+    if (bytes) *bytes = (uint64_t)screen_w * screen_h * 4u;
     return VRT_OK;
 }
 

@@ -304,7 +304,7 @@ __global__ void quantize_rgba8_kernel(const Texel *out, uint8_t *rgba8, uint32_t
 }
 
 // Presentation: fs_main of screen_shader.wgsl:43-65 over the rgba8unorm result texture (ray_tracer.wgsl:179), one lane
-// per screen pixel: Nearest sample of the texture at the pixel centre, crosshair mask, blend, unorm8 store.
+// per screen pixel: the sampler's (bilinear) sample of the texture at the pixel centre, crosshair mask, blend, unorm8 store.
 __device__ __forceinline__ uint32_t unorm8(float x) { return (uint32_t)rintf(vclamp(x, 0.0f, 1.0f) * 255.0f) & 0xFFu; }
 
 __global__ void present_kernel(const Texel *out, uint32_t w, uint32_t h, uint32_t screen_w, uint32_t screen_h, vrt_crosshair ch,
@@ -325,10 +325,24 @@ __global__ void present_kernel(const Texel *out, uint32_t w, uint32_t h, uint32_
         const float wd = ch.size * 0.25f;
         mask = (((dx < ch.size && dy < wd) || (dy < ch.size && dx < wd)) ? 1.0f : 0.0f) * ch.color[3];
     }
-    const uint32_t tx = min((uint32_t)floorf(u * (float)w), w - 1u), ty = min((uint32_t)floorf(v * (float)h), h - 1u);
-    const Texel t = out[(size_t)ty * w + tx];
-    const float texel[4] = {(float)unorm8(__uint_as_float(t.x)) / 255.0f, (float)unorm8(__uint_as_float(t.y)) / 255.0f,
-                            (float)unorm8(__uint_as_float(t.z)) / 255.0f, 1.0f};
+    // textureSample through the reference's sampler (texture.rs:31-44): lod clamped to [1, 1] => the minification filter,
+    // Linear, at every window size (oracle/vrt_oracle.c:orc_present spells the rule out); bilinear in f32, ClampToEdge
+    const float ut = u * (float)w - 0.5f, vt = v * (float)h - 0.5f;
+    const float fu = floorf(ut), fv = floorf(vt);
+    const float a = ut - fu, b = vt - fv;
+    const int x0 = min(max((int)fu, 0), (int)w - 1), x1 = min(max((int)fu + 1, 0), (int)w - 1);
+    const int y0 = min(max((int)fv, 0), (int)h - 1), y1 = min(max((int)fv + 1, 0), (int)h - 1);
+    const Texel t00 = out[(size_t)y0 * w + x0], t10 = out[(size_t)y0 * w + x1], t01 = out[(size_t)y1 * w + x0], t11 = out[(size_t)y1 * w + x1];
+    const uint32_t c00[3] = {t00.x, t00.y, t00.z}, c10[3] = {t10.x, t10.y, t10.z}, c01[3] = {t01.x, t01.y, t01.z}, c11[3] = {t11.x, t11.y, t11.z};
+    float texel[4];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float v00 = (float)unorm8(__uint_as_float(c00[k])) / 255.0f, v10 = (float)unorm8(__uint_as_float(c10[k])) / 255.0f;
+        const float v01 = (float)unorm8(__uint_as_float(c01[k])) / 255.0f, v11 = (float)unorm8(__uint_as_float(c11[k])) / 255.0f;
+        const float top = v00 * (1.0f - a) + v10 * a, bot = v01 * (1.0f - a) + v11 * a;
+        texel[k] = top * (1.0f - b) + bot * b;
+    }
+    texel[3] = 1.0f * (1.0f - b) + 1.0f * b;
     const float cc[4] = {ch.color[0], ch.color[1], ch.color[2], 1.0f};
     uint32_t q = 0u;
 #pragma unroll

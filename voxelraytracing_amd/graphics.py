@@ -153,13 +153,21 @@ class Gpu:
         return a_rgb, a_ids, a_q
 
     def present(self, screen_size=None, color=(1.0, 1.0, 1.0, 0.33), style: int = 2, size: float = 5.0) -> np.ndarray:
-        """ScreenShader::encode_pass into host memory: rgba8 [screen_h, screen_w, 4] of the last frame under the
-        crosshair (defaults = Crosshair::default(), mod.rs:71-80)."""
+        """ScreenShader::encode_pass into host memory: rgba8 [screen_h, screen_w, 4] of the last frame, sampled through the
+        reference's (bilinear) sampler at any window size, under the crosshair (defaults = Crosshair::default(), mod.rs:71-80)."""
         sw, sh = screen_size or self.result_size
         ch = _ffi.Crosshair((C.c_float * 4)(*color), style, size)
         out = np.empty((sh, sw, 4), dtype=np.uint8)
         self._ck(self._lib.vrt_present(self._h, C.byref(ch), sw, sh, out.ctypes.data_as(C.c_void_p)))
         return out
+
+    def present_device(self, screen_size=None, color=(1.0, 1.0, 1.0, 0.33), style: int = 2, size: float = 5.0):
+        """vrt_present_device: (device pointer, bytes) of the presented rgba8 image, left on the GPU."""
+        sw, sh = screen_size or self.result_size
+        ch = _ffi.Crosshair((C.c_float * 4)(*color), style, size)
+        ptr, nb = C.c_void_p(), C.c_uint64()
+        self._ck(self._lib.vrt_present_device(self._h, C.byref(ch), sw, sh, C.byref(ptr), C.byref(nb)))
+        return ptr.value, nb.value
 
     def read_steps(self) -> np.ndarray:
         w, h = self.result_size
