@@ -14,5 +14,5 @@ restore() { cp $T/host.bak voxelraytracing_amd/libvrt_host.so; cp $T/oracle.bak 
 trap restore EXIT
 cp $T/libvrt_host.so voxelraytracing_amd/libvrt_host.so; cp $T/libvrt_oracle.so oracle/libvrt_oracle.so; touch oracle/libvrt_oracle.so
 LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) ASAN_OPTIONS=detect_leaks=0 OMP_NUM_THREADS=4 \
-    python -m pytest tests/test_oracle_kat.py tests/test_golden.py tests/test_host_world.py tests/test_regionfile.py tests/test_netmsg.py \
+    python -m pytest tests/test_oracle_kat.py tests/test_golden.py tests/test_host_world.py tests/test_regionfile.py tests/test_netmsg.py tests/test_formats_fuzz.py \
     -x -q -m "not gpu"
