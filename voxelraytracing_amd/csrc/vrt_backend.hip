@@ -177,7 +177,9 @@ struct vrt_ctx {
 };
 
 static constexpr size_t kSegBytes = (size_t)vrt::kHitSegments * vrt::kSegStride * sizeof(uint32_t);
-static constexpr size_t kCounterBytes = vrt::kCtrCount * sizeof(unsigned long long) + 2 * kSegBytes;  // two counter sets (path ping-pong)
+// three sets of segment cursors: launch g of a path frame appends to set g % 3, reads set (g - 1) % 3 and clears set
+// (g + 1) % 3 for its successor, so no memset sits between two launches
+static constexpr size_t kCounterBytes = vrt::kCtrCount * sizeof(unsigned long long) + 3 * kSegBytes;
 
 enum EvKind : uint8_t { kEvNone = 0, kEvOneKernel = 1, kEvTwoKernels = 2, kEvRecorded = 3 };
 
@@ -953,7 +955,7 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
     }
     const size_t cap = (size_t)vrt::kHitSegments * c->hit_seg_cap;
     if (!*f.path_buf) HIP_TRY(c, hipMalloc(f.path_buf, 2 * 3 * cap * sizeof(uint4)));
-    uint32_t *seg[2] = {P.seg_counts, P.seg_counts + vrt::kHitSegments * vrt::kSegStride};
+    uint32_t *seg[3] = {P.seg_counts, P.seg_counts + vrt::kHitSegments * vrt::kSegStride, P.seg_counts + 2 * vrt::kHitSegments * vrt::kSegStride};
     uint4 *buf[2] = {*f.path_buf, *f.path_buf + 3 * cap};
     P.path_cap = (uint32_t)cap;
     P.spp = spp;
@@ -961,15 +963,17 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
     HIP_TRY(c, hipEventRecord(ev[0], f.st));
     if (bounces == 0) HIP_TRY(c, hipMemsetAsync(f.out, 0, (size_t)c->slots * sizeof(vrt::Texel), f.st));
     bool first = true;
+    uint32_t g = 0;   // launch number within the frame (all three cursor sets are zero when it starts: vrt_render cleared them)
     for (uint32_t smp = 0; smp < spp && bounces > 0; smp++) {
         P.sample = smp;
-        for (uint32_t b = 0; b < bounces; b++) {
-            if (!(smp == 0 && b == 0)) HIP_TRY(c, hipMemsetAsync(seg[b & 1], 0, kSegBytes, f.st));
-            P.seg_counts = seg[b & 1];
-            P.path_out = buf[b & 1];
-            P.seg_in = seg[(b + 1) & 1];
-            P.path_in = buf[(b + 1) & 1];
+        for (uint32_t b = 0; b < bounces; b++, g++) {
+            P.seg_counts = seg[g % 3u];
+            P.seg_in = seg[(g + 2u) % 3u];
+            P.seg_clear = seg[(g + 1u) % 3u];
+            P.path_out = buf[g & 1u];
+            P.path_in = buf[(g + 1u) & 1u];
             P.last_bounce = b + 1 == bounces;
+            // one sample per pixel: the lane that ends a path has the pixel's final value (x / 1 = x) — no finishing pass
             if (b == 0) vrt::launch_path_primary(P, kstats, literal, f.st);
             else vrt::launch_path_bounce(P, kstats, literal, f.st);
             HIP_TRY(c, hipGetLastError());
@@ -977,7 +981,7 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
         }
     }
     if (first) HIP_TRY(c, hipEventRecord(ev[1], f.st));
-    if (bounces > 0) {
+    if (bounces > 0 && spp > 1u) {
         vrt::launch_path_finish(f.out, c->slots, spp, f.st);
         HIP_TRY(c, hipGetLastError());
     }

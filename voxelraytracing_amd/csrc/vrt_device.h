@@ -45,6 +45,7 @@ struct FrameParams {
     const uint4 *path_in;
     uint4 *path_out;
     const uint32_t *seg_in;  // segment counters of path_in
+    uint32_t *seg_clear;     // the counter set the NEXT launch of the frame appends to: this launch zeroes it (nobody reads it meanwhile)
     uint32_t path_cap;       // entries per plane = kHitSegments * hit_seg_cap
     uint32_t spp, sample, seed;
     uint32_t last_bounce;    // 1: paths that hit on this segment end (max_ray_bounces reached)

@@ -127,6 +127,8 @@ __device__ __forceinline__ void append_paths(const FrameParams &P, bool alive, c
     }
 }
 
+static_assert(kHitSegments == 256, "a launch's first workgroup (256 threads) clears the next launch's 256 segment cursors");
+
 // Bounce 0: primary rays of sample P.sample. Sample 0 initialises the texel {light, id}; later samples add.
 template <int MARCH, bool LDS_ROOTS, bool STATS>
 __global__ void __launch_bounds__(256) path_primary_kernel(FrameParams P) {
@@ -139,6 +141,7 @@ __global__ void __launch_bounds__(256) path_primary_kernel(FrameParams P) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t t_local = blockIdx.x * 4u + (threadIdx.x >> 6);
     const bool live = t_local < P.tiles_local;
+    if (blockIdx.x == 0 && P.seg_clear) P.seg_clear[threadIdx.x * kSegStride] = 0u;   // kHitSegments == blockDim.x cursors
     if (!STATS && !live) return;
     MarchResult R;
     R.iters = 0; R.visits = 0; R.hit = false;
@@ -202,6 +205,7 @@ __global__ void __launch_bounds__(256) path_bounce_kernel(FrameParams P) {
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t seg = blockIdx.x % kHitSegments, part = blockIdx.x / kHitSegments;
+    if (blockIdx.x == 0 && P.seg_clear) P.seg_clear[threadIdx.x * kSegStride] = 0u;
     const uint32_t count = P.seg_in[seg * kSegStride];
     const uint32_t j = part * blockDim.x + threadIdx.x;
     const bool active = j < count;
