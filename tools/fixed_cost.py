@@ -1,19 +1,25 @@
-"""Fixed (non-march) cost of the primary kernel: frames where every ray stops immediately.
-Run under rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES to read VALU instructions per wave for each case."""
-import sys
+"""Fixed (non-march) cost of the default primary + shadow kernel: frames whose rays stop at once, one launch at a time.
+   outside       the camera is outside the world: every ray is a miss before its first lookup (no shadow rays)
+   inside_solid  the camera sits in solid rock: every primary ray hits at its first lookup and launches a shadow ray that
+                 does the same
+   normal        the bench's frame"""
 import os
+import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from voxelraytracing_amd import Gpu, MODE_PRIMARY_SHADOW, MODE_PRIMARY, graphics as g, scenes
+from voxelraytracing_amd import Gpu, MODE_PRIMARY_SHADOW, graphics as g, scenes
 
 sc = scenes.c2()
 gpu = Gpu(sc.world.max_nodes(), sc.world.size_in_chunks(), sc.size)
 gpu.upload_world(sc.world, sc.materials)
 gpu.write_settings(sc.settings)
+gpu.set_frames_in_flight(1)
 cases = {"outside": (-10.0, 300.0, -10.0), "inside_solid": (128.5, 20.5, 128.5), "normal": sc.eye}
 for name, eye in cases.items():
     gpu.write_cam_data(g.cam_data_create(sc.rot, eye, 70.0, (1920.0, 1080.0)))
-    for mode in (MODE_PRIMARY, MODE_PRIMARY_SHADOW):
-        gpu.render(mode)
-        gpu.synchronize()
+    for _ in range(300):
+        gpu.render(MODE_PRIMARY_SHADOW)
+    gpu.stats()
+    for _ in range(500):
+        gpu.render(MODE_PRIMARY_SHADOW)
     s = gpu.stats()
-    print(name, "primary us", s.ms_primary * 1e3, "shadow us", s.ms_secondary * 1e3)
+    print(f"{name:13s} {s.sum_ms_primary / s.frames * 1e3:7.1f} us per launch (1 in flight, {s.frames} frames)")

@@ -912,7 +912,9 @@ static int pick_frame_set(vrt_ctx *c, const vrt_render_opts &o, uint32_t variant
 // The next free event quadruple of the pool (folding the pool into the accumulated times when it is full).
 static int next_events(vrt_ctx *c, std::array<hipEvent_t, 4> **ev, uint8_t **kind) {
     if (c->ev_used == c->ev_pool.size()) {
-        if (c->ev_pool.size() >= 1024) {
+        // (512 frames of events: creating one costs the host a few microseconds, so a context is at full speed once it has
+        // rendered that many frames between two vrt_get_stats calls; folding costs one drain per 512 frames)
+        if (c->ev_pool.size() >= 512) {
             const int rc = fold_events(c, nullptr);
             if (rc) return rc;
         } else {

@@ -28,10 +28,16 @@ def _f(vals, n):
     return (C.c_float * n)(*[float(v) for v in vals])
 
 
+_scratch3a, _scratch3b, _scratch2 = (C.c_float * 3)(), (C.c_float * 3)(), (C.c_float * 2)()
+
+
 def cam_data_create(rot_deg, eye, fov_deg: float, proj_size) -> CamData:
     """CamData::create(cam, eye, fov, proj_size) — mod.rs:92-111 (rot and fov in degrees)."""
     out = CamData()
-    _ffi.host().vrth_cam_data_create(_f(rot_deg, 3), _f(eye, 3), float(fov_deg), _f(proj_size, 2), C.byref(out))
+    _scratch3a[0], _scratch3a[1], _scratch3a[2] = rot_deg      # (per-frame call of the frame loop: no allocations here)
+    _scratch3b[0], _scratch3b[1], _scratch3b[2] = eye
+    _scratch2[0], _scratch2[1] = proj_size
+    _ffi.host().vrth_cam_data_create(_scratch3a, _scratch3b, fov_deg, _scratch2, C.byref(out))
     return out
 
 
