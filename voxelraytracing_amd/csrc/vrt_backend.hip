@@ -162,6 +162,8 @@ struct vrt_ctx {
 
     vrt_material h_mats[256];
     uint32_t liquid_mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // bit v <=> h_mats[v].is_liquid == 1 (kept by vrt_write_materials)
+    bool liquid_is_range = true;                          // the liquid ids are one range below 255, or none
+    uint32_t liquid_lo = 0x80000000u, liquid_span = 0u;   // (none: no 15-bit voxel id is 0x80000000)
     vrt_cam_data cam;
     vrt_settings settings;
     vrt_world_data world;
@@ -702,8 +704,18 @@ int vrt_write_materials(vrt_ctx *c, uint32_t first, const vrt_material *mats, ui
     if (n == 0) return VRT_OK;
     memcpy(c->h_mats + first, mats, (size_t)n * sizeof(vrt_material));
     memset(c->liquid_mask, 0, sizeof c->liquid_mask);
+    int lo = -1, hi = -1, n_liquid = 0;
     for (int v = 0; v < 256; v++)
-        if (c->h_mats[v].is_liquid == 1u) c->liquid_mask[v >> 5] |= 1u << (v & 31);
+        if (c->h_mats[v].is_liquid == 1u) {
+            c->liquid_mask[v >> 5] |= 1u << (v & 31);
+            if (lo < 0) lo = v;
+            hi = v;
+            n_liquid++;
+        }
+    // one contiguous id range, and material 255 (which every id >= 255 clamps to) not in it
+    c->liquid_is_range = n_liquid == 0 || (hi - lo + 1 == n_liquid && hi < 255);
+    c->liquid_lo = n_liquid ? (uint32_t)lo : 0x80000000u;
+    c->liquid_span = n_liquid ? (uint32_t)(hi - lo) : 0u;
     HIP_TRY(c, hipSetDevice(c->device));
     return stage_upload(c, c->d_mats + first, mats, (size_t)n * sizeof(vrt_material));
 }
@@ -849,6 +861,9 @@ static void fill_uniforms(const vrt_ctx *c, vrt::FrameParams &P) {
                         std::isfinite(s.sky_color[2]) && std::isfinite(s.sun_pos[0]) && std::isfinite(s.sun_pos[1]) &&
                         std::isfinite(s.sun_pos[2]);
     memcpy(P.liquid, c->liquid_mask, sizeof P.liquid);
+    P.liquid_is_range = c->liquid_is_range ? 1u : 0u;
+    P.liquid_lo = c->liquid_lo;
+    P.liquid_span = c->liquid_span;
 
     P.ndc_x = c->d_ndc;
     P.ndc_y = c->d_ndc + c->width;

@@ -62,6 +62,9 @@ struct FrameParams {
     vrt_settings settings;
     vrt_world_data world;
     uint32_t liquid[8];      // bit v set <=> materials[v].is_liquid == 1, v < 256
+    // the same set as an id range when it is one ([liquid_lo, liquid_lo + liquid_span], all below 255 — the standard pack's
+    // lava 2, water 3 — or empty): the march then asks with a subtract and a compare instead of the mask lookup in LDS
+    uint32_t liquid_is_range, liquid_lo, liquid_span;
     // frame-uniform subexpressions of the shader, evaluated once on the host in the same IEEE binary32 operations
     // (the host half of vrt_backend.hip is built with -ffp-contract=off like the kernels):
     const float *ndc_x;      // [width]  ((float)px * 2) / proj_size.x - 1        (create_ray_from_screen :160)

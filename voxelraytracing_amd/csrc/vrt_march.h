@@ -34,6 +34,12 @@ __device__ __forceinline__ bool is_liquid(const uint32_t *s_liquid, uint32_t vox
     return (s_liquid[v >> 5] >> (v & 31u)) & 1u;
 }
 
+// The same question for the grid march: the liquid ids as a range when they form one (wave-uniform choice).
+__device__ __forceinline__ bool is_liquid_ranged(const FrameParams &P, const uint32_t *s_liquid, uint32_t voxel) {
+    if (P.liquid_is_range) return voxel - P.liquid_lo <= P.liquid_span;
+    return is_liquid(s_liquid, voxel);
+}
+
 // ------------------------------------------------------------------------------------------------
 // MARCH = 1: literal restatement of ray_world (ray_tracer.wgsl:182-316) with the descent restarted from
 // the chunk root every step.  Kept as the A/B baseline for DESIGN.md's evidence table and as an
@@ -489,7 +495,7 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
                 }
                 if (STATS) { looked_up += 1u; R.visits += (uint32_t)__clz((int)(lo + 1u)) - 25u; }
                 if (voxel != 0u) {
-                    if (!is_liquid(s_liquid, voxel)) stop = true;                          // solid: the hit
+                    if (!is_liquid_ranged(P, s_liquid, voxel)) stop = true;                // solid: the hit
                     else if (dew == -1.0f) { dew = total_len; slow_bit = 0x80000000u; }    // liquid: water bookkeeping (:231-242)
                 } else if (dew != -1.0f) {
                     R.water_dist += total_len - dew;

@@ -345,7 +345,7 @@ __device__ __forceinline__ bool segment_trip(const FrameParams &P, const uint32_
             m.voxel = e >> 16;
         }
         if (m.voxel != 0u) {
-            if (!is_liquid(s_liquid, m.voxel)) return true;   // solid: the hit
+            if (!is_liquid_ranged(P, s_liquid, m.voxel)) return true;   // solid: the hit
             if (m.dew == -1.0f) { m.dew = m.total_len; m.slow_bit = 0x80000000u; }
         } else if (m.dew != -1.0f) {
             m.water_dist += m.total_len - m.dew;
