@@ -455,11 +455,19 @@ def main():
         roof["period_used_ms"] = period_fixed * 1e3
         # the same with every class at its measured issue cost (tools/valu_rates.hip): SIMD cycles the launch's
         # instructions need / SIMD cycles the frame period offers
-        cls = pmc.get("issue_cycles_by_class")
-        if cls:
-            need = sum(cls.values())
-            roof["class_weighted"] = {"issue_cycles_per_launch": cls, "simd_cycles_available": N_SIMD * peak_clock * 1e9 * period_fixed,
-                                      "frac": need / (N_SIMD * peak_clock * 1e9 * period_fixed)}
+        nominal, cls = pmc.get("valu_issue_cycles_by_class_nominal"), pmc.get("issue_cycles_by_class")
+        if nominal and cls:
+            avail = N_SIMD * peak_clock * 1e9 * period_fixed
+            valu_measured = sum(v for k, v in cls.items() if k.startswith("valu"))
+            roof["class_weighted"] = {
+                # VALU wave-instructions x their class's architectural issue time on a SIMD-32 (2 / 4 / 8 cycles for full rate /
+                # half rate + packed / transcendental), classes in the proportions of the march loop's fast path (profiles/*isa_mix*)
+                "valu_issue_cycles_per_launch_nominal": nominal, "simd_cycles_available": avail,
+                "frac": sum(nominal.values()) / avail,
+                # the same at the costs tools/valu_rates.hip measured (upper bounds: they carry the microbenchmark's own loop)
+                "valu_issue_cycles_per_launch_at_measured_costs": valu_measured, "frac_at_measured_costs": valu_measured / avail,
+                "salu_unit_cycles_per_launch_at_measured_cost": cls.get("salu"),
+                "note": "the scalar unit is shared by a CU's four SIMDs and issues beside the VALU; its cycles are not additive"}
     # §8(d)'s algorithmic bytes stay as a secondary object; a fraction above 1 says the kernel does not move those bytes
     # (the derived tables answer from L1 / L2); `measured_hbm` is what the PMC passes saw
     hbm = {"algorithmic_bytes_per_launch": dom_bytes, "algorithmic_gbs_at_frame_period": dom_bytes / period_s / 1e9,

@@ -51,9 +51,13 @@ for k, v in pick.items():
     c = vals[v]
     by = {cl: c["SQ_INSTS_VALU"] * fp.get(cl, 0) / n_v * cost[cl] for cl in ("valu_simple", "valu_half", "valu_pk", "valu_trans")}
     by["salu"] = c.get("SQ_INSTS_SALU", 0.0) * cost["salu"]
+    # the same at the architectural rates of a SIMD-32: a full-rate wave64 instruction holds it 2 cycles, half rate 4,
+    # transcendental 8 (the microbenchmark's costs are these plus its own loop's scalar instructions and VOP2 operand reads)
+    nominal = {"valu_simple": 2.0, "valu_half": 4.0, "valu_pk": 4.0, "valu_trans": 8.0}
+    by_nominal = {cl: c["SQ_INSTS_VALU"] * fp.get(cl, 0) / n_v * nominal[cl] for cl in nominal}
     kernels[k] = {"hbm_bytes": (c["FETCH_SIZE"] * 2 + c["WRITE_SIZE"]) * 1024.0 if "FETCH_SIZE" in c and "WRITE_SIZE" in c else None,
                   "valu_wave_instructions": c["SQ_INSTS_VALU"], "salu_wave_instructions": c.get("SQ_INSTS_SALU"),
-                  "issue_cycles_by_class": by, "counters": c}
+                  "issue_cycles_by_class": by, "valu_issue_cycles_by_class_nominal": by_nominal, "counters": c}
 res = {"code_object_sha256": mix.get("code_object_sha256"), "workload": workload, "kernels": kernels,
        "issue_cost_cycles": cost, "fast_path_mix": fp,
        "_source": f"{summary} (tools/pmc.sh: separate --pmc passes), {mix_path}, {rates_path}"}
