@@ -167,9 +167,9 @@ typedef struct {
     float ms_total;               /* hipEvent time of the last frame's kernels, same stream */
     float ms_primary;             /* the march kernel over primary rays */
     float ms_secondary;           /* shadow / bounce kernels */
-    uint32_t frames;              /* frames rendered since the previous vrt_get_stats, and their summed */
-    double sum_ms_primary;        /* kernel times (one hipEvent triple per frame, recorded on the stream */
-    double sum_ms_secondary;      /* the kernels run on) */
+    uint32_t frames;              /* frames *timed* since the previous vrt_get_stats — every stats frame, and every 8th plain */
+    double sum_ms_primary;        /* frame (the first included; a launch that carries timing events costs the host three times */
+    double sum_ms_secondary;      /* one that does not) — and their summed kernel times (events stamped by the dispatches) */
     double sum_ms_total;
     uint64_t clock_shader_ticks;  /* clock-probe frames (opts.stats = 2) since the previous vrt_get_stats: summed s_memtime */
     uint64_t clock_ref_ticks;     /* ... and s_memrealtime (100 MHz) differences: shader clock = 100 MHz x their ratio */

@@ -132,6 +132,10 @@ struct vrt_ctx {
     bool accel_dirty = true;
     bool accel_ok = false;        // false: world too large for the tables, variant 0 runs as variant 2
     uint32_t accel_max_s = 0;     // kAccelMaxS, or less through VRT_ACCEL_MAX_S (tests of the fallback)
+    // Every 8th plain frame carries the dispatch-stamped timing events (VRT_TIMING_EVERY=N changes it): a launch with events
+    // costs the host 13 us, one without 4 us (tools/host_cost.py) — nothing on one device, the frame period of a
+    // multi-device context that issues to eight from one thread.
+    uint32_t timing_every = 8, frame_no = 0;
     bool path_persistent = false;  // VRT_PATH_PERSISTENT=1: plain path frames as one persistent launch instead of one launch per bounce
     uint32_t accel_builds = 0, accel_chunk_builds = 0;
     float accel_last_ms = 0.f;
@@ -581,6 +585,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         if (v >= 0 && v < (long)kAccelMaxS) c->accel_max_s = (uint32_t)v;
     }
     if (const char *e = getenv("VRT_PATH_PERSISTENT")) c->path_persistent = e[0] == '1';
+    if (const char *e = getenv("VRT_TIMING_EVERY")) { const long v = strtol(e, nullptr, 10); if (v >= 1 && v <= 1000000) c->timing_every = (uint32_t)v; }
     memset(c->h_mats, 0, sizeof c->h_mats);
     memset(&c->cam, 0, sizeof c->cam);
     memset(&c->settings, 0, sizeof c->settings);
@@ -961,12 +966,14 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
         }
         P.spp = spp;
         P.seed = o.seed;
-        HIP_TRY(c, hipEventRecord(ev[0], f.st));
+        if (ev[0]) HIP_TRY(c, hipEventRecord(ev[0], f.st));
         vrt::launch_path_persistent(P, P.seg_counts, c->n_cus, f.st);
         HIP_TRY(c, hipGetLastError());
-        HIP_TRY(c, hipEventRecord(ev[1], f.st));
-        HIP_TRY(c, hipEventRecord(ev[3], f.st));
-        ev_kind = kEvRecorded;
+        if (ev[0]) {
+            HIP_TRY(c, hipEventRecord(ev[1], f.st));
+            HIP_TRY(c, hipEventRecord(ev[3], f.st));
+            ev_kind = kEvRecorded;
+        }
         c->last_spp = spp;
         return VRT_OK;
     }
@@ -977,7 +984,8 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
     P.path_cap = (uint32_t)cap;
     P.spp = spp;
     P.seed = o.seed;
-    HIP_TRY(c, hipEventRecord(ev[0], f.st));
+    const bool timed = ev[0] != nullptr;
+    if (timed) HIP_TRY(c, hipEventRecord(ev[0], f.st));
     if (bounces == 0) HIP_TRY(c, hipMemsetAsync(f.out, 0, (size_t)c->slots * sizeof(vrt::Texel), f.st));
     bool first = true;
     uint32_t g = 0;   // launch number within the frame (all three cursor sets are zero when it starts: vrt_render cleared them)
@@ -994,16 +1002,18 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
             if (b == 0) vrt::launch_path_primary(P, kstats, literal, f.st);
             else vrt::launch_path_bounce(P, kstats, literal, f.st);
             HIP_TRY(c, hipGetLastError());
-            if (first) { HIP_TRY(c, hipEventRecord(ev[1], f.st)); first = false; }
+            if (first) { if (timed) HIP_TRY(c, hipEventRecord(ev[1], f.st)); first = false; }
         }
     }
-    if (first) HIP_TRY(c, hipEventRecord(ev[1], f.st));
+    if (first && timed) HIP_TRY(c, hipEventRecord(ev[1], f.st));
     if (bounces > 0 && spp > 1u) {
         vrt::launch_path_finish(f.out, c->slots, spp, f.st);
         HIP_TRY(c, hipGetLastError());
     }
-    HIP_TRY(c, hipEventRecord(ev[3], f.st));
-    ev_kind = kEvRecorded;
+    if (timed) {
+        HIP_TRY(c, hipEventRecord(ev[3], f.st));
+        ev_kind = kEvRecorded;
+    }
     c->last_spp = spp;
     return VRT_OK;
 }
@@ -1024,7 +1034,7 @@ static int launch_march_frame(vrt_ctx *c, const vrt::FrameParams &P, const Frame
         c->n_counts = c->tiles_local;
         vrt::launch_primary_shadow_persistent(P, c->d_heads, c->n_cus, f.st, ev[0], ev[1]);
         HIP_TRY(c, hipGetLastError());
-        ev_kind = kEvOneKernel;
+        if (ev[0]) ev_kind = kEvOneKernel;
         return VRT_OK;
     }
     // primary + shadow in one launch: the default march, and — on a context whose pixel slots are 8-byte records — the
@@ -1035,11 +1045,11 @@ static int launch_march_frame(vrt_ctx *c, const vrt::FrameParams &P, const Frame
     if (fused) vrt::launch_primary_shadow_fused(P, march, kstats, f.st, ev[0], ev[1]);
     else vrt::launch_primary(P, march, kstats, shadow, f.st, ev[0], ev[1]);
     HIP_TRY(c, hipGetLastError());
-    ev_kind = kEvOneKernel;
+    if (ev[0]) ev_kind = kEvOneKernel;
     if (shadow && !fused) {
         vrt::launch_shadow(P, march, kstats, f.st, ev[2], ev[3]);
         HIP_TRY(c, hipGetLastError());
-        ev_kind = kEvTwoKernels;
+        if (ev[0]) ev_kind = kEvTwoKernels;
     }
     return VRT_OK;
 }
@@ -1128,8 +1138,15 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
 
     std::array<hipEvent_t, 4> *ev = nullptr;
     uint8_t *ev_kind = nullptr;
-    rc = next_events(c, &ev, &ev_kind);
-    if (rc) return rc;
+    static std::array<hipEvent_t, 4> no_events{nullptr, nullptr, nullptr, nullptr};
+    static uint8_t no_kind = 0;
+    if (c->timing_every > 1u && (c->frame_no++ % c->timing_every) != 0u && !kstats) {
+        ev = &no_events;   // an untimed frame: the launches carry no events (vrt_stats' kernel times average the timed ones)
+        ev_kind = &no_kind;
+    } else {
+        rc = next_events(c, &ev, &ev_kind);
+        if (rc) return rc;
+    }
     // the counters feed stats frames and the path trace's segment cursors; a plain primary(+shadow) frame reads none
     if (kstats || o.mode == VRT_MODE_PATH) HIP_TRY(c, hipMemsetAsync(f.counters, 0, kCounterBytes, f.st));
     if (o.mode == VRT_MODE_PATH) rc = launch_path_frame(c, P, f, o, kstats, air_liquid, *ev, *ev_kind);
