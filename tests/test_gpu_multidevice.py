@@ -149,3 +149,20 @@ def test_cpp_host_renders_through_a_multi_device_context(tmp_path):
         assert r.returncode == 0, r.stderr
         outs.append(np.fromfile(out, dtype=np.uint32))
     assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("extra", [["--gpus", "2"], ["--gpus", "3", "--single-process"]])
+def test_bench_starts_its_own_ranks_and_prints_one_line(extra):
+    """`python bench.py --gpus N` without a launcher: the script starts its own N processes (one per GPU, here all on this
+    one GPU with a gloo gather staged through the host) and relays rank 0's JSON line; `--single-process` drives N device
+    contexts through one multi-device vrt context instead.  Both verify the assembled frame against an unsharded render."""
+    import json
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *extra, "--rehearse-on-one-gpu", "--steps", "12", "--warmup", "2",
+                        "--width", "640", "--height", "360"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == int(extra[1]) and d["value"] > 0 and d["steps"] == 12 and d["scaling"] == "strong"
