@@ -115,6 +115,13 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.single_process:
         sys.exit(self_launch(args))
 
+    # stdout carries ONE JSON line and nothing else: RCCL prints a version banner to file descriptor 1 when a communicator is
+    # created (and other native code might), so descriptor 1 points at stderr for the whole run and the line goes to the
+    # saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     from voxelraytracing_amd import Gpu, MODE_PATH, MODE_PRIMARY, MODE_PRIMARY_SHADOW, _ffi, scenes
@@ -524,7 +531,9 @@ def main():
         out["config"]["workload"] = out["config"]["workload"].replace("C2:", "non-headline:").replace("1 primary + 1 shadow ray per solid hit", f"mode {args.mode}")
     if world == 1 and not devices and not args.no_cpu_baseline and args.mode == "shadow":
         out["cpu_baseline"] = cpu_baseline(sc, args, rays_fixed)
-    print(json.dumps(out), flush=True)
+    sys.stdout.flush()
+    with os.fdopen(json_fd, "w") as real_stdout:
+        real_stdout.write(json.dumps(out) + "\n")
     if sharded:
         dist.destroy_process_group()
 
