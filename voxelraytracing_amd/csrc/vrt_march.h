@@ -436,7 +436,8 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
         sqrtf(1.0f + (dir.y / dir.x) * (dir.y / dir.x) + (dir.z / dir.x) * (dir.z / dir.x)),
         sqrtf(1.0f + (dir.x / dir.y) * (dir.x / dir.y) + (dir.z / dir.y) * (dir.z / dir.y)),
         sqrtf(1.0f + (dir.x / dir.z) * (dir.x / dir.z) + (dir.y / dir.z) * (dir.y / dir.z))};
-    const float ux = fabsf(unit.x), uy = fabsf(unit.y), uz = fabsf(unit.z);
+    float ux = fabsf(unit.x), uy = fabsf(unit.y), uz = fabsf(unit.z);
+    asm("" : "+v"(ux), "+v"(uy), "+v"(uz));   // (held in registers: the compiler would otherwise redo the three |.| on every step)
     const uint32_t mxm = mx ? ~0u : 0u, mym = my ? ~0u : 0u, mzm = mz ? ~0u : 0u;
 
     const uint32_t wsize = P.world.size;
@@ -463,12 +464,56 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
     uint32_t exp_acc = 0u;
 #endif
 
-    for (;;) {
-        iter += 1u;
-        // ---- find_node: cell, then brick ----
-        uint32_t e = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(
+    // ---- the step to the leaf's exit face (:243-283), for a leaf of size lo + 1 ----
+    auto take_step = [&](uint32_t lo) __attribute__((always_inline)) {
+        // (h) the exit plane: low = v & ~lo, high = (v | lo) + 1; the direction mask is 0 or ~0 = -1, so "+ 1" is "- mask"
+        const float tx = (float)(int)(bfi(lo, mxm, (uint32_t)vx) - mxm) - pos.x;
+        const float ty = (float)(int)(bfi(lo, mym, (uint32_t)vy) - mym) - pos.y;
+        const float tz = (float)(int)(bfi(lo, mzm, (uint32_t)vz) - mzm) - pos.z;
+        // (b'') |t| * |unit| has the bits of (mask ? t : -t) * unit, except that a zero is always +0 (never observed)
+        adx = abs_mul(tx, ux);
+        ady = abs_mul(ty, uy);
+        adz = abs_mul(tz, uz);
+        // (c') the minimum over the non-zero distances, on bit patterns: non-negative floats order like unsigned integers,
+        // NaNs above every number, and bits - 1 sends +0 to the very top, so one unsigned min3 replaces the shader's
+        // branch tree (:247-270): the smallest non-zero number; a NaN only if nothing else is non-zero; +0 if all are zero
+        step = __uint_as_float(min3_u32(__float_as_uint(adx) - 1u, __float_as_uint(ady) - 1u, __float_as_uint(adz) - 1u) + 1u);
+        total_len += step;
+        const float sp = step + 0.001f;
+        pos.x += dir.x * (step == adx ? sp : step);
+        pos.y += dir.y * (step == ady ? sp : step);
+        pos.z += dir.z * (step == adz ? sp : step);
+        // the next lookup's coordinates: floor — just beyond a face it is -1 or `size`, which the grid's border answers
+        // with 0 (a `careful` wave looks its coordinates up again, as the shader has them)
+        vx = flr2i(pos.x);
+        vy = flr2i(pos.y);
+        vz = flr2i(pos.z);
+    };
+    auto lookup = [&]() __attribute__((always_inline)) {
+        return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(
             gb, mad_i24(vz >> 2, slab_bytes, mad_i24(vy >> 2, row_bytes, (uint32_t)vx & ~3u)), 0, 0);
-        uint32_t lo = e;    // an air leaf of the cell grid: the entry is lo, nothing else to do
+    };
+
+    // Two loops (m): the inner one runs the steps in which NO lane of the wave has anything to decide — every lane in a
+    // plain air leaf — and has only wave-uniform branches: no exec-mask bookkeeping, four scalar instructions per step.
+    // A step in which some lane is in the slow path (brick, hit, water, leaving the world; 28 % of the wave's steps)
+    // leaves it, runs once through the general body below — where a lane that is done breaks out, divergently — and
+    // returns.  Same steps in the same order for every lane; `iter` counts them for the whole wave.
+    for (;;) {
+        uint32_t e;
+        bool exhausted = false;
+        for (;;) {
+            e = lookup();
+            if (__ballot((e | slow_bit) - 1u >= 31u) != 0ull) break;
+            iter += 1u;
+            if (STATS) { looked_up += 1u; R.visits += (uint32_t)__clz((int)(e + 1u)) - 25u; }
+            take_step(e);   // an air leaf of the cell grid: the entry is lo
+            if (iter >= kMaxSteps) { exhausted = true; break; }
+        }
+        if (exhausted) break;   // (wave-uniform) at most kMaxSteps lookups (:220)
+        // ---- the general step: find_node's answer may be a brick, a non-air leaf, the border ----
+        iter += 1u;
+        uint32_t lo = e;
         bool stop = false;
         if ((e | slow_bit) - 1u >= 31u) {
             if (careful) {  // wave-uniform: the shader's test (:285) on the shader's coordinates (i32(NaN) = 0), then its lookup
@@ -477,8 +522,7 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
                 vz = trunc2i(pos.z);
                 e = 0u;
                 if (!(min3_nan_ignoring(pos.x, pos.y, pos.z) < 0.0f || max(max((uint32_t)vx, (uint32_t)vy), (uint32_t)vz) >= wsize))
-                    e = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(
-                        gb, mad_i24(vz >> 2, slab_bytes, mad_i24(vy >> 2, row_bytes, (uint32_t)vx & ~3u)), 0, 0);
+                    e = lookup();
                 lo = e;
             }
             stop = e == 0u;  // border, or past either end of the grid: the position is outside the world
@@ -508,40 +552,12 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
             R.visits += (uint32_t)__clz((int)(lo + 1u)) - 25u;  // depth + 1 node words on the reference's walk
         }
         if (stop) break;
-
 #ifdef VRT_EXP_VALU   // tools/ab experiments only: marginal cost of VRT_EXP_VALU extra simple VALU instructions per step
 #pragma unroll
         for (int k_ = 0; k_ < VRT_EXP_VALU; k_++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(exp_acc) : "v"(lo));
 #endif
-#ifdef VRT_EXP_SALU   // ... of VRT_EXP_SALU extra scalar instructions per step
-#pragma unroll
-        for (int k_ = 0; k_ < VRT_EXP_SALU; k_++) asm volatile("s_mov_b32 vcc_lo, 0" ::: "vcc");
-#endif
-        // ---- step to the leaf's exit face ----
-        // (h) the exit plane: low = v & ~lo, high = (v | lo) + 1; the direction mask is 0 or ~0 = -1, so "+ 1" is "- mask"
-        const float tx = (float)(int)(bfi(lo, mxm, (uint32_t)vx) - mxm) - pos.x;
-        const float ty = (float)(int)(bfi(lo, mym, (uint32_t)vy) - mym) - pos.y;
-        const float tz = (float)(int)(bfi(lo, mzm, (uint32_t)vz) - mzm) - pos.z;
-        // (b'') |t| * |unit| has the bits of (mask ? t : -t) * unit, except that a zero is always +0 (never observed)
-        adx = abs_mul(tx, ux);
-        ady = abs_mul(ty, uy);
-        adz = abs_mul(tz, uz);
-        // (c') the minimum over the non-zero distances, on bit patterns: non-negative floats order like unsigned integers,
-        // NaNs above every number, and bits - 1 sends +0 to the very top, so one unsigned min3 replaces the shader's
-        // branch tree (:247-270): the smallest non-zero number; a NaN only if nothing else is non-zero; +0 if all are zero
-        step = __uint_as_float(min3_u32(__float_as_uint(adx) - 1u, __float_as_uint(ady) - 1u, __float_as_uint(adz) - 1u) + 1u);
-        total_len += step;
-        const float sp = step + 0.001f;
-        pos.x += dir.x * (step == adx ? sp : step);
-        pos.y += dir.y * (step == ady ? sp : step);
-        pos.z += dir.z * (step == adz ? sp : step);
-
-        // the next lookup's coordinates: floor — just beyond a face it is -1 or `size`, which the grid's border answers
-        // with 0 (a `careful` wave looks its coordinates up again, as the shader has them)
-        vx = flr2i(pos.x);
-        vy = flr2i(pos.y);
-        vz = flr2i(pos.z);
-        if (iter >= kMaxSteps) break;  // at most kMaxSteps lookups (:220); every lane still here has looked up exactly `iter` nodes
+        take_step(lo);
+        if (iter >= kMaxSteps) break;  // every lane still here has looked up exactly `iter` nodes
     }
     // per-lane lookup counts are kept by the STATS kernels only (counters, step-count debug view)
     R.iters = STATS ? looked_up : 0u;
