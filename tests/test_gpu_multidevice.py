@@ -37,8 +37,11 @@ def reference_frames(sc, cams, mode, **kw):
     return out, st
 
 
+@pytest.mark.parametrize("threads", ["0", "1"])
 @pytest.mark.parametrize("n", [2, 3, 8])
-def test_group_frames_equal_single_device_frames(c2_small, n):
+def test_group_frames_equal_single_device_frames(c2_small, n, threads, monkeypatch):
+    # VRT_GROUP_THREADS: one issuing thread per device besides the caller's (the default when the device ids differ)
+    monkeypatch.setenv("VRT_GROUP_THREADS", threads)
     w, h = c2_small.size
     cams = [g.cam_data_create((18.0 + 7 * k, 30.0 + 33 * k, 0.0), (c2_small.eye[0] + k, c2_small.eye[1], c2_small.eye[2] - k), 70.0,
                               (float(w), float(h))) for k in range(5)]

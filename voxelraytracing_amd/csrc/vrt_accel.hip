@@ -274,12 +274,9 @@ void launch_accel_bricks(const uint16_t *nodes, uint32_t n_nodes, const uint32_t
 void launch_accel_chunks(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S, uint32_t *grid,
                          uint32_t *chunk_bricks, uint32_t *chunk_bases, uint32_t *chunk_caps, uint32_t *tail, uint16_t *bricks,
                          uint32_t brick_cap, const uint32_t *chunks, uint32_t n, hipStream_t st) {
-    static bool lds_set = false;   // 64 KiB + of dynamic LDS needs opting in (the CU has 160 KiB)
-    if (!lds_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(accel_chunks_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)((kChunkNodesMax + 1u) * sizeof(uint16_t)));
-        lds_set = true;
-    }
+    // 64 KiB + of dynamic LDS needs opting in (the CU has 160 KiB); per device, and any thread may be the first
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(accel_chunks_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)((kChunkNodesMax + 1u) * sizeof(uint16_t)));
     for (uint32_t i = 0; i < n; i += 64u) {
         ChunkList list;
         const uint32_t m = n - i < 64u ? n - i : 64u;

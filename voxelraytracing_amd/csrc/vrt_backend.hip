@@ -9,6 +9,12 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1479,8 +1485,60 @@ int vrt_assemble_compact(vrt_ctx *c, const void *gathered, uint64_t rank_stride_
 // all enqueued from the calling thread without waiting for anything: two message slots and device 0's two frame buffers
 // give the same two frames in flight a single device has.  No collective library, no second process.
 // ---------------------------------------------------------------------------------------------------------------------
+// One issuing thread per device other than the root: the caller stays one thread (the reference's shape), but issuing a
+// frame to N devices from it alone costs N x (launch + event record + waits) and makes eight devices host-bound
+// (DESIGN.md §7).  A worker sleeps on a condition variable between frames' bursts and spins briefly first, so a frame
+// loop finds it awake; every API call joins the workers before it returns — nothing of a context is ever touched by
+// two threads at once.
+struct GrpWorker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::atomic<uint64_t> posted{0}, finished{0};
+    std::function<int()> job;
+    int rc = 0;
+    bool quit = false;
+
+    void run() {
+        uint64_t seen = 0;
+        for (;;) {
+            for (int spin = 0; spin < 20000 && posted.load(std::memory_order_acquire) == seen; spin++) __builtin_ia32_pause();
+            if (posted.load(std::memory_order_acquire) == seen) {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return quit || posted.load(std::memory_order_acquire) != seen; });
+                if (quit) return;
+            }
+            seen = posted.load(std::memory_order_acquire);
+            rc = job();
+            finished.store(seen, std::memory_order_release);
+        }
+    }
+    void post(std::function<int()> f) {
+        job = std::move(f);
+        {
+            std::lock_guard<std::mutex> lk(m);
+            posted.fetch_add(1, std::memory_order_release);
+        }
+        cv.notify_one();
+    }
+    int join() {
+        const uint64_t want = posted.load(std::memory_order_acquire);
+        while (finished.load(std::memory_order_acquire) != want) __builtin_ia32_pause();
+        return rc;
+    }
+    void stop() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            quit = true;
+        }
+        cv.notify_one();
+        if (th.joinable()) th.join();
+    }
+};
+
 struct vrt_group {
     std::vector<vrt_ctx *> dev;      // dev[0] = the root
+    std::vector<std::unique_ptr<GrpWorker>> workers;   // [r - 1] issues for dev[r]; empty: the calling thread issues for all (VRT_GROUP_THREADS=0)
     bool texels = false;             // VRT_FLAG_TEXEL_MESSAGES
     static constexpr uint32_t kSlots = 2;
     void *recv[kSlots] = {nullptr, nullptr};               // on device 0: [n_devices][tiles_padded * 64] records or texels
@@ -1561,6 +1619,20 @@ static int grp_create(const vrt_config *cfg, vrt_ctx **out) {
         }
         HIP_TRY(c, hipSetDevice(g->dev[0]->device));
         for (auto &ev : g->consumed) HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        // issuing threads pay off when the devices are different ones: launches to one device serialise inside the
+        // runtime whichever thread makes them (measured with device_ids = {0, ...}: 168 us of host time per frame for 8
+        // contexts with workers, 145 without).  VRT_GROUP_THREADS=1 / 0 forces them on / off.
+        bool distinct = true;
+        for (uint32_t a = 0; a < n; a++)
+            for (uint32_t b = a + 1; b < n; b++)
+                if (cfg->device_ids[a] == cfg->device_ids[b]) distinct = false;
+        const char *e = getenv("VRT_GROUP_THREADS");
+        if (e ? e[0] == '1' : distinct)
+            for (uint32_t r = 1; r < n; r++) {
+                g->workers.emplace_back(new GrpWorker());
+                GrpWorker *w = g->workers.back().get();
+                w->th = std::thread([w] { w->run(); });
+            }
         return grp_alloc_messages(c);
     };
     const int rc = body();
@@ -1575,6 +1647,7 @@ static int grp_create(const vrt_config *cfg, vrt_ctx **out) {
 
 static void grp_destroy(vrt_ctx *c) {
     vrt_group *g = c->grp;
+    for (auto &w : g->workers) w->stop();
     for (vrt_ctx *d : g->dev) {
         (void)hipSetDevice(d->device);
         (void)vrt_synchronize(d);
@@ -1629,20 +1702,38 @@ static int grp_render(vrt_ctx *c, const vrt_render_opts *opts) {
     const uint32_t k = g->slot;
     g->slot = (g->slot + 1u) % (g->in_flight > 1u ? vrt_group::kSlots : 1u);
     o.flags |= VRT_RENDER_OWN_STREAMS;   // every device's frame runs on that context's in-flight streams, into the buffer bound here
-    for (uint32_t r = 1; r < n; r++) {
+    // what is issued to device r >= 1 for this frame — by its worker thread, or here
+    auto issue = [g, k, o](uint32_t r) -> int {
         vrt_ctx *d = g->dev[r];
-        HIP_TRY(c, hipSetDevice(d->device));
+        if (hipSetDevice(d->device) != hipSuccess) return fail(d, VRT_ERR_DEVICE, "hipSetDevice(%d) failed", d->device);
         int rc = vrt_bind_output(d, (uint8_t *)g->recv[k] + (size_t)r * g->rank_stride);
         // the slot's previous message must have been consumed by device 0 before this frame overwrites it
         d->wait_before_frame = g->consumed_used[k] ? g->consumed[k] : nullptr;
         if (!rc) rc = vrt_render(d, &o);
         d->wait_before_frame = nullptr;
-        if (rc) { c->err = d->err; return rc; }
-        if (d->tiles_local) HIP_TRY(c, hipEventRecord(g->done[r][k], d->last_stream));
+        if (rc) return rc;
+        if (d->tiles_local && hipEventRecord(g->done[r][k], d->last_stream) != hipSuccess)
+            return fail(d, VRT_ERR_DEVICE, "hipEventRecord failed on device %d", d->device);
+        return VRT_OK;
+    };
+    if (!g->workers.empty()) {
+        for (uint32_t r = 1; r < n; r++) g->workers[r - 1]->post([issue, r] { return issue(r); });
+    } else {
+        for (uint32_t r = 1; r < n; r++) {
+            const int rc = issue(r);
+            if (rc) { c->err = g->dev[r]->err; return rc; }
+        }
     }
     HIP_TRY(c, hipSetDevice(root->device));
     int rc = vrt_render(root, &o);
+    // the workers have *enqueued* their frames (their done events are recorded) before the root's stream is told to wait
+    int wrc = VRT_OK;
+    for (uint32_t r = 1; r < n && !g->workers.empty(); r++) {
+        const int one = g->workers[r - 1]->join();
+        if (one && !wrc) { wrc = one; c->err = g->dev[r]->err; }
+    }
     if (rc) { c->err = root->err; return rc; }
+    if (wrc) return wrc;
     hipStream_t X = root->last_stream ? root->last_stream : root->stream;
     for (uint32_t r = 1; r < n; r++)
         if (g->dev[r]->tiles_local) HIP_TRY(c, hipStreamWaitEvent(X, g->done[r][k], 0));
