@@ -359,6 +359,11 @@ def main():
             gpu.write_cam_data(sc.cam)
             run_frames(gpu, fg, 50, True)
             d1 = timed(gpu, fg, args.steps, True)
+            gpu.stats()
+            # the lone launch's own duration: every frame timed (VRT_RENDER_TIMED) — between untimed neighbours a timed
+            # launch's begin stamp falls into its predecessor's tail
+            for _ in range(300):
+                gpu.render(MODE, timed=True, **rkw)
             k1 = gpu.stats()
             extras["value_1_in_flight"] = rays_fixed * args.steps / d1 / 1e6
             extras["ms_per_step_1_in_flight"] = d1 / args.steps * 1e3

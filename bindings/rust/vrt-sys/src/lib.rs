@@ -97,6 +97,7 @@ pub const VRT_MODE_PRIMARY_SHADOW: u32 = 1;
 pub const VRT_MODE_PATH: u32 = 2;
 
 pub const VRT_RENDER_OWN_STREAMS: u32 = 1;
+pub const VRT_RENDER_TIMED: u32 = 2;
 
 #[repr(C)]
 #[derive(Clone, Copy, Default)]

@@ -154,6 +154,9 @@ typedef struct {
  * output before vrt_synchronize (or a device-wide synchronise), and that frames in flight are bound to different
  * buffers.  For a gather root that renders its own tiles in place: they never feed the collective. */
 #define VRT_RENDER_OWN_STREAMS 1u
+/* This frame's launches carry timing events (vrt_stats.frames / sum_ms_*) whatever the context's sampling of plain frames
+ * is (every 8th: a launch with events costs the host three times one without). */
+#define VRT_RENDER_TIMED 2u
 
 /* New relative to the reference (it presents to a swapchain and never reads back). */
 typedef struct {

@@ -16,9 +16,9 @@ march loops (primary ray, shadow ray) and classifies every instruction of every 
     vmem / lds / smem
 
 (the classes and their issue costs are measured by tools/valu_rates.hip -> profiles/rNN_valu_issue_rates.txt).  The *fast
-path* of a loop is what a wave executes on a march step in which every lane is in a plain air leaf of the cell grid: the
-header block, the block where the slow region rejoins, the step arithmetic and the latch.  Writes <out>.json (counts,
-code-object hash of the library in the tree) and <out>.txt (the listing of both loops, block by block).
+path* is what a wave executes on a march step in which every lane is in a plain air leaf of the cell grid: since the march
+is two loops (DESIGN.md §3 m) that is exactly the inner loop.  Writes <out>.json (counts, code-object hash of the library
+in the tree) and <out>.txt (the listing of both inner loops, block by block).
 """
 import argparse
 import json
@@ -74,24 +74,29 @@ def kernel_text(asm: str) -> list:
 
 
 def blocks_of(lines):
-    """[(label, [instruction lines], is_loop_header, in_loop_of)] in layout order."""
-    out, cur, label = [], [], "entry"
-    hdr, inloop = False, None
+    """[(label, [instruction lines], loop header this block belongs to (innermost) or None, is an inner-loop header)] in layout order."""
+    out, cur, label, inloop, hdr = [], [], "entry", None, False
+    pending = None   # a label line whose loop comment continues on the next comment line
     for l in lines:
         m = re.match(r"^(\.LBB\d+_\d+):\s*(;.*)?$", l) or re.match(r"^; %bb\.(\d+):\s*(;.*)?$", l)
         if m:
-            out.append((label, cur, hdr, inloop))
+            out.append((label, cur, inloop, hdr))
             label, cur = (m.group(1) if l.startswith(".") else "bb." + m.group(1)), []
             c = m.group(2) or ""
-            hdr = "Loop Header" in c and "in Loop" not in c.split("Loop Header")[0][-12:] and "=>This" in c
+            hdr = "=>This Inner Loop Header" in c
             mm = re.search(r"in Loop: Header=(BB\d+_\d+)", c)
-            inloop = ("." + "L" + mm.group(1)) if mm else (label if hdr else None)
+            inloop = (".L" + mm.group(1)) if mm else (label if hdr else None)
+            pending = label
+            continue
+        if pending and l.strip().startswith(";") and "This Inner Loop Header" in l:   # "Parent Loop ..." / "=>  This Inner Loop Header: Depth=2"
+            hdr, inloop = True, pending
             continue
         t = l.split(";")[0].strip()
         if not t or t.startswith((".", ";")) or t.startswith(";;#"):
             continue
+        pending = None
         cur.append(t)
-    out.append((label, cur, hdr, inloop))
+    out.append((label, cur, inloop, hdr))
     return out
 
 
@@ -121,8 +126,8 @@ def main():
                                    os.path.join(ROOT, "voxelraytracing_amd", "csrc", "vrt_kernels.hip")], stderr=subprocess.DEVNULL)
             asm = open(s).read()
     bl = blocks_of(kernel_text(asm))
-    headers = [b[0] for b in bl if b[2]]
-    assert len(headers) == 2, f"expected the primary and the shadow march loop, found {headers}"
+    headers = [b[0] for b in bl if b[3]]
+    assert len(headers) == 2, f"expected the inner march loop of the primary and of the shadow ray, found {headers}"
     res = {"kernel": "primary_shadow_wave_kernel<0, false, false, 4>", "loops": {}}
     listing = []
     total = {}
@@ -130,35 +135,16 @@ def main():
         total = add(total, count(b[1]))
     res["whole_kernel_static"] = total
     for name, h in zip(("primary", "shadow"), headers):
-        loop = [b for b in bl if b[3] == h]
-        # the latch is laid out just before the header: blocks "in Loop" that precede it
-        idx = {b[0]: i for i, b in enumerate(loop)}
+        # the inner loop (DESIGN.md §3 m) IS the fast path: the steps in which no lane of the wave has anything to decide
+        loop = [b for b in bl if b[2] == h]
         per_block = {b[0]: count(b[1]) for b in loop}
-        # fast path: header -> (first s_cbranch_execz target = rejoin) -> fall through (step arithmetic) -> its s_branch target (latch) .. header
-        hb = next(b for b in loop if b[0] == h)
-        rejoin = next(t.split()[-1] for t in hb[1] if t.startswith("s_cbranch_execz"))
-        order = [b[0] for b in loop]
-        step = order[order.index(rejoin) + 1]
-        sb = next(b for b in loop if b[0] == step)
-        latch = next(t.split()[-1] for t in sb[1] if t.startswith("s_branch"))
-        fast = [h, rejoin, step, latch]
-        # blocks between the latch label and the header in layout order belong to the latch path too
-        li = order.index(latch)
-        hi = order.index(h)
-        if li < hi:
-            fast = [h, rejoin, step] + order[li:hi]
         fp = {}
-        for lab in fast:
-            fp = add(fp, per_block[lab])
-        allc = {}
         for lab in per_block:
-            allc = add(allc, per_block[lab])
-        res["loops"][name] = {"header": h, "fast_path_blocks": fast, "fast_path": fp, "all_blocks_static": allc,
-                              "per_block": per_block}
-        listing.append(f"==== {name} march loop (header {h}); fast path = {' -> '.join(fast)} ====")
+            fp = add(fp, per_block[lab])
+        res["loops"][name] = {"header": h, "fast_path_blocks": [b[0] for b in loop], "fast_path": fp, "per_block": per_block}
+        listing.append(f"==== {name} ray: inner march loop (header {h}) = the fast path, one trip per step ====")
         for b in loop:
-            mark = " [fast path]" if b[0] in fast else ""
-            listing.append(f"{b[0]}:{mark}   {per_block[b[0]]}")
+            listing.append(f"{b[0]}:   {per_block[b[0]]}")
             listing += ["    " + t for t in b[1]]
     try:
         from voxelraytracing_amd import _ffi

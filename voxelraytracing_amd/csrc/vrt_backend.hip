@@ -1146,7 +1146,7 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     uint8_t *ev_kind = nullptr;
     static std::array<hipEvent_t, 4> no_events{nullptr, nullptr, nullptr, nullptr};
     static uint8_t no_kind = 0;
-    if (c->timing_every > 1u && (c->frame_no++ % c->timing_every) != 0u && !kstats) {
+    if (c->timing_every > 1u && (c->frame_no++ % c->timing_every) != 0u && !kstats && !(o.flags & VRT_RENDER_TIMED)) {
         ev = &no_events;   // an untimed frame: the launches carry no events (vrt_stats' kernel times average the timed ones)
         ev_kind = &no_kind;
     } else {

@@ -133,10 +133,10 @@ class Gpu:
 
     # --- PixelShader (shader.rs:295-380) ---
     def encode_pass(self, mode: int = MODE_PRIMARY, variant: int = 0, stats: bool = False, spp: int = 1, seed: int = 0,
-                    own_streams: bool = False):
+                    own_streams: bool = False, timed: bool = False):
         """PixelShader::encode_pass + queue.submit (shader.rs:371-379, main.rs:453,565). Asynchronous.
         own_streams: VRT_RENDER_OWN_STREAMS (include/vrt.h)."""
-        o = RenderOpts(mode, variant, int(stats), spp, seed, 1 if own_streams else 0)   # stats: False/True, or 2 = clock probe
+        o = RenderOpts(mode, variant, int(stats), spp, seed, (1 if own_streams else 0) | (2 if timed else 0))   # stats: False/True, or 2 = clock probe; timed: VRT_RENDER_TIMED
         self._ck(self._lib.vrt_render(self._h, C.byref(o)))
 
     render = encode_pass
