@@ -34,6 +34,9 @@ void launch_primary_shadow_fused(const FrameParams &P, uint32_t march, bool stat
 void launch_primary_shadow_persistent(const FrameParams &P, uint32_t *heads, uint32_t n_cus, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
 void launch_path_primary(const FrameParams &P, bool stats, bool literal, hipStream_t st);
 void launch_path_bounce(const FrameParams &P, bool stats, bool literal, hipStream_t st);
+void launch_path_bounce_pool(const FrameParams &P, bool continuations, hipStream_t st);
+bool path_pool_enabled();
+bool path_pool_chain_enabled();
 void launch_path_finish(Texel *out, uint32_t n, uint32_t spp, hipStream_t st);
 void launch_path_persistent(const FrameParams &P, uint32_t *heads, uint32_t n_cus, hipStream_t st);
 void launch_quantize(const Texel *out, uint8_t *rgba8, uint32_t n, hipStream_t st);
@@ -78,6 +81,10 @@ struct vrt_ctx {
     uint32_t *extra_blk[kMaxInFlight - 1] = {nullptr, nullptr, nullptr};
     uint4 *extra_path[kMaxInFlight - 1] = {nullptr, nullptr, nullptr};                   // path mode: its own path buffers
     unsigned long long *extra_counters[kMaxInFlight - 1] = {nullptr, nullptr, nullptr};  // ... and segment cursors
+    // path mode, straggler chain (launch_path_frame): per frame set [0] = the context's own, [k] = extra set k - 1
+    uint4 *path_cont[kMaxInFlight] = {nullptr, nullptr, nullptr, nullptr};        // kContSets x 4 planes
+    hipStream_t side_stream[kMaxInFlight] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t side_ev[kMaxInFlight][6] = {};                                     // [0..3] bounce launch done, [4] chain done, [5] frame start
     uint32_t in_flight = 2;        // vrt_set_frames_in_flight
     bool alt_pending = false;      // frames may still be running on the extra streams
     bool own_pending = false;      // ... or on own_stream while the caller's stream is the context's stream (VRT_RENDER_OWN_STREAMS)
@@ -191,7 +198,8 @@ struct vrt_ctx {
 static constexpr size_t kSegBytes = (size_t)vrt::kHitSegments * vrt::kSegStride * sizeof(uint32_t);
 // three sets of segment cursors: launch g of a path frame appends to set g % 3, reads set (g - 1) % 3 and clears set
 // (g + 1) % 3 for its successor, so no memset sits between two launches
-static constexpr size_t kCounterBytes = vrt::kCtrCount * sizeof(unsigned long long) + 3 * kSegBytes;
+static constexpr uint32_t kContSets = 4;   // straggler-chain record sets of a path frame (one per bounce launch; more bounces: no chain)
+static constexpr size_t kCounterBytes = vrt::kCtrCount * sizeof(unsigned long long) + (3 + kContSets) * kSegBytes;   // 3 path cursor sets + the chain's
 
 enum EvKind : uint8_t { kEvNone = 0, kEvOneKernel = 1, kEvTwoKernels = 2, kEvRecorded = 3 };
 
@@ -257,6 +265,7 @@ static int alloc_output(vrt_ctx *c) {
     for (auto &p : c->extra_out) { (void)hipFree(p); p = nullptr; }
     for (auto &p : c->extra_blk) { (void)hipFree(p); p = nullptr; }
     for (auto &p : c->extra_path) { (void)hipFree(p); p = nullptr; }
+    for (auto &p : c->path_cont) { (void)hipFree(p); p = nullptr; }
     layout_tiles(c);
     const size_t n = c->slots ? c->slots : 1;
     HIP_TRY(c, hipMalloc(&c->own_out, n * sizeof(vrt::Texel)));
@@ -637,6 +646,12 @@ void vrt_destroy(vrt_ctx *c) {
     for (auto p : c->extra_blk) (void)hipFree(p);
     for (auto p : c->extra_path) (void)hipFree(p);
     for (auto p : c->extra_counters) (void)hipFree(p);
+    for (auto p : c->path_cont) (void)hipFree(p);
+    for (auto st : c->side_stream)
+        if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    for (auto &evs : c->side_ev)
+        for (auto ev : evs)
+            if (ev) (void)hipEventDestroy(ev);
     (void)hipFree(c->d_nodes); (void)hipFree(c->d_roots); (void)hipFree(c->d_mats); (void)hipFree(c->own_out);
     (void)hipFree(c->d_hits); (void)hipFree(c->d_counters); (void)hipFree(c->d_steps); (void)hipFree(c->d_rgba8); (void)hipFree(c->d_path);
     (void)hipFree(c->d_blk_counts); (void)hipFree(c->d_clock);
@@ -885,6 +900,7 @@ static void fill_uniforms(const vrt_ctx *c, vrt::FrameParams &P) {
 // Where one frame runs and what it writes: the caller's stream and the current output, or — frames in flight — one of
 // the context's own (stream, output, launched-ray counts, path buffers, cursors) sets.
 struct FrameSet {
+    uint32_t slot = 0;   // 0: the context's own set, k: extra set k - 1
     hipStream_t st;
     vrt::Texel *out;
     uint32_t *blk;
@@ -904,13 +920,14 @@ static int pick_frame_set(vrt_ctx *c, const vrt_render_opts &o, uint32_t variant
     const bool own_streams = (o.flags & VRT_RENDER_OWN_STREAMS) != 0u;
     const bool pipelined = c->in_flight > 1u && chain && !kstats && (own_streams || (c->stream == c->own_stream && c->d_out == c->own_out));
     const bool bound = c->d_out != c->own_out;
-    f = FrameSet{c->stream, c->d_out, c->d_blk_counts, &c->d_path, c->d_counters};
+    f = FrameSet{0u, c->stream, c->d_out, c->d_blk_counts, &c->d_path, c->d_counters};
     if (!pipelined) {
         QUIESCE(c);
         return VRT_OK;
     }
     if (c->flip) {
         const uint32_t k = c->flip - 1u;
+        f.slot = k + 1u;
         if (o.mode == VRT_MODE_PATH) {
             if (!c->extra_counters[k]) HIP_TRY(c, hipMalloc(&c->extra_counters[k], kCounterBytes));
             f.counters = c->extra_counters[k];
@@ -985,11 +1002,36 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
     }
     const size_t cap = (size_t)vrt::kHitSegments * c->hit_seg_cap;
     if (!*f.path_buf) HIP_TRY(c, hipMalloc(f.path_buf, 2 * 3 * cap * sizeof(uint4)));
-    uint32_t *seg[3] = {P.seg_counts, P.seg_counts + vrt::kHitSegments * vrt::kSegStride, P.seg_counts + 2 * vrt::kHitSegments * vrt::kSegStride};
+    constexpr uint32_t kSegWords = vrt::kHitSegments * vrt::kSegStride;
+    uint32_t *seg[3] = {P.seg_counts, P.seg_counts + kSegWords, P.seg_counts + 2 * kSegWords};
     uint4 *buf[2] = {*f.path_buf, *f.path_buf + 3 * cap};
     P.path_cap = (uint32_t)cap;
+    P.in_cap = (uint32_t)cap;
+    P.in_seg_cap = c->hit_seg_cap;
+    P.cont_out = nullptr;
+    P.cont_counts = nullptr;
     P.spp = spp;
     P.seed = o.seed;
+    // Bounce launches over the derived tables use the pool kernel (vrt_path.hip).  With up to kContSets of them per sample
+    // they hand the rays still marching when a wave's pool runs dry to a *straggler chain* on a side stream: launch S(b)
+    // marches what bounce launch b handed on plus the next segments of S(b - 1)'s own survivors, while bounce launch
+    // b + 1 already runs — the few rays that graze the terrain for a hundred steps, which every bounce launch used to
+    // wait for, are off the frame's critical path.  A path is in exactly one of the two chains, so nothing is shared but
+    // the record sets' cursors (atomics).  The chains join at the end of every sample.
+    const bool pool = !kstats && !literal && P.grid && bounces > 1 && vrt::path_pool_enabled();
+    const bool chain = pool && bounces - 1u <= kContSets && vrt::path_pool_chain_enabled();
+    uint32_t *cont_seg[kContSets];
+    for (uint32_t i = 0; i < kContSets; i++) cont_seg[i] = P.seg_counts + (3 + i) * kSegWords;
+    hipStream_t side = nullptr;
+    hipEvent_t *sev = c->side_ev[f.slot];
+    if (chain) {
+        if (!c->path_cont[f.slot]) HIP_TRY(c, hipMalloc(&c->path_cont[f.slot], (size_t)kContSets * 4 * cap * sizeof(uint4)));
+        if (!c->side_stream[f.slot]) HIP_TRY(c, hipStreamCreateWithFlags(&c->side_stream[f.slot], hipStreamNonBlocking));
+        for (int i = 0; i < 6; i++)
+            if (!sev[i]) HIP_TRY(c, hipEventCreateWithFlags(&sev[i], hipEventDisableTiming));
+        side = c->side_stream[f.slot];
+    }
+    uint4 *cont = c->path_cont[f.slot];
     const bool timed = ev[0] != nullptr;
     if (timed) HIP_TRY(c, hipEventRecord(ev[0], f.st));
     if (bounces == 0) HIP_TRY(c, hipMemsetAsync(f.out, 0, (size_t)c->slots * sizeof(vrt::Texel), f.st));
@@ -997,6 +1039,9 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
     uint32_t g = 0;   // launch number within the frame (all three cursor sets are zero when it starts: vrt_render cleared them)
     for (uint32_t smp = 0; smp < spp && bounces > 0; smp++) {
         P.sample = smp;
+        // (the chain's cursors are zero at the start of a frame — vrt_render cleared the counters — and again for every
+        // further sample; the chains have joined by then)
+        if (chain && smp > 0) HIP_TRY(c, hipMemsetAsync(cont_seg[0], 0, kContSets * kSegBytes, f.st));
         for (uint32_t b = 0; b < bounces; b++, g++) {
             P.seg_counts = seg[g % 3u];
             P.seg_in = seg[(g + 2u) % 3u];
@@ -1004,11 +1049,41 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
             P.path_out = buf[g & 1u];
             P.path_in = buf[(g + 1u) & 1u];
             P.last_bounce = b + 1 == bounces;
+            P.cont_out = nullptr;
+            P.cont_counts = nullptr;
             // one sample per pixel: the lane that ends a path has the pixel's final value (x / 1 = x) — no finishing pass
-            if (b == 0) vrt::launch_path_primary(P, kstats, literal, f.st);
-            else vrt::launch_path_bounce(P, kstats, literal, f.st);
+            if (b == 0) {
+                vrt::launch_path_primary(P, kstats, literal, f.st);
+            } else if (!pool) {
+                vrt::launch_path_bounce(P, kstats, literal, f.st);
+            } else {
+                if (chain) {
+                    P.cont_out = cont + (size_t)(b - 1u) * 4 * cap;
+                    P.cont_counts = cont_seg[b - 1u];
+                }
+                vrt::launch_path_bounce_pool(P, false, f.st);
+                if (chain) {
+                    HIP_TRY(c, hipGetLastError());
+                    // S(b): after bounce launch b (its hand-overs) and S(b - 1) (stream order: its survivors)
+                    HIP_TRY(c, hipEventRecord(sev[b - 1u], f.st));
+                    HIP_TRY(c, hipStreamWaitEvent(side, sev[b - 1u], 0));
+                    vrt::FrameParams Q = P;
+                    Q.path_in = P.cont_out;
+                    Q.seg_in = P.cont_counts;
+                    Q.seg_clear = nullptr;
+                    Q.path_out = nullptr;
+                    Q.seg_counts = nullptr;
+                    Q.cont_out = P.last_bounce ? nullptr : cont + (size_t)b * 4 * cap;
+                    Q.cont_counts = P.last_bounce ? nullptr : cont_seg[b];
+                    vrt::launch_path_bounce_pool(Q, true, side);
+                }
+            }
             HIP_TRY(c, hipGetLastError());
             if (first) { if (timed) HIP_TRY(c, hipEventRecord(ev[1], f.st)); first = false; }
+        }
+        if (chain) {   // the sample's two chains join
+            HIP_TRY(c, hipEventRecord(sev[4], side));
+            HIP_TRY(c, hipStreamWaitEvent(f.st, sev[4], 0));
         }
     }
     if (first && timed) HIP_TRY(c, hipEventRecord(ev[1], f.st));

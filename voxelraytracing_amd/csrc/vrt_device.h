@@ -47,6 +47,13 @@ struct FrameParams {
     const uint32_t *seg_in;  // segment counters of path_in
     uint32_t *seg_clear;     // the counter set the NEXT launch of the frame appends to: this launch zeroes it (nobody reads it meanwhile)
     uint32_t path_cap;       // entries per plane = kHitSegments * hit_seg_cap
+    // Records of the straggler chain of the pool bounce kernel (vrt_path.hip): four planes {slot, origin} {dir, rng}
+    // {throughput, 0} {pos, steps taken | exit faces << 16 | kContFresh}, segmented like the paths and as large (a path is
+    // in exactly one place).  A bounce launch appends the rays it hands on; a straggler launch appends its survivors.
+    uint32_t in_seg_cap;     // capacity of one segment of path_in (hit_seg_cap)
+    uint32_t in_cap;         // entries per plane of path_in; path_cap is path_out's
+    uint4 *cont_out;         // null: a bounce launch marches every ray to its end / a straggler launch has no survivors
+    uint32_t *cont_counts;   // segment counters of cont_out
     uint32_t spp, sample, seed;
     uint32_t last_bounce;    // 1: paths that hit on this segment end (max_ray_bounces reached)
     uint32_t n_nodes, n_roots;
@@ -79,6 +86,7 @@ struct FrameParams {
 // per workgroup in LDS instead: vrt_kernels.hip.)
 constexpr uint32_t kHitSegments = 256;
 constexpr uint32_t kSegStride = 16;  // u32 words between counters (64 B)
+constexpr uint32_t kContFresh = 0x80000000u;   // plane 3, w: not a ray in mid-march but a path's next segment, to be started
 
 enum Counter : int {
     kCtrHitCount = 0,       // unused by the kernels (the host sums the segment counters)

@@ -84,12 +84,9 @@ struct PathState {
     uint32_t rng;
 };
 
-// One segment of a path (the body of ray_color's loop, path_tracer.wgsl:155-192). Returns true if the path
-// goes on (st updated to the next segment); adds a miss's sky light to `light`.
-template <int MARCH, bool LDS_ROOTS, bool STATS>
-__device__ __forceinline__ bool path_segment(const FrameParams &P, const uint32_t *s_roots, const uint32_t *s_liquid,
-                                             PathState &st, MarchResult &R, V3 &light, bool &missed) {
-    R = march<MARCH, LDS_ROOTS, STATS>(P, s_roots, s_liquid, st.origin, st.dir);
+// What follows a segment's march (the rest of the body of ray_color's loop, path_tracer.wgsl:155-192).  Returns true if the
+// path goes on (st updated to the next segment); a miss puts the sky's light, weighted, into `light`.
+__device__ __forceinline__ bool path_after_march(const FrameParams &P, PathState &st, const MarchResult &R, V3 &light, bool &missed) {
     missed = !R.hit;
     if (!R.hit) {
         const V3 sky = ray_sky(P, st.origin, st.dir);
@@ -107,6 +104,14 @@ __device__ __forceinline__ bool path_segment(const FrameParams &P, const uint32_
     st.origin = V3{R.pos.x + R.norm.x * kShadowBias, R.pos.y + R.norm.y * kShadowBias, R.pos.z + R.norm.z * kShadowBias};
     st.dir = nd;
     return true;
+}
+
+// One segment of a path: its march, then path_after_march.
+template <int MARCH, bool LDS_ROOTS, bool STATS>
+__device__ __forceinline__ bool path_segment(const FrameParams &P, const uint32_t *s_roots, const uint32_t *s_liquid,
+                                             PathState &st, MarchResult &R, V3 &light, bool &missed) {
+    R = march<MARCH, LDS_ROOTS, STATS>(P, s_roots, s_liquid, st.origin, st.dir);
+    return path_after_march(P, st, R, light, missed);
 }
 
 // Append the wave's surviving paths to this workgroup's segment of the out buffer (one atomic per wave).
@@ -396,6 +401,368 @@ __device__ __forceinline__ MarchResult segment_end(const FrameParams &P, const S
     return R;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Bounce b >= 1 with a wave-local ray pool (the default for plain frames over the derived tables).
+//
+// A bounce launch marches rays whose directions were just drawn at random: most end within a few steps on the terrain
+// next to their origin, a few graze it for a hundred.  With lane = path for the whole kernel a wave runs as long as its
+// longest ray: 65 wave-steps for a mean of 12 per ray — 19 % lane utilisation inside the march loop, which is three
+// quarters of the kernel's instructions (profiles/r02_path_pmc_summary.txt).  Here a wave owns K x 64 paths and works
+// in three phases, the two arithmetic-heavy ones at full width:
+//   A  K batches, lane = path: load the record, do the march's prologue (the nudge off a voxel face, the nine divides
+//      and three square roots of the unit steps), park {pos, dir, unit} in the wave's own LDS pool;
+//   B  march: a lane takes the next ray of the pool when it has none; when `refill_at` lanes have finished theirs (each
+//      parks its end state in the pool entry it came from) the wave leaves the loop once and those lanes take the
+//      next ones — a dozen LDS reads, not the ~800 instructions of shading and set-up that made the persistent kernel
+//      below lose what it won;
+//   C  K batches, lane = path again: the record once more, the march's end state from the pool, then exactly what
+//      path_bounce_kernel does after its march (shade, draw the bounce, accumulate a miss, append the survivor).
+// Every ray executes the instructions the other kernels execute for it: bit-identical frames (tests).  The pool is
+// wave-local: no barriers between the phases, a wave that has nothing left leaves.
+// ------------------------------------------------------------------------------------------------
+#ifndef VRT_POOL_K
+#define VRT_POOL_K 4
+#endif
+constexpr uint32_t kPoolBatches = VRT_POOL_K;            // K
+constexpr uint32_t kPoolEntries = kPoolBatches * 64u;
+constexpr uint32_t kPoolWords = 4u * kPoolEntries;       // per wave, field-major: unit[3] (A -> B), then pos[3] + the packed end state (B -> C): 4 KiB
+constexpr uint32_t kPoolRefillAt = 16;
+constexpr uint32_t kPoolEjectAt = 16;
+constexpr uint32_t kPoolEjected = 0xFFFFFFFFu;   // a pool entry's packed end state: the ray went on to the continuation launch
+
+// segment_begin's nudge off a voxel face (ray_tracer.wgsl:204-207)
+__device__ __forceinline__ V3 nudged(V3 pos, V3 dir) {
+    if (pos.x - floorf(pos.x) < 0.001f || pos.y - floorf(pos.y) < 0.001f || pos.z - floorf(pos.z) < 0.001f) {
+        pos.x += 0.001f * dir.x;
+        pos.y += 0.001f * dir.y;
+        pos.z += 0.001f * dir.z;
+    }
+    return pos;
+}
+
+#ifdef VRT_EXP_POOLDBG
+__device__ unsigned long long g_pool_dbg[16384 * 8];   // experiment: per wave {n, A, B, C cycles, wave-steps, refills, start, end (100 MHz)}
+#define POOLDBG_T(x) const unsigned long long x = __builtin_amdgcn_s_memtime()
+#else
+#define POOLDBG_T(x)
+#endif
+
+template <bool CONT>
+__global__ void __launch_bounds__(256) path_bounce_pool_kernel(FrameParams P, uint32_t refill_at, uint32_t eject_at) {
+    extern __shared__ uint32_t smem[];
+    uint32_t *s_liquid = smem;
+    if (threadIdx.x < 8) s_liquid[threadIdx.x] = P.liquid[threadIdx.x];
+    if (blockIdx.x == 0 && P.seg_clear) P.seg_clear[threadIdx.x * kSegStride] = 0u;   // kHitSegments == blockDim.x cursors
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    float *pool = reinterpret_cast<float *>(smem + 8) + wave * kPoolWords;
+    constexpr uint32_t E = kPoolEntries;
+
+    // this wave's paths: the workgroup takes up to 4 E records of its segment, split evenly over its waves
+    const uint32_t seg = blockIdx.x % kHitSegments, part = blockIdx.x / kHitSegments;
+    const uint32_t count = P.seg_in[seg * kSegStride];
+    const uint32_t wg_begin = part * 4u * E;
+    if (wg_begin >= count) return;
+    const uint32_t n_wg = min(4u * E, count - wg_begin), per = (n_wg + 3u) / 4u;
+    if (wave * per >= n_wg) return;
+    const uint32_t n = min(per, n_wg - wave * per);   // <= E
+    const uint32_t base = seg * P.in_seg_cap + wg_begin + wave * per;
+    const float world_max = 0.0f + (float)P.world.size;
+#ifdef VRT_EXP_POOLDBG
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    uint32_t dbg_steps = 0, dbg_refills = 0, dbg_bricks = 0, dbg_dry_steps = 0, dbg_dry_lanes = 0, dbg_wet_lanes = 0;
+    unsigned long long dbg_lat_grid = 0, dbg_lat_brick = 0;
+#endif
+    POOLDBG_T(t0);
+
+    // ---- A: the unit steps of every ray (nine divides, three square roots), full width ----
+    for (uint32_t k = 0; k * 64u < n; k++) {
+        const uint32_t i = k * 64u + lane;
+        if (i < n) {
+            const uint4 b = P.path_in[P.in_cap + base + i];
+            const V3 dir{__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z)};
+            pool[0u * E + i] = fabsf(sqrtf(1.0f + (dir.y / dir.x) * (dir.y / dir.x) + (dir.z / dir.x) * (dir.z / dir.x)));
+            pool[1u * E + i] = fabsf(sqrtf(1.0f + (dir.x / dir.y) * (dir.x / dir.y) + (dir.z / dir.y) * (dir.z / dir.y)));
+            pool[2u * E + i] = fabsf(sqrtf(1.0f + (dir.x / dir.z) * (dir.x / dir.z) + (dir.y / dir.z) * (dir.y / dir.z)));
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    POOLDBG_T(t1);
+    // ---- B: the marches, lanes refilled from the pool.  march_grid's loop (vrt_march.h) made resumable: a lane that has
+    // stopped keeps its end state in its registers until the wave's next refill parks it; water is not tracked (no
+    // output of a path segment depends on it), so a liquid voxel is simply not a hit ----
+    {
+        const TableBuf gb = table_buffer(P.grid, P.grid_bytes), bb = table_buffer(P.bricks, P.brick_bytes);
+        const uint32_t row_bytes = (P.grid_dim + 1u) * 4u, slab_bytes = (P.grid_dim + 1u) * row_bytes;
+        const uint32_t wsize = P.world.size;
+        V3 pos{0.f, 0.f, 0.f}, dir{0.f, 0.f, 0.f};
+        float ux = 0.f, uy = 0.f, uz = 0.f, step = -1.f, adx = 0.f, ady = 0.f, adz = 0.f;
+        uint32_t mxm = 0u, mym = 0u, mzm = 0u, voxel = 0u, iter = 0u, idx = 0u;
+        int vx = 0, vy = 0, vz = 0;
+        bool marching = false, parked = true, not_finite = false;
+        uint32_t next = 0u;   // wave-uniform: the pool's first ray not handed out yet
+        auto park = [&]() __attribute__((always_inline)) {   // the end state segment_end needs: where, through which faces, on what
+            uint32_t packed = voxel << 8;
+            if (step != -1.0f) packed |= (step == adx ? 1u : 0u) | (step == ady ? 2u : 0u) | (step == adz ? 4u : 0u);
+            pool[0u * E + idx] = pos.x; pool[1u * E + idx] = pos.y; pool[2u * E + idx] = pos.z;
+            pool[3u * E + idx] = __uint_as_float(packed);
+            parked = true;
+        };
+        for (;;) {
+            if (!marching && !parked) park();
+            const unsigned long long idle = __ballot(!marching);
+            const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            if (!marching && next + rank < n) {
+                // the rest of segment_begin: consecutive records for the lanes that refill, so the loads coalesce
+                idx = next + rank;
+                const uint32_t rec = base + idx;
+                const uint4 a = P.path_in[rec], b = P.path_in[P.in_cap + rec];
+                const V3 origin{__uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w)};
+                dir = V3{__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z)};
+                not_finite = !(finite3(origin) && finite3(dir));
+                ux = pool[0u * E + idx]; uy = pool[1u * E + idx]; uz = pool[2u * E + idx];
+                mxm = dir.x >= 0.0f ? ~0u : 0u; mym = dir.y >= 0.0f ? ~0u : 0u; mzm = dir.z >= 0.0f ? ~0u : 0u;
+                voxel = 0u;
+                marching = true;
+                parked = false;
+                uint4 d = make_uint4(0u, 0u, 0u, kContFresh);
+                if (CONT) d = P.path_in[3u * P.in_cap + rec];
+                if (CONT && !(d.w & kContFresh)) {
+                    // a ray the bounce launch handed on: where it stood, how many lookups it has had, and through which
+                    // faces its last step left (as a step / distances triple that compares the same way)
+                    pos = V3{__uint_as_float(d.x), __uint_as_float(d.y), __uint_as_float(d.z)};
+                    iter = d.w & 0xFFFFu;
+                    step = 1.0f;
+                    adx = (d.w & 0x10000u) ? 1.0f : 2.0f; ady = (d.w & 0x20000u) ? 1.0f : 2.0f; adz = (d.w & 0x40000u) ? 1.0f : 2.0f;
+                    vx = flr2i(pos.x); vy = flr2i(pos.y); vz = flr2i(pos.z);   // as take_step left them
+                } else {
+                    pos = nudged(origin, dir);
+                    step = -1.0f; adx = ady = adz = 0.0f;
+                    iter = 0u;
+                    if ((pos.x <= 0.0f || pos.y <= 0.0f || pos.z <= 0.0f) || (pos.x >= world_max || pos.y >= world_max || pos.z >= world_max)) {
+                        // starts outside the world: a miss before any lookup.  Its end state says so (a position outside)
+                        marching = false;
+                        pos = V3{-1.0f, -1.0f, -1.0f};
+                    }
+                    vx = trunc2i(pos.x); vy = trunc2i(pos.y); vz = trunc2i(pos.z);
+                }
+            }
+            next = min(n, next + (uint32_t)__popcll(idle));
+#ifdef VRT_EXP_POOLDBG
+            dbg_refills++;
+#endif
+            if (__ballot(marching) == 0ull) {
+                if (next >= n) break;   // the pool is empty and nobody marches
+                continue;               // (every ray handed out started outside the world)
+            }
+            // (l) of vrt_march.h, per refill round: with a ray that is not finite among them the lanes take the slow path,
+            // the shader's own bounds test and its lookup at i32(f32) coordinates
+            const bool careful = __ballot(marching && not_finite) != 0ull;
+            for (;;) {
+                if (marching) {
+#ifdef VRT_EXP_POOLDBG
+                    const unsigned long long l0 = __builtin_amdgcn_s_memtime();
+#endif
+                    uint32_t e = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(
+                        gb, mad_i24(vz >> 2, slab_bytes, mad_i24(vy >> 2, row_bytes, (uint32_t)vx & ~3u)), 0, 0);
+#ifdef VRT_EXP_POOLDBG
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    dbg_lat_grid += __builtin_amdgcn_s_memtime() - l0;
+#endif
+                    iter += 1u;
+                    uint32_t lo;
+                    bool stop;
+                    if (careful) {   // wave-uniform, rare: the general step as march_grid has it, on the shader's coordinates
+                        lo = e;
+                        stop = false;
+                        vx = trunc2i(pos.x);
+                        vy = trunc2i(pos.y);
+                        vz = trunc2i(pos.z);
+                        e = 0u;
+                        if (!(min3_nan_ignoring(pos.x, pos.y, pos.z) < 0.0f || max(max((uint32_t)vx, (uint32_t)vy), (uint32_t)vz) >= wsize))
+                            e = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(
+                                gb, mad_i24(vz >> 2, slab_bytes, mad_i24(vy >> 2, row_bytes, (uint32_t)vx & ~3u)), 0, 0);
+                        lo = e;
+                        stop = e == 0u;   // border, or past either end of the grid: the position is outside the world
+                        if (!stop) {
+                            voxel = 0u;
+                            if ((int)e < 0) {
+                                const uint32_t u = ((uint32_t)vx & 3u) | (((uint32_t)vy & 3u) << 2) | (((uint32_t)vz & 3u) << 4);
+                                const uint32_t b = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(bb, (e + u) << 1, 0, 0);
+                                lo = b & 1u;
+                                voxel = b >> 1;
+                            } else if (e > 31u) {
+                                lo = e & 31u;
+                                voxel = e >> 16;
+                            }
+                            stop = voxel != 0u && !is_liquid_ranged(P, s_liquid, voxel);   // solid: the hit
+                        }
+                    } else {
+                        // the same decisions without a branch per case — a bounce wave has a lane in every case on nearly
+                        // every step, and each divergent branch is half a dozen scalar instructions of exec-mask bookkeeping:
+                        // an air leaf is the e <= 31 instance of "leaf" (lo = e & 31, voxel = e >> 16 = 0), the border
+                        // (e = 0) is a leaf of nothing
+                        const bool is_brick = (int)e < 0;
+                        uint32_t b = 0u;
+                        if (__ballot(is_brick) != 0ull) {   // wave-uniform: the second, dependent load only if some lane needs it
+                            const uint32_t u = ((uint32_t)vx & 3u) | (((uint32_t)vy & 3u) << 2) | (((uint32_t)vz & 3u) << 4);
+                            if (is_brick) b = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(bb, (e + u) << 1, 0, 0);  // the shift drops bit 31
+                        }
+                        lo = is_brick ? (b & 1u) : (e & 31u);
+                        voxel = is_brick ? (b >> 1) : (e >> 16);
+                        const bool liquid = P.liquid_is_range ? (voxel - P.liquid_lo <= P.liquid_span) : is_liquid(s_liquid, voxel);
+                        stop = (e == 0u) | ((voxel != 0u) & !liquid);
+                    }
+                    if (!stop) {
+                        const float tx = (float)(int)(bfi(lo, mxm, (uint32_t)vx) - mxm) - pos.x;
+                        const float ty = (float)(int)(bfi(lo, mym, (uint32_t)vy) - mym) - pos.y;
+                        const float tz = (float)(int)(bfi(lo, mzm, (uint32_t)vz) - mzm) - pos.z;
+                        adx = abs_mul(tx, ux);
+                        ady = abs_mul(ty, uy);
+                        adz = abs_mul(tz, uz);
+                        step = __uint_as_float(min3_u32(__float_as_uint(adx) - 1u, __float_as_uint(ady) - 1u, __float_as_uint(adz) - 1u) + 1u);
+                        const float sp = step + 0.001f;
+                        pos.x += dir.x * (step == adx ? sp : step);
+                        pos.y += dir.y * (step == ady ? sp : step);
+                        pos.z += dir.z * (step == adz ? sp : step);
+                        vx = flr2i(pos.x);
+                        vy = flr2i(pos.y);
+                        vz = flr2i(pos.z);
+                        stop = iter >= kMaxSteps;
+                    }
+                    marching = !stop;
+                }
+                const uint32_t n_march = (uint32_t)__popcll(__ballot(marching));
+#ifdef VRT_EXP_POOLDBG
+                dbg_steps++;
+                if (next >= n) { dbg_dry_steps++; dbg_dry_lanes += n_march; } else dbg_wet_lanes += n_march;
+#endif
+                if (n_march == 0u || (next < n && 64u - n_march >= refill_at)) break;
+                if (!CONT && next >= n && n_march <= eject_at) break;   // the pool is dry and few lanes are left: hand them on
+            }
+            if (!CONT && next >= n && P.cont_out) {
+                // ---- the stragglers go to the continuation launch: their path record and where they stand.  (The wave
+                // would otherwise march a dozen lanes for as many steps again as it took to empty the pool.) ----
+                const unsigned long long ballot = __ballot(marching);
+                const uint32_t n_eject = (uint32_t)__popcll(ballot);
+                if (n_eject != 0u && n_eject <= eject_at) {
+                    const int leader = __ffsll((long long)ballot) - 1;
+                    uint32_t at = 0;
+                    if ((int)lane == leader) at = atomicAdd(&P.cont_counts[seg * kSegStride], n_eject);
+                    at = (uint32_t)__shfl((int)at, leader, 64) + (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
+                    if (marching) {   // (a segment of the straggler records is as large as a segment of the paths)
+                        const uint32_t rec = base + idx, o = seg * P.hit_seg_cap + at;
+                        uint32_t w = iter;
+                        if (step != -1.0f) w |= (step == adx ? 0x10000u : 0u) | (step == ady ? 0x20000u : 0u) | (step == adz ? 0x40000u : 0u);
+                        P.cont_out[o] = P.path_in[rec];
+                        P.cont_out[P.path_cap + o] = P.path_in[P.in_cap + rec];
+                        P.cont_out[2u * P.path_cap + o] = P.path_in[2u * P.in_cap + rec];
+                        P.cont_out[3u * P.path_cap + o] = make_uint4(__float_as_uint(pos.x), __float_as_uint(pos.y), __float_as_uint(pos.z), w);
+                        pool[3u * E + idx] = __uint_as_float(kPoolEjected);
+                        marching = false;
+                        parked = true;
+                    }
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    POOLDBG_T(t2);
+
+    // ---- C: what follows the march, full width ----
+    for (uint32_t k = 0; k * 64u < n; k++) {
+        const uint32_t i = k * 64u + lane;
+        bool alive = false;
+        PathState st;
+        st.slot = 0; st.rng = 0;
+        st.origin = st.dir = st.thr = V3{0.f, 0.f, 0.f};
+        if (i < n) {
+            const uint32_t rec = base + i;
+            const uint4 a = P.path_in[rec], b = P.path_in[P.in_cap + rec], c = P.path_in[2u * P.in_cap + rec];
+            st.slot = a.x;
+            st.origin = V3{__uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w)};
+            st.dir = V3{__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z)};
+            st.rng = b.w;
+            st.thr = V3{__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z)};
+            // segment_end on the parked end state (a path segment's water is nobody's business: DESIGN.md, path trace)
+            const V3 pos{pool[0u * E + i], pool[1u * E + i], pool[2u * E + i]};
+            const uint32_t packed = __float_as_uint(pool[3u * E + i]);
+            if (packed != kPoolEjected) {
+            MarchResult R;
+            R.hit = false;
+            R.pos = V3{0.f, 0.f, 0.f};
+            R.norm = V3{0.f, 0.f, 0.f};
+            R.water_dist = 0.0f;
+            R.voxel = 0u;
+            R.iters = 0u;
+            R.visits = 0u;
+            if (!(min3_nan_ignoring(pos.x, pos.y, pos.z) < 0.0f ||
+                  max(max((uint32_t)trunc2i(pos.x), (uint32_t)trunc2i(pos.y)), (uint32_t)trunc2i(pos.z)) >= P.world.size)) {
+                R.hit = true;
+                R.pos = pos;
+                R.norm = V3{((packed & 1u) ? 1.0f : 0.0f) * -vsign(st.dir.x), ((packed & 2u) ? 1.0f : 0.0f) * -vsign(st.dir.y),
+                            ((packed & 4u) ? 1.0f : 0.0f) * -vsign(st.dir.z)};
+                R.voxel = packed >> 8;
+            }
+            V3 light{0.f, 0.f, 0.f};
+            bool missed;
+            alive = path_after_march(P, st, R, light, missed) && !P.last_bounce;
+            if (missed) {
+                uint4 t = P.out[st.slot];
+                t.x = __float_as_uint(__uint_as_float(t.x) + light.x);
+                t.y = __float_as_uint(__uint_as_float(t.y) + light.y);
+                t.z = __float_as_uint(__uint_as_float(t.z) + light.z);
+                P.out[st.slot] = t;
+            }
+            }
+        }
+        if (!CONT) {
+            append_paths(P, alive, st, lane);
+        } else {
+            // a straggler's next segment stays with the stragglers: the bounce launch that marches its generation is
+            // already running (or done)
+            const unsigned long long ballot = __ballot(alive);
+            const uint32_t n_alive = (uint32_t)__popcll(ballot);
+            if (n_alive != 0u) {   // (alive implies !P.last_bounce, and then the host gave a cont_out)
+                const int leader = __ffsll((long long)ballot) - 1;
+                uint32_t at = 0;
+                if ((int)lane == leader) at = atomicAdd(&P.cont_counts[seg * kSegStride], n_alive);
+                at = (uint32_t)__shfl((int)at, leader, 64) + (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
+                if (alive) {
+                    const uint32_t o = seg * P.hit_seg_cap + at;
+                    P.cont_out[o] = make_uint4(st.slot, __float_as_uint(st.origin.x), __float_as_uint(st.origin.y), __float_as_uint(st.origin.z));
+                    P.cont_out[P.path_cap + o] = make_uint4(__float_as_uint(st.dir.x), __float_as_uint(st.dir.y), __float_as_uint(st.dir.z), st.rng);
+                    P.cont_out[2u * P.path_cap + o] = make_uint4(__float_as_uint(st.thr.x), __float_as_uint(st.thr.y), __float_as_uint(st.thr.z), 0u);
+                    P.cont_out[3u * P.path_cap + o] = make_uint4(0u, 0u, 0u, kContFresh);
+                }
+            }
+        }
+    }
+#ifdef VRT_EXP_POOLDBG
+    {
+        POOLDBG_T(t3);
+        const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0 && blockIdx.x * 4u + wave < 16384u) {
+            unsigned long long *d = &g_pool_dbg[(blockIdx.x * 4u + wave) * 8u];
+            d[0] = n | (CONT ? (1ull << 32) : 0ull); d[1] = t1 - t0; d[2] = t2 - t1; d[3] = t3 - t2; d[4] = dbg_steps | ((unsigned long long)dbg_dry_steps << 32); d[5] = dbg_wet_lanes | ((unsigned long long)dbg_dry_lanes << 32); d[6] = r0; d[7] = r1;
+        }
+    }
+#endif
+}
+
+#ifdef VRT_EXP_POOLDBG
+extern "C" void vrt_exp_pool_dbg(unsigned long long *out) {   // read (16384 x 8 words) and reset
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pool_dbg), sizeof(unsigned long long) * 16384 * 8);
+    void *p = nullptr;
+    (void)hipGetSymbolAddress(&p, HIP_SYMBOL(g_pool_dbg));
+    (void)hipMemset(p, 0, sizeof(unsigned long long) * 16384 * 8);
+}
+#endif
+
 __device__ __forceinline__ uint32_t path_xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u; }
 
 // Next tile of the frame for this wave: its own XCD's queue first, then the others (tile i of queue x = x + 8 i).
@@ -596,6 +963,44 @@ void launch_path_primary(const FrameParams &P, bool stats, bool literal, hipStre
     if (P.tiles_local == 0) return;
     const dim3 grid((P.tiles_local + 3u) / 4u), block(256);
     VRT_PATH_LAUNCH(path_primary_kernel);
+}
+
+// The pool bounce kernel applies (plain frames over the derived tables; VRT_PATH_POOL=0: lane = path, the A/B baseline)
+bool path_pool_enabled() {
+    static int pool = -1;
+    if (pool < 0) {
+        const char *e = getenv("VRT_PATH_POOL");
+        pool = e ? (e[0] != '0') : 1;
+    }
+    return pool != 0;
+}
+// The bounce launches hand their stragglers to a chain of launches on a side stream (vrt_backend.hip: launch_path_frame);
+// VRT_PATH_POOL_CHAIN=1 (built and measured, not the default: DESIGN.md §5); otherwise every bounce launch marches all its
+// rays itself
+bool path_pool_chain_enabled() {
+    static int chain = -1;
+    if (chain < 0) {
+        const char *e = getenv("VRT_PATH_POOL_CHAIN");
+        chain = e ? (e[0] == '1') : 0;
+    }
+    return chain != 0;
+}
+
+// `continuations`: a launch of the straggler chain (P.path_in = four-plane records: rays a bounce launch handed on and the
+// next segments of the chain's own survivors), which marches every ray to its end.
+void launch_path_bounce_pool(const FrameParams &P, bool continuations, hipStream_t st) {
+    if (P.tiles_local == 0) return;
+    static uint32_t refill = 0, eject = kPoolEjectAt;
+    if (!refill) {
+        refill = kPoolRefillAt;
+        if (const char *r = getenv("VRT_PATH_POOL_REFILL")) { const int v = atoi(r); if (v >= 1 && v <= 64) refill = (uint32_t)v; }
+        if (const char *r = getenv("VRT_PATH_POOL_EJECT")) { const int v = atoi(r); if (v >= 0 && v <= 64) eject = (uint32_t)v; }
+    }
+    const uint32_t parts = (P.in_seg_cap + 4u * kPoolEntries - 1u) / (4u * kPoolEntries);
+    const dim3 grid(kHitSegments * parts), block(256);
+    const size_t sh = (8u + 4u * kPoolWords) * 4u;
+    if (continuations) hipLaunchKernelGGL(path_bounce_pool_kernel<true>, grid, block, sh, st, P, refill, 0u);
+    else hipLaunchKernelGGL(path_bounce_pool_kernel<false>, grid, block, sh, st, P, refill, P.cont_out ? eject : 0u);
 }
 
 void launch_path_bounce(const FrameParams &P, bool stats, bool literal, hipStream_t st) {
