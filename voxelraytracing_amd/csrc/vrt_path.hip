@@ -426,7 +426,13 @@ __device__ __forceinline__ MarchResult segment_end(const FrameParams &P, const S
 constexpr uint32_t kPoolBatches = VRT_POOL_K;            // K
 constexpr uint32_t kPoolEntries = kPoolBatches * 64u;
 constexpr uint32_t kPoolWords = 4u * kPoolEntries;       // per wave, field-major: unit[3] (A -> B), then pos[3] + the packed end state (B -> C): 4 KiB
-constexpr uint32_t kPoolRefillAt = 16;
+#ifndef VRT_POOL_RAYS
+#define VRT_POOL_RAYS 1
+#endif
+// rays a lane marches at once.  2 and 3 were measured (their loads in flight together, their arithmetic interleaved): 117 and
+// more registers instead of 60, half the waves per SIMD, 12.4 and 10.4 Grays/s on C4 against 14.5 — profiles/r02_path_pool_sweeps.txt
+constexpr uint32_t kPoolRays = VRT_POOL_RAYS;
+constexpr uint32_t kPoolRefillAt = 16u * kPoolRays;       // idle ray slots (of 64 x kPoolRays) that send the wave back to the pool
 constexpr uint32_t kPoolEjectAt = 16;
 constexpr uint32_t kPoolEjected = 0xFFFFFFFFu;   // a pool entry's packed end state: the ray went on to the continuation launch
 
@@ -490,179 +496,229 @@ __global__ void __launch_bounds__(256) path_bounce_pool_kernel(FrameParams P, ui
     __builtin_amdgcn_wave_barrier();
 
     POOLDBG_T(t1);
-    // ---- B: the marches, lanes refilled from the pool.  march_grid's loop (vrt_march.h) made resumable: a lane that has
+    // ---- B: the marches, lanes refilled from the pool.  march_grid's loop (vrt_march.h) made resumable: a ray that has
     // stopped keeps its end state in its registers until the wave's next refill parks it; water is not tracked (no
-    // output of a path segment depends on it), so a liquid voxel is simply not a hit ----
+    // output of a path segment depends on it), so a liquid voxel is simply not a hit.
+    // (Written for kPoolRays rays per lane — independent rays, their loads in flight together; one is what is built.) ----
     {
         const TableBuf gb = table_buffer(P.grid, P.grid_bytes), bb = table_buffer(P.bricks, P.brick_bytes);
         const uint32_t row_bytes = (P.grid_dim + 1u) * 4u, slab_bytes = (P.grid_dim + 1u) * row_bytes;
         const uint32_t wsize = P.world.size;
-        V3 pos{0.f, 0.f, 0.f}, dir{0.f, 0.f, 0.f};
-        float ux = 0.f, uy = 0.f, uz = 0.f, step = -1.f, adx = 0.f, ady = 0.f, adz = 0.f;
-        uint32_t mxm = 0u, mym = 0u, mzm = 0u, voxel = 0u, iter = 0u, idx = 0u;
-        int vx = 0, vy = 0, vz = 0;
-        bool marching = false, parked = true, not_finite = false;
+        struct Ray {
+            V3 pos, dir;
+            float ux, uy, uz, step, adx, ady, adz;
+            uint32_t mxm, mym, mzm, voxel, iter, idx;
+            int vx, vy, vz;
+            bool marching, parked, not_finite;
+        };
+        Ray ray[kPoolRays];
+#pragma unroll
+        for (uint32_t r = 0; r < kPoolRays; r++) {
+            Ray &q = ray[r];
+            q.pos = q.dir = V3{0.f, 0.f, 0.f};
+            q.ux = q.uy = q.uz = 0.f; q.step = -1.f; q.adx = q.ady = q.adz = 0.f;
+            q.mxm = q.mym = q.mzm = 0u; q.voxel = 0u; q.iter = 0u; q.idx = 0u;
+            q.vx = q.vy = q.vz = 0;
+            q.marching = false; q.parked = true; q.not_finite = false;
+        }
         uint32_t next = 0u;   // wave-uniform: the pool's first ray not handed out yet
-        auto park = [&]() __attribute__((always_inline)) {   // the end state segment_end needs: where, through which faces, on what
-            uint32_t packed = voxel << 8;
-            if (step != -1.0f) packed |= (step == adx ? 1u : 0u) | (step == ady ? 2u : 0u) | (step == adz ? 4u : 0u);
-            pool[0u * E + idx] = pos.x; pool[1u * E + idx] = pos.y; pool[2u * E + idx] = pos.z;
-            pool[3u * E + idx] = __uint_as_float(packed);
-            parked = true;
+        const unsigned long long below = (1ull << lane) - 1ull;
+        auto cell_offset = [&](const Ray &q) __attribute__((always_inline)) {
+            return mad_i24(q.vz >> 2, slab_bytes, mad_i24(q.vy >> 2, row_bytes, (uint32_t)q.vx & ~3u));
+        };
+        auto park = [&](Ray &q) __attribute__((always_inline)) {   // the end state segment_end needs: where, through which faces, on what
+            uint32_t packed = q.voxel << 8;
+            if (q.step != -1.0f) packed |= (q.step == q.adx ? 1u : 0u) | (q.step == q.ady ? 2u : 0u) | (q.step == q.adz ? 4u : 0u);
+            pool[0u * E + q.idx] = q.pos.x; pool[1u * E + q.idx] = q.pos.y; pool[2u * E + q.idx] = q.pos.z;
+            pool[3u * E + q.idx] = __uint_as_float(packed);
+            q.parked = true;
+        };
+        auto take = [&](Ray &q, uint32_t idx) __attribute__((always_inline)) {
+            // the rest of segment_begin: consecutive records for the lanes that refill, so the loads coalesce
+            q.idx = idx;
+            const uint32_t rec = base + idx;
+            const uint4 a = P.path_in[rec], b = P.path_in[P.in_cap + rec];
+            const V3 origin{__uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w)};
+            q.dir = V3{__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z)};
+            q.not_finite = !(finite3(origin) && finite3(q.dir));
+            q.ux = pool[0u * E + idx]; q.uy = pool[1u * E + idx]; q.uz = pool[2u * E + idx];
+            q.mxm = q.dir.x >= 0.0f ? ~0u : 0u; q.mym = q.dir.y >= 0.0f ? ~0u : 0u; q.mzm = q.dir.z >= 0.0f ? ~0u : 0u;
+            q.voxel = 0u;
+            q.marching = true;
+            q.parked = false;
+            uint4 d = make_uint4(0u, 0u, 0u, kContFresh);
+            if (CONT) d = P.path_in[3u * P.in_cap + rec];
+            if (CONT && !(d.w & kContFresh)) {
+                // a ray the bounce launch handed on: where it stood, how many lookups it has had, and through which
+                // faces its last step left (as a step / distances triple that compares the same way)
+                q.pos = V3{__uint_as_float(d.x), __uint_as_float(d.y), __uint_as_float(d.z)};
+                q.iter = d.w & 0xFFFFu;
+                q.step = 1.0f;
+                q.adx = (d.w & 0x10000u) ? 1.0f : 2.0f; q.ady = (d.w & 0x20000u) ? 1.0f : 2.0f; q.adz = (d.w & 0x40000u) ? 1.0f : 2.0f;
+                q.vx = flr2i(q.pos.x); q.vy = flr2i(q.pos.y); q.vz = flr2i(q.pos.z);   // as take_step left them
+            } else {
+                q.pos = nudged(origin, q.dir);
+                q.step = -1.0f; q.adx = q.ady = q.adz = 0.0f;
+                q.iter = 0u;
+                if ((q.pos.x <= 0.0f || q.pos.y <= 0.0f || q.pos.z <= 0.0f) || (q.pos.x >= world_max || q.pos.y >= world_max || q.pos.z >= world_max)) {
+                    // starts outside the world: a miss before any lookup.  Its end state says so (a position outside)
+                    q.marching = false;
+                    q.pos = V3{-1.0f, -1.0f, -1.0f};
+                }
+                q.vx = trunc2i(q.pos.x); q.vy = trunc2i(q.pos.y); q.vz = trunc2i(q.pos.z);
+            }
+        };
+        // the step to the leaf's exit face for a leaf of size lo + 1 (take_step of march_grid), then the lookup limit
+        auto step_or_stop = [&](Ray &q, uint32_t lo, bool stop) __attribute__((always_inline)) {
+            if (!stop) {
+                const float tx = (float)(int)(bfi(lo, q.mxm, (uint32_t)q.vx) - q.mxm) - q.pos.x;
+                const float ty = (float)(int)(bfi(lo, q.mym, (uint32_t)q.vy) - q.mym) - q.pos.y;
+                const float tz = (float)(int)(bfi(lo, q.mzm, (uint32_t)q.vz) - q.mzm) - q.pos.z;
+                q.adx = abs_mul(tx, q.ux);
+                q.ady = abs_mul(ty, q.uy);
+                q.adz = abs_mul(tz, q.uz);
+                q.step = __uint_as_float(min3_u32(__float_as_uint(q.adx) - 1u, __float_as_uint(q.ady) - 1u, __float_as_uint(q.adz) - 1u) + 1u);
+                const float sp = q.step + 0.001f;
+                q.pos.x += q.dir.x * (q.step == q.adx ? sp : q.step);
+                q.pos.y += q.dir.y * (q.step == q.ady ? sp : q.step);
+                q.pos.z += q.dir.z * (q.step == q.adz ? sp : q.step);
+                q.vx = flr2i(q.pos.x);
+                q.vy = flr2i(q.pos.y);
+                q.vz = flr2i(q.pos.z);
+                stop = q.iter >= kMaxSteps;
+            }
+            q.marching = !stop;
+        };
+        // (l) of vrt_march.h: the general step as march_grid has it for a wave with a ray that is not finite — the shader's
+        // own bounds test, its lookup at i32(f32) coordinates
+        auto careful_step = [&](Ray &q) __attribute__((always_inline)) {
+            q.iter += 1u;
+            q.vx = trunc2i(q.pos.x);
+            q.vy = trunc2i(q.pos.y);
+            q.vz = trunc2i(q.pos.z);
+            uint32_t e = 0u;
+            if (!(min3_nan_ignoring(q.pos.x, q.pos.y, q.pos.z) < 0.0f || max(max((uint32_t)q.vx, (uint32_t)q.vy), (uint32_t)q.vz) >= wsize))
+                e = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(gb, cell_offset(q), 0, 0);
+            uint32_t lo = e;
+            bool stop = e == 0u;   // border, or past either end of the grid: the position is outside the world
+            if (!stop) {
+                q.voxel = 0u;
+                if ((int)e < 0) {
+                    const uint32_t u = ((uint32_t)q.vx & 3u) | (((uint32_t)q.vy & 3u) << 2) | (((uint32_t)q.vz & 3u) << 4);
+                    const uint32_t b = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(bb, (e + u) << 1, 0, 0);
+                    lo = b & 1u;
+                    q.voxel = b >> 1;
+                } else if (e > 31u) {
+                    lo = e & 31u;
+                    q.voxel = e >> 16;
+                }
+                stop = q.voxel != 0u && !is_liquid_ranged(P, s_liquid, q.voxel);   // solid: the hit
+            }
+            step_or_stop(q, lo, stop);
         };
         for (;;) {
-            if (!marching && !parked) park();
-            const unsigned long long idle = __ballot(!marching);
-            const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-            if (!marching && next + rank < n) {
-                // the rest of segment_begin: consecutive records for the lanes that refill, so the loads coalesce
-                idx = next + rank;
-                const uint32_t rec = base + idx;
-                const uint4 a = P.path_in[rec], b = P.path_in[P.in_cap + rec];
-                const V3 origin{__uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w)};
-                dir = V3{__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z)};
-                not_finite = !(finite3(origin) && finite3(dir));
-                ux = pool[0u * E + idx]; uy = pool[1u * E + idx]; uz = pool[2u * E + idx];
-                mxm = dir.x >= 0.0f ? ~0u : 0u; mym = dir.y >= 0.0f ? ~0u : 0u; mzm = dir.z >= 0.0f ? ~0u : 0u;
-                voxel = 0u;
-                marching = true;
-                parked = false;
-                uint4 d = make_uint4(0u, 0u, 0u, kContFresh);
-                if (CONT) d = P.path_in[3u * P.in_cap + rec];
-                if (CONT && !(d.w & kContFresh)) {
-                    // a ray the bounce launch handed on: where it stood, how many lookups it has had, and through which
-                    // faces its last step left (as a step / distances triple that compares the same way)
-                    pos = V3{__uint_as_float(d.x), __uint_as_float(d.y), __uint_as_float(d.z)};
-                    iter = d.w & 0xFFFFu;
-                    step = 1.0f;
-                    adx = (d.w & 0x10000u) ? 1.0f : 2.0f; ady = (d.w & 0x20000u) ? 1.0f : 2.0f; adz = (d.w & 0x40000u) ? 1.0f : 2.0f;
-                    vx = flr2i(pos.x); vy = flr2i(pos.y); vz = flr2i(pos.z);   // as take_step left them
-                } else {
-                    pos = nudged(origin, dir);
-                    step = -1.0f; adx = ady = adz = 0.0f;
-                    iter = 0u;
-                    if ((pos.x <= 0.0f || pos.y <= 0.0f || pos.z <= 0.0f) || (pos.x >= world_max || pos.y >= world_max || pos.z >= world_max)) {
-                        // starts outside the world: a miss before any lookup.  Its end state says so (a position outside)
-                        marching = false;
-                        pos = V3{-1.0f, -1.0f, -1.0f};
-                    }
-                    vx = trunc2i(pos.x); vy = trunc2i(pos.y); vz = trunc2i(pos.z);
-                }
+            // ---- refill: park what has stopped, hand out the pool's next rays (ray 0 of every lane first) ----
+            uint32_t handed = 0u;
+#pragma unroll
+            for (uint32_t r = 0; r < kPoolRays; r++) {
+                Ray &q = ray[r];
+                if (!q.marching && !q.parked) park(q);
+                const unsigned long long idle = __ballot(!q.marching);
+                const uint32_t at = next + handed + (uint32_t)__popcll(idle & below);
+                if (!q.marching && at < n) take(q, at);
+                handed += (uint32_t)__popcll(idle);
             }
-            next = min(n, next + (uint32_t)__popcll(idle));
+            next = min(n, next + handed);
 #ifdef VRT_EXP_POOLDBG
             dbg_refills++;
 #endif
-            if (__ballot(marching) == 0ull) {
+            bool any = false, nf = false;
+#pragma unroll
+            for (uint32_t r = 0; r < kPoolRays; r++) { any |= ray[r].marching; nf |= ray[r].marching && ray[r].not_finite; }
+            if (__ballot(any) == 0ull) {
                 if (next >= n) break;   // the pool is empty and nobody marches
                 continue;               // (every ray handed out started outside the world)
             }
-            // (l) of vrt_march.h, per refill round: with a ray that is not finite among them the lanes take the slow path,
-            // the shader's own bounds test and its lookup at i32(f32) coordinates
-            const bool careful = __ballot(marching && not_finite) != 0ull;
+            const bool careful = __ballot(nf) != 0ull;   // per refill round
             for (;;) {
-                if (marching) {
-#ifdef VRT_EXP_POOLDBG
-                    const unsigned long long l0 = __builtin_amdgcn_s_memtime();
-#endif
-                    uint32_t e = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(
-                        gb, mad_i24(vz >> 2, slab_bytes, mad_i24(vy >> 2, row_bytes, (uint32_t)vx & ~3u)), 0, 0);
-#ifdef VRT_EXP_POOLDBG
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    dbg_lat_grid += __builtin_amdgcn_s_memtime() - l0;
-#endif
-                    iter += 1u;
-                    uint32_t lo;
-                    bool stop;
-                    if (careful) {   // wave-uniform, rare: the general step as march_grid has it, on the shader's coordinates
-                        lo = e;
-                        stop = false;
-                        vx = trunc2i(pos.x);
-                        vy = trunc2i(pos.y);
-                        vz = trunc2i(pos.z);
-                        e = 0u;
-                        if (!(min3_nan_ignoring(pos.x, pos.y, pos.z) < 0.0f || max(max((uint32_t)vx, (uint32_t)vy), (uint32_t)vz) >= wsize))
-                            e = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(
-                                gb, mad_i24(vz >> 2, slab_bytes, mad_i24(vy >> 2, row_bytes, (uint32_t)vx & ~3u)), 0, 0);
-                        lo = e;
-                        stop = e == 0u;   // border, or past either end of the grid: the position is outside the world
-                        if (!stop) {
-                            voxel = 0u;
-                            if ((int)e < 0) {
-                                const uint32_t u = ((uint32_t)vx & 3u) | (((uint32_t)vy & 3u) << 2) | (((uint32_t)vz & 3u) << 4);
-                                const uint32_t b = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(bb, (e + u) << 1, 0, 0);
-                                lo = b & 1u;
-                                voxel = b >> 1;
-                            } else if (e > 31u) {
-                                lo = e & 31u;
-                                voxel = e >> 16;
-                            }
-                            stop = voxel != 0u && !is_liquid_ranged(P, s_liquid, voxel);   // solid: the hit
-                        }
-                    } else {
-                        // the same decisions without a branch per case — a bounce wave has a lane in every case on nearly
-                        // every step, and each divergent branch is half a dozen scalar instructions of exec-mask bookkeeping:
-                        // an air leaf is the e <= 31 instance of "leaf" (lo = e & 31, voxel = e >> 16 = 0), the border
-                        // (e = 0) is a leaf of nothing
-                        const bool is_brick = (int)e < 0;
-                        uint32_t b = 0u;
-                        if (__ballot(is_brick) != 0ull) {   // wave-uniform: the second, dependent load only if some lane needs it
-                            const uint32_t u = ((uint32_t)vx & 3u) | (((uint32_t)vy & 3u) << 2) | (((uint32_t)vz & 3u) << 4);
-                            if (is_brick) b = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(bb, (e + u) << 1, 0, 0);  // the shift drops bit 31
-                        }
-                        lo = is_brick ? (b & 1u) : (e & 31u);
-                        voxel = is_brick ? (b >> 1) : (e >> 16);
-                        const bool liquid = P.liquid_is_range ? (voxel - P.liquid_lo <= P.liquid_span) : is_liquid(s_liquid, voxel);
-                        stop = (e == 0u) | ((voxel != 0u) & !liquid);
+                if (careful) {   // wave-uniform, rare
+#pragma unroll
+                    for (uint32_t r = 0; r < kPoolRays; r++)
+                        if (ray[r].marching) careful_step(ray[r]);
+                } else {
+                    // the same decisions without a branch per case — a bounce wave has a ray in every case on nearly every
+                    // step, and each divergent branch is half a dozen scalar instructions of exec-mask bookkeeping: an air
+                    // leaf is the e <= 31 instance of "leaf" (lo = e & 31, voxel = e >> 16 = 0), the border (e = 0) is a
+                    // leaf of nothing.  First all the grid loads, then all the brick loads, then the arithmetic
+                    uint32_t e[kPoolRays], b[kPoolRays];
+                    bool brick[kPoolRays], any_brick = false;
+#pragma unroll
+                    for (uint32_t r = 0; r < kPoolRays; r++) {
+                        e[r] = 0u;
+                        if (ray[r].marching) e[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(gb, cell_offset(ray[r]), 0, 0);
                     }
-                    if (!stop) {
-                        const float tx = (float)(int)(bfi(lo, mxm, (uint32_t)vx) - mxm) - pos.x;
-                        const float ty = (float)(int)(bfi(lo, mym, (uint32_t)vy) - mym) - pos.y;
-                        const float tz = (float)(int)(bfi(lo, mzm, (uint32_t)vz) - mzm) - pos.z;
-                        adx = abs_mul(tx, ux);
-                        ady = abs_mul(ty, uy);
-                        adz = abs_mul(tz, uz);
-                        step = __uint_as_float(min3_u32(__float_as_uint(adx) - 1u, __float_as_uint(ady) - 1u, __float_as_uint(adz) - 1u) + 1u);
-                        const float sp = step + 0.001f;
-                        pos.x += dir.x * (step == adx ? sp : step);
-                        pos.y += dir.y * (step == ady ? sp : step);
-                        pos.z += dir.z * (step == adz ? sp : step);
-                        vx = flr2i(pos.x);
-                        vy = flr2i(pos.y);
-                        vz = flr2i(pos.z);
-                        stop = iter >= kMaxSteps;
+#pragma unroll
+                    for (uint32_t r = 0; r < kPoolRays; r++) {
+                        brick[r] = ray[r].marching && (int)e[r] < 0;
+                        any_brick |= brick[r];
+                        b[r] = 0u;
                     }
-                    marching = !stop;
+                    if (__ballot(any_brick) != 0ull) {   // wave-uniform: the second, dependent load only if some ray needs it
+#pragma unroll
+                        for (uint32_t r = 0; r < kPoolRays; r++) {
+                            const Ray &q = ray[r];
+                            const uint32_t u = ((uint32_t)q.vx & 3u) | (((uint32_t)q.vy & 3u) << 2) | (((uint32_t)q.vz & 3u) << 4);
+                            if (brick[r]) b[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(bb, (e[r] + u) << 1, 0, 0);  // the shift drops bit 31
+                        }
+                    }
+#pragma unroll
+                    for (uint32_t r = 0; r < kPoolRays; r++) {
+                        Ray &q = ray[r];
+                        if (q.marching) {
+                            q.iter += 1u;
+                            const uint32_t lo = brick[r] ? (b[r] & 1u) : (e[r] & 31u);
+                            q.voxel = brick[r] ? (b[r] >> 1) : (e[r] >> 16);
+                            const bool liquid = P.liquid_is_range ? (q.voxel - P.liquid_lo <= P.liquid_span) : is_liquid(s_liquid, q.voxel);
+                            step_or_stop(q, lo, (e[r] == 0u) | ((q.voxel != 0u) & !liquid));
+                        }
+                    }
                 }
-                const uint32_t n_march = (uint32_t)__popcll(__ballot(marching));
+                uint32_t n_march = 0u;
+#pragma unroll
+                for (uint32_t r = 0; r < kPoolRays; r++) n_march += (uint32_t)__popcll(__ballot(ray[r].marching));
 #ifdef VRT_EXP_POOLDBG
                 dbg_steps++;
                 if (next >= n) { dbg_dry_steps++; dbg_dry_lanes += n_march; } else dbg_wet_lanes += n_march;
 #endif
-                if (n_march == 0u || (next < n && 64u - n_march >= refill_at)) break;
-                if (!CONT && next >= n && n_march <= eject_at) break;   // the pool is dry and few lanes are left: hand them on
+                if (n_march == 0u || (next < n && 64u * kPoolRays - n_march >= refill_at)) break;
+                if (!CONT && next >= n && n_march <= eject_at) break;   // the pool is dry and few rays are left: hand them on
             }
             if (!CONT && next >= n && P.cont_out) {
-                // ---- the stragglers go to the continuation launch: their path record and where they stand.  (The wave
-                // would otherwise march a dozen lanes for as many steps again as it took to empty the pool.) ----
-                const unsigned long long ballot = __ballot(marching);
-                const uint32_t n_eject = (uint32_t)__popcll(ballot);
-                if (n_eject != 0u && n_eject <= eject_at) {
-                    const int leader = __ffsll((long long)ballot) - 1;
-                    uint32_t at = 0;
-                    if ((int)lane == leader) at = atomicAdd(&P.cont_counts[seg * kSegStride], n_eject);
-                    at = (uint32_t)__shfl((int)at, leader, 64) + (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
-                    if (marching) {   // (a segment of the straggler records is as large as a segment of the paths)
-                        const uint32_t rec = base + idx, o = seg * P.hit_seg_cap + at;
-                        uint32_t w = iter;
-                        if (step != -1.0f) w |= (step == adx ? 0x10000u : 0u) | (step == ady ? 0x20000u : 0u) | (step == adz ? 0x40000u : 0u);
-                        P.cont_out[o] = P.path_in[rec];
-                        P.cont_out[P.path_cap + o] = P.path_in[P.in_cap + rec];
-                        P.cont_out[2u * P.path_cap + o] = P.path_in[2u * P.in_cap + rec];
-                        P.cont_out[3u * P.path_cap + o] = make_uint4(__float_as_uint(pos.x), __float_as_uint(pos.y), __float_as_uint(pos.z), w);
-                        pool[3u * E + idx] = __uint_as_float(kPoolEjected);
-                        marching = false;
-                        parked = true;
+                // ---- the stragglers go to the straggler chain: their path record and where they stand ----
+                uint32_t n_left = 0u;
+#pragma unroll
+                for (uint32_t r = 0; r < kPoolRays; r++) n_left += (uint32_t)__popcll(__ballot(ray[r].marching));
+                if (n_left != 0u && n_left <= eject_at) {
+                    uint32_t at0 = 0;
+                    if (lane == 0) at0 = atomicAdd(&P.cont_counts[seg * kSegStride], n_left);
+                    at0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)at0);
+#pragma unroll
+                    for (uint32_t r = 0; r < kPoolRays; r++) {
+                        Ray &q = ray[r];
+                        const unsigned long long ballot = __ballot(q.marching);
+                        if (q.marching) {   // (a segment of the straggler records is as large as a segment of the paths)
+                            const uint32_t rec = base + q.idx, o = seg * P.hit_seg_cap + at0 + (uint32_t)__popcll(ballot & below);
+                            uint32_t w = q.iter;
+                            if (q.step != -1.0f) w |= (q.step == q.adx ? 0x10000u : 0u) | (q.step == q.ady ? 0x20000u : 0u) | (q.step == q.adz ? 0x40000u : 0u);
+                            P.cont_out[o] = P.path_in[rec];
+                            P.cont_out[P.path_cap + o] = P.path_in[P.in_cap + rec];
+                            P.cont_out[2u * P.path_cap + o] = P.path_in[2u * P.in_cap + rec];
+                            P.cont_out[3u * P.path_cap + o] = make_uint4(__float_as_uint(q.pos.x), __float_as_uint(q.pos.y), __float_as_uint(q.pos.z), w);
+                            pool[3u * E + q.idx] = __uint_as_float(kPoolEjected);
+                            q.marching = false;
+                            q.parked = true;
+                        }
+                        at0 += (uint32_t)__popcll(ballot);
                     }
                 }
             }
@@ -993,7 +1049,7 @@ void launch_path_bounce_pool(const FrameParams &P, bool continuations, hipStream
     static uint32_t refill = 0, eject = kPoolEjectAt;
     if (!refill) {
         refill = kPoolRefillAt;
-        if (const char *r = getenv("VRT_PATH_POOL_REFILL")) { const int v = atoi(r); if (v >= 1 && v <= 64) refill = (uint32_t)v; }
+        if (const char *r = getenv("VRT_PATH_POOL_REFILL")) { const int v = atoi(r); if (v >= 1 && v <= (int)(64u * kPoolRays)) refill = (uint32_t)v; }
         if (const char *r = getenv("VRT_PATH_POOL_EJECT")) { const int v = atoi(r); if (v >= 0 && v <= 64) eject = (uint32_t)v; }
     }
     const uint32_t parts = (P.in_seg_cap + 4u * kPoolEntries - 1u) / (4u * kPoolEntries);
