@@ -172,6 +172,7 @@ extern "C" {
     pub fn vrt_synchronize(ctx: *mut vrt_ctx) -> c_int;
     pub fn vrt_read_output(ctx: *mut vrt_ctx, rgb: *mut f32, ids: *mut u32, rgba8: *mut u8) -> c_int;
     pub fn vrt_present(ctx: *mut vrt_ctx, crosshair: *const vrt_crosshair, screen_w: u32, screen_h: u32, rgba8: *mut u8) -> c_int;
+    pub fn vrt_selftest_exact_math(device: i32, n: u32, seed: u32, mismatches: *mut u64) -> c_int;
     pub fn vrt_present_device(ctx: *mut vrt_ctx, crosshair: *const vrt_crosshair, screen_w: u32, screen_h: u32, rgba8_device: *mut *mut c_void, bytes: *mut u64) -> c_int;
     pub fn vrt_get_stats(ctx: *mut vrt_ctx, out: *mut vrt_stats) -> c_int;
     pub fn vrt_get_accel_info(ctx: *mut vrt_ctx, out: *mut vrt_accel_info) -> c_int;

@@ -258,6 +258,12 @@ int vrt_present_device(vrt_ctx *ctx, const vrt_crosshair *crosshair, uint32_t sc
 
 int vrt_get_stats(vrt_ctx *ctx, vrt_stats *out);
 
+/* Self-test of the kernels' exact-arithmetic shortcuts (csrc/vrt_march.h: division and square root without the general
+ * case's scaling and special-value handling, taken when every operand's magnitude is in [2^-30, 2^30]): n pseudo-random
+ * operand sets (seed) on `device`, each computed both ways; *mismatches = results whose bits differ (0 on a correct
+ * build).  Diagnostic only; no context needed. */
+int vrt_selftest_exact_math(int32_t device, uint32_t n, uint32_t seed, uint64_t *mismatches);
+
 /* New relative to the reference: the lookup tables the default march derives on the device from the node pool
  * and chunk_roots (brought up to date before the next frame: only the chunks a vrt_write_nodes range or a changed
  * vrt_write_chunk_roots slot touched, the whole world after a resize or a write that touches many chunks; DESIGN.md §HBM

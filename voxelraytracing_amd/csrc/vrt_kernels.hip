@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(256) shadow_kernel(FrameParams P) {
         const uint4 rec = P.hits[blockIdx.x * 256u + threadIdx.x];
         slot = rec.x;
         const V3 so{__uint_as_float(rec.y), __uint_as_float(rec.z), __uint_as_float(rec.w)};
-        const V3 sd = vnormalize(V3{P.settings.sun_pos[0] - (float)P.world.min[0] - so.x,
+        const V3 sd = normalize_wave(V3{P.settings.sun_pos[0] - (float)P.world.min[0] - so.x,
                                     P.settings.sun_pos[1] - (float)P.world.min[1] - so.y,
                                     P.settings.sun_pos[2] - (float)P.world.min[2] - so.z});
         R = march<MARCH, LDS_ROOTS, STATS>(P, s_roots, s_liquid, so, sd);
@@ -185,7 +185,7 @@ __device__ __forceinline__ void trace_tile(const FrameParams &P, const uint32_t 
     if (launch) {
         id |= VRT_ID_SHADOW_RAY;
         const V3 so{R.pos.x + R.norm.x * kShadowBias, R.pos.y + R.norm.y * kShadowBias, R.pos.z + R.norm.z * kShadowBias};
-        const V3 sd = vnormalize(V3{P.settings.sun_pos[0] - (float)P.world.min[0] - so.x,
+        const V3 sd = normalize_wave(V3{P.settings.sun_pos[0] - (float)P.world.min[0] - so.x,
                                     P.settings.sun_pos[1] - (float)P.world.min[1] - so.y,
                                     P.settings.sun_pos[2] - (float)P.world.min[2] - so.z});
         S = march<MARCH, LDS_ROOTS, STATS>(P, s_roots, s_liquid, so, sd);
@@ -528,4 +528,64 @@ void launch_assemble(const Texel *gathered, Texel *dst, uint32_t width, uint32_t
                        tiles_x, tiles_total, root_weight, period, skip_root ? 1u : 0u, rank_stride);
 }
 
+// ------------------------------------------------------------------------------------------------
+// vrt_selftest_exact_math: the banded division / square root of vrt_march.h against the compiler's general sequences
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t st_hash(uint32_t x) {
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+// a float with a random sign and mantissa and an exponent field in [lo, hi]
+__device__ __forceinline__ float st_float(uint32_t h, uint32_t lo, uint32_t hi) {
+    const uint32_t e = lo + (h >> 9) % (hi - lo + 1u);
+    return __uint_as_float((h & 0x807FFFFFu) | (e << 23));
+}
+__device__ __noinline__ float st_div_general(float n, float d) { return n / d; }
+__device__ __noinline__ float st_sqrt_general(float x) { return sqrtf(x); }
+
+__global__ void selftest_exact_math_kernel(uint32_t n, uint32_t seed, unsigned long long *mismatches) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t bad = 0u;
+    if (i < n) {
+        const uint32_t h0 = st_hash(i * 4u + seed), h1 = st_hash(i * 4u + 1u + seed * 0x9E3779B9u), h2 = st_hash(i * 4u + 2u + seed), h3 = st_hash(i * 4u + 3u + seed);
+        // exponent fields 97 .. 157 = the band [2^-30, 2^31); every 16th operand set sits on the band's edges
+        const bool edge = (i & 15u) == 0u;
+        const V3 v{st_float(h0, edge ? 97u : 97u, edge ? 97u : 157u), st_float(h1, edge ? 157u : 97u, 157u), st_float(h2, 97u, 157u)};
+        // one division, bit for bit
+        const float q_fast = div_refined(v.x, v.y, rcp_refined(v.y)), q_gen = st_div_general(v.x, v.y);
+        bad += __float_as_uint(q_fast) != __float_as_uint(q_gen);
+        // square root over its whole claimed range: exponent fields 31 (2^-96) .. 254
+        const float x = fabsf(st_float(h3, 31u, 254u));
+        bad += __float_as_uint(sqrt_banded(x)) != __float_as_uint(st_sqrt_general(x));
+        // the two composites the kernels use, against their plain texts
+        const V3 u = unit_steps(v);
+        const V3 ug{fabsf(st_sqrt_general(1.0f + st_div_general(v.y, v.x) * st_div_general(v.y, v.x) + st_div_general(v.z, v.x) * st_div_general(v.z, v.x))),
+                    fabsf(st_sqrt_general(1.0f + st_div_general(v.x, v.y) * st_div_general(v.x, v.y) + st_div_general(v.z, v.y) * st_div_general(v.z, v.y))),
+                    fabsf(st_sqrt_general(1.0f + st_div_general(v.x, v.z) * st_div_general(v.x, v.z) + st_div_general(v.y, v.z) * st_div_general(v.y, v.z)))};
+        bad += __float_as_uint(u.x) != __float_as_uint(ug.x) || __float_as_uint(u.y) != __float_as_uint(ug.y) || __float_as_uint(u.z) != __float_as_uint(ug.z);
+        const V3 nn = normalize_wave(v);
+        const float len = st_sqrt_general(vdot(v, v));
+        const V3 ng{st_div_general(v.x, len), st_div_general(v.y, len), st_div_general(v.z, len)};
+        bad += __float_as_uint(nn.x) != __float_as_uint(ng.x) || __float_as_uint(nn.y) != __float_as_uint(ng.y) || __float_as_uint(nn.z) != __float_as_uint(ng.z);
+    }
+    if (bad) atomicAdd(mismatches, (unsigned long long)bad);
+}
+
 }  // namespace vrt
+
+extern "C" int vrt_selftest_exact_math(int32_t device, uint32_t n, uint32_t seed, uint64_t *mismatches) {
+    if (!mismatches || n == 0u) return VRT_ERR_INVALID_ARG;
+    if (hipSetDevice(device) != hipSuccess) return VRT_ERR_DEVICE;
+    unsigned long long *d = nullptr;
+    if (hipMalloc(&d, sizeof *d) != hipSuccess) return VRT_ERR_DEVICE;
+    int rc = VRT_OK;
+    unsigned long long h = 0;
+    if (hipMemset(d, 0, sizeof *d) != hipSuccess) rc = VRT_ERR_DEVICE;
+    if (rc == VRT_OK) {
+        hipLaunchKernelGGL(vrt::selftest_exact_math_kernel, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, n, seed, d);
+        if (hipGetLastError() != hipSuccess || hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) rc = VRT_ERR_DEVICE;
+    }
+    (void)hipFree(d);
+    *mismatches = h;
+    return rc;
+}

@@ -17,6 +17,78 @@ __device__ __forceinline__ int trunc2i(float x) {
     return r;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Correctly rounded f32 division and square root, without the general case's scaffolding.
+//
+// With -fhip-fp32-correctly-rounded-divide-sqrt `n / d` is 11 instructions: two v_div_scale (pre-scale operands whose
+// exponents are extreme), v_rcp, two FMAs that refine the reciprocal, a multiply and three FMAs that refine the quotient,
+// v_div_fmas (the last FMA, undoing the scaling) and v_div_fixup (zeros, infinities, NaNs); sqrtf is 17: scale a tiny
+// argument by 2^32, v_sqrt, try one ulp up and down with two FMA residuals, scale back, pass 0 / inf / NaN through.
+// ~38 and ~60 issue cycles — and a ray's set-up is 9 divides and 4 square roots (normalise, the three unit steps), twice
+// per pixel with the shadow ray: two thirds of a frame's non-march work.
+// When every operand's magnitude is in [2^-30, 2^30] none of the scaffolding does anything: v_div_scale returns its
+// operand and clears VCC, v_div_fmas is a plain FMA, v_div_fixup returns its first operand, the square root's argument is
+// neither tiny nor special.  What is left is below — the *same* instructions on the same values, so the same bits — and
+// the reciprocal's refinement is shared by the divides that share a denominator.  The choice is made per wave (one
+// ballot): a wave with a lane outside the band takes the compiler's general sequence for all its lanes.
+// tests/test_gpu_exact_math.py compares both forms bit for bit over the band's whole exponent range.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kBandLo = 0x30800000u;              // 2^-30
+constexpr uint32_t kBandSpan = 0x4E800000u - kBandLo;  // .. 2^30 (both ends' binades included: ample margin either side)
+__device__ __forceinline__ bool in_band(float x) { return (__float_as_uint(x) & 0x7FFFFFFFu) - kBandLo <= kBandSpan; }   // NaN, inf, 0: no
+__device__ __forceinline__ bool in_band3(V3 v) {
+    const uint32_t a = (__float_as_uint(v.x) & 0x7FFFFFFFu) - kBandLo, b = (__float_as_uint(v.y) & 0x7FFFFFFFu) - kBandLo,
+                   c = (__float_as_uint(v.z) & 0x7FFFFFFFu) - kBandLo;
+    return max(max(a, b), c) <= kBandSpan;
+}
+// the reciprocal of d as the division's expansion refines it (v_rcp_f32, two FMAs)
+__device__ __forceinline__ float rcp_refined(float d) {
+    const float r = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+}
+// n / d given r = rcp_refined(d): the expansion's multiply and four FMAs
+__device__ __forceinline__ float div_refined(float n, float d, float r) {
+    const float q0 = n * r;
+    const float e0 = __builtin_fmaf(-d, q0, n);
+    const float q1 = __builtin_fmaf(e0, r, q0);
+    const float e1 = __builtin_fmaf(-d, q1, n);
+    return __builtin_fmaf(e1, r, q1);
+}
+// sqrt(x) for 2^-96 <= x < inf: v_sqrt_f32, then one ulp down / up if the residual says so
+__device__ __forceinline__ float sqrt_banded(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float dn = __uint_as_float(__float_as_uint(s) - 1u), up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rd = __builtin_fmaf(-dn, s, x), ru = __builtin_fmaf(-up, s, x);
+    float r = (0.0f >= rd) ? dn : s;
+    r = (0.0f < ru) ? up : r;
+    return r;
+}
+// |unit step| per axis (ray_tracer.wgsl:209-213): sqrt(1 + (dir.b / dir.a)^2 + (dir.c / dir.a)^2)
+__device__ __forceinline__ V3 unit_steps(V3 dir) {
+    if (__ballot(!in_band3(dir)) == 0ull) {
+        // (ratios within 2^+-60, their squares within 2^+-120: the sums are finite and >= 1)
+        const float rx = rcp_refined(dir.x), ry = rcp_refined(dir.y), rz = rcp_refined(dir.z);
+        const float yx = div_refined(dir.y, dir.x, rx), zx = div_refined(dir.z, dir.x, rx);
+        const float xy = div_refined(dir.x, dir.y, ry), zy = div_refined(dir.z, dir.y, ry);
+        const float xz = div_refined(dir.x, dir.z, rz), yz = div_refined(dir.y, dir.z, rz);
+        return V3{fabsf(sqrt_banded(1.0f + yx * yx + zx * zx)), fabsf(sqrt_banded(1.0f + xy * xy + zy * zy)),
+                  fabsf(sqrt_banded(1.0f + xz * xz + yz * yz))};
+    }
+    return V3{fabsf(sqrtf(1.0f + (dir.y / dir.x) * (dir.y / dir.x) + (dir.z / dir.x) * (dir.z / dir.x))),
+              fabsf(sqrtf(1.0f + (dir.x / dir.y) * (dir.x / dir.y) + (dir.z / dir.y) * (dir.z / dir.y))),
+              fabsf(sqrtf(1.0f + (dir.x / dir.z) * (dir.x / dir.z) + (dir.y / dir.z) * (dir.y / dir.z)))};
+}
+// vnormalize for a whole wave (same choice)
+__device__ __forceinline__ V3 normalize_wave(V3 v) {
+    if (__ballot(!in_band3(v)) == 0ull) {
+        const float len = sqrt_banded(vdot(v, v));   // in [2^-30, 2^31]
+        const float r = rcp_refined(len);
+        return V3{div_refined(v.x, len, r), div_refined(v.y, len, r), div_refined(v.z, len, r)};
+    }
+    return vnormalize(v);
+}
+
 // Node words are read through a raw buffer descriptor over the pool: the hardware range check makes a read
 // past the end return 0 (an air leaf) instead of faulting, for free — no per-load clamp, 32-bit offsets.
 // (What a storage read past the end yields is implementation-defined in WGSL; the oracle reads 0 too.)
@@ -224,10 +296,7 @@ __device__ __forceinline__ MarchResult march_fast(const FrameParams &P, const ui
     if ((pos.x <= 0.0f || pos.y <= 0.0f || pos.z <= 0.0f) || (pos.x >= world_max || pos.y >= world_max || pos.z >= world_max))
         return R;
 
-    const V3 unit{
-        sqrtf(1.0f + (dir.y / dir.x) * (dir.y / dir.x) + (dir.z / dir.x) * (dir.z / dir.x)),
-        sqrtf(1.0f + (dir.x / dir.y) * (dir.x / dir.y) + (dir.z / dir.y) * (dir.z / dir.y)),
-        sqrtf(1.0f + (dir.x / dir.z) * (dir.x / dir.z) + (dir.y / dir.z) * (dir.y / dir.z))};
+    const V3 unit = unit_steps(dir);   // (:209-213)
 
     const uint32_t S = P.world.size_in_chunks;
     const uint32_t wsize = P.world.size;
@@ -432,10 +501,7 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
     if ((pos.x <= 0.0f || pos.y <= 0.0f || pos.z <= 0.0f) || (pos.x >= world_max || pos.y >= world_max || pos.z >= world_max))
         return R;
 
-    const V3 unit{
-        sqrtf(1.0f + (dir.y / dir.x) * (dir.y / dir.x) + (dir.z / dir.x) * (dir.z / dir.x)),
-        sqrtf(1.0f + (dir.x / dir.y) * (dir.x / dir.y) + (dir.z / dir.y) * (dir.z / dir.y)),
-        sqrtf(1.0f + (dir.x / dir.z) * (dir.x / dir.z) + (dir.y / dir.z) * (dir.y / dir.z))};
+    const V3 unit = unit_steps(dir);   // (:209-213)
     float ux = fabsf(unit.x), uy = fabsf(unit.y), uz = fabsf(unit.z);
     asm("" : "+v"(ux), "+v"(uy), "+v"(uz));   // (held in registers: the compiler would otherwise redo the three |.| on every step)
     const uint32_t mxm = mx ? ~0u : 0u, mym = my ? ~0u : 0u, mzm = mz ? ~0u : 0u;
@@ -600,7 +666,7 @@ __device__ __forceinline__ V3 ray_sky(const FrameParams &P, V3 origin, V3 dir) {
     const V3 grad{vmix(1.0f, P.settings.sky_color[0], sky_gradient_t), vmix(0.3f, P.settings.sky_color[1], sky_gradient_t),
                   vmix(0.0f, P.settings.sky_color[2], sky_gradient_t)};
     const V3 sun_dir = CAM_ORIGIN ? V3{P.cam_sun_dir[0], P.cam_sun_dir[1], P.cam_sun_dir[2]}
-                                  : vnormalize(V3{P.settings.sun_pos[0] - (float)P.world.min[0] - origin.x,
+                                  : normalize_wave(V3{P.settings.sun_pos[0] - (float)P.world.min[0] - origin.x,
                                                   P.settings.sun_pos[1] - (float)P.world.min[1] - origin.y,
                                                   P.settings.sun_pos[2] - (float)P.world.min[2] - origin.z});
     const float sun = (vdot(dir, sun_dir) > (1.0f - 0.01f) && ground_to_sky_t >= 1.0f) ? 1.0f : 0.0f;
@@ -621,7 +687,7 @@ __device__ __forceinline__ void create_ray(const FrameParams &P, int sx, int sy,
     const float e2 = -1.0f, e3 = 0.0f;
     const V3 w{e0 * iv[0] + e1 * iv[1] + e2 * iv[2] + e3 * iv[3], e0 * iv[4] + e1 * iv[5] + e2 * iv[6] + e3 * iv[7],
                e0 * iv[8] + e1 * iv[9] + e2 * iv[10] + e3 * iv[11]};
-    dir = vnormalize(w);
+    dir = normalize_wave(w);
     origin = V3{P.cam.pos[0] - (float)P.world.min[0], P.cam.pos[1] - (float)P.world.min[1],
                 P.cam.pos[2] - (float)P.world.min[2]};
 }

@@ -61,7 +61,7 @@ __device__ __forceinline__ V3 rng_next_dir(uint32_t &state) {
     const float x = rng_next_norm(state);
     const float y = rng_next_norm(state);
     const float z = rng_next_norm(state);
-    return vnormalize(V3{x, y, z});
+    return normalize_wave(V3{x, y, z});
 }
 
 // The material colour of a hit after face shading (ray_tracer.wgsl:296-314) — shade()'s first half.
@@ -97,9 +97,9 @@ __device__ __forceinline__ bool path_after_march(const FrameParams &P, PathState
     const float d = vdot(R.norm, st.dir);
     const V3 spec{st.dir.x - 2.0f * R.norm.x * d, st.dir.y - 2.0f * R.norm.y * d, st.dir.z - 2.0f * R.norm.z * d};
     const V3 rd = rng_next_dir(st.rng);
-    const V3 sc = vnormalize(V3{R.norm.x + rd.x, R.norm.y + rd.y, R.norm.z + rd.z});
+    const V3 sc = normalize_wave(V3{R.norm.x + rd.x, R.norm.y + rd.y, R.norm.z + rd.z});
     const float scatter = P.mats[min(R.voxel, 255u)].scatter;
-    const V3 nd = vnormalize(V3{vmix(spec.x, sc.x, scatter), vmix(spec.y, sc.y, scatter), vmix(spec.z, sc.z, scatter)});
+    const V3 nd = normalize_wave(V3{vmix(spec.x, sc.x, scatter), vmix(spec.y, sc.y, scatter), vmix(spec.z, sc.z, scatter)});
     st.thr = V3{st.thr.x * mc.x, st.thr.y * mc.y, st.thr.z * mc.z};
     st.origin = V3{R.pos.x + R.norm.x * kShadowBias, R.pos.y + R.norm.y * kShadowBias, R.pos.z + R.norm.z * kShadowBias};
     st.dir = nd;
@@ -309,10 +309,7 @@ __device__ __forceinline__ bool segment_begin(const FrameParams &P, V3 origin, V
     m.slow_bit = m.careful ? 0x80000000u : 0u;
     const float world_max = 0.0f + (float)P.world.size;
     if ((pos.x <= 0.0f || pos.y <= 0.0f || pos.z <= 0.0f) || (pos.x >= world_max || pos.y >= world_max || pos.z >= world_max)) return false;
-    const V3 unit{
-        sqrtf(1.0f + (dir.y / dir.x) * (dir.y / dir.x) + (dir.z / dir.x) * (dir.z / dir.x)),
-        sqrtf(1.0f + (dir.x / dir.y) * (dir.x / dir.y) + (dir.z / dir.y) * (dir.z / dir.y)),
-        sqrtf(1.0f + (dir.x / dir.z) * (dir.x / dir.z) + (dir.y / dir.z) * (dir.y / dir.z))};
+    const V3 unit = unit_steps(dir);
     m.ux = fabsf(unit.x); m.uy = fabsf(unit.y); m.uz = fabsf(unit.z);
     m.mxm = dir.x >= 0.0f ? ~0u : 0u; m.mym = dir.y >= 0.0f ? ~0u : 0u; m.mzm = dir.z >= 0.0f ? ~0u : 0u;
     m.vx = trunc2i(pos.x); m.vy = trunc2i(pos.y); m.vz = trunc2i(pos.z);
@@ -487,9 +484,8 @@ __global__ void __launch_bounds__(256) path_bounce_pool_kernel(FrameParams P, ui
         if (i < n) {
             const uint4 b = P.path_in[P.in_cap + base + i];
             const V3 dir{__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z)};
-            pool[0u * E + i] = fabsf(sqrtf(1.0f + (dir.y / dir.x) * (dir.y / dir.x) + (dir.z / dir.x) * (dir.z / dir.x)));
-            pool[1u * E + i] = fabsf(sqrtf(1.0f + (dir.x / dir.y) * (dir.x / dir.y) + (dir.z / dir.y) * (dir.z / dir.y)));
-            pool[2u * E + i] = fabsf(sqrtf(1.0f + (dir.x / dir.z) * (dir.x / dir.z) + (dir.y / dir.z) * (dir.y / dir.z)));
+            const V3 unit = unit_steps(dir);
+            pool[0u * E + i] = unit.x; pool[1u * E + i] = unit.y; pool[2u * E + i] = unit.z;
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -890,9 +886,9 @@ __global__ void __launch_bounds__(256) path_persistent_kernel(FrameParams P, uin
                 const float d = vdot(R.norm, st.dir);
                 const V3 spec{st.dir.x - 2.0f * R.norm.x * d, st.dir.y - 2.0f * R.norm.y * d, st.dir.z - 2.0f * R.norm.z * d};
                 const V3 rd = rng_next_dir(st.rng);
-                const V3 sc = vnormalize(V3{R.norm.x + rd.x, R.norm.y + rd.y, R.norm.z + rd.z});
+                const V3 sc = normalize_wave(V3{R.norm.x + rd.x, R.norm.y + rd.y, R.norm.z + rd.z});
                 const float scatter = P.mats[min(R.voxel, 255u)].scatter;
-                const V3 nd = vnormalize(V3{vmix(spec.x, sc.x, scatter), vmix(spec.y, sc.y, scatter), vmix(spec.z, sc.z, scatter)});
+                const V3 nd = normalize_wave(V3{vmix(spec.x, sc.x, scatter), vmix(spec.y, sc.y, scatter), vmix(spec.z, sc.z, scatter)});
                 st.thr = V3{st.thr.x * mc.x, st.thr.y * mc.y, st.thr.z * mc.z};
                 st.origin = V3{R.pos.x + R.norm.x * kShadowBias, R.pos.y + R.norm.y * kShadowBias, R.pos.z + R.norm.z * kShadowBias};
                 st.dir = nd;
