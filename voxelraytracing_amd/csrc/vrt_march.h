@@ -522,7 +522,10 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
     // (l) lanes that have more to do than step through an air leaf carry a bit that pushes every entry out of the air-leaf
     // range, so the fast path asks one question only: lanes inside water (dew != -1: bookkeeping even in air), and every
     // lane of a `careful` wave (the shader's own bounds test, the lookup repeated at its i32(f32) coordinates)
-    uint32_t slow_bit = careful ? 0x80000000u : 0u;
+    // (as an addend: e - 1 for a plain lane; e + 0x7FFFFFFF for the others, which is >= 63 for every entry there is — 0, a
+    // leaf below 2^31, 0x80000000 | brick * 64 — so one add and one compare ask the question)
+    constexpr uint32_t kPlain = 0xFFFFFFFFu, kSlow = 0x7FFFFFFFu;
+    uint32_t slow_bias = careful ? kSlow : kPlain;
     float total_len = 0.0f;
     uint32_t iter = 0u;      // wave-uniform trip count (loop control)
     uint32_t looked_up = 0u; // STATS: node lookups of this lane (:221) — one less than its trips if it left through the border
@@ -570,7 +573,7 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
         bool exhausted = false;
         for (;;) {
             e = lookup();
-            if (__ballot((e | slow_bit) - 1u >= 31u) != 0ull) break;
+            if (__ballot(e + slow_bias >= 31u) != 0ull) break;
             iter += 1u;
             if (STATS) { looked_up += 1u; R.visits += (uint32_t)__clz((int)(e + 1u)) - 25u; }
             take_step(e);   // an air leaf of the cell grid: the entry is lo
@@ -581,7 +584,7 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
         iter += 1u;
         uint32_t lo = e;
         bool stop = false;
-        if ((e | slow_bit) - 1u >= 31u) {
+        if (e + slow_bias >= 31u) {
             if (careful) {  // wave-uniform: the shader's test (:285) on the shader's coordinates (i32(NaN) = 0), then its lookup
                 vx = trunc2i(pos.x);
                 vy = trunc2i(pos.y);
@@ -606,11 +609,11 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
                 if (STATS) { looked_up += 1u; R.visits += (uint32_t)__clz((int)(lo + 1u)) - 25u; }
                 if (voxel != 0u) {
                     if (!is_liquid_ranged(P, s_liquid, voxel)) stop = true;                // solid: the hit
-                    else if (dew == -1.0f) { dew = total_len; slow_bit = 0x80000000u; }    // liquid: water bookkeeping (:231-242)
+                    else if (dew == -1.0f) { dew = total_len; slow_bias = kSlow; }    // liquid: water bookkeeping (:231-242)
                 } else if (dew != -1.0f) {
                     R.water_dist += total_len - dew;
                     dew = -1.0f;
-                    if (!careful) slow_bit = 0u;
+                    if (!careful) slow_bias = kPlain;
                 }
             }
         } else if (STATS) {
