@@ -163,36 +163,60 @@ __global__ void __launch_bounds__(512) accel_bricks_kernel(const uint16_t *nodes
 // slack); otherwise the chunk moves to a fresh 512-brick region — the most a chunk can ever need — taken from the tail of
 // the pool with one atomic.  The host keeps the tail from overflowing: it counts the chunks that may have moved since
 // the last whole-world build and asks for one of those instead when the tail could run out (vrt_backend.hip).
-struct ChunkList { uint32_t chunk[64]; };
+struct ChunkList { uint32_t chunk[64]; uint32_t extent[64]; };   // extent: nodes from the chunk's root up to the next chunk's (host's estimate)
 
 constexpr uint32_t kChunkNodesMax = 0x7FFFu + 8u;  // child_idx <= 0x7FFF, + 8 children
 
-__device__ __forceinline__ uint32_t lds_node(const uint16_t *s_nodes, uint32_t idx) {
-    return idx < kChunkNodesMax ? (uint32_t)s_nodes[idx] : 0u;  // (garbage pools: an index the 15-bit child field cannot form)
-}
+// Node `idx` of the chunk rooted at `root`: from LDS if it was staged, else from the pool (a pool whose child indices reach
+// past the chunk's own extent — no world the host mirror builds; garbage pools in the tests — is still read as the march
+// reads it); an index the 15-bit child field cannot form, or one past the end of the pool, is an air leaf.
+struct ChunkNodes {
+    const uint16_t *lds;     // staged words, relative to the root
+    const uint16_t *pool;
+    uint32_t staged, root, n_nodes;
+    __device__ __forceinline__ uint32_t operator()(uint32_t idx) const {
+        if (idx < staged) return (uint32_t)lds[idx];
+        if (idx >= kChunkNodesMax) return 0u;
+        const uint64_t g = (uint64_t)root + idx;
+        return g < n_nodes ? (uint32_t)pool[g] : 0u;
+    }
+};
 
 __global__ void __launch_bounds__(512) accel_chunks_kernel(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S,
                                                            uint32_t *grid, uint32_t *chunk_bricks, uint32_t *chunk_bases,
                                                            uint32_t *chunk_caps, uint32_t *tail, uint16_t *bricks, uint32_t brick_cap,
                                                            ChunkList list) {
-    extern __shared__ uint16_t s_nodes[];  // kChunkNodesMax node words of this chunk, relative to its root (+ padding)
+    extern __shared__ __attribute__((aligned(16))) uint16_t s_raw[];  // the chunk's node words from the 16-byte boundary at or below its root
     __shared__ uint32_t s_wave[8];
     __shared__ uint32_t s_base;
     const uint32_t chunk = list.chunk[blockIdx.x];
     const uint32_t t = threadIdx.x, cx = t & 7u, cy = (t >> 3) & 7u, cz = t >> 6;
     const uint32_t root = roots[chunk];
-    // stage: pairs of nodes as one 32-bit load where the pair is aligned and inside the pool, else word by word
-    for (uint32_t i = t; i < kChunkNodesMax; i += 512u) {
-        const uint64_t g = (uint64_t)root + i;
-        s_nodes[i] = g < n_nodes ? nodes[g] : (uint16_t)0;   // past the end of the pool: an air leaf (what the march's buffer loads return)
+    // stage the chunk's own extent, eight nodes (16 bytes) per load; the pool is 16-byte aligned (hipMalloc)
+    const uint32_t head = root & 7u, first = root - head;
+    const uint32_t staged = min(list.extent[blockIdx.x], kChunkNodesMax);
+    const uint32_t vecs = (head + staged + 7u) / 8u;
+    for (uint32_t v = t; v < vecs; v += 512u) {
+        const uint64_t g = (uint64_t)first + (uint64_t)v * 8u;
+        uint4 w = make_uint4(0u, 0u, 0u, 0u);
+        if (g + 8u <= n_nodes) {
+            w = *reinterpret_cast<const uint4 *>(nodes + g);
+        } else {   // the pool ends inside this vector: past the end reads as air leaves (what the march's buffer loads return)
+            uint32_t h[8];
+#pragma unroll
+            for (uint32_t k = 0; k < 8u; k++) h[k] = g + k < n_nodes ? (uint32_t)nodes[g + k] : 0u;
+            w = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+        }
+        reinterpret_cast<uint4 *>(s_raw)[v] = w;
     }
     __syncthreads();
+    const ChunkNodes lds_node{s_raw + head, nodes, staged, root, n_nodes};
     // the three levels above this thread's cell
-    uint32_t node = lds_node(s_nodes, 0u), depth = 0u;
+    uint32_t node = lds_node(0u), depth = 0u;
     while ((node & 0x8000u) && depth < 3u) {
         const uint32_t sh = 2u - depth;
         const uint32_t sel = ((cx >> sh) & 1u) | (((cy >> sh) & 1u) << 1) | (((cz >> sh) & 1u) << 2);
-        node = lds_node(s_nodes, (node & 0x7FFFu) + sel);
+        node = lds_node((node & 0x7FFFu) + sel);
         depth += 1u;
     }
     const bool split = (node & 0x8000u) != 0u;
@@ -222,13 +246,13 @@ __global__ void __launch_bounds__(512) accel_chunks_kernel(const uint16_t *nodes
     for (uint32_t k = 0; k < 32u; k++) w[k] = 0u;
 #pragma unroll
     for (uint32_t c = 0; c < 8u; c++) {
-        const uint32_t n4 = lds_node(s_nodes, (node & 0x7FFFu) + c);
+        const uint32_t n4 = lds_node((node & 0x7FFFu) + c);
         const uint32_t x1 = (c & 1u) * 2u, y1 = ((c >> 1) & 1u) * 2u, z1 = ((c >> 2) & 1u) * 2u;
 #pragma unroll
         for (uint32_t g = 0; g < 8u; g++) {
             const uint32_t x = x1 + (g & 1u), y = y1 + ((g >> 1) & 1u), z = z1 + ((g >> 2) & 1u);
             uint32_t word;
-            if (n4 & 0x8000u) word = (lds_node(s_nodes, (n4 & 0x7FFFu) + g) & 0x7FFFu) << 1;  // depth 5: the walk stops here, size 1
+            if (n4 & 0x8000u) word = (lds_node((n4 & 0x7FFFu) + g) & 0x7FFFu) << 1;  // depth 5: the walk stops here, size 1
             else word = ((n4 & 0x7FFFu) << 1) | 1u;                                            // depth-4 leaf, size 2
             const uint32_t e = x | (y << 2) | (z << 4);
             w[e >> 1] |= word << ((e & 1u) * 16u);
@@ -273,16 +297,16 @@ void launch_accel_bricks(const uint16_t *nodes, uint32_t n_nodes, const uint32_t
 
 void launch_accel_chunks(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S, uint32_t *grid,
                          uint32_t *chunk_bricks, uint32_t *chunk_bases, uint32_t *chunk_caps, uint32_t *tail, uint16_t *bricks,
-                         uint32_t brick_cap, const uint32_t *chunks, uint32_t n, hipStream_t st) {
+                         uint32_t brick_cap, const uint32_t *chunks, const uint32_t *extents, uint32_t n, hipStream_t st) {
     // 64 KiB + of dynamic LDS needs opting in (the CU has 160 KiB); per device, and any thread may be the first
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(accel_chunks_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)((kChunkNodesMax + 1u) * sizeof(uint16_t)));
+    const size_t lds = (size_t)(kChunkNodesMax + 16u) * sizeof(uint16_t);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(accel_chunks_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     for (uint32_t i = 0; i < n; i += 64u) {
         ChunkList list;
         const uint32_t m = n - i < 64u ? n - i : 64u;
-        for (uint32_t k = 0; k < m; k++) list.chunk[k] = chunks[i + k];
-        hipLaunchKernelGGL(accel_chunks_kernel, dim3(m), dim3(512), (kChunkNodesMax + 1u) * sizeof(uint16_t), st, nodes, n_nodes, roots, S,
-                           grid, chunk_bricks, chunk_bases, chunk_caps, tail, bricks, brick_cap, list);
+        for (uint32_t k = 0; k < m; k++) { list.chunk[k] = chunks[i + k]; list.extent[k] = extents[i + k]; }
+        hipLaunchKernelGGL(accel_chunks_kernel, dim3(m), dim3(512), lds, st, nodes, n_nodes, roots, S, grid, chunk_bricks, chunk_bases,
+                           chunk_caps, tail, bricks, brick_cap, list);
     }
 }
 

@@ -54,7 +54,7 @@ void launch_accel_bricks(const uint16_t *nodes, uint32_t n_nodes, const uint32_t
 void launch_upload_words(void *dst, const void *pinned_src, uint32_t n_words, hipStream_t st);
 void launch_accel_chunks(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S, uint32_t *grid,
                          uint32_t *chunk_bricks, uint32_t *chunk_bases, uint32_t *chunk_caps, uint32_t *tail, uint16_t *bricks,
-                         uint32_t brick_cap, const uint32_t *chunks, uint32_t n, hipStream_t st);
+                         uint32_t brick_cap, const uint32_t *chunks, const uint32_t *extents, uint32_t n, hipStream_t st);
 }  // namespace vrt
 
 static_assert(sizeof(vrt_material) == 32, "Material layout (mod.rs:20-28)");
@@ -403,19 +403,22 @@ static void mark_chunk_dirty(vrt_ctx *c, uint32_t chunk) {
     c->dirty_chunks.push_back(chunk);
 }
 
+static void refresh_roots_index(vrt_ctx *c) {   // (root, chunk) of every present chunk, sorted
+    if (!c->roots_index_stale) return;
+    c->roots_index.clear();
+    for (uint32_t i = 0; i < c->n_roots; i++)
+        if (c->h_roots[i]) c->roots_index.emplace_back(c->h_roots[i], i);
+    std::sort(c->roots_index.begin(), c->roots_index.end());
+    c->roots_index_stale = false;
+}
+
 // Nodes [start, end) were overwritten: the chunks whose octrees may have changed are the ones whose root lies in the range
 // and the one whose root precedes it (a chunk's nodes follow its root up to the next chunk's root: ChunkAlloc hands out
 // disjoint ranges, client/src/world.rs:239-256).  Node 0 is the root of every missing chunk: a write to it is everything.
 static void mark_node_range_dirty(vrt_ctx *c, uint32_t start, uint32_t end) {
     if (c->accel_dirty) return;
     if (start == 0u) { mark_all_dirty(c); return; }
-    if (c->roots_index_stale) {
-        c->roots_index.clear();
-        for (uint32_t i = 0; i < c->n_roots; i++)
-            if (c->h_roots[i]) c->roots_index.emplace_back(c->h_roots[i], i);
-        std::sort(c->roots_index.begin(), c->roots_index.end());
-        c->roots_index_stale = false;
-    }
+    refresh_roots_index(c);
     auto it = std::upper_bound(c->roots_index.begin(), c->roots_index.end(), std::make_pair(start, 0xFFFFFFFFu));
     // chunks sharing the root that precedes the range (normally one), then every chunk rooted inside it
     if (it != c->roots_index.begin()) {
@@ -448,8 +451,18 @@ static int ensure_accel(vrt_ctx *c) {
         if (c->chunks_moved + fresh <= kTailChunks) {
             int rc = order_after_frames(c);
             if (rc) return rc;
+            // how far each chunk's nodes can reach: up to the next chunk's root (ChunkAlloc's ranges are disjoint); the kernel
+            // stages that much of the pool and reads anything beyond from the pool itself
+            refresh_roots_index(c);
+            std::vector<uint32_t> extents(c->dirty_chunks.size());
+            for (size_t i = 0; i < extents.size(); i++) {
+                const uint32_t r = c->dirty_chunks[i] < c->n_roots ? c->h_roots[c->dirty_chunks[i]] : 0u;
+                auto nx = std::upper_bound(c->roots_index.begin(), c->roots_index.end(), std::make_pair(r, 0xFFFFFFFFu));
+                const uint32_t end = nx != c->roots_index.end() ? nx->first : c->max_nodes;
+                extents[i] = r ? (end > r ? end - r : 0u) : 1u;   // (a missing chunk is node 0 alone: one air leaf)
+            }
             vrt::launch_accel_chunks(c->d_nodes, c->max_nodes, c->d_roots, S, c->d_grid, c->d_chunk_bricks, c->d_chunk_bases,
-                                     c->d_chunk_caps, c->d_brick_tail, c->d_bricks, c->brick_cap, c->dirty_chunks.data(),
+                                     c->d_chunk_caps, c->d_brick_tail, c->d_bricks, c->brick_cap, c->dirty_chunks.data(), extents.data(),
                                      (uint32_t)c->dirty_chunks.size(), c->stream);
             HIP_TRY(c, hipGetLastError());
             for (uint32_t ch : c->dirty_chunks) {
