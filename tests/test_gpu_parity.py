@@ -826,3 +826,36 @@ def test_persistent_path_kernel_gives_the_same_frames(orc, monkeypatch):
         acc_ids |= s_ids
         sh.close()
     assert np.array_equal(acc_ids, ids) and np.array_equal(acc_rgb, rgb)
+
+
+@pytest.mark.parametrize("env", [{"VRT_PATH_POOL": "0"}, {"VRT_PATH_POOL_CHAIN": "1"}, {"VRT_PATH_POOL_CHAIN": "1", "VRT_PATH_POOL_EJECT": "40"}])
+def test_every_form_of_the_bounce_launch_gives_the_same_frames(orc, monkeypatch, env):
+    """The default bounce launch is the pool kernel (a wave refills its lanes from its own LDS pool of rays).  VRT_PATH_POOL=0:
+    lane = path for the whole kernel, the round-1 structure.  VRT_PATH_POOL_CHAIN=1 (built and measured, not the default):
+    rays still marching when a wave's pool runs dry go to a chain of launches on a side stream.  All bit for bit the same
+    frame, with several samples (the chains join per sample), sharded, and with two frames in flight."""
+    sc = scenes.c4((320, 184), bounces=4)
+    ref = gpu_for_scene(sc)
+    ref.render(MODE_PATH, spp=3, seed=11)
+    rgb, ids, _ = ref.read_output()
+    r_rgb, r_ids, _, _ = orc.from_package_scene(sc).render(orc.MODE_PATH, *sc.size, spp=3, seed=11)
+    assert_frame_parity(rgb, ids, r_rgb, r_ids, "pool bounce kernel")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    gpu = gpu_for_scene(sc)
+    for _ in range(4):   # frames in flight alternate between the context's frame sets
+        gpu.render(MODE_PATH, spp=3, seed=11)
+    rgb2, ids2, _ = gpu.read_output()
+    assert np.array_equal(ids2, ids) and np.array_equal(rgb2, rgb)
+    gpu.close()
+    acc_rgb, acc_ids = np.zeros_like(rgb), np.zeros_like(ids)
+    for r in range(2):
+        sh = gpu_for_scene(sc, shard_rank=r, shard_count=2)
+        sh.render(MODE_PATH, spp=3, seed=11)
+        s_rgb, s_ids, _ = sh.read_output()
+        acc_rgb += s_rgb
+        acc_ids |= s_ids
+        sh.close()
+    assert np.array_equal(acc_ids, ids) and np.array_equal(acc_rgb, rgb)
+    ref.close()
+

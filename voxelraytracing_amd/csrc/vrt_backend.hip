@@ -34,9 +34,7 @@ void launch_primary_shadow_fused(const FrameParams &P, uint32_t march, bool stat
 void launch_primary_shadow_persistent(const FrameParams &P, uint32_t *heads, uint32_t n_cus, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
 void launch_path_primary(const FrameParams &P, bool stats, bool literal, hipStream_t st);
 void launch_path_bounce(const FrameParams &P, bool stats, bool literal, hipStream_t st);
-void launch_path_bounce_pool(const FrameParams &P, bool continuations, hipStream_t st);
-bool path_pool_enabled();
-bool path_pool_chain_enabled();
+void launch_path_bounce_pool(const FrameParams &P, bool continuations, uint32_t refill_at, uint32_t eject_at, hipStream_t st);
 void launch_path_finish(Texel *out, uint32_t n, uint32_t spp, hipStream_t st);
 void launch_path_persistent(const FrameParams &P, uint32_t *heads, uint32_t n_cus, hipStream_t st);
 void launch_quantize(const Texel *out, uint8_t *rgba8, uint32_t n, hipStream_t st);
@@ -150,6 +148,9 @@ struct vrt_ctx {
     // multi-device context that issues to eight from one thread.
     uint32_t timing_every = 8, frame_no = 0;
     bool path_persistent = false;  // VRT_PATH_PERSISTENT=1: plain path frames as one persistent launch instead of one launch per bounce
+    bool path_pool = true;         // VRT_PATH_POOL=0: bounce launches with lane = path (the round-1 structure) instead of the pool kernel
+    bool path_chain = false;       // VRT_PATH_POOL_CHAIN=1: the pool kernel's stragglers go to a chain of launches on a side stream
+    uint32_t path_refill = 0, path_eject = ~0u;   // VRT_PATH_POOL_REFILL / _EJECT: the pool kernel's thresholds (experiments; 0 / ~0: defaults)
     uint32_t accel_builds = 0, accel_chunk_builds = 0;
     float accel_last_ms = 0.f;
     std::vector<uint32_t> dirty_chunks;     // chunk slots whose nodes or root changed since the tables were last brought up to date
@@ -613,6 +614,10 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         if (v >= 0 && v < (long)kAccelMaxS) c->accel_max_s = (uint32_t)v;
     }
     if (const char *e = getenv("VRT_PATH_PERSISTENT")) c->path_persistent = e[0] == '1';
+    if (const char *e = getenv("VRT_PATH_POOL")) c->path_pool = e[0] != '0';
+    if (const char *e = getenv("VRT_PATH_POOL_CHAIN")) c->path_chain = e[0] == '1';
+    if (const char *e = getenv("VRT_PATH_POOL_REFILL")) c->path_refill = (uint32_t)atoi(e);
+    if (const char *e = getenv("VRT_PATH_POOL_EJECT")) c->path_eject = (uint32_t)atoi(e);
     if (const char *e = getenv("VRT_TIMING_EVERY")) { const long v = strtol(e, nullptr, 10); if (v >= 1 && v <= 1000000) c->timing_every = (uint32_t)v; }
     memset(c->h_mats, 0, sizeof c->h_mats);
     memset(&c->cam, 0, sizeof c->cam);
@@ -1031,8 +1036,8 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
     // b + 1 already runs — the few rays that graze the terrain for a hundred steps, which every bounce launch used to
     // wait for, are off the frame's critical path.  A path is in exactly one of the two chains, so nothing is shared but
     // the record sets' cursors (atomics).  The chains join at the end of every sample.
-    const bool pool = !kstats && !literal && P.grid && bounces > 1 && vrt::path_pool_enabled();
-    const bool chain = pool && bounces - 1u <= kContSets && vrt::path_pool_chain_enabled();
+    const bool pool = !kstats && !literal && P.grid && bounces > 1 && c->path_pool;
+    const bool chain = pool && bounces - 1u <= kContSets && c->path_chain;
     uint32_t *cont_seg[kContSets];
     for (uint32_t i = 0; i < kContSets; i++) cont_seg[i] = P.seg_counts + (3 + i) * kSegWords;
     hipStream_t side = nullptr;
@@ -1074,7 +1079,7 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
                     P.cont_out = cont + (size_t)(b - 1u) * 4 * cap;
                     P.cont_counts = cont_seg[b - 1u];
                 }
-                vrt::launch_path_bounce_pool(P, false, f.st);
+                vrt::launch_path_bounce_pool(P, false, c->path_refill, c->path_eject, f.st);
                 if (chain) {
                     HIP_TRY(c, hipGetLastError());
                     // S(b): after bounce launch b (its hand-overs) and S(b - 1) (stream order: its survivors)
@@ -1088,7 +1093,7 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
                     Q.seg_counts = nullptr;
                     Q.cont_out = P.last_bounce ? nullptr : cont + (size_t)b * 4 * cap;
                     Q.cont_counts = P.last_bounce ? nullptr : cont_seg[b];
-                    vrt::launch_path_bounce_pool(Q, true, side);
+                    vrt::launch_path_bounce_pool(Q, true, c->path_refill, 0u, side);
                 }
             }
             HIP_TRY(c, hipGetLastError());

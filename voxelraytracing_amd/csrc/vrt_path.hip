@@ -1017,37 +1017,14 @@ void launch_path_primary(const FrameParams &P, bool stats, bool literal, hipStre
     VRT_PATH_LAUNCH(path_primary_kernel);
 }
 
-// The pool bounce kernel applies (plain frames over the derived tables; VRT_PATH_POOL=0: lane = path, the A/B baseline)
-bool path_pool_enabled() {
-    static int pool = -1;
-    if (pool < 0) {
-        const char *e = getenv("VRT_PATH_POOL");
-        pool = e ? (e[0] != '0') : 1;
-    }
-    return pool != 0;
-}
-// The bounce launches hand their stragglers to a chain of launches on a side stream (vrt_backend.hip: launch_path_frame);
-// VRT_PATH_POOL_CHAIN=1 (built and measured, not the default: DESIGN.md §5); otherwise every bounce launch marches all its
-// rays itself
-bool path_pool_chain_enabled() {
-    static int chain = -1;
-    if (chain < 0) {
-        const char *e = getenv("VRT_PATH_POOL_CHAIN");
-        chain = e ? (e[0] == '1') : 0;
-    }
-    return chain != 0;
-}
-
 // `continuations`: a launch of the straggler chain (P.path_in = four-plane records: rays a bounce launch handed on and the
 // next segments of the chain's own survivors), which marches every ray to its end.
-void launch_path_bounce_pool(const FrameParams &P, bool continuations, hipStream_t st) {
+void launch_path_bounce_pool(const FrameParams &P, bool continuations, uint32_t refill_at, uint32_t eject_at, hipStream_t st) {
     if (P.tiles_local == 0) return;
-    static uint32_t refill = 0, eject = kPoolEjectAt;
-    if (!refill) {
-        refill = kPoolRefillAt;
-        if (const char *r = getenv("VRT_PATH_POOL_REFILL")) { const int v = atoi(r); if (v >= 1 && v <= (int)(64u * kPoolRays)) refill = (uint32_t)v; }
-        if (const char *r = getenv("VRT_PATH_POOL_EJECT")) { const int v = atoi(r); if (v >= 0 && v <= 64) eject = (uint32_t)v; }
-    }
+    // refill_at: idle ray slots that send a wave back to its pool (0: the default); eject_at: marching rays at or below which
+    // a wave whose pool is dry hands them to the straggler chain (only with a cont_out)
+    const uint32_t refill = refill_at >= 1u && refill_at <= 64u * kPoolRays ? refill_at : kPoolRefillAt;
+    const uint32_t eject = eject_at <= 64u ? eject_at : kPoolEjectAt;
     const uint32_t parts = (P.in_seg_cap + 4u * kPoolEntries - 1u) / (4u * kPoolEntries);
     const dim3 grid(kHitSegments * parts), block(256);
     const size_t sh = (8u + 4u * kPoolWords) * 4u;
