@@ -859,3 +859,32 @@ def test_every_form_of_the_bounce_launch_gives_the_same_frames(orc, monkeypatch,
     assert np.array_equal(acc_ids, ids) and np.array_equal(acc_rgb, rgb)
     ref.close()
 
+
+@pytest.mark.parametrize("per_chain", ["1", "2", "4", "16"])
+def test_samples_per_launch_chain_do_not_change_the_frame(orc, monkeypatch, per_chain):
+    """A path-traced frame with spp > 1 runs its samples several per launch chain (default 4; VRT_PATH_SAMPLES_PER_CHAIN):
+    every sample accumulates into its own plane and the chain's finishing pass adds the planes in sample order — the frame
+    is bit for bit the one that one sample per chain gives, for chains that divide spp and chains that do not."""
+    sc = scenes.c4((320, 184), bounces=4)
+    monkeypatch.setenv("VRT_PATH_SAMPLES_PER_CHAIN", "1")
+    ref = gpu_for_scene(sc)
+    ref.render(MODE_PATH, spp=5, seed=3)
+    rgb, ids, _ = ref.read_output()
+    ref.close()
+    r_rgb, r_ids, _, _ = orc.from_package_scene(sc).render(orc.MODE_PATH, *sc.size, spp=5, seed=3)
+    assert_frame_parity(rgb, ids, r_rgb, r_ids, "one sample per chain")
+    monkeypatch.setenv("VRT_PATH_SAMPLES_PER_CHAIN", per_chain)
+    gpu = gpu_for_scene(sc)
+    for _ in range(3):
+        gpu.render(MODE_PATH, spp=5, seed=3)
+    rgb2, ids2, _ = gpu.read_output()
+    assert np.array_equal(ids2, ids) and np.array_equal(rgb2, rgb)
+    gpu.render(MODE_PATH, spp=1, seed=3)    # and a one-sample frame on the same context afterwards
+    rgb1, ids1, _ = gpu.read_output()
+    gpu.close()
+    one = gpu_for_scene(sc)
+    one.render(MODE_PATH, spp=1, seed=3)
+    o_rgb, o_ids, _ = one.read_output()
+    one.close()
+    assert np.array_equal(ids1, o_ids) and np.array_equal(rgb1, o_rgb)
+

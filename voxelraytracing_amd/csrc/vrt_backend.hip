@@ -36,6 +36,7 @@ void launch_path_primary(const FrameParams &P, bool stats, bool literal, hipStre
 void launch_path_bounce(const FrameParams &P, bool stats, bool literal, hipStream_t st);
 void launch_path_bounce_pool(const FrameParams &P, bool continuations, uint32_t refill_at, uint32_t eject_at, hipStream_t st);
 void launch_path_finish(Texel *out, uint32_t n, uint32_t spp, hipStream_t st);
+void launch_path_chain_finish(Texel *out, const Texel *acc, uint32_t n, uint32_t chain, bool first, bool last, uint32_t spp, hipStream_t st);
 void launch_path_persistent(const FrameParams &P, uint32_t *heads, uint32_t n_cus, hipStream_t st);
 void launch_quantize(const Texel *out, uint8_t *rgba8, uint32_t n, hipStream_t st);
 void launch_assemble(const Texel *gathered, Texel *dst, uint32_t width, uint32_t tiles_x, uint32_t tiles_total,
@@ -150,6 +151,9 @@ struct vrt_ctx {
     bool path_persistent = false;  // VRT_PATH_PERSISTENT=1: plain path frames as one persistent launch instead of one launch per bounce
     bool path_pool = true;         // VRT_PATH_POOL=0: bounce launches with lane = path (the round-1 structure) instead of the pool kernel
     bool path_chain = false;       // VRT_PATH_POOL_CHAIN=1: the pool kernel's stragglers go to a chain of launches on a side stream
+    uint32_t path_samples = 4;     // VRT_PATH_SAMPLES_PER_CHAIN: samples a launch chain traces at once when spp > 1 (1: one, as round 1 did)
+    vrt::Texel *path_acc[kMaxInFlight] = {nullptr, nullptr, nullptr, nullptr};   // ... their accumulation planes, per frame set
+    size_t path_acc_texels[kMaxInFlight] = {0, 0, 0, 0}, path_buf_records[kMaxInFlight] = {0, 0, 0, 0}, path_cont_records[kMaxInFlight] = {0, 0, 0, 0};
     uint32_t path_refill = 0, path_eject = ~0u;   // VRT_PATH_POOL_REFILL / _EJECT: the pool kernel's thresholds (experiments; 0 / ~0: defaults)
     uint32_t accel_builds = 0, accel_chunk_builds = 0;
     float accel_last_ms = 0.f;
@@ -267,6 +271,10 @@ static int alloc_output(vrt_ctx *c) {
     for (auto &p : c->extra_blk) { (void)hipFree(p); p = nullptr; }
     for (auto &p : c->extra_path) { (void)hipFree(p); p = nullptr; }
     for (auto &p : c->path_cont) { (void)hipFree(p); p = nullptr; }
+    for (auto &p : c->path_acc) { (void)hipFree(p); p = nullptr; }
+    for (auto &n : c->path_acc_texels) n = 0;
+    for (auto &n : c->path_buf_records) n = 0;
+    for (auto &n : c->path_cont_records) n = 0;
     layout_tiles(c);
     const size_t n = c->slots ? c->slots : 1;
     HIP_TRY(c, hipMalloc(&c->own_out, n * sizeof(vrt::Texel)));
@@ -616,6 +624,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     if (const char *e = getenv("VRT_PATH_PERSISTENT")) c->path_persistent = e[0] == '1';
     if (const char *e = getenv("VRT_PATH_POOL")) c->path_pool = e[0] != '0';
     if (const char *e = getenv("VRT_PATH_POOL_CHAIN")) c->path_chain = e[0] == '1';
+    if (const char *e = getenv("VRT_PATH_SAMPLES_PER_CHAIN")) { const int v = atoi(e); if (v >= 1 && v <= 16) c->path_samples = (uint32_t)v; }
     if (const char *e = getenv("VRT_PATH_POOL_REFILL")) c->path_refill = (uint32_t)atoi(e);
     if (const char *e = getenv("VRT_PATH_POOL_EJECT")) c->path_eject = (uint32_t)atoi(e);
     if (const char *e = getenv("VRT_TIMING_EVERY")) { const long v = strtol(e, nullptr, 10); if (v >= 1 && v <= 1000000) c->timing_every = (uint32_t)v; }
@@ -665,6 +674,7 @@ void vrt_destroy(vrt_ctx *c) {
     for (auto p : c->extra_path) (void)hipFree(p);
     for (auto p : c->extra_counters) (void)hipFree(p);
     for (auto p : c->path_cont) (void)hipFree(p);
+    for (auto p : c->path_acc) (void)hipFree(p);
     for (auto st : c->side_stream)
         if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     for (auto &evs : c->side_ev)
@@ -1018,14 +1028,38 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
         c->last_spp = spp;
         return VRT_OK;
     }
-    const size_t cap = (size_t)vrt::kHitSegments * c->hit_seg_cap;
-    if (!*f.path_buf) HIP_TRY(c, hipMalloc(f.path_buf, 2 * 3 * cap * sizeof(uint4)));
+    // Several samples per launch chain (plain frames, spp > 1): every launch of the chain carries `samples` times the rays —
+    // 2.7 rays per lane are not enough to cover a bounce launch's tail — and a frame of 16 spp is 4 x 4
+    // launches instead of 16 x 4.  Each sample accumulates into its own plane; the chain's finishing pass adds the planes
+    // to the frame in sample order, which is the order one sample per chain adds them in.
+    const uint32_t samples = (spp > 1u && !kstats && bounces > 0) ? (spp < c->path_samples ? spp : c->path_samples) : 1u;
+    const bool planes = samples > 1u;
+    const uint32_t seg_cap = c->hit_seg_cap * samples;
+    const size_t cap = (size_t)vrt::kHitSegments * seg_cap;
+    if (c->path_buf_records[f.slot] < cap) {   // (grows only; hipFree waits for whatever still uses the old one)
+        (void)hipFree(*f.path_buf);
+        *f.path_buf = nullptr; c->path_buf_records[f.slot] = 0;
+        HIP_TRY(c, hipMalloc(f.path_buf, 2 * 3 * cap * sizeof(uint4)));
+        c->path_buf_records[f.slot] = cap;
+    }
+    if (planes && c->path_acc_texels[f.slot] < (size_t)samples * c->slots) {
+        (void)hipFree(c->path_acc[f.slot]);
+        c->path_acc[f.slot] = nullptr; c->path_acc_texels[f.slot] = 0;
+        HIP_TRY(c, hipMalloc(&c->path_acc[f.slot], (size_t)samples * c->slots * sizeof(vrt::Texel)));
+        c->path_acc_texels[f.slot] = (size_t)samples * c->slots;
+    }
+    vrt::Texel *const frame_out = P.out;
+    P.hit_seg_cap = seg_cap;
+    P.acc = planes ? c->path_acc[f.slot] : nullptr;
+    P.acc_slots = c->slots;
+    P.chain = 1u;
+    if (planes) P.out = c->path_acc[f.slot];   // what the bounce launches accumulate into, through slots that carry the plane
     constexpr uint32_t kSegWords = vrt::kHitSegments * vrt::kSegStride;
     uint32_t *seg[3] = {P.seg_counts, P.seg_counts + kSegWords, P.seg_counts + 2 * kSegWords};
     uint4 *buf[2] = {*f.path_buf, *f.path_buf + 3 * cap};
     P.path_cap = (uint32_t)cap;
     P.in_cap = (uint32_t)cap;
-    P.in_seg_cap = c->hit_seg_cap;
+    P.in_seg_cap = seg_cap;
     P.cont_out = nullptr;
     P.cont_counts = nullptr;
     P.spp = spp;
@@ -1043,7 +1077,12 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
     hipStream_t side = nullptr;
     hipEvent_t *sev = c->side_ev[f.slot];
     if (chain) {
-        if (!c->path_cont[f.slot]) HIP_TRY(c, hipMalloc(&c->path_cont[f.slot], (size_t)kContSets * 4 * cap * sizeof(uint4)));
+        if (c->path_cont_records[f.slot] < cap) {
+            (void)hipFree(c->path_cont[f.slot]);
+            c->path_cont[f.slot] = nullptr; c->path_cont_records[f.slot] = 0;
+            HIP_TRY(c, hipMalloc(&c->path_cont[f.slot], (size_t)kContSets * 4 * cap * sizeof(uint4)));
+            c->path_cont_records[f.slot] = cap;
+        }
         if (!c->side_stream[f.slot]) HIP_TRY(c, hipStreamCreateWithFlags(&c->side_stream[f.slot], hipStreamNonBlocking));
         for (int i = 0; i < 6; i++)
             if (!sev[i]) HIP_TRY(c, hipEventCreateWithFlags(&sev[i], hipEventDisableTiming));
@@ -1055,8 +1094,9 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
     if (bounces == 0) HIP_TRY(c, hipMemsetAsync(f.out, 0, (size_t)c->slots * sizeof(vrt::Texel), f.st));
     bool first = true;
     uint32_t g = 0;   // launch number within the frame (all three cursor sets are zero when it starts: vrt_render cleared them)
-    for (uint32_t smp = 0; smp < spp && bounces > 0; smp++) {
+    for (uint32_t smp = 0; smp < spp && bounces > 0; smp += samples) {
         P.sample = smp;
+        P.chain = spp - smp < samples ? spp - smp : samples;
         // (the chain's cursors are zero at the start of a frame — vrt_render cleared the counters — and again for every
         // further sample; the chains have joined by then)
         if (chain && smp > 0) HIP_TRY(c, hipMemsetAsync(cont_seg[0], 0, kContSets * kSegBytes, f.st));
@@ -1103,9 +1143,14 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
             HIP_TRY(c, hipEventRecord(sev[4], side));
             HIP_TRY(c, hipStreamWaitEvent(f.st, sev[4], 0));
         }
+        if (planes) {
+            vrt::launch_path_chain_finish(frame_out, c->path_acc[f.slot], c->slots, P.chain, smp == 0u, smp + P.chain >= spp, spp, f.st);
+            HIP_TRY(c, hipGetLastError());
+        }
     }
+    P.out = frame_out;
     if (first && timed) HIP_TRY(c, hipEventRecord(ev[1], f.st));
-    if (bounces > 0 && spp > 1u) {
+    if (bounces > 0 && spp > 1u && !planes) {
         vrt::launch_path_finish(f.out, c->slots, spp, f.st);
         HIP_TRY(c, hipGetLastError());
     }

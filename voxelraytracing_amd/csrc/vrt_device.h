@@ -55,6 +55,11 @@ struct FrameParams {
     uint4 *cont_out;         // null: a bounce launch marches every ray to its end / a straggler launch has no survivors
     uint32_t *cont_counts;   // segment counters of cont_out
     uint32_t spp, sample, seed;
+    // several samples per launch chain (plain frames with spp > 1): the primary launch traces samples sample .. sample +
+    // chain - 1 of every pixel, sample s into its own plane of `acc` ({light, id} at [s - sample][slot]); the bounce launches
+    // see `out` = acc and slots that carry the plane; path_chain_finish_kernel adds the planes to the frame in sample order
+    Texel *acc;              // null: one sample per chain, radiance accumulates in `out` itself
+    uint32_t chain, acc_slots;
     uint32_t last_bounce;    // 1: paths that hit on this segment end (max_ray_bounces reached)
     uint32_t n_nodes, n_roots;
     uint32_t width, height;

@@ -144,8 +144,11 @@ __global__ void __launch_bounds__(256) path_primary_kernel(FrameParams P) {
     stage_lds(P, s_roots, s_liquid, LDS_ROOTS);
 
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t t_local = blockIdx.x * 4u + (threadIdx.x >> 6);
-    const bool live = t_local < P.tiles_local;
+    // wave = one tile of one sample: the chain's samples one after the other (P.chain = 1 unless P.acc)
+    const uint32_t t_all = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const bool live = t_all < P.tiles_local * P.chain;
+    const uint32_t s_local = live && P.chain > 1u ? t_all / P.tiles_local : 0u, t_local = t_all - s_local * P.tiles_local;
+    const uint32_t sample = P.sample + s_local;
     if (blockIdx.x == 0 && P.seg_clear) P.seg_clear[threadIdx.x * kSegStride] = 0u;   // kHitSegments == blockDim.x cursors
     if (!STATS && !live) return;
     MarchResult R;
@@ -159,12 +162,26 @@ __global__ void __launch_bounds__(256) path_primary_kernel(FrameParams P) {
         create_ray(P, (int)px, (int)py, st.origin, st.dir);
         st.thr = V3{1.0f, 1.0f, 1.0f};
         // seed: path_tracer.wgsl:328 (y*W + x) + the per-sample stride and frame seed of SURVEY §8d
-        st.rng = py * P.width + px + P.sample * (P.width * P.height) + P.seed * 0x9E3779B9u;
+        st.rng = py * P.width + px + sample * (P.width * P.height) + P.seed * 0x9E3779B9u;
         const V3 o0 = st.origin, d0 = st.dir;
         V3 light{0.f, 0.f, 0.f};
         bool missed;
         const bool alive = path_segment<MARCH, LDS_ROOTS, STATS>(P, s_roots, s_liquid, st, R, light, missed) && !P.last_bounce;
-        if (P.sample == 0u) {
+        if (P.acc) {
+            // this sample's own plane: its light so far and, for the frame's first sample, the id word (0 otherwise);
+            // the path's later segments find the plane through the slot
+            uint32_t id = 0u;
+            if (sample == 0u) {
+                id = R.voxel & VRT_ID_VOXEL_MASK;
+                if (R.hit) id |= VRT_ID_HIT;
+                if (R.norm.x != 0.0f) id |= VRT_ID_NX;
+                if (R.norm.y != 0.0f) id |= VRT_ID_NY;
+                if (R.norm.z != 0.0f) id |= VRT_ID_NZ;
+                if (R.water_dist != 0.0f) id |= VRT_ID_WATER;
+            }
+            st.slot += s_local * P.acc_slots;
+            P.acc[st.slot] = make_uint4(__float_as_uint(light.x), __float_as_uint(light.y), __float_as_uint(light.z), id);
+        } else if (P.sample == 0u) {
             // the id word of the primary segment, composed as shade() does
             uint32_t id = R.voxel & VRT_ID_VOXEL_MASK;
             if (R.hit) id |= VRT_ID_HIT;
@@ -977,6 +994,33 @@ void launch_path_persistent(const FrameParams &P, uint32_t *heads, uint32_t n_cu
     hipLaunchKernelGGL(path_persistent_kernel, dim3((waves + 3u) / 4u), dim3(256), 8u * 4u, st, P, heads, refill_at);
 }
 
+// The end of a launch chain of several samples: the frame's running sum plus the chain's planes, in sample order — the
+// order the one-sample-per-chain launches add them in and the oracle's — and the division once the last chain is in.
+__global__ void path_chain_finish_kernel(Texel *out, const Texel *acc, uint32_t n, uint32_t chain, uint32_t first, uint32_t last, float spp) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint4 t = acc[i];   // the chain's first sample: the frame's first (light and id word as they are), or one more term
+    if (!first) {
+        const uint4 o = out[i];
+        t.x = __float_as_uint(__uint_as_float(o.x) + __uint_as_float(t.x));
+        t.y = __float_as_uint(__uint_as_float(o.y) + __uint_as_float(t.y));
+        t.z = __float_as_uint(__uint_as_float(o.z) + __uint_as_float(t.z));
+        t.w = o.w;
+    }
+    for (uint32_t s = 1; s < chain; s++) {
+        const uint4 a = acc[(size_t)s * n + i];
+        t.x = __float_as_uint(__uint_as_float(t.x) + __uint_as_float(a.x));
+        t.y = __float_as_uint(__uint_as_float(t.y) + __uint_as_float(a.y));
+        t.z = __float_as_uint(__uint_as_float(t.z) + __uint_as_float(a.z));
+    }
+    if (last) {
+        t.x = __float_as_uint(__uint_as_float(t.x) / spp);
+        t.y = __float_as_uint(__uint_as_float(t.y) / spp);
+        t.z = __float_as_uint(__uint_as_float(t.z) / spp);
+    }
+    out[i] = t;
+}
+
 // rgb /= spp after the last sample
 __global__ void path_finish_kernel(Texel *out, uint32_t n, float spp) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1013,7 +1057,7 @@ static size_t lds_bytes_path(const FrameParams &P, bool lds_roots) { return (24u
 
 void launch_path_primary(const FrameParams &P, bool stats, bool literal, hipStream_t st) {
     if (P.tiles_local == 0) return;
-    const dim3 grid((P.tiles_local + 3u) / 4u), block(256);
+    const dim3 grid((P.tiles_local * P.chain + 3u) / 4u), block(256);
     VRT_PATH_LAUNCH(path_primary_kernel);
 }
 
@@ -1038,6 +1082,12 @@ void launch_path_bounce(const FrameParams &P, bool stats, bool literal, hipStrea
     VRT_PATH_LAUNCH(path_bounce_kernel);
 }
 #undef VRT_PATH_LAUNCH
+
+void launch_path_chain_finish(Texel *out, const Texel *acc, uint32_t n, uint32_t chain, bool first, bool last, uint32_t spp, hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(path_chain_finish_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, out, acc, n, chain, first ? 1u : 0u, last ? 1u : 0u,
+                       (float)spp);
+}
 
 void launch_path_finish(Texel *out, uint32_t n, uint32_t spp, hipStream_t st) {
     if (!n) return;
