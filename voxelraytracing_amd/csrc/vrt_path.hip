@@ -583,6 +583,14 @@ __global__ void __launch_bounds__(256) path_bounce_pool_kernel(FrameParams P, ui
         };
         // the step to the leaf's exit face for a leaf of size lo + 1 (take_step of march_grid), then the lookup limit
         auto step_or_stop = [&](Ray &q, uint32_t lo, bool stop) __attribute__((always_inline)) {
+#ifdef VRT_EXP_POOL_VALU   // tools/ab experiments only: the marginal cost of extra instructions per step
+#pragma unroll
+            for (int k_ = 0; k_ < VRT_EXP_POOL_VALU; k_++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(q.idx) : "v"(0u));
+#endif
+#ifdef VRT_EXP_POOL_SALU
+#pragma unroll
+            for (int k_ = 0; k_ < VRT_EXP_POOL_SALU; k_++) asm volatile("s_mov_b32 vcc_lo, 0" ::: "vcc");
+#endif
             if (!stop) {
                 const float tx = (float)(int)(bfi(lo, q.mxm, (uint32_t)q.vx) - q.mxm) - q.pos.x;
                 const float ty = (float)(int)(bfi(lo, q.mym, (uint32_t)q.vy) - q.mym) - q.pos.y;
@@ -658,6 +666,25 @@ __global__ void __launch_bounds__(256) path_bounce_pool_kernel(FrameParams P, ui
 #pragma unroll
                     for (uint32_t r = 0; r < kPoolRays; r++)
                         if (ray[r].marching) careful_step(ray[r]);
+                } else if (kPoolRays == 1u) {
+                    // one ray per lane (what is built): everything inside one region of marching lanes — the scalar unit's
+                    // time shows in this kernel (61 % of it, against 42 % of the VALU's: profiles/r02_path_pool_sweeps.txt),
+                    // and every region of lanes is four or five scalar instructions
+                    Ray &q = ray[0];
+                    if (q.marching) {
+                        const uint32_t e = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(gb, cell_offset(q), 0, 0);
+                        q.iter += 1u;
+                        const bool brick = (int)e < 0;
+                        uint32_t b = 0u;
+                        if (brick) {
+                            const uint32_t u = ((uint32_t)q.vx & 3u) | (((uint32_t)q.vy & 3u) << 2) | (((uint32_t)q.vz & 3u) << 4);
+                            b = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(bb, (e + u) << 1, 0, 0);  // the shift drops bit 31
+                        }
+                        const uint32_t lo = brick ? (b & 1u) : (e & 31u);
+                        q.voxel = brick ? (b >> 1) : (e >> 16);
+                        const bool liquid = P.liquid_is_range ? (q.voxel - P.liquid_lo <= P.liquid_span) : is_liquid(s_liquid, q.voxel);
+                        step_or_stop(q, lo, (e == 0u) | ((q.voxel != 0u) & !liquid));
+                    }
                 } else {
                     // the same decisions without a branch per case — a bounce wave has a ray in every case on nearly every
                     // step, and each divergent branch is half a dozen scalar instructions of exec-mask bookkeeping: an air
