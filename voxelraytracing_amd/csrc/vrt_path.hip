@@ -673,6 +673,13 @@ __global__ void __launch_bounds__(256) path_bounce_pool_kernel(FrameParams P, ui
                     Ray &q = ray[0];
                     if (q.marching) {
                         const uint32_t e = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(gb, cell_offset(q), 0, 0);
+#ifdef VRT_EXP_POOL_LOAD   // tools/ab experiments only: one more load per step, 1 = the line just read, 2 = a line nobody shares
+                        {
+                            const uint32_t off_ = VRT_EXP_POOL_LOAD == 1 ? cell_offset(q) : ((q.iter * 0x9E3779B9u + q.idx * 0x85EBCA6Bu + lane * 0xC2B2AE35u) % (P.grid_bytes / 4u)) * 4u;
+                            const uint32_t x_ = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(gb, off_, 0, 0);
+                            asm volatile("" :: "v"(x_));
+                        }
+#endif
                         q.iter += 1u;
                         const bool brick = (int)e < 0;
                         uint32_t b = 0u;
