@@ -268,7 +268,9 @@ int vrt_selftest_exact_math(int32_t device, uint32_t n, uint32_t seed, uint64_t 
  * and chunk_roots (brought up to date before the next frame: only the chunks a vrt_write_nodes range or a changed
  * vrt_write_chunk_roots slot touched, the whole world after a resize or a write that touches many chunks; DESIGN.md §HBM
  * layout).  `available` = 0 while a rebuild is pending or when the world is too large for them (variant 0 then runs
- * as variant 2). */
+ * as variant 2).  While edits arrive every frame set in flight keeps its own copy of the tables, brought up to date on its
+ * own stream with the chunks dirtied since its last frame (an edit then does not wait for the frame in flight); the
+ * figures below are those of the copy the last frame used, vrt_read_accel returns the first copy, brought up to date. */
 typedef struct {
     uint32_t available;
     uint32_t world_size_chunks;
@@ -279,7 +281,8 @@ typedef struct {
     uint32_t builds;       /* whole-world builds since vrt_create (first frame, resized / recentred grid) */
     float last_build_ms;   /* hipEvent time of the last whole-world build */
     uint32_t chunk_builds; /* chunks rebuilt alone since vrt_create: a vrt_write_nodes range or a changed chunk_roots slot
-                            * rebuilds only the chunks it touches, stream-ordered, with no host round trip */
+                            * rebuilds only the chunks it touches, stream-ordered, with no host round trip (every copy of the
+                            * tables rebuilds every dirtied chunk once: the count of the copy that has rebuilt most) */
     uint32_t _reserved;
 } vrt_accel_info;
 int vrt_get_accel_info(vrt_ctx *ctx, vrt_accel_info *out);

@@ -205,3 +205,62 @@ def test_world_too_large_for_the_tables_walks_the_octree(orc, monkeypatch):
     assert np.array_equal(gpu.read_steps(), r_steps) and gpu.stats().node_visits == st.node_visits
     with pytest.raises(Exception):
         gpu.read_accel()
+
+
+@pytest.mark.parametrize("in_flight", [1, 2, 3])
+def test_edits_between_frames_in_flight_reach_every_table_set(orc, in_flight):
+    """An edit before every frame, nothing waiting for the device in between (the reference's edit loop, main.rs:340-362 with
+    a swapchain's frames in flight): uploads run on their own stream, every frame set brings its own copy of the tables up to
+    date with the chunks dirtied since *its* last frame.  Whatever the number of edits since a set's last frame, whichever set
+    renders last, after quiet stretches (the sets merge again after 64 frames without an edit) and whole-world rebuilds (a
+    write to node 0), the last frame is the oracle's frame of the final world."""
+    sc = scenes.c2((160, 96))
+    gpu = gpu_for_scene(sc)
+    gpu.set_frames_in_flight(in_flight)
+    rng = np.random.default_rng(100 + in_flight)
+    ex, ey, ez = (int(v) for v in sc.eye)
+
+    def edit():
+        for _ in range(20):
+            p = (ex + int(rng.integers(-16, 17)), ey + int(rng.integers(-20, 4)), ez + int(rng.integers(-16, 17)))
+            try:
+                start, n = sc.world.set_voxel(p, int(rng.choice([0, 0, 3, 4, 40, 62])))
+            except Exception as e:
+                assert getattr(e, "kind", "") in ("NoChange", "NoChunk", "OutOfMemory")
+                continue
+            gpu.write_nodes(sc.world.nodes_ptr(), start, start + n)
+            gpu.write_chunk_roots(sc.world.chunk_roots())
+            return
+        raise AssertionError("no voxel could be edited")
+
+    def check(what):
+        rgb, ids, _ = gpu.read_output()
+        r_rgb, r_ids, _, _ = orc.from_package_scene(sc).render(MODE_PRIMARY_SHADOW, 160, 96)   # the world as it is now
+        assert_frame_parity(rgb, ids, r_rgb, r_ids, what)
+
+    gpu.render(MODE_PRIMARY_SHADOW)
+    for burst in (1, 2, 3, 4, 5, 8, 13):            # edits + frames back to back, then one look at the last frame
+        for _ in range(burst):
+            edit()
+            gpu.render(MODE_PRIMARY_SHADOW)
+        check(f"after a burst of {burst} edit frames, {in_flight} in flight")
+    for _ in range(70):                             # a quiet stretch: the table sets merge
+        gpu.render(MODE_PRIMARY_SHADOW)
+    for burst in (1, 3, 2):
+        for _ in range(burst):
+            edit()
+            edit()                                  # two edits before one frame
+            gpu.render(MODE_PRIMARY_SHADOW)
+        check(f"after the quiet stretch, burst of {burst}")
+    # a whole-world rebuild in the middle of a burst (a write that covers node 0 dirties everything)
+    edit()
+    gpu.render(MODE_PRIMARY_SHADOW)
+    gpu.write_nodes(sc.world.nodes_ptr(), 0, 2)
+    gpu.render(MODE_PRIMARY_SHADOW)
+    edit()
+    gpu.render(MODE_PRIMARY_SHADOW)
+    check("after a whole-world rebuild between edit frames")
+    a = gpu.accel_info()
+    assert a.available == 1 and a.builds == 2 and a.chunk_builds >= 20
+    gpu.close()
+

@@ -132,14 +132,35 @@ struct vrt_ctx {
     uint8_t *d_screen = nullptr;   // vrt_present's target
     size_t screen_cap = 0;
 
-    // derived lookup tables of the grid march (vrt_accel.hip), rebuilt lazily when their inputs changed: the whole world
-    // (accel_dirty) or only the chunks a write touched (dirty_chunks)
-    uint32_t *d_grid = nullptr;
-    size_t grid_cap = 0;          // entries allocated ([8S][8S+1][8S+1] with the zero border)
-    uint16_t *d_bricks = nullptr;
-    uint32_t brick_cap = 0, n_bricks = 0;   // n_bricks: bricks inside the chunks' regions after the last whole-world build
-    uint32_t *d_chunk_bricks = nullptr, *d_chunk_bases = nullptr, *d_chunk_caps = nullptr, *d_brick_total = nullptr, *d_brick_tail = nullptr;
-    uint32_t chunk_cap = 0;
+    // derived lookup tables of the grid march (vrt_accel.hip), brought up to date lazily when their inputs changed: the whole
+    // world (accel_dirty) or only the chunks a write touched.  One set per frame set in use (tabs[0] always; tabs[k] once
+    // frame set k has rendered): a frame in flight reads its own set, so bringing the next frame's set up to date does not
+    // have to wait for it — each set keeps its own list of the chunks dirtied since *it* was last brought up to date.
+    struct Tables {
+        uint32_t *d_grid = nullptr;
+        size_t grid_cap = 0;          // entries allocated ([8S][8S+1][8S+1] with the zero border)
+        uint16_t *d_bricks = nullptr;
+        uint32_t brick_cap = 0;
+        uint32_t *d_chunk_bricks = nullptr, *d_chunk_bases = nullptr, *d_chunk_caps = nullptr, *d_brick_tail = nullptr;
+        uint32_t chunk_cap = 0;
+        bool live = false;            // a copy of tabs[0] as of the last whole-world build, plus its own chunk updates since
+        std::vector<uint32_t> dirty_chunks;     // chunk slots whose nodes or root changed since this set was last brought up to date
+        std::vector<uint8_t> chunk_is_dirty;    // ... as flags, [n_roots]
+        std::vector<uint8_t> chunk_may_have_moved;  // rebuilt alone since the last whole-world build: may sit in the pool's tail
+        uint32_t chunks_moved = 0;
+        uint32_t chunk_builds = 0;              // chunks this set has rebuilt alone (vrt_accel_info reports the most advanced set's)
+        hipEvent_t ev_updated = nullptr;        // behind this set's last chunk update (a reader of the node pool and chunk_roots)
+        bool update_pending = false;            // ... recorded and not yet known to be over
+    };
+    Tables tabs[kMaxInFlight];
+    // The sets are split — every frame set its own — only while edits arrive: two copies of the tables are twice the lines
+    // in every XCD's 4 MB L2 (measured: + 1.0 % on the C2 frame period).  After kQuietFrames frames without a dirtied chunk
+    // every frame set reads tabs[0] again; the next edit splits them (one wait for the frames in flight, then copies).
+    bool tables_split = false;
+    uint32_t quiet_frames = 0;
+    bool shared_readers_in_flight = false;   // a frame on another frame set is reading tabs[0] (cleared with the frames in flight)
+    uint32_t *d_brick_total = nullptr;
+    uint32_t n_bricks = 0;        // bricks inside the chunks' regions after the last whole-world build
     uint32_t accel_S = 0;         // world size the tables were built for
     bool accel_dirty = true;
     bool accel_ok = false;        // false: world too large for the tables, variant 0 runs as variant 2
@@ -155,12 +176,9 @@ struct vrt_ctx {
     vrt::Texel *path_acc[kMaxInFlight] = {nullptr, nullptr, nullptr, nullptr};   // ... their accumulation planes, per frame set
     size_t path_acc_texels[kMaxInFlight] = {0, 0, 0, 0}, path_buf_records[kMaxInFlight] = {0, 0, 0, 0}, path_cont_records[kMaxInFlight] = {0, 0, 0, 0};
     uint32_t path_refill = 0, path_eject = ~0u;   // VRT_PATH_POOL_REFILL / _EJECT: the pool kernel's thresholds (experiments; 0 / ~0: defaults)
-    uint32_t accel_builds = 0, accel_chunk_builds = 0;
+    uint32_t accel_builds = 0;
+    uint32_t last_slot = 0, last_tab = 0;   // the frame set and the table set of the last frame
     float accel_last_ms = 0.f;
-    std::vector<uint32_t> dirty_chunks;     // chunk slots whose nodes or root changed since the tables were last brought up to date
-    std::vector<uint8_t> chunk_is_dirty;    // ... as flags, [n_roots]
-    std::vector<uint8_t> chunk_may_have_moved;  // rebuilt alone since the last whole-world build: may sit in the pool's tail
-    uint32_t chunks_moved = 0;
     std::vector<uint32_t> h_roots;  // what chunk_roots holds, to recognise the reference's per-frame rewrite of the same table
     std::vector<std::pair<uint32_t, uint32_t>> roots_index;  // (root, chunk slot) sorted by root, roots != 0: which chunk owns a node
     bool roots_index_stale = true;
@@ -169,12 +187,21 @@ struct vrt_ctx {
     // the frames in flight by events, not by draining them
     uint8_t *h_ring = nullptr, *d_ring = nullptr;   // the pinned ring, and where the device sees it
     static constexpr size_t kRingSegBytes = 1u << 20, kRingSegs = 8;
-    hipEvent_t ring_ev[kRingSegs] = {};
-    bool ring_ev_used[kRingSegs] = {};
+    hipEvent_t ring_ev[kRingSegs][2] = {};   // behind a segment's last copy on c->stream [0] / the upload stream [1]
+    bool ring_ev_used[kRingSegs][2] = {};
     uint32_t ring_seg = 0;
     size_t ring_off = 0;
     hipEvent_t ev_frames = nullptr;   // scratch: "everything enqueued on that frame stream so far"
     hipEvent_t ev_upload = nullptr;   // the last upload / table rebuild on c->stream
+    // Node-pool and chunk_roots uploads have a stream of their own: frame set 0 runs on c->stream, and an upload queued
+    // behind a frame there would wait for it.  What reads those two buffers — the table updates, and frames that walk the
+    // octree itself (variants 1 / 2, worlds beyond the tables) — is what an upload waits for, nothing else.
+    hipStream_t up_stream = nullptr;
+    hipEvent_t ev_pool_upload = nullptr;      // the last upload on up_stream
+    uint64_t pool_gen = 0;                    // bumped by every upload on up_stream
+    uint64_t seen_pool_gen[kMaxInFlight + 1] = {0, 0, 0, 0, 0};  // [slot] of the frame streams as seen_gen, [kMaxInFlight] c->stream
+    bool walkers_in_flight = false;           // a frame that reads the node pool has been enqueued since the last full synchronise
+    hipEvent_t ev_walkers = nullptr;
     uint64_t upload_gen = 0;          // bumped by every upload; a frame stream waits for ev_upload when it has not seen it
     uint64_t seen_gen[kMaxInFlight] = {0, 0, 0, 0};  // [0] own_stream, [k] extra_stream[k - 1]
 
@@ -240,6 +267,7 @@ static int quiesce(vrt_ctx *c) {
         HIP_TRY(c, hipStreamSynchronize(c->own_stream));
         c->own_pending = false;
     }
+    c->shared_readers_in_flight = false;
     return VRT_OK;
 }
 #define QUIESCE(c)                     \
@@ -300,18 +328,22 @@ static int alloc_output(vrt_ctx *c) {
 static int alloc_roots(vrt_ctx *c, uint32_t world_size) {
     const uint64_t n = (uint64_t)world_size * world_size * world_size;
     if (world_size == 0 || n > (1ull << 28)) return fail(c, VRT_ERR_INVALID_ARG, "world_size_chunks %u out of range", world_size);
+    if (c->up_stream) HIP_TRY(c, hipStreamSynchronize(c->up_stream));   // uploads into the table that goes away
     (void)hipFree(c->d_roots);
     c->d_roots = nullptr;
     HIP_TRY(c, hipMalloc(&c->d_roots, n * sizeof(uint32_t)));
     // A fresh wgpu buffer is zero-initialised: every chunk resolves to pool[0], the air leaf.
     HIP_TRY(c, hipMemsetAsync(c->d_roots, 0, n * sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));   // (later uploads run on their own stream)
     c->world_size = world_size;
     c->n_roots = (uint32_t)n;
     c->h_roots.assign((size_t)n, 0u);
-    c->dirty_chunks.clear();
-    c->chunk_is_dirty.assign((size_t)n, 0);
-    c->chunk_may_have_moved.assign((size_t)n, 0);
-    c->chunks_moved = 0;
+    for (auto &T : c->tabs) {
+        T.dirty_chunks.clear();
+        T.chunk_is_dirty.assign((size_t)n, 0);
+        T.chunk_may_have_moved.assign((size_t)n, 0);
+        T.chunks_moved = 0;
+    }
     c->roots_index_stale = true;
     c->accel_dirty = true;
     return VRT_OK;
@@ -332,20 +364,22 @@ static constexpr uint32_t kMaxDirtyChunks = 256;
 // after every frame enqueued before it (they read what it overwrites) and before every frame enqueued after it: both are
 // stream waits on events, the host never blocks on the device here.
 
-// c->stream waits for everything enqueued so far on the other frame streams.
-static int order_after_frames(vrt_ctx *c) {
+// `target` waits for everything enqueued so far on the frame streams other than itself.
+static int order_after_frames(vrt_ctx *c, hipStream_t target) {
     auto wait_for = [&](hipStream_t st) -> int {
-        if (!st || st == c->stream) return VRT_OK;
+        if (!st || st == target) return VRT_OK;
         if (!c->ev_frames) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_frames, hipEventDisableTiming));
         HIP_TRY(c, hipEventRecord(c->ev_frames, st));
-        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_frames, 0));
+        HIP_TRY(c, hipStreamWaitEvent(target, c->ev_frames, 0));
         return VRT_OK;
     };
     if (c->alt_pending)
         for (hipStream_t st : c->extra_stream) { const int rc = wait_for(st); if (rc) return rc; }
     if (c->own_pending) { const int rc = wait_for(c->own_stream); if (rc) return rc; }
+    if (target != c->stream) { const int rc = wait_for(c->stream); if (rc) return rc; }
     return VRT_OK;
 }
+static int order_after_frames(vrt_ctx *c) { return order_after_frames(c, c->stream); }
 
 // Everything enqueued on c->stream so far (an upload, a table rebuild) happens before later frames on other streams.
 static int publish_upload(vrt_ctx *c) {
@@ -355,8 +389,18 @@ static int publish_upload(vrt_ctx *c) {
     return VRT_OK;
 }
 
+// `st` (a frame stream's slot, or kMaxInFlight for c->stream) waits for the node-pool / chunk_roots uploads so far.
+static int wait_for_pool_uploads(vrt_ctx *c, hipStream_t st, uint32_t slot) {
+    if (!c->ev_pool_upload || c->seen_pool_gen[slot] == c->pool_gen) return VRT_OK;
+    HIP_TRY(c, hipStreamWaitEvent(st, c->ev_pool_upload, 0));
+    c->seen_pool_gen[slot] = c->pool_gen;
+    return VRT_OK;
+}
+
 // Called before a frame is enqueued on frame stream `st` (slot 0 = own_stream, k = extra_stream[k - 1]).
 static int frame_waits_for_uploads(vrt_ctx *c, hipStream_t st, uint32_t slot) {
+    const int rc = wait_for_pool_uploads(c, st, st == c->stream ? vrt_ctx::kMaxInFlight : slot);
+    if (rc) return rc;
     if (st == c->stream || c->seen_gen[slot] == c->upload_gen) return VRT_OK;
     HIP_TRY(c, hipStreamWaitEvent(st, c->ev_upload, 0));
     c->seen_gen[slot] = c->upload_gen;
@@ -365,16 +409,38 @@ static int frame_waits_for_uploads(vrt_ctx *c, hipStream_t st, uint32_t slot) {
 
 // Copy `bytes` of host memory to the device with wgpu's write_buffer semantics — the caller may reuse `src` as soon as
 // this returns, the data is visible to the next frame — without waiting for the device: the bytes are copied into a
-// pinned ring now, the ring feeds an asynchronous copy on c->stream ordered after the frames in flight.  Transfers larger
-// than a ring segment (the initial pool upload) take the synchronous route.
-static int stage_upload(vrt_ctx *c, void *dst, const void *src, size_t bytes) {
+// pinned ring now, the ring feeds an asynchronous copy kernel.  `pool`: the destination is the node pool or chunk_roots —
+// the copy runs on the upload stream behind the readers of those two buffers (the table updates; every frame only if one
+// that walks the octree is in flight); otherwise on c->stream behind the frames in flight.  Transfers larger than a ring
+// segment (the initial pool upload) take the synchronous route.
+static int stage_upload(vrt_ctx *c, void *dst, const void *src, size_t bytes, bool pool = false) {
     if (bytes == 0) return VRT_OK;
-    int rc = order_after_frames(c);
-    if (rc) return rc;
+    hipStream_t st = c->stream;
+    if (pool) {
+        if (!c->up_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
+        if (!c->ev_pool_upload) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_pool_upload, hipEventDisableTiming));
+        st = c->up_stream;
+        if (c->ev_upload) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_upload, 0));   // whole-world builds and the other uploads so far
+        for (auto &T : c->tabs)
+            if (T.update_pending) HIP_TRY(c, hipStreamWaitEvent(st, T.ev_updated, 0));
+        if (c->walkers_in_flight) {
+            const int rc = order_after_frames(c, st);
+            if (rc) return rc;
+        }
+    } else {
+        const int rc = order_after_frames(c);
+        if (rc) return rc;
+    }
+    auto publish = [&]() -> int {
+        if (!pool) return publish_upload(c);
+        HIP_TRY(c, hipEventRecord(c->ev_pool_upload, st));
+        c->pool_gen += 1;
+        return VRT_OK;
+    };
     if (bytes > vrt_ctx::kRingSegBytes || (bytes & 3u) || ((uintptr_t)dst & 3u)) {
-        HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        return publish_upload(c);
+        HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        return publish();
     }
     if (!c->h_ring) {
         HIP_TRY(c, hipHostMalloc((void **)&c->h_ring, vrt_ctx::kRingSegBytes * vrt_ctx::kRingSegs, hipHostMallocMapped));
@@ -385,31 +451,42 @@ static int stage_upload(vrt_ctx *c, void *dst, const void *src, size_t bytes) {
         c->ring_seg = (c->ring_seg + 1u) % vrt_ctx::kRingSegs;
         c->ring_off = 0;
         // the segment's previous copies must have left it (seven segments ago: practically always long done)
-        if (c->ring_ev_used[c->ring_seg]) HIP_TRY(c, hipEventSynchronize(c->ring_ev[c->ring_seg]));
+        for (int k = 0; k < 2; k++)
+            if (c->ring_ev_used[c->ring_seg][k]) HIP_TRY(c, hipEventSynchronize(c->ring_ev[c->ring_seg][k]));
     }
     const size_t at = (size_t)c->ring_seg * vrt_ctx::kRingSegBytes + c->ring_off;
     memcpy(c->h_ring + at, src, bytes);
     c->ring_off += need;
-    vrt::launch_upload_words(dst, c->d_ring + at, (uint32_t)(bytes / 4u), c->stream);
+    vrt::launch_upload_words(dst, c->d_ring + at, (uint32_t)(bytes / 4u), st);
     HIP_TRY(c, hipGetLastError());
-    if (!c->ring_ev[c->ring_seg]) HIP_TRY(c, hipEventCreateWithFlags(&c->ring_ev[c->ring_seg], hipEventDisableTiming));
-    HIP_TRY(c, hipEventRecord(c->ring_ev[c->ring_seg], c->stream));
-    c->ring_ev_used[c->ring_seg] = true;
-    return publish_upload(c);
+    hipEvent_t &rev = c->ring_ev[c->ring_seg][pool ? 1 : 0];
+    if (!rev) HIP_TRY(c, hipEventCreateWithFlags(&rev, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(rev, st));
+    c->ring_ev_used[c->ring_seg][pool ? 1 : 0] = true;
+    return publish();
 }
 
 // ---- which chunks a write touched ----------------------------------------------------------------------------------
 static void mark_all_dirty(vrt_ctx *c) {
     c->accel_dirty = true;
-    for (uint32_t ch : c->dirty_chunks) c->chunk_is_dirty[ch] = 0;
-    c->dirty_chunks.clear();
+    for (auto &T : c->tabs) {
+        for (uint32_t ch : T.dirty_chunks) T.chunk_is_dirty[ch] = 0;
+        T.dirty_chunks.clear();
+    }
 }
 
+// every table set in use hears of it (a set's list: what changed since *that set* was last brought up to date)
 static void mark_chunk_dirty(vrt_ctx *c, uint32_t chunk) {
-    if (c->accel_dirty || c->chunk_is_dirty[chunk]) return;
-    if (c->dirty_chunks.size() >= kMaxDirtyChunks) { mark_all_dirty(c); return; }
-    c->chunk_is_dirty[chunk] = 1;
-    c->dirty_chunks.push_back(chunk);
+    if (c->accel_dirty) return;
+    c->tables_split = true;   // (from the next frame on; see vrt_render)
+    c->quiet_frames = 0;
+    for (uint32_t k = 0; k < vrt_ctx::kMaxInFlight; k++) {
+        auto &T = c->tabs[k];
+        if ((k && !T.live) || T.chunk_is_dirty[chunk]) continue;
+        if (T.dirty_chunks.size() >= kMaxDirtyChunks) { mark_all_dirty(c); return; }
+        T.chunk_is_dirty[chunk] = 1;
+        T.dirty_chunks.push_back(chunk);
+    }
 }
 
 static void refresh_roots_index(vrt_ctx *c) {   // (root, chunk) of every present chunk, sorted
@@ -441,97 +518,142 @@ static void mark_node_range_dirty(vrt_ctx *c, uint32_t start, uint32_t end) {
     for (; it != c->roots_index.end() && it->first < end && !c->accel_dirty; ++it) mark_chunk_dirty(c, it->second);
 }
 
-// (Re)build the cell grid and brick pool from the node pool and chunk_roots when they changed (vrt_accel.hip): the whole
-// world, or — after a voxel edit or a chunk's arrival — only the chunks that were written, with no host round trip.
-static int ensure_accel(vrt_ctx *c) {
+// The cell grid and brick pool (vrt_accel.hip) follow the node pool and chunk_roots in two steps.
+//   ensure_accel_world  before a frame picks its frame set: the whole-world build when it is due (first frame, resized or
+//                       recentred grid, too many single-chunk updates since the last one) — on c->stream with the frames
+//                       in flight waited for, into tabs[0], copied to the other sets in use;
+//   update_tables       once the frame has its set and stream: the chunks dirtied since *that set* was last brought up to
+//                       date, rebuilt alone on the frame's own stream — nothing waits for the frames in flight, which read
+//                       other sets (or are earlier on this very stream).
+static int free_tables(vrt_ctx *c, vrt_ctx::Tables &T) {
+    (void)c;
+    (void)hipFree(T.d_grid); (void)hipFree(T.d_bricks); (void)hipFree(T.d_chunk_bricks); (void)hipFree(T.d_chunk_bases);
+    (void)hipFree(T.d_chunk_caps); (void)hipFree(T.d_brick_tail);
+    T.d_grid = nullptr; T.d_bricks = nullptr; T.d_chunk_bricks = T.d_chunk_bases = T.d_chunk_caps = T.d_brick_tail = nullptr;
+    T.grid_cap = 0; T.brick_cap = 0; T.chunk_cap = 0;
+    T.live = false;
+    return VRT_OK;
+}
+
+// tabs[k] becomes a copy of tabs[0] (device tables and host bookkeeping); everything on c->stream, the caller has waited
+// for the frames in flight.
+static int copy_tables_from_first(vrt_ctx *c, uint32_t k) {
+    auto &A = c->tabs[0];
+    auto &T = c->tabs[k];
+    const uint32_t S = c->accel_S, n_chunks = S * S * S;
+    const size_t G = (size_t)S * 8u, entries = G * (G + 1u) * (G + 1u);
+    if (T.grid_cap < entries) {
+        (void)hipFree(T.d_grid); T.d_grid = nullptr; T.grid_cap = 0;
+        HIP_TRY(c, hipMalloc(&T.d_grid, entries * sizeof(uint32_t)));
+        T.grid_cap = entries;
+    }
+    if (T.chunk_cap < n_chunks) {
+        (void)hipFree(T.d_chunk_bricks); (void)hipFree(T.d_chunk_bases); (void)hipFree(T.d_chunk_caps);
+        T.d_chunk_bricks = T.d_chunk_bases = T.d_chunk_caps = nullptr; T.chunk_cap = 0;
+        HIP_TRY(c, hipMalloc(&T.d_chunk_bricks, (size_t)n_chunks * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc(&T.d_chunk_bases, (size_t)n_chunks * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc(&T.d_chunk_caps, (size_t)n_chunks * sizeof(uint32_t)));
+        T.chunk_cap = n_chunks;
+    }
+    if (T.brick_cap != A.brick_cap || !T.d_bricks) {
+        (void)hipFree(T.d_bricks); T.d_bricks = nullptr; T.brick_cap = 0;
+        HIP_TRY(c, hipMalloc(&T.d_bricks, (size_t)A.brick_cap * 64u * sizeof(uint16_t)));
+        T.brick_cap = A.brick_cap;
+    }
+    if (!T.d_brick_tail) HIP_TRY(c, hipMalloc(&T.d_brick_tail, sizeof(uint32_t)));
+    HIP_TRY(c, hipMemcpyAsync(T.d_grid, A.d_grid, entries * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(T.d_chunk_bricks, A.d_chunk_bricks, (size_t)n_chunks * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(T.d_chunk_bases, A.d_chunk_bases, (size_t)n_chunks * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(T.d_chunk_caps, A.d_chunk_caps, (size_t)n_chunks * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(T.d_brick_tail, A.d_brick_tail, sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(T.d_bricks, A.d_bricks, (size_t)A.brick_cap * 64u * sizeof(uint16_t), hipMemcpyDeviceToDevice, c->stream));
+    T.chunk_may_have_moved = A.chunk_may_have_moved;
+    T.chunks_moved = A.chunks_moved;
+    T.chunk_builds = A.chunk_builds;
+    T.dirty_chunks = A.dirty_chunks;   // what tabs[0] has not caught up with yet, this copy has not either
+    T.chunk_is_dirty = A.chunk_is_dirty;
+    T.update_pending = false;
+    T.live = true;
+    return VRT_OK;
+}
+
+static int ensure_accel_world(vrt_ctx *c) {
     const uint32_t S = c->world.size_in_chunks;
-    if (!c->accel_dirty && c->accel_S == S && c->dirty_chunks.empty()) return VRT_OK;
     if (S > c->accel_max_s) {  // too large for the tables: nothing to keep up to date, the octree walk reads the pool itself
-        mark_all_dirty(c);
-        c->accel_ok = false;
-        c->accel_S = S;
-        c->accel_dirty = false;
+        if (c->accel_dirty || c->accel_S != S) {
+            mark_all_dirty(c);
+            c->accel_ok = false;
+            c->accel_S = S;
+            c->accel_dirty = false;
+        }
         return VRT_OK;
     }
-    if (!c->accel_dirty && c->accel_S == S && c->accel_ok) {
-        // single chunks; a chunk that outgrew its region moves to the tail once — make sure the tail has room for all of them
-        uint32_t fresh = 0;
-        for (uint32_t ch : c->dirty_chunks) fresh += c->chunk_may_have_moved[ch] ? 0u : 1u;
-        if (c->chunks_moved + fresh <= kTailChunks) {
-            int rc = order_after_frames(c);
-            if (rc) return rc;
-            // how far each chunk's nodes can reach: up to the next chunk's root (ChunkAlloc's ranges are disjoint); the kernel
-            // stages that much of the pool and reads anything beyond from the pool itself
-            refresh_roots_index(c);
-            std::vector<uint32_t> extents(c->dirty_chunks.size());
-            for (size_t i = 0; i < extents.size(); i++) {
-                const uint32_t r = c->dirty_chunks[i] < c->n_roots ? c->h_roots[c->dirty_chunks[i]] : 0u;
-                auto nx = std::upper_bound(c->roots_index.begin(), c->roots_index.end(), std::make_pair(r, 0xFFFFFFFFu));
-                const uint32_t end = nx != c->roots_index.end() ? nx->first : c->max_nodes;
-                extents[i] = r ? (end > r ? end - r : 0u) : 1u;   // (a missing chunk is node 0 alone: one air leaf)
-            }
-            vrt::launch_accel_chunks(c->d_nodes, c->max_nodes, c->d_roots, S, c->d_grid, c->d_chunk_bricks, c->d_chunk_bases,
-                                     c->d_chunk_caps, c->d_brick_tail, c->d_bricks, c->brick_cap, c->dirty_chunks.data(), extents.data(),
-                                     (uint32_t)c->dirty_chunks.size(), c->stream);
-            HIP_TRY(c, hipGetLastError());
-            for (uint32_t ch : c->dirty_chunks) {
-                if (!c->chunk_may_have_moved[ch]) { c->chunk_may_have_moved[ch] = 1; c->chunks_moved += 1; }
-                c->chunk_is_dirty[ch] = 0;
-            }
-            c->accel_chunk_builds += (uint32_t)c->dirty_chunks.size();
-            c->dirty_chunks.clear();
-            return publish_upload(c);
+    if (!c->accel_dirty && c->accel_S == S) {
+        if (!c->accel_ok) return VRT_OK;   // (the brick pool would be too large: stays off until something changes)
+        // single chunks; a chunk that outgrew its region moves to the tail once — every set's tail must have room for all of them
+        bool room = true;
+        for (uint32_t k = 0; k < vrt_ctx::kMaxInFlight; k++) {
+            const auto &T = c->tabs[k];
+            if (k && !T.live) continue;
+            uint32_t fresh = 0;
+            for (uint32_t ch : T.dirty_chunks) fresh += T.chunk_may_have_moved[ch] ? 0u : 1u;
+            room = room && T.chunks_moved + fresh <= kTailChunks;
         }
+        if (room) return VRT_OK;
     }
-    mark_all_dirty(c);   // (clears the chunk list: a whole-world build covers it)
+    mark_all_dirty(c);   // (clears the chunk lists: a whole-world build covers them)
     QUIESCE(c);  // frames on the other streams may still be reading the old tables; this path reads a count back anyway
+    {   // ... and the node pool and chunk_roots as uploaded so far
+        const int rc = wait_for_pool_uploads(c, c->stream, vrt_ctx::kMaxInFlight);
+        if (rc) return rc;
+    }
+    auto &A = c->tabs[0];
     c->accel_ok = false;
     c->accel_S = S;
     c->accel_dirty = false;
     const uint32_t n_chunks = S * S * S;
     const size_t G = (size_t)S * 8u;
     const size_t entries = G * (G + 1u) * (G + 1u);
-    if (entries > c->grid_cap) {
-        (void)hipFree(c->d_grid);
-        c->d_grid = nullptr; c->grid_cap = 0;
-        HIP_TRY(c, hipMalloc(&c->d_grid, entries * sizeof(uint32_t)));
-        c->grid_cap = entries;
+    if (entries > A.grid_cap) {
+        (void)hipFree(A.d_grid);
+        A.d_grid = nullptr; A.grid_cap = 0;
+        HIP_TRY(c, hipMalloc(&A.d_grid, entries * sizeof(uint32_t)));
+        A.grid_cap = entries;
     }
     // the border rows / entries are never written by the kernels: zero = "outside the world"
-    HIP_TRY(c, hipMemsetAsync(c->d_grid, 0, entries * sizeof(uint32_t), c->stream));
-    if (n_chunks > c->chunk_cap) {
-        (void)hipFree(c->d_chunk_bricks); (void)hipFree(c->d_chunk_bases); (void)hipFree(c->d_chunk_caps);
-        c->d_chunk_bricks = c->d_chunk_bases = c->d_chunk_caps = nullptr; c->chunk_cap = 0;
-        HIP_TRY(c, hipMalloc(&c->d_chunk_bricks, (size_t)n_chunks * sizeof(uint32_t)));
-        HIP_TRY(c, hipMalloc(&c->d_chunk_bases, (size_t)n_chunks * sizeof(uint32_t)));
-        HIP_TRY(c, hipMalloc(&c->d_chunk_caps, (size_t)n_chunks * sizeof(uint32_t)));
-        c->chunk_cap = n_chunks;
+    HIP_TRY(c, hipMemsetAsync(A.d_grid, 0, entries * sizeof(uint32_t), c->stream));
+    if (n_chunks > A.chunk_cap) {
+        (void)hipFree(A.d_chunk_bricks); (void)hipFree(A.d_chunk_bases); (void)hipFree(A.d_chunk_caps);
+        A.d_chunk_bricks = A.d_chunk_bases = A.d_chunk_caps = nullptr; A.chunk_cap = 0;
+        HIP_TRY(c, hipMalloc(&A.d_chunk_bricks, (size_t)n_chunks * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc(&A.d_chunk_bases, (size_t)n_chunks * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc(&A.d_chunk_caps, (size_t)n_chunks * sizeof(uint32_t)));
+        A.chunk_cap = n_chunks;
     }
     if (!c->d_brick_total) HIP_TRY(c, hipMalloc(&c->d_brick_total, sizeof(uint32_t)));
-    if (!c->d_brick_tail) HIP_TRY(c, hipMalloc(&c->d_brick_tail, sizeof(uint32_t)));
+    if (!A.d_brick_tail) HIP_TRY(c, hipMalloc(&A.d_brick_tail, sizeof(uint32_t)));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     HIP_TRY(c, hipEventCreate(&e0));
     HIP_TRY(c, hipEventCreate(&e1));
     auto body = [&]() -> int {
         HIP_TRY(c, hipEventRecord(e0, c->stream));
-        vrt::launch_accel_cells(c->d_nodes, c->max_nodes, c->d_roots, S, c->d_grid, c->d_chunk_bricks, c->d_chunk_bases, c->d_chunk_caps,
-                                c->d_brick_total, c->d_brick_tail, c->stream);
+        vrt::launch_accel_cells(c->d_nodes, c->max_nodes, c->d_roots, S, A.d_grid, A.d_chunk_bricks, A.d_chunk_bases, A.d_chunk_caps,
+                                c->d_brick_total, A.d_brick_tail, c->stream);
         HIP_TRY(c, hipGetLastError());
         uint32_t total = 0;  // bricks in all chunk regions (counts + slack)
         HIP_TRY(c, hipMemcpyAsync(&total, c->d_brick_total, sizeof total, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         const uint64_t want = (uint64_t)total + (uint64_t)kTailChunks * 512u;
         if (want > kAccelMaxBricks) return VRT_OK;  // accel_ok stays false
-        if (want > c->brick_cap || !c->d_bricks) {
-            (void)hipFree(c->d_bricks);
-            c->d_bricks = nullptr; c->brick_cap = 0;
+        if (want > A.brick_cap || !A.d_bricks) {
+            (void)hipFree(A.d_bricks);
+            A.d_bricks = nullptr; A.brick_cap = 0;
             uint64_t cap = want + total / 4u;  // room to grow before the next reallocation
             if (cap > kAccelMaxBricks) cap = kAccelMaxBricks;
-            HIP_TRY(c, hipMalloc(&c->d_bricks, (size_t)cap * 64u * sizeof(uint16_t)));
-            c->brick_cap = (uint32_t)cap;
+            HIP_TRY(c, hipMalloc(&A.d_bricks, (size_t)cap * 64u * sizeof(uint16_t)));
+            A.brick_cap = (uint32_t)cap;
         }
-        vrt::launch_accel_bricks(c->d_nodes, c->max_nodes, c->d_roots, S, c->d_grid, c->d_chunk_bases, c->d_bricks, c->brick_cap,
-                                 c->stream);
+        vrt::launch_accel_bricks(c->d_nodes, c->max_nodes, c->d_roots, S, A.d_grid, A.d_chunk_bases, A.d_bricks, A.brick_cap, c->stream);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipEventRecord(e1, c->stream));
         HIP_TRY(c, hipEventSynchronize(e1));
@@ -539,8 +661,15 @@ static int ensure_accel(vrt_ctx *c) {
         c->n_bricks = total;
         c->accel_builds += 1;
         c->accel_ok = true;
-        std::fill(c->chunk_may_have_moved.begin(), c->chunk_may_have_moved.end(), (uint8_t)0);
-        c->chunks_moved = 0;
+        std::fill(A.chunk_may_have_moved.begin(), A.chunk_may_have_moved.end(), (uint8_t)0);
+        A.chunks_moved = 0;
+        A.update_pending = false;
+        A.live = true;
+        for (uint32_t k = 1; k < vrt_ctx::kMaxInFlight; k++)   // the other sets in use start over as copies
+            if (c->tabs[k].live) {
+                const int rc = copy_tables_from_first(c, k);
+                if (rc) return rc;
+            }
         return publish_upload(c);
     };
     const int rc = body();
@@ -548,6 +677,61 @@ static int ensure_accel(vrt_ctx *c) {
     (void)hipEventDestroy(e1);
     if (rc) c->accel_dirty = true;
     return rc;
+}
+
+// The frame about to be enqueued on `st` uses table set `k`: bring it up to date there.  `st` has been made to wait for the
+// uploads so far (frame_waits_for_uploads).
+static int update_tables(vrt_ctx *c, uint32_t k, hipStream_t st) {
+    if (!c->accel_ok || c->accel_dirty) return VRT_OK;
+    auto &T = c->tabs[k];
+    if (!T.live) {   // this frame set's first frame since the last whole-world build of a smaller crowd: a copy of tabs[0]
+        // (wait for the frames in flight; the frame about to be enqueued has already been announced on its stream)
+        const bool alt = c->alt_pending, own = c->own_pending;
+        QUIESCE(c);
+        c->alt_pending = alt;
+        c->own_pending = own;
+        {
+            const int rc = wait_for_pool_uploads(c, c->stream, vrt_ctx::kMaxInFlight);
+            if (rc) return rc;
+        }
+        if (c->tabs[0].update_pending) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->tabs[0].ev_updated, 0));
+        int rc = copy_tables_from_first(c, k);
+        if (rc) return rc;
+        rc = publish_upload(c);
+        if (rc) return rc;
+        if (st != c->stream) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_upload, 0));
+    }
+    if (T.dirty_chunks.empty()) return VRT_OK;
+    if (k == 0u && c->shared_readers_in_flight) {   // frames of other frame sets still read this set (it was shared until now)
+        const bool alt = c->alt_pending, own = c->own_pending;
+        QUIESCE(c);
+        c->alt_pending = alt;
+        c->own_pending = own;
+    }
+    // how far each chunk's nodes can reach: up to the next chunk's root (ChunkAlloc's ranges are disjoint); the kernel
+    // stages that much of the pool and reads anything beyond from the pool itself
+    refresh_roots_index(c);
+    std::vector<uint32_t> extents(T.dirty_chunks.size());
+    for (size_t i = 0; i < extents.size(); i++) {
+        const uint32_t r = T.dirty_chunks[i] < c->n_roots ? c->h_roots[T.dirty_chunks[i]] : 0u;
+        auto nx = std::upper_bound(c->roots_index.begin(), c->roots_index.end(), std::make_pair(r, 0xFFFFFFFFu));
+        const uint32_t end = nx != c->roots_index.end() ? nx->first : c->max_nodes;
+        extents[i] = r ? (end > r ? end - r : 0u) : 1u;   // (a missing chunk is node 0 alone: one air leaf)
+    }
+    vrt::launch_accel_chunks(c->d_nodes, c->max_nodes, c->d_roots, c->accel_S, T.d_grid, T.d_chunk_bricks, T.d_chunk_bases, T.d_chunk_caps,
+                             T.d_brick_tail, T.d_bricks, T.brick_cap, T.dirty_chunks.data(), extents.data(), (uint32_t)T.dirty_chunks.size(), st);
+    HIP_TRY(c, hipGetLastError());
+    // the next upload of nodes or roots waits for this reader
+    if (!T.ev_updated) HIP_TRY(c, hipEventCreateWithFlags(&T.ev_updated, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(T.ev_updated, st));
+    T.update_pending = true;
+    for (uint32_t ch : T.dirty_chunks) {
+        if (!T.chunk_may_have_moved[ch]) { T.chunk_may_have_moved[ch] = 1; T.chunks_moved += 1; }
+        T.chunk_is_dirty[ch] = 0;
+    }
+    T.chunk_builds += (uint32_t)T.dirty_chunks.size();
+    T.dirty_chunks.clear();
+    return VRT_OK;
 }
 
 // ---- one context over several devices (vrt_config.n_devices > 1); defined behind the C ABI below ----
@@ -641,6 +825,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         HIP_TRY(c, hipMalloc(&c->d_nodes, (size_t)c->max_nodes * sizeof(uint16_t)));
         // fresh buffer = zeros = every node an air leaf (client/src/world.rs:273-274)
         HIP_TRY(c, hipMemsetAsync(c->d_nodes, 0, (size_t)c->max_nodes * sizeof(uint16_t), c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));   // (uploads run on their own stream)
         HIP_TRY(c, hipMalloc(&c->d_mats, sizeof c->h_mats));
         HIP_TRY(c, hipMemsetAsync(c->d_mats, 0, sizeof c->h_mats, c->stream));
         HIP_TRY(c, hipMalloc(&c->d_counters, kCounterBytes));
@@ -667,6 +852,8 @@ void vrt_destroy(vrt_ctx *c) {
     if (c->grp) { grp_destroy(c); return; }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    if (c->up_stream) (void)hipStreamSynchronize(c->up_stream);
     for (hipStream_t st : c->extra_stream)
         if (st) (void)hipStreamSynchronize(st);
     for (auto p : c->extra_out) (void)hipFree(p);
@@ -683,11 +870,18 @@ void vrt_destroy(vrt_ctx *c) {
     (void)hipFree(c->d_nodes); (void)hipFree(c->d_roots); (void)hipFree(c->d_mats); (void)hipFree(c->own_out);
     (void)hipFree(c->d_hits); (void)hipFree(c->d_counters); (void)hipFree(c->d_steps); (void)hipFree(c->d_rgba8); (void)hipFree(c->d_path);
     (void)hipFree(c->d_blk_counts); (void)hipFree(c->d_clock);
-    (void)hipFree(c->d_grid); (void)hipFree(c->d_bricks); (void)hipFree(c->d_chunk_bricks); (void)hipFree(c->d_chunk_bases);
-    (void)hipFree(c->d_chunk_caps); (void)hipFree(c->d_brick_tail); (void)hipFree(c->d_brick_total);
+    for (auto &T : c->tabs) {
+        (void)free_tables(c, T);
+        if (T.ev_updated) (void)hipEventDestroy(T.ev_updated);
+    }
+    (void)hipFree(c->d_brick_total);
+    if (c->up_stream) { (void)hipStreamSynchronize(c->up_stream); (void)hipStreamDestroy(c->up_stream); }
+    if (c->ev_pool_upload) (void)hipEventDestroy(c->ev_pool_upload);
+    if (c->ev_walkers) (void)hipEventDestroy(c->ev_walkers);
     if (c->h_ring) (void)hipHostFree(c->h_ring);
-    for (auto ev : c->ring_ev)
-        if (ev) (void)hipEventDestroy(ev);
+    for (auto &evs : c->ring_ev)
+        for (auto ev : evs)
+            if (ev) (void)hipEventDestroy(ev);
     if (c->ev_frames) (void)hipEventDestroy(c->ev_frames);
     if (c->ev_upload) (void)hipEventDestroy(c->ev_upload); (void)hipFree(c->d_ndc); (void)hipFree(c->d_screen); (void)hipFree(c->d_heads);
     for (auto &t : c->ev_pool)
@@ -715,7 +909,7 @@ int vrt_write_nodes(vrt_ctx *c, const uint16_t *pool, uint32_t start, uint32_t e
     HIP_TRY(c, hipSetDevice(c->device));
     // copy-at-call-time (write_buffer semantics: the caller may reuse `pool` as soon as this returns) through the pinned
     // ring, ordered after the frames in flight without waiting for them
-    const int rc = stage_upload(c, c->d_nodes + root, pool + root, (size_t)count * sizeof(uint16_t));
+    const int rc = stage_upload(c, c->d_nodes + root, pool + root, (size_t)count * sizeof(uint16_t), true);
     if (rc) return rc;
     mark_node_range_dirty(c, start, end);   // (the widening repeats a neighbour's node: nothing of its octree changes)
     return VRT_OK;
@@ -731,7 +925,7 @@ int vrt_write_chunk_roots(vrt_ctx *c, uint32_t offset, const uint32_t *roots, ui
     // the reference rewrites the whole table every frame (main.rs:446); an identical rewrite changes nothing
     if (memcmp(c->h_roots.data() + offset, roots, (size_t)cut * sizeof(uint32_t)) == 0) return VRT_OK;
     HIP_TRY(c, hipSetDevice(c->device));
-    const int rc = stage_upload(c, c->d_roots + offset, roots, (size_t)cut * sizeof(uint32_t));
+    const int rc = stage_upload(c, c->d_roots + offset, roots, (size_t)cut * sizeof(uint32_t), true);
     if (rc) return rc;
     // the slots whose root changed are the chunks to rebuild (a chunk arrived or was dropped); a recentred grid changes
     // nearly all of them and becomes a whole-world build
@@ -1238,7 +1432,7 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
         variant = 1u;
     }
     if (variant == 0u || variant == 3u || variant == 4u || (o.mode == VRT_MODE_PATH && !air_liquid)) {
-        rc = ensure_accel(c);
+        rc = ensure_accel_world(c);
         if (rc) return rc;
         if (!c->accel_ok && (variant == 0u || variant == 3u || variant == 4u)) variant = 2u;  // world too large for the tables: walk the octree
     }
@@ -1252,9 +1446,34 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     c->last_out = f.out;
     c->last_blk = f.blk;
     c->last_stream = f.st;
+    c->last_slot = f.slot;
     if (c->wait_before_frame) {
         HIP_TRY(c, hipStreamWaitEvent(f.st, c->wait_before_frame, 0));
         c->wait_before_frame = nullptr;
+    }
+
+    // this frame's table set, brought up to date on its own stream (which waits for the uploads so far first)
+    const bool wants_tables = variant == 0u || variant == 3u || variant == 4u || (o.mode == VRT_MODE_PATH && !air_liquid);
+    constexpr uint32_t kQuietFrames = 64;
+    if (c->tables_split && ++c->quiet_frames > kQuietFrames && c->tabs[0].dirty_chunks.empty()) {
+        c->tables_split = false;   // no edit for a while: everybody reads tabs[0] again; the other sets go stale
+        for (uint32_t k = 1; k < vrt_ctx::kMaxInFlight; k++) c->tabs[k].live = false;
+    }
+    const uint32_t tab = c->tables_split ? f.slot : 0u;
+    const vrt_ctx::Tables &T = c->tabs[tab];
+    c->last_tab = tab;
+    if (wants_tables && c->accel_ok) {
+        rc = frame_waits_for_uploads(c, f.st, f.slot);
+        if (rc) return rc;
+        rc = update_tables(c, tab, f.st);
+        if (rc) return rc;
+        if (tab == 0u && f.slot != 0u) {   // the shared set from another frame set's stream: behind its last update
+            if (c->tabs[0].update_pending && f.st != c->stream) HIP_TRY(c, hipStreamWaitEvent(f.st, c->tabs[0].ev_updated, 0));
+            c->shared_readers_in_flight = true;
+        }
+    } else {
+        rc = frame_waits_for_uploads(c, f.st, f.slot);   // (a frame on c->stream too: the node pool's uploads have their own stream)
+        if (rc) return rc;
     }
 
     vrt::FrameParams P;
@@ -1262,14 +1481,16 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     P.nodes = c->d_nodes;
     P.roots = c->d_roots;
     P.mats = c->d_mats;
-    if (c->accel_ok && c->accel_S == c->world.size_in_chunks && !c->accel_dirty && c->dirty_chunks.empty() && !air_liquid) {
-        P.grid = c->d_grid;
-        P.bricks = c->d_bricks;
+    if (wants_tables && c->accel_ok && c->accel_S == c->world.size_in_chunks && !c->accel_dirty && T.live && T.dirty_chunks.empty() && !air_liquid) {
+        P.grid = T.d_grid;
+        P.bricks = T.d_bricks;
         P.grid_dim = c->accel_S * 8u;
         const size_t G = (size_t)c->accel_S * 8u;
         P.grid_bytes = (uint32_t)(G * (G + 1u) * (G + 1u) * sizeof(uint32_t));  // [8S][8S+1][8S+1]: the zero border
-        P.brick_bytes = (uint32_t)((size_t)c->brick_cap * 64u * sizeof(uint16_t));
+        P.brick_bytes = (uint32_t)((size_t)T.brick_cap * 64u * sizeof(uint16_t));
     }
+    // a march that walks the octree reads the node pool and chunk_roots: uploads then wait for the frames in flight
+    if (!P.grid || variant == 1u || variant == 2u) c->walkers_in_flight = true;
     P.out = f.out;
     P.hits = c->d_hits;
     P.blk_counts = f.blk;
@@ -1309,6 +1530,9 @@ int vrt_synchronize(vrt_ctx *c) {
     HIP_TRY(c, hipSetDevice(c->device));
     QUIESCE(c);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->up_stream) HIP_TRY(c, hipStreamSynchronize(c->up_stream));
+    c->walkers_in_flight = false;   // nothing is in flight any more
+    for (auto &T : c->tabs) T.update_pending = false;
     return VRT_OK;
 }
 
@@ -1464,13 +1688,28 @@ int vrt_get_stats(vrt_ctx *c, vrt_stats *out) {
     return VRT_OK;
 }
 
-// Bricks of the pool in use: the chunks' regions plus the tail regions of chunks that moved.
-static int bricks_in_use(vrt_ctx *c, uint32_t *n) {
-    *n = 0;
-    if (!c->accel_ok || !c->d_brick_tail) return VRT_OK;
-    HIP_TRY(c, hipMemcpyAsync(n, c->d_brick_tail, sizeof *n, hipMemcpyDeviceToHost, c->stream));
+// tabs[0] is what vrt_get_accel_info / vrt_read_accel report: apply what it has not caught up with (the frames since may
+// have run on other frame sets).  Waits for the frames in flight.
+static int first_tables_up_to_date(vrt_ctx *c) {
+    if (!c->accel_ok || c->accel_dirty || !c->tabs[0].live) return VRT_OK;
+    QUIESCE(c);
+    int rc = wait_for_pool_uploads(c, c->stream, vrt_ctx::kMaxInFlight);
+    if (rc) return rc;
+    if (c->ev_upload && c->stream != c->own_stream) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_upload, 0));
+    rc = update_tables(c, 0, c->stream);
+    if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (*n > c->brick_cap) *n = c->brick_cap;
+    return VRT_OK;
+}
+
+// Bricks of the pool in use: the chunks' regions plus the tail regions of chunks that moved.
+static int bricks_in_use(vrt_ctx *c, const vrt_ctx::Tables &T, uint32_t *n) {
+    *n = 0;
+    if (!c->accel_ok || !T.live || !T.d_brick_tail) return VRT_OK;
+    QUIESCE(c);   // (the set's last update may be on another frame stream)
+    HIP_TRY(c, hipMemcpyAsync(n, T.d_brick_tail, sizeof *n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (*n > T.brick_cap) *n = T.brick_cap;
     return VRT_OK;
 }
 
@@ -1479,42 +1718,48 @@ int vrt_get_accel_info(vrt_ctx *c, vrt_accel_info *out) {
     if (!c || !out) return fail(c, VRT_ERR_INVALID_ARG, "vrt_get_accel_info: null argument");
     memset(out, 0, sizeof *out);
     HIP_TRY(c, hipSetDevice(c->device));
-    const bool up_to_date = c->accel_ok && !c->accel_dirty && c->dirty_chunks.empty();
+    // (as of the table set the last frame used; the other sets catch up when their frame set renders next)
+    const vrt_ctx::Tables &L = c->tabs[c->last_tab];
+    const bool up_to_date = c->accel_ok && !c->accel_dirty && L.live && L.dirty_chunks.empty();
     out->available = up_to_date ? 1u : 0u;
     out->world_size_chunks = c->accel_S;
     out->cells = (uint64_t)c->accel_S * c->accel_S * c->accel_S * 512u;
     uint32_t used = 0;
-    const int rc = bricks_in_use(c, &used);
+    const int rc = bricks_in_use(c, L, &used);
     if (rc) return rc;
     out->bricks = used;
     const uint64_t G = (uint64_t)c->accel_S * 8u;
     out->bytes = G * (G + 1u) * (G + 1u) * sizeof(uint32_t) + (uint64_t)used * 64u * sizeof(uint16_t);
     out->builds = c->accel_builds;
     out->last_build_ms = c->accel_last_ms;
-    out->chunk_builds = c->accel_chunk_builds;
+    for (const auto &T : c->tabs)
+        if (T.live && T.chunk_builds > out->chunk_builds) out->chunk_builds = T.chunk_builds;   // every set rebuilds every dirty chunk once
     return VRT_OK;
 }
 
 int vrt_read_accel(vrt_ctx *c, uint32_t *grid, uint16_t *bricks) {
     GRP_ROOT(c, vrt_read_accel(d, grid, bricks));
     if (!c) return VRT_ERR_INVALID_ARG;
-    if (!c->accel_ok || c->accel_dirty || !c->dirty_chunks.empty())
+    if (!c->accel_ok || c->accel_dirty)
         return fail(c, VRT_ERR_STATE, "vrt_read_accel: the tables are not up to date (render a frame first)");
     HIP_TRY(c, hipSetDevice(c->device));
-    QUIESCE(c);
+    {
+        const int rc = first_tables_up_to_date(c);   // (the last frame may have used another frame set's tables)
+        if (rc) return rc;
+    }
     const size_t G = (size_t)c->accel_S * 8u, G1 = G + 1u;
     if (grid) {  // the device layout carries a zero border row / entry ([G][G+1][G+1]); the caller gets the G^3 cells
         std::vector<uint32_t> t(G * G1 * G1);
-        HIP_TRY(c, hipMemcpyAsync(t.data(), c->d_grid, t.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(t.data(), c->tabs[0].d_grid, t.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         for (size_t z = 0; z < G; z++)
             for (size_t y = 0; y < G; y++) memcpy(grid + (z * G + y) * G, t.data() + (z * G1 + y) * G1, G * sizeof(uint32_t));
     }
     uint32_t used = 0;
-    const int rc = bricks_in_use(c, &used);
+    const int rc = bricks_in_use(c, c->tabs[0], &used);
     if (rc) return rc;
     if (bricks && used)
-        HIP_TRY(c, hipMemcpyAsync(bricks, c->d_bricks, (size_t)used * 64u * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(bricks, c->tabs[0].d_bricks, (size_t)used * 64u * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return VRT_OK;
 }
