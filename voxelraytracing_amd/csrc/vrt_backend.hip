@@ -420,9 +420,15 @@ static int stage_upload(vrt_ctx *c, void *dst, const void *src, size_t bytes, bo
         if (!c->up_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
         if (!c->ev_pool_upload) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_pool_upload, hipEventDisableTiming));
         st = c->up_stream;
-        if (c->ev_upload) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_upload, 0));   // whole-world builds and the other uploads so far
+        // whole-world builds and the other uploads so far, every set's last update — those that are not over yet (a wait is
+        // a barrier packet on the stream, a query is a load)
+        if (c->ev_upload && hipEventQuery(c->ev_upload) != hipSuccess) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_upload, 0));
         for (auto &T : c->tabs)
-            if (T.update_pending) HIP_TRY(c, hipStreamWaitEvent(st, T.ev_updated, 0));
+            if (T.update_pending) {
+                if (hipEventQuery(T.ev_updated) == hipSuccess) T.update_pending = false;
+                else HIP_TRY(c, hipStreamWaitEvent(st, T.ev_updated, 0));
+            }
+        (void)hipGetLastError();   // (hipErrorNotReady from the queries is not an error)
         if (c->walkers_in_flight) {
             const int rc = order_after_frames(c, st);
             if (rc) return rc;
