@@ -543,7 +543,7 @@ static int free_tables(vrt_ctx *c, vrt_ctx::Tables &T) {
 
 // tabs[k] becomes a copy of tabs[0] (device tables and host bookkeeping); everything on c->stream, the caller has waited
 // for the frames in flight.
-static int copy_tables_from_first(vrt_ctx *c, uint32_t k) {
+static int alloc_tables_like_first(vrt_ctx *c, uint32_t k) {
     auto &A = c->tabs[0];
     auto &T = c->tabs[k];
     const uint32_t S = c->accel_S, n_chunks = S * S * S;
@@ -567,6 +567,18 @@ static int copy_tables_from_first(vrt_ctx *c, uint32_t k) {
         T.brick_cap = A.brick_cap;
     }
     if (!T.d_brick_tail) HIP_TRY(c, hipMalloc(&T.d_brick_tail, sizeof(uint32_t)));
+    return VRT_OK;
+}
+
+static int copy_tables_from_first(vrt_ctx *c, uint32_t k) {
+    auto &A = c->tabs[0];
+    auto &T = c->tabs[k];
+    const uint32_t S = c->accel_S, n_chunks = S * S * S;
+    const size_t G = (size_t)S * 8u, entries = G * (G + 1u) * (G + 1u);
+    {
+        const int rc = alloc_tables_like_first(c, k);
+        if (rc) return rc;
+    }
     HIP_TRY(c, hipMemcpyAsync(T.d_grid, A.d_grid, entries * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(T.d_chunk_bricks, A.d_chunk_bricks, (size_t)n_chunks * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(T.d_chunk_bases, A.d_chunk_bases, (size_t)n_chunks * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
@@ -671,11 +683,15 @@ static int ensure_accel_world(vrt_ctx *c) {
         A.chunks_moved = 0;
         A.update_pending = false;
         A.live = true;
-        for (uint32_t k = 1; k < vrt_ctx::kMaxInFlight; k++)   // the other sets in use start over as copies
+        for (uint32_t k = 1; k < vrt_ctx::kMaxInFlight; k++) {   // the other sets in use start over as copies
             if (c->tabs[k].live) {
                 const int rc = copy_tables_from_first(c, k);
                 if (rc) return rc;
+            } else if (k < c->in_flight) {   // (memory for the sets the first edit will want: an allocation is milliseconds)
+                const int rc = alloc_tables_like_first(c, k);
+                if (rc) return rc;
             }
+        }
         return publish_upload(c);
     };
     const int rc = body();
@@ -832,6 +848,11 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         // fresh buffer = zeros = every node an air leaf (client/src/world.rs:273-274)
         HIP_TRY(c, hipMemsetAsync(c->d_nodes, 0, (size_t)c->max_nodes * sizeof(uint16_t), c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));   // (uploads run on their own stream)
+        // the upload path's fixtures now, not at the first edit (a mapped pinned allocation is tens of milliseconds)
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_pool_upload, hipEventDisableTiming));
+        HIP_TRY(c, hipHostMalloc((void **)&c->h_ring, vrt_ctx::kRingSegBytes * vrt_ctx::kRingSegs, hipHostMallocMapped));
+        HIP_TRY(c, hipHostGetDevicePointer((void **)&c->d_ring, c->h_ring, 0));
         HIP_TRY(c, hipMalloc(&c->d_mats, sizeof c->h_mats));
         HIP_TRY(c, hipMemsetAsync(c->d_mats, 0, sizeof c->h_mats, c->stream));
         HIP_TRY(c, hipMalloc(&c->d_counters, kCounterBytes));
