@@ -144,11 +144,8 @@ __global__ void __launch_bounds__(256) path_primary_kernel(FrameParams P) {
     stage_lds(P, s_roots, s_liquid, LDS_ROOTS);
 
     const uint32_t lane = threadIdx.x & 63u;
-    // wave = one tile of one sample: the chain's samples one after the other (P.chain = 1 unless P.acc)
-    const uint32_t t_all = blockIdx.x * 4u + (threadIdx.x >> 6);
-    const bool live = t_all < P.tiles_local * P.chain;
-    const uint32_t s_local = live && P.chain > 1u ? t_all / P.tiles_local : 0u, t_local = t_all - s_local * P.tiles_local;
-    const uint32_t sample = P.sample + s_local;
+    const uint32_t t_local = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const bool live = t_local < P.tiles_local;
     if (blockIdx.x == 0 && P.seg_clear) P.seg_clear[threadIdx.x * kSegStride] = 0u;   // kHitSegments == blockDim.x cursors
     if (!STATS && !live) return;
     MarchResult R;
@@ -157,49 +154,47 @@ __global__ void __launch_bounds__(256) path_primary_kernel(FrameParams P) {
         const uint32_t tile = shard_tile(t_local, P.shard_first, P.shard_run, P.shard_period);
         const uint32_t px = (tile % P.tiles_x) * 8u + (lane & 7u);
         const uint32_t py = (tile / P.tiles_x) * 8u + (lane >> 3);
-        PathState st;
-        st.slot = P.tile_major ? t_local * 64u + lane : py * P.width + px;
-        create_ray(P, (int)px, (int)py, st.origin, st.dir);
-        st.thr = V3{1.0f, 1.0f, 1.0f};
-        // seed: path_tracer.wgsl:328 (y*W + x) + the per-sample stride and frame seed of SURVEY §8d
-        st.rng = py * P.width + px + sample * (P.width * P.height) + P.seed * 0x9E3779B9u;
-        const V3 o0 = st.origin, d0 = st.dir;
-        V3 light{0.f, 0.f, 0.f};
-        bool missed;
-        const bool alive = path_segment<MARCH, LDS_ROOTS, STATS>(P, s_roots, s_liquid, st, R, light, missed) && !P.last_bounce;
-        if (P.acc) {
-            // this sample's own plane: its light so far and, for the frame's first sample, the id word (0 otherwise);
-            // the path's later segments find the plane through the slot
-            uint32_t id = 0u;
-            if (sample == 0u) {
-                id = R.voxel & VRT_ID_VOXEL_MASK;
-                if (R.hit) id |= VRT_ID_HIT;
-                if (R.norm.x != 0.0f) id |= VRT_ID_NX;
-                if (R.norm.y != 0.0f) id |= VRT_ID_NY;
-                if (R.norm.z != 0.0f) id |= VRT_ID_NZ;
-                if (R.water_dist != 0.0f) id |= VRT_ID_WATER;
+        const uint32_t pixel_slot = P.tile_major ? t_local * 64u + lane : py * P.width + px;
+        V3 origin, dir;
+        create_ray(P, (int)px, (int)py, origin, dir);
+        // every sample of a pixel starts with the same ray (the samples differ from their first bounce on: the RNG is not
+        // asked before a hit), so the primary segment is marched once for all the samples of this launch chain
+        R = march<MARCH, LDS_ROOTS, STATS>(P, s_roots, s_liquid, origin, dir);
+        uint32_t id0 = R.voxel & VRT_ID_VOXEL_MASK;   // the id word of the primary segment, composed as shade() does
+        if (R.hit) id0 |= VRT_ID_HIT;
+        if (R.norm.x != 0.0f) id0 |= VRT_ID_NX;
+        if (R.norm.y != 0.0f) id0 |= VRT_ID_NY;
+        if (R.norm.z != 0.0f) id0 |= VRT_ID_NZ;
+        if (R.water_dist != 0.0f) id0 |= VRT_ID_WATER;
+        for (uint32_t s_local = 0; s_local < P.chain; s_local++) {   // (P.chain = 1 unless P.acc)
+            const uint32_t sample = P.sample + s_local;
+            PathState st;
+            st.slot = pixel_slot;
+            st.origin = origin;
+            st.dir = dir;
+            st.thr = V3{1.0f, 1.0f, 1.0f};
+            // seed: path_tracer.wgsl:328 (y*W + x) + the per-sample stride and frame seed of SURVEY §8d
+            st.rng = py * P.width + px + sample * (P.width * P.height) + P.seed * 0x9E3779B9u;
+            V3 light{0.f, 0.f, 0.f};
+            bool missed;
+            const bool alive = path_after_march(P, st, R, light, missed) && !P.last_bounce;
+            if (P.acc) {
+                // this sample's own plane: its light so far and, for the frame's first sample, the id word (0 otherwise);
+                // the path's later segments find the plane through the slot
+                st.slot += s_local * P.acc_slots;
+                P.acc[st.slot] = make_uint4(__float_as_uint(light.x), __float_as_uint(light.y), __float_as_uint(light.z), sample == 0u ? id0 : 0u);
+            } else if (P.sample == 0u) {
+                P.out[st.slot] = make_uint4(__float_as_uint(light.x), __float_as_uint(light.y), __float_as_uint(light.z), id0);
+            } else if (missed) {
+                uint4 t = P.out[st.slot];
+                t.x = __float_as_uint(__uint_as_float(t.x) + light.x);
+                t.y = __float_as_uint(__uint_as_float(t.y) + light.y);
+                t.z = __float_as_uint(__uint_as_float(t.z) + light.z);
+                P.out[st.slot] = t;
             }
-            st.slot += s_local * P.acc_slots;
-            P.acc[st.slot] = make_uint4(__float_as_uint(light.x), __float_as_uint(light.y), __float_as_uint(light.z), id);
-        } else if (P.sample == 0u) {
-            // the id word of the primary segment, composed as shade() does
-            uint32_t id = R.voxel & VRT_ID_VOXEL_MASK;
-            if (R.hit) id |= VRT_ID_HIT;
-            if (R.norm.x != 0.0f) id |= VRT_ID_NX;
-            if (R.norm.y != 0.0f) id |= VRT_ID_NY;
-            if (R.norm.z != 0.0f) id |= VRT_ID_NZ;
-            if (R.water_dist != 0.0f) id |= VRT_ID_WATER;
-            P.out[st.slot] = make_uint4(__float_as_uint(light.x), __float_as_uint(light.y), __float_as_uint(light.z), id);
-        } else if (missed) {
-            uint4 t = P.out[st.slot];
-            t.x = __float_as_uint(__uint_as_float(t.x) + light.x);
-            t.y = __float_as_uint(__uint_as_float(t.y) + light.y);
-            t.z = __float_as_uint(__uint_as_float(t.z) + light.z);
-            P.out[st.slot] = t;
+            append_paths(P, alive, st, lane);
         }
-        (void)o0; (void)d0;
-        append_paths(P, alive, st, lane);
-        if (STATS && P.steps && P.sample == 0u) P.steps[st.slot] = R.iters;
+        if (STATS && P.steps && P.sample == 0u) P.steps[pixel_slot] = R.iters;
     }
     if (STATS) {
         block_add(s_acc, 0, R.iters);
@@ -1091,7 +1086,7 @@ static size_t lds_bytes_path(const FrameParams &P, bool lds_roots) { return (24u
 
 void launch_path_primary(const FrameParams &P, bool stats, bool literal, hipStream_t st) {
     if (P.tiles_local == 0) return;
-    const dim3 grid((P.tiles_local * P.chain + 3u) / 4u), block(256);
+    const dim3 grid((P.tiles_local + 3u) / 4u), block(256);
     VRT_PATH_LAUNCH(path_primary_kernel);
 }
 
