@@ -1253,7 +1253,7 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
     // 2.7 rays per lane are not enough to cover a bounce launch's tail — and a frame of 16 spp is 4 x 4
     // launches instead of 16 x 4.  Each sample accumulates into its own plane; the chain's finishing pass adds the planes
     // to the frame in sample order, which is the order one sample per chain adds them in.
-    const uint32_t samples = (spp > 1u && !kstats && bounces > 0) ? (spp < c->path_samples ? spp : c->path_samples) : 1u;
+    const uint32_t samples = (spp > 1u && !kstats && !literal && P.grid && bounces > 0) ? (spp < c->path_samples ? spp : c->path_samples) : 1u;
     const bool planes = samples > 1u;
     const uint32_t seg_cap = c->hit_seg_cap * samples;
     const size_t cap = (size_t)vrt::kHitSegments * seg_cap;

@@ -135,7 +135,8 @@ __device__ __forceinline__ void append_paths(const FrameParams &P, bool alive, c
 static_assert(kHitSegments == 256, "a launch's first workgroup (256 threads) clears the next launch's 256 segment cursors");
 
 // Bounce 0: primary rays of sample P.sample. Sample 0 initialises the texel {light, id}; later samples add.
-template <int MARCH, bool LDS_ROOTS, bool STATS>
+// MULTI: the samples of a launch chain (P.acc, P.chain) share the primary march; otherwise one sample, straight into `out`
+template <int MARCH, bool LDS_ROOTS, bool STATS, bool MULTI = false>
 __global__ void __launch_bounds__(256) path_primary_kernel(FrameParams P) {
     extern __shared__ uint32_t smem[];
     uint32_t *s_liquid = smem, *s_roots = smem + 24;
@@ -166,7 +167,7 @@ __global__ void __launch_bounds__(256) path_primary_kernel(FrameParams P) {
         if (R.norm.y != 0.0f) id0 |= VRT_ID_NY;
         if (R.norm.z != 0.0f) id0 |= VRT_ID_NZ;
         if (R.water_dist != 0.0f) id0 |= VRT_ID_WATER;
-        for (uint32_t s_local = 0; s_local < P.chain; s_local++) {   // (P.chain = 1 unless P.acc)
+        for (uint32_t s_local = 0; s_local < (MULTI ? P.chain : 1u); s_local++) {
             const uint32_t sample = P.sample + s_local;
             PathState st;
             st.slot = pixel_slot;
@@ -178,7 +179,7 @@ __global__ void __launch_bounds__(256) path_primary_kernel(FrameParams P) {
             V3 light{0.f, 0.f, 0.f};
             bool missed;
             const bool alive = path_after_march(P, st, R, light, missed) && !P.last_bounce;
-            if (P.acc) {
+            if (MULTI) {
                 // this sample's own plane: its light so far and, for the frame's first sample, the id word (0 otherwise);
                 // the path's later segments find the plane through the slot
                 st.slot += s_local * P.acc_slots;
@@ -1087,6 +1088,10 @@ static size_t lds_bytes_path(const FrameParams &P, bool lds_roots) { return (24u
 void launch_path_primary(const FrameParams &P, bool stats, bool literal, hipStream_t st) {
     if (P.tiles_local == 0) return;
     const dim3 grid((P.tiles_local + 3u) / 4u), block(256);
+    if (P.acc) {   // several samples per launch chain: plain frames over the derived tables only (vrt_backend.hip)
+        hipLaunchKernelGGL((path_primary_kernel<0, false, false, true>), grid, block, lds_bytes_path(P, false), st, P);
+        return;
+    }
     VRT_PATH_LAUNCH(path_primary_kernel);
 }
 
