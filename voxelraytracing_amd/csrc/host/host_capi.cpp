@@ -1,6 +1,7 @@
 // host_capi.cpp — include/vrt_host.h over the C++ host mirror (world.hpp, graphics.hpp, worldgen.hpp).
 #include <algorithm>
 #include <atomic>
+#include <system_error>
 #include <thread>
 
 #include "../../../include/vrt_host.h"
@@ -180,7 +181,9 @@ int vrth_world_generate(vrth_world *w, uint32_t kind, uint32_t seed, int threads
     std::vector<std::vector<Node>> built(total);
     std::atomic<size_t> next{0};
     std::atomic<int> failed{0};
-    unsigned nt = threads > 0 ? (unsigned)threads : std::max(1u, std::thread::hardware_concurrency());
+    // (at most 16 workers unless asked for more: a chunk is ~0.1 ms of work, and a host with hundreds of hardware threads —
+    // or a limit on tasks per process — gains nothing from one thread per core here)
+    unsigned nt = threads > 0 ? (unsigned)threads : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
     nt = (unsigned)std::min<size_t>(nt, total);
     WorldGen g;
     g.seed = seed;
@@ -206,7 +209,11 @@ int vrth_world_generate(vrth_world *w, uint32_t kind, uint32_t seed, int threads
         }
     };
     std::vector<std::thread> pool;
-    for (unsigned t = 1; t < nt; t++) pool.emplace_back(work);
+    try {
+        for (unsigned t = 1; t < nt; t++) pool.emplace_back(work);
+    } catch (const std::system_error &) {
+        // no more threads to be had: the ones that started (and this one) do the work
+    }
     work();
     for (auto &t : pool) t.join();
     if (failed) return failed;
