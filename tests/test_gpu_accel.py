@@ -264,3 +264,13 @@ def test_edits_between_frames_in_flight_reach_every_table_set(orc, in_flight):
     assert a.available == 1 and a.builds == 2 and a.chunk_builds >= 20
     gpu.close()
 
+
+def test_soak_session_against_the_oracle():
+    """tools/soak_edits.py for a few seconds: random edits, camera moves, in-flight changes, rebuilds, both modes, two
+    variants; every burst's last frame against the oracle (profiles/r02_soak_edits.txt holds a four-minute run)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_edits.py"), "6", "77"], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and "soak ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+

@@ -1,0 +1,77 @@
+"""tools/soak_edits.py [seconds] [seed] — a long random session against the oracle: edits (0-3 before a frame), camera moves,
+chunk_roots rewrites, quiet stretches, changes of the number of frames in flight, whole-world rebuilds, the primary and the
+primary + shadow mode, variants 0 and 2 — and every few dozen frames the last frame is compared with the oracle's frame of
+the world as it is.  Exercises the upload stream / per-frame-set table machinery for races that a short
+test would not meet.  Exit status 1 on the first mismatch."""
+import os
+import sys
+import time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from voxelraytracing_amd import Gpu, MODE_PRIMARY, MODE_PRIMARY_SHADOW, graphics as g, scenes
+from oracle import orc
+
+seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+W, H = 160, 96
+sc = scenes.c2((W, H))
+gpu = Gpu(sc.world.max_nodes(), sc.world.size_in_chunks(), sc.size)
+gpu.upload_world(sc.world, sc.materials); gpu.write_settings(sc.settings)
+ex, ey, ez = (float(v) for v in sc.eye)
+cam = sc.cam
+mode = MODE_PRIMARY_SHADOW
+variant = 0
+frames = checks = edits = 0
+t_end = time.time() + seconds
+next_report = time.time() + 20
+while time.time() < t_end:
+    burst = int(rng.integers(5, 60))
+    for _ in range(burst):
+        r = rng.random()
+        if r < 0.5:
+            for _ in range(int(rng.integers(1, 4))):
+                p = (int(ex) + int(rng.integers(-24, 25)), int(ey) + int(rng.integers(-28, 6)), int(ez) + int(rng.integers(-24, 25)))
+                try:
+                    start, n = sc.world.set_voxel(p, int(rng.choice([0, 0, 0, 3, 4, 40, 47, 62])))
+                except Exception as e:
+                    if getattr(e, "kind", "") not in ("NoChange", "NoChunk", "OutOfMemory"):
+                        raise
+                    if getattr(e, "kind", "") != "OutOfMemory":
+                        continue
+                    start, n = e.range
+                gpu.write_nodes(sc.world.nodes_ptr(), start, start + n)
+                edits += 1
+        elif r < 0.55:
+            gpu.write_nodes(sc.world.nodes_ptr(), 0, 2)          # node 0: a whole-world rebuild
+        elif r < 0.6:
+            gpu.set_frames_in_flight(int(rng.integers(1, 4)))
+        elif r < 0.65:
+            for _ in range(int(rng.integers(60, 90))):           # a quiet stretch: the table sets merge
+                gpu.render(mode, variant=variant)
+                frames += 1
+        if rng.random() < 0.3:
+            rot = (float(rng.uniform(-40, 10)), float(rng.uniform(0, 360)), 0.0)
+            eye = (ex + float(rng.uniform(-6, 6)), ey + float(rng.uniform(-3, 3)), ez + float(rng.uniform(-6, 6)))
+            cam = g.cam_data_create(rot, eye, float(rng.uniform(50, 100)), (float(W), float(H)))
+            gpu.write_cam_data(cam)
+        if rng.random() < 0.1:
+            mode = MODE_PRIMARY if rng.random() < 0.3 else MODE_PRIMARY_SHADOW
+            variant = 2 if rng.random() < 0.2 else 0
+        gpu.write_chunk_roots(sc.world.chunk_roots())
+        gpu.render(mode, variant=variant)
+        frames += 1
+    rgb, ids, _ = gpu.read_output()
+    o = orc.from_package_scene(sc)
+    o.set_cam(cam)
+    r_rgb, r_ids, _, _ = o.render(mode, W, H)
+    checks += 1
+    if not np.array_equal(ids, r_ids) or float(np.nanmax(np.abs(rgb - r_rgb))) > 1e-4:
+        print(f"MISMATCH at check {checks}, frame {frames}: {int((ids != r_ids).sum())} id words differ (mode {mode}, variant {variant})", flush=True)
+        sys.exit(1)
+    if time.time() > next_report:
+        a = gpu.accel_info()
+        print(f"{frames} frames, {edits} edits, {checks} checks ok; whole-world builds {a.builds}, chunks rebuilt alone {a.chunk_builds}", flush=True)
+        next_report = time.time() + 20
+a = gpu.accel_info()
+print(f"soak ok: {frames} frames, {edits} edits, {checks} checks against the oracle; whole-world builds {a.builds}, chunks rebuilt alone {a.chunk_builds}")
