@@ -69,9 +69,21 @@ while time.time() < t_end:
     if not np.array_equal(ids, r_ids) or float(np.nanmax(np.abs(rgb - r_rgb))) > 1e-4:
         print(f"MISMATCH at check {checks}, frame {frames}: {int((ids != r_ids).sum())} id words differ (mode {mode}, variant {variant})", flush=True)
         sys.exit(1)
+    if checks % 8 == 0:   # and a path-traced frame of the same world: random samples per pixel, seed and bounce count
+        from voxelraytracing_amd import MODE_PATH
+        spp, pseed = int(rng.integers(1, 7)), int(rng.integers(0, 1000))
+        for _ in range(int(rng.integers(1, 4))):
+            gpu.render(MODE_PATH, spp=spp, seed=pseed)
+        rgb, ids, _ = gpu.read_output()
+        r_rgb, r_ids, _, _ = o.render(orc.MODE_PATH, W, H, spp=spp, seed=pseed)
+        path_checks = globals().get("path_checks", 0) + 1
+        globals()["path_checks"] = path_checks
+        if not np.array_equal(ids, r_ids) or float(np.nanmax(np.abs(rgb - r_rgb))) > 1e-4 * (1.0 + sc.settings.sun_intensity):
+            print(f"PATH MISMATCH at check {checks}: {int((ids != r_ids).sum())} id words differ, max radiance error {float(np.nanmax(np.abs(rgb - r_rgb))):.3g} (spp {spp}, seed {pseed})", flush=True)
+            sys.exit(1)
     if time.time() > next_report:
         a = gpu.accel_info()
         print(f"{frames} frames, {edits} edits, {checks} checks ok; whole-world builds {a.builds}, chunks rebuilt alone {a.chunk_builds}", flush=True)
         next_report = time.time() + 20
 a = gpu.accel_info()
-print(f"soak ok: {frames} frames, {edits} edits, {checks} checks against the oracle; whole-world builds {a.builds}, chunks rebuilt alone {a.chunk_builds}")
+print(f"soak ok: {frames} frames, {edits} edits, {checks} checks against the oracle (+ {globals().get('path_checks', 0)} of path-traced frames); whole-world builds {a.builds}, chunks rebuilt alone {a.chunk_builds}")
