@@ -888,3 +888,47 @@ def test_samples_per_launch_chain_do_not_change_the_frame(orc, monkeypatch, per_
     one.close()
     assert np.array_equal(ids1, o_ids) and np.array_equal(rgb1, o_rgb)
 
+
+def test_longest_tiles_first_is_the_same_frame(orc, monkeypatch):
+    """A context that renders one frame at a time launches its tiles longest first (the order from the trips an earlier
+    frame's waves noted, re-made every few frames): any order of the tiles is the same frame.  Full size, a moving camera,
+    re-sorts every second frame, against the screen-order context and the oracle."""
+    sc = scenes.c2()
+    monkeypatch.setenv("VRT_TILE_EVERY", "2")
+    lpt = gpu_for_scene(sc)
+    lpt.set_frames_in_flight(1)
+    monkeypatch.setenv("VRT_TILE_ORDER", "0")
+    ref = gpu_for_scene(sc)
+    ref.set_frames_in_flight(1)
+    from voxelraytracing_amd import graphics as g
+    cam = sc.cam
+    for k in range(12):
+        cam = g.cam_data_create((sc.rot[0] + 2.0 * k, sc.rot[1] + 17.0 * k, 0.0), (sc.eye[0] + 3.0 * k, sc.eye[1] + (k % 3), sc.eye[2] - 2.0 * k), 70.0, (1920.0, 1080.0))
+        for gpu in (lpt, ref):
+            gpu.write_cam_data(cam)
+            gpu.render(MODE_PRIMARY_SHADOW)
+        if k % 4 == 3:
+            a_rgb, a_ids, _ = lpt.read_output()
+            b_rgb, b_ids, _ = ref.read_output()
+            assert np.array_equal(a_ids, b_ids) and np.array_equal(a_rgb, b_rgb)
+    o = orc.from_package_scene(sc)
+    o.set_cam(cam)
+    r_rgb, r_ids, _, _ = o.render(MODE_PRIMARY_SHADOW, 1920, 1080)
+    assert_frame_parity(a_rgb, a_ids, r_rgb, r_ids, "longest tiles first")
+    # sharded contexts order their own tiles
+    monkeypatch.delenv("VRT_TILE_ORDER")
+    acc_rgb, acc_ids = np.zeros_like(a_rgb), np.zeros_like(a_ids)
+    for r in range(2):
+        sh = gpu_for_scene(sc, shard_rank=r, shard_count=2)
+        sh.set_frames_in_flight(1)
+        sh.write_cam_data(cam)
+        for _ in range(5):
+            sh.render(MODE_PRIMARY_SHADOW)
+        s_rgb, s_ids, _ = sh.read_output()
+        acc_rgb += s_rgb
+        acc_ids |= s_ids
+        sh.close()
+    assert np.array_equal(acc_ids, a_ids) and np.array_equal(acc_rgb, a_rgb)
+    lpt.close()
+    ref.close()
+

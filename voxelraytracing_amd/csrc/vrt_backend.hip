@@ -36,6 +36,7 @@ void launch_path_primary(const FrameParams &P, bool stats, bool literal, hipStre
 void launch_path_bounce(const FrameParams &P, bool stats, bool literal, hipStream_t st);
 void launch_path_bounce_pool(const FrameParams &P, bool continuations, uint32_t refill_at, uint32_t eject_at, hipStream_t st);
 void launch_path_finish(Texel *out, uint32_t n, uint32_t spp, hipStream_t st);
+void launch_tile_order(const uint32_t *cost, uint32_t n, uint32_t shift, uint32_t *scratch, uint32_t *order, hipStream_t st);
 void launch_path_chain_finish(Texel *out, const Texel *acc, uint32_t n, uint32_t chain, bool first, bool last, uint32_t spp, hipStream_t st);
 void launch_path_persistent(const FrameParams &P, uint32_t *heads, uint32_t n_cus, hipStream_t st);
 void launch_quantize(const Texel *out, uint8_t *rgba8, uint32_t n, hipStream_t st);
@@ -177,6 +178,16 @@ struct vrt_ctx {
     size_t path_acc_texels[kMaxInFlight] = {0, 0, 0, 0}, path_buf_records[kMaxInFlight] = {0, 0, 0, 0}, path_cont_records[kMaxInFlight] = {0, 0, 0, 0};
     uint32_t path_refill = 0, path_eject = ~0u;   // VRT_PATH_POOL_REFILL / _EJECT: the pool kernel's thresholds (experiments; 0 / ~0: defaults)
     uint32_t accel_builds = 0;
+    // longest tiles first (vrt_kernels.hip: tile_order_*), for a context that renders one frame at a time
+    // (vrt_set_frames_in_flight(1)): every tile_every-th plain frame notes its tiles' march-loop trips, and right behind it on
+    // the stream three small launches turn them into the order the following frames launch their tiles in.  With two frames
+    // in flight the other frame already fills a launch's tail and the order buys nothing (measured).
+    uint32_t tile_every = 32;           // VRT_TILE_EVERY
+    bool tile_lpt = true;               // VRT_TILE_ORDER=0: screen order always
+    uint32_t *d_tile_cost = nullptr, *d_tile_order = nullptr, *d_tile_scratch = nullptr;
+    uint32_t tile_buf_tiles = 0;        // what the buffers are sized for
+    bool tile_order_valid = false;
+    uint32_t tile_frames = 0;           // plain frames since the last sort
     uint32_t last_slot = 0, last_tab = 0;   // the frame set and the table set of the last frame
     float accel_last_ms = 0.f;
     std::vector<uint32_t> h_roots;  // what chunk_roots holds, to recognise the reference's per-frame rewrite of the same table
@@ -300,6 +311,12 @@ static int alloc_output(vrt_ctx *c) {
     for (auto &p : c->extra_path) { (void)hipFree(p); p = nullptr; }
     for (auto &p : c->path_cont) { (void)hipFree(p); p = nullptr; }
     for (auto &p : c->path_acc) { (void)hipFree(p); p = nullptr; }
+    (void)hipFree(c->d_tile_cost); c->d_tile_cost = nullptr;
+    (void)hipFree(c->d_tile_order); c->d_tile_order = nullptr;
+    (void)hipFree(c->d_tile_scratch); c->d_tile_scratch = nullptr;
+    c->tile_buf_tiles = 0;
+    c->tile_order_valid = false;
+    c->tile_frames = 0;
     for (auto &n : c->path_acc_texels) n = 0;
     for (auto &n : c->path_buf_records) n = 0;
     for (auto &n : c->path_cont_records) n = 0;
@@ -828,6 +845,8 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         if (v >= 0 && v < (long)kAccelMaxS) c->accel_max_s = (uint32_t)v;
     }
     if (const char *e = getenv("VRT_PATH_PERSISTENT")) c->path_persistent = e[0] == '1';
+    if (const char *e = getenv("VRT_TILE_ORDER")) c->tile_lpt = e[0] != '0';
+    if (const char *e = getenv("VRT_TILE_EVERY")) { const int v = atoi(e); if (v >= 1) c->tile_every = (uint32_t)v; }
     if (const char *e = getenv("VRT_PATH_POOL")) c->path_pool = e[0] != '0';
     if (const char *e = getenv("VRT_PATH_POOL_CHAIN")) c->path_chain = e[0] == '1';
     if (const char *e = getenv("VRT_PATH_SAMPLES_PER_CHAIN")) { const int v = atoi(e); if (v >= 1 && v <= 16) c->path_samples = (uint32_t)v; }
@@ -889,6 +908,7 @@ void vrt_destroy(vrt_ctx *c) {
     for (auto p : c->extra_counters) (void)hipFree(p);
     for (auto p : c->path_cont) (void)hipFree(p);
     for (auto p : c->path_acc) (void)hipFree(p);
+    (void)hipFree(c->d_tile_cost); (void)hipFree(c->d_tile_order); (void)hipFree(c->d_tile_scratch);
     for (auto st : c->side_stream)
         if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     for (auto &evs : c->side_ev)
@@ -1539,11 +1559,36 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
         rc = next_events(c, &ev, &ev_kind);
         if (rc) return rc;
     }
+    // longest tiles first: the one-launch primary + shadow kernel over the derived tables, plain frames, one frame at a time
+    // on the context's own stream (a frame, the sort behind it and the next frame are then ordered by the stream alone)
+    const bool lpt = c->tile_lpt && c->in_flight == 1u && f.st == c->stream && o.mode == VRT_MODE_PRIMARY_SHADOW && variant == 0u && !kstats &&
+                     o.stats == 0u && P.grid && c->tiles_local >= 128u;
+    bool tile_sort = false;
+    if (lpt) {
+        if (c->tile_buf_tiles != c->tiles_local) {
+            const uint32_t chunks = (c->tiles_local + 63u) / 64u;
+            HIP_TRY(c, hipMalloc(&c->d_tile_cost, (size_t)c->tiles_local * sizeof(uint32_t)));
+            HIP_TRY(c, hipMalloc(&c->d_tile_order, (size_t)c->tiles_local * sizeof(uint32_t)));
+            HIP_TRY(c, hipMalloc(&c->d_tile_scratch, (size_t)64u * (chunks + 1u) * sizeof(uint32_t)));
+            c->tile_buf_tiles = c->tiles_local;
+            c->tile_order_valid = false;
+            c->tile_frames = 0;
+        }
+        if (c->tile_order_valid) P.tile_order = c->d_tile_order;
+        tile_sort = !c->tile_order_valid || ++c->tile_frames >= c->tile_every;
+        if (tile_sort) P.tile_cost = c->d_tile_cost;
+    }
     // the counters feed stats frames and the path trace's segment cursors; a plain primary(+shadow) frame reads none
     if (kstats || o.mode == VRT_MODE_PATH) HIP_TRY(c, hipMemsetAsync(f.counters, 0, kCounterBytes, f.st));
     if (o.mode == VRT_MODE_PATH) rc = launch_path_frame(c, P, f, o, kstats, air_liquid, *ev, *ev_kind);
     else rc = launch_march_frame(c, P, f, o.mode == VRT_MODE_PRIMARY_SHADOW, variant, kstats, *ev, *ev_kind);
     if (rc) return rc;
+    if (tile_sort) {   // (the frame above read the old order and is over when this runs; the next frame starts after it)
+        vrt::launch_tile_order(c->d_tile_cost, c->tiles_local, 1u, c->d_tile_scratch, c->d_tile_order, f.st);   // classes of two trips
+        HIP_TRY(c, hipGetLastError());
+        c->tile_order_valid = true;
+        c->tile_frames = 0;
+    }
     c->rendered = true;
     c->last_stats = o.stats == 1u;
     c->last_mode = o.mode;

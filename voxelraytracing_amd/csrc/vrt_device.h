@@ -67,6 +67,10 @@ struct FrameParams {
     // this context's t_local-th tile is screen tile (t_local / shard_run) * shard_period + shard_first + t_local % shard_run
     uint32_t shard_first, shard_run, shard_period, tiles_local;
     uint32_t hit_seg_cap;    // capacity of one hit-buffer segment, a multiple of 256
+    // Longest tiles first (vrt_kernels.hip: tile_order_*): a wave notes how many trips its two march loops took and a
+    // later frame launches its tiles in descending order of that, so the launch's last waves are its cheapest
+    const uint32_t *tile_order;  // null, or a permutation of [0, tiles_local): the t-th wave of the launch takes tile tile_order[t]
+    uint32_t *tile_cost;         // null, or [tiles_local]: what this frame's waves note
     uint32_t tile_major;     // output slots are [t_local][64] (sharded, or VRT_FLAG_TILE_MAJOR) instead of row-major
     uint32_t compact;        // VRT_FLAG_COMPACT: a slot is an 8-byte record {id word | kIdNormYNeg, water_dist} instead of a texel
     uint32_t finite_settings;  // 1: every Settings float is finite (lets hits skip the sky term exactly)
@@ -139,6 +143,7 @@ struct MarchResult {
     uint32_t voxel;
     uint32_t iters;
     uint32_t visits;
+    uint32_t trips;     // grid march: the march loop's trips this lane was in (the wave's trip count = the maximum over its lanes)
 };
 
 }  // namespace vrt

@@ -219,11 +219,21 @@ __global__ void __launch_bounds__(64 * WAVES) primary_shadow_wave_kernel(FramePa
     stage_lds(P, s_roots, s_liquid, LDS_ROOTS);
 
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t t_local = blockIdx.x * (uint32_t)WAVES + (threadIdx.x >> 6);
+    uint32_t t_local = blockIdx.x * (uint32_t)WAVES + (threadIdx.x >> 6);
+    if (P.tile_order && t_local < P.tiles_local) t_local = P.tile_order[t_local];
     MarchResult R, S;
     R.iters = 0; R.visits = 0; R.hit = false;
     S.iters = 0; S.visits = 0; S.hit = false;
-    if (t_local < P.tiles_local) trace_tile<MARCH, LDS_ROOTS, STATS>(P, s_roots, s_liquid, t_local, lane, R, S);
+    R.trips = 0; S.trips = 0;
+    if (t_local < P.tiles_local) {
+        trace_tile<MARCH, LDS_ROOTS, STATS>(P, s_roots, s_liquid, t_local, lane, R, S);
+        if (P.tile_cost) {   // the wave's trips through its two march loops: what the tile costs, whoever else is on the machine
+            uint32_t trips = R.trips + S.trips;   // (S.trips: 0 for a lane without a shadow ray)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) trips = max(trips, (uint32_t)__shfl_xor((int)trips, o, 64));
+            if (lane == 0) P.tile_cost[t_local] = trips;
+        }
+    }
     if (PROBE) {
         const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
         if ((blockIdx.x & 3u) == 0u && threadIdx.x == 0 && P.clock) {
@@ -285,6 +295,90 @@ __global__ void __launch_bounds__(256) primary_shadow_persistent_kernel(FramePar
             t_local = pop_tile(heads, queue, lane);  // (taking the next ticket before tracing this tile was slower still: 183 us)
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Longest tiles first.  The dispatcher hands out workgroups in index order, and a launch ends when its slowest late
+// workgroup does: with the tiles in screen order the expensive ones (terrain near the horizon) are spread through the
+// launch and the last waves to start are as long as any — a lone launch spends its last fifth with the machine half
+// empty.  Ordered by cost, the last waves are the cheapest (longest-processing-time-first scheduling): measured on C2, one
+// launch at a time, 115.3 -> 100.6 us per frame with the order taken from the frame before (two frames in flight:
+// 94.3 -> 93.7 us — the other frame already filled most of that tail).  A *random* order costs 133 us: consecutive tiles
+// share lines of the tables, so the order is a stable counting sort into 64 cost classes — screen order within a class.
+// Four small launches behind the frame that noted the trips: per-chunk class counts, the scan (class totals, then the rows),
+// the scatter.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kCostClasses = 64;
+__device__ __forceinline__ uint32_t cost_class(uint32_t trips, uint32_t shift) { return min(trips >> shift, kCostClasses - 1u); }
+
+// counts[(kCostClasses - 1 - class) * chunks + chunk]: tiles of that class in that chunk of 64 tiles (descending classes first)
+__global__ void __launch_bounds__(256) tile_order_count_kernel(const uint32_t *cost, uint32_t n, uint32_t chunks, uint32_t shift, uint32_t *counts) {
+    __shared__ uint32_t s_h[4][kCostClasses];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t chunk = blockIdx.x * 4u + wave, t = chunk * 64u + lane;
+    s_h[wave][lane] = 0u;
+    __syncthreads();
+    if (t < n) atomicAdd(&s_h[wave][cost_class(cost[t], shift)], 1u);
+    __syncthreads();
+    if (chunk < chunks) counts[(kCostClasses - 1u - lane) * chunks + chunk] = s_h[wave][lane];
+}
+
+// The exclusive scan of counts[class'][chunk] (class' descending) in two launches of one wave per class: the classes'
+// totals, then every class's own chunks behind the totals of the classes before it.  Rows are read 64 consecutive words at
+// a time.
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x, uint32_t lane) {
+#pragma unroll
+    for (uint32_t o = 1; o < 64u; o <<= 1) {
+        const uint32_t y = (uint32_t)__shfl_up((int)x, o, 64);
+        if (lane >= o) x += y;
+    }
+    return x;
+}
+__global__ void __launch_bounds__(64) tile_order_totals_kernel(const uint32_t *counts, uint32_t chunks, uint32_t *totals) {
+    const uint32_t cls = blockIdx.x, lane = threadIdx.x;
+    uint32_t sum = 0;
+    for (uint32_t i = lane; i < chunks; i += 64u) sum += counts[cls * chunks + i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += (uint32_t)__shfl_xor((int)sum, o, 64);
+    if (lane == 0) totals[cls] = sum;
+}
+__global__ void __launch_bounds__(64) tile_order_scan_kernel(uint32_t *counts, uint32_t chunks, const uint32_t *totals) {
+    const uint32_t cls = blockIdx.x, lane = threadIdx.x;
+    const uint32_t t = totals[lane];   // kCostClasses == 64 == the wave
+    uint32_t carry = (uint32_t)__shfl((int)(wave_inclusive_scan(t, lane) - t), (int)cls, 64);   // the classes before this one
+    for (uint32_t i0 = 0; i0 < chunks; i0 += 64u) {
+        const uint32_t i = i0 + lane;
+        const uint32_t x = i < chunks ? counts[cls * chunks + i] : 0u;
+        const uint32_t incl = wave_inclusive_scan(x, lane);
+        if (i < chunks) counts[cls * chunks + i] = carry + incl - x;
+        carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+}
+
+// order[start of (class, chunk) + rank among the chunk's tiles of that class, in tile order] = tile
+__global__ void __launch_bounds__(256) tile_order_scatter_kernel(const uint32_t *cost, uint32_t n, uint32_t chunks, uint32_t shift,
+                                                                 const uint32_t *starts, uint32_t *order) {
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t chunk = blockIdx.x * 4u + wave, t = chunk * 64u + lane;
+    const bool valid = t < n;
+    const uint32_t cls = valid ? cost_class(cost[t], shift) : 0xFFFFFFFFu;
+    unsigned long long todo = __ballot(valid);
+    while (todo) {   // one round per class present in the wave
+        const uint32_t pick = (uint32_t)__builtin_amdgcn_readlane((int)cls, __ffsll((long long)todo) - 1);
+        const unsigned long long same = __ballot(cls == pick);
+        if (cls == pick) order[starts[(kCostClasses - 1u - pick) * chunks + chunk] + (uint32_t)__popcll(same & ((1ull << lane) - 1ull))] = t;
+        todo &= ~same;
+    }
+}
+
+void launch_tile_order(const uint32_t *cost, uint32_t n, uint32_t shift, uint32_t *scratch, uint32_t *order, hipStream_t st) {
+    if (!n) return;
+    const uint32_t chunks = (n + 63u) / 64u;
+    hipLaunchKernelGGL(tile_order_count_kernel, dim3((chunks + 3u) / 4u), dim3(256), 0, st, cost, n, chunks, shift, scratch);
+    uint32_t *totals = scratch + (size_t)kCostClasses * chunks;   // (the scratch holds kCostClasses * (chunks + 1) words)
+    hipLaunchKernelGGL(tile_order_totals_kernel, dim3(kCostClasses), dim3(64), 0, st, (const uint32_t *)scratch, chunks, totals);
+    hipLaunchKernelGGL(tile_order_scan_kernel, dim3(kCostClasses), dim3(64), 0, st, scratch, chunks, (const uint32_t *)totals);
+    hipLaunchKernelGGL(tile_order_scatter_kernel, dim3((chunks + 3u) / 4u), dim3(256), 0, st, cost, n, chunks, shift, (const uint32_t *)scratch, order);
 }
 
 // ------------------------------------------------------------------------------------------------

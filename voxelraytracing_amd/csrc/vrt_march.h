@@ -161,6 +161,7 @@ __device__ __forceinline__ MarchResult march_literal(const FrameParams &P, const
     R.voxel = 0u;
     R.iters = 0u;
     R.visits = 0u;
+    R.trips = 0u;
 
     const V3 mask{dir.x >= 0.0f ? 1.0f : 0.0f, dir.y >= 0.0f ? 1.0f : 0.0f, dir.z >= 0.0f ? 1.0f : 0.0f};
     const V3 imask{1.0f - mask.x, 1.0f - mask.y, 1.0f - mask.z};
@@ -283,6 +284,7 @@ __device__ __forceinline__ MarchResult march_fast(const FrameParams &P, const ui
     R.voxel = 0u;
     R.iters = 0u;
     R.visits = 0u;
+    R.trips = 0u;
 
     const bool mx = dir.x >= 0.0f, my = dir.y >= 0.0f, mz = dir.z >= 0.0f;
 
@@ -486,6 +488,7 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
     R.voxel = 0u;
     R.iters = 0u;
     R.visits = 0u;
+    R.trips = 0u;
 
     const bool mx = dir.x >= 0.0f, my = dir.y >= 0.0f, mz = dir.z >= 0.0f;
     // (l): is any ray of this wave not finite?  (Wave-uniform; evaluated before lanes leave.)
@@ -630,6 +633,7 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
     }
     // per-lane lookup counts are kept by the STATS kernels only (counters, step-count debug view)
     R.iters = STATS ? looked_up : 0u;
+    R.trips = iter;
     if (dew != -1.0f) R.water_dist += total_len - dew;
     // (i): "left the world" (:285-290) from the position itself; a lane that left through a solid leaf or by exhaustion
     // holds a position that passes this test
