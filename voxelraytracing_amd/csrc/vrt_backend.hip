@@ -1561,7 +1561,7 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     }
     // longest tiles first: the one-launch primary + shadow kernel over the derived tables, plain frames, one frame at a time
     // on the context's own stream (a frame, the sort behind it and the next frame are then ordered by the stream alone)
-    const bool lpt = c->tile_lpt && c->in_flight == 1u && f.st == c->stream && o.mode == VRT_MODE_PRIMARY_SHADOW && variant == 0u && !kstats &&
+    const bool lpt = c->tile_lpt && c->in_flight == 1u && f.st == c->stream && (o.mode == VRT_MODE_PRIMARY_SHADOW || o.mode == VRT_MODE_PRIMARY) && variant == 0u && !kstats &&
                      o.stats == 0u && P.grid && c->tiles_local >= 128u;
     bool tile_sort = false;
     if (lpt) {

@@ -44,10 +44,11 @@ __global__ void __launch_bounds__(256) primary_tile_kernel(FrameParams P) {
     stage_lds(P, s_roots, s_liquid, LDS_ROOTS);
 
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t t_local = blockIdx.x * 4u + (threadIdx.x >> 6);
+    uint32_t t_local = blockIdx.x * 4u + (threadIdx.x >> 6);
     const bool live = t_local < P.tiles_local;
+    if (!SHADOW && P.tile_order && live) t_local = P.tile_order[t_local];   // longest tiles first (primary-only frames; below)
     MarchResult R;
-    R.iters = 0; R.visits = 0; R.hit = false;
+    R.iters = 0; R.visits = 0; R.hit = false; R.trips = 0;
     if (live) {
         const uint32_t tile = shard_tile(t_local, P.shard_first, P.shard_run, P.shard_period);
         const uint32_t px = (tile % P.tiles_x) * 8u + (lane & 7u);
@@ -92,6 +93,12 @@ __global__ void __launch_bounds__(256) primary_tile_kernel(FrameParams P) {
             }
         }
         if (STATS && P.steps) P.steps[slot] = R.iters;
+        if (!SHADOW && P.tile_cost) {
+            uint32_t trips = R.trips;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) trips = max(trips, (uint32_t)__shfl_xor((int)trips, o, 64));
+            if (lane == 0) P.tile_cost[t_local] = trips;
+        }
     }
     if (STATS) {
         block_add(s_acc, 0, R.iters);
