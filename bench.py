@@ -461,6 +461,8 @@ def main():
         period_fixed = (extras.get("ms_per_step_fixed_camera", period_s * 1e3) if not fixed else period_s * 1e3) * 1e-3
         roof["achieved"] = n_valu / period_fixed / 1e9          # the counters are of the fixed-camera frame: its period
         roof["frac"] = roof["achieved"] / roof["peak"]
+        roof["frac_note"] = ("instructions per second over the peak at 2 cycles per wave-instruction: removing instructions lowers it; "
+                             "class_weighted.frac (each class at its issue time) says how full the VALU pipes are")
         roof["traffic"] = pmc["hbm_bytes"]
         roof["valu_wave_instructions_per_launch"] = n_valu
         roof["salu_wave_instructions_per_launch"] = n_salu
