@@ -1018,6 +1018,15 @@ int vrt_write_materials(vrt_ctx *c, uint32_t first, const vrt_material *mats, ui
 int vrt_set_camera(vrt_ctx *c, const vrt_cam_data *cam) {
     GRP_EACH(c, vrt_set_camera(d, cam));
     if (!c || !cam) return fail(c, VRT_ERR_INVALID_ARG, "vrt_set_camera: null argument");
+    // a cut — the eye more than four voxels away or the view turned by more than ~6 degrees since the last frame — makes the
+    // tile order of a one-frame-at-a-time context stale at once: the next frame notes its tiles' trips again
+    if (c->tile_order_valid) {
+        float moved = 0.f, turned = 0.f;
+        for (int i = 0; i < 3; i++) moved = std::max(moved, std::fabs(cam->pos[i] - c->cam.pos[i]));
+        for (int col = 0; col < 3; col++)   // (the rotation part of the column-major matrix; its fourth column is the eye again)
+            for (int row = 0; row < 3; row++) turned = std::max(turned, std::fabs(cam->inv_view_mat[col * 4 + row] - c->cam.inv_view_mat[col * 4 + row]));
+        if (!(moved <= 4.0f) || !(turned <= 0.1f)) c->tile_frames = c->tile_every;
+    }
     c->cam = *cam;
     return VRT_OK;
 }
