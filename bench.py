@@ -9,7 +9,8 @@ A "step" is one frame: 1920x1080, 8x8x8-chunk procedural SVO world, 1 primary ra
 hit (config C2; scene, derived tables and ndc tables resident in HBM before the timed region).  A timed frame issues
 the reference frame loop's whole seam (clientdesktop/src/main.rs:426-453: settings, camera, chunk_roots, world data,
 dispatch) with a camera that orbits slowly, so the frames in flight are different frames; `value_fixed_camera` is the
-same loop with the camera standing still and `value_1_in_flight` with one launch at a time.
+same loop with the camera standing still and `value_1_in_flight` the standing camera with one launch at a time (a view
+at rest: its tiles are launched longest first; `--frames-in-flight 1` gives the orbiting one-at-a-time loop, screen order).
 
 N > 1: the frame is sharded by interleaved 8x8 screen tiles (total work fixed: "strong" scaling), one process per GPU
 over RCCL (under torch.distributed.run, or started by this script itself when WORLD_SIZE is not set), or — with

@@ -229,9 +229,11 @@ int vrt_render(vrt_ctx *ctx, const vrt_render_opts *opts);
  * consecutive vrt_render calls of plain frames (default march, no stats, the context's own stream and output buffers;
  * also path-trace frames) alternate between that many internal streams, each with its own output (and path) buffers, so
  * one frame's tail overlaps the next one's ramp-up.  Every other call waits for all of them first; vrt_read_output / vrt_present /
- * vrt_device_output refer to the most recent frame.  1 = strictly one frame at a time; the launch's tail is then shortened
- * from within: primary + shadow frames launch their 8x8 tiles longest first, in an order re-made every 32 frames from the
- * march-loop trips an earlier frame's waves noted (same frame whatever the order; VRT_TILE_ORDER=0 keeps screen order). */
+ * vrt_device_output refer to the most recent frame.  1 = strictly one frame at a time; while the view is at rest (camera,
+ * settings, world and materials unchanged since the previous frame) the launch's tail is then shortened from within:
+ * primary + shadow frames launch their 8x8 tiles longest first, in the order of the march-loop trips the view's second frame
+ * noted.  Any change of the view returns to screen order: an order made for another view, however close, is worse than
+ * none.  The frame is the same whatever the order; VRT_TILE_ORDER=0 keeps screen order always. */
 int vrt_set_frames_in_flight(vrt_ctx *ctx, uint32_t n);
 
 /* Block until everything enqueued on the context's stream has finished. */

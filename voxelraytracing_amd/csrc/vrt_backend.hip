@@ -179,15 +179,19 @@ struct vrt_ctx {
     uint32_t path_refill = 0, path_eject = ~0u;   // VRT_PATH_POOL_REFILL / _EJECT: the pool kernel's thresholds (experiments; 0 / ~0: defaults)
     uint32_t accel_builds = 0;
     // longest tiles first (vrt_kernels.hip: tile_order_*), for a context that renders one frame at a time
-    // (vrt_set_frames_in_flight(1)): every tile_every-th plain frame notes its tiles' march-loop trips, and right behind it on
-    // the stream three small launches turn them into the order the following frames launch their tiles in.  With two frames
-    // in flight the other frame already fills a launch's tail and the order buys nothing (measured).
-    uint32_t tile_every = 32;           // VRT_TILE_EVERY
+    // (vrt_set_frames_in_flight(1)) and whose view is at rest: the second plain frame of an unchanged view (camera, settings,
+    // world, materials) notes its tiles' march-loop trips, right behind it on the stream four small launches turn them into the
+    // order the following frames of that view launch their tiles in.  The order is only worth anything for the very view it
+    // was made from (a launch's tail is a handful of tiles with grazing rays, and which tiles those are changes with a hundredth
+    // of a voxel of camera travel; measured): any change of the view goes back to screen order.  With two
+    // frames in flight the other frame already fills a launch's tail and the order buys nothing.
     bool tile_lpt = true;               // VRT_TILE_ORDER=0: screen order always
     uint32_t *d_tile_cost = nullptr, *d_tile_order = nullptr, *d_tile_scratch = nullptr;
     uint32_t tile_buf_tiles = 0;        // what the buffers are sized for
     bool tile_order_valid = false;
-    uint32_t tile_frames = 0;           // plain frames since the last sort
+    uint32_t view_gen = 0;              // counts the changes of anything a tile's trips depend on
+    uint32_t frame_view_gen = ~0u;      // ... as of the last frame rendered
+    uint32_t order_view_gen = ~0u;      // ... as of the frame the order was made from
     uint32_t last_slot = 0, last_tab = 0;   // the frame set and the table set of the last frame
     float accel_last_ms = 0.f;
     std::vector<uint32_t> h_roots;  // what chunk_roots holds, to recognise the reference's per-frame rewrite of the same table
@@ -316,7 +320,6 @@ static int alloc_output(vrt_ctx *c) {
     (void)hipFree(c->d_tile_scratch); c->d_tile_scratch = nullptr;
     c->tile_buf_tiles = 0;
     c->tile_order_valid = false;
-    c->tile_frames = 0;
     for (auto &n : c->path_acc_texels) n = 0;
     for (auto &n : c->path_buf_records) n = 0;
     for (auto &n : c->path_cont_records) n = 0;
@@ -491,6 +494,7 @@ static int stage_upload(vrt_ctx *c, void *dst, const void *src, size_t bytes, bo
 
 // ---- which chunks a write touched ----------------------------------------------------------------------------------
 static void mark_all_dirty(vrt_ctx *c) {
+    c->view_gen++;
     c->accel_dirty = true;
     for (auto &T : c->tabs) {
         for (uint32_t ch : T.dirty_chunks) T.chunk_is_dirty[ch] = 0;
@@ -500,6 +504,7 @@ static void mark_all_dirty(vrt_ctx *c) {
 
 // every table set in use hears of it (a set's list: what changed since *that set* was last brought up to date)
 static void mark_chunk_dirty(vrt_ctx *c, uint32_t chunk) {
+    c->view_gen++;
     if (c->accel_dirty) return;
     c->tables_split = true;   // (from the next frame on; see vrt_render)
     c->quiet_frames = 0;
@@ -846,7 +851,6 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     }
     if (const char *e = getenv("VRT_PATH_PERSISTENT")) c->path_persistent = e[0] == '1';
     if (const char *e = getenv("VRT_TILE_ORDER")) c->tile_lpt = e[0] != '0';
-    if (const char *e = getenv("VRT_TILE_EVERY")) { const int v = atoi(e); if (v >= 1) c->tile_every = (uint32_t)v; }
     if (const char *e = getenv("VRT_PATH_POOL")) c->path_pool = e[0] != '0';
     if (const char *e = getenv("VRT_PATH_POOL_CHAIN")) c->path_chain = e[0] == '1';
     if (const char *e = getenv("VRT_PATH_SAMPLES_PER_CHAIN")) { const int v = atoi(e); if (v >= 1 && v <= 16) c->path_samples = (uint32_t)v; }
@@ -997,6 +1001,7 @@ int vrt_write_materials(vrt_ctx *c, uint32_t first, const vrt_material *mats, ui
     if (!c || (!mats && n)) return fail(c, VRT_ERR_INVALID_ARG, "vrt_write_materials: null argument");
     if ((uint64_t)first + n > 256) return fail(c, VRT_ERR_OUT_OF_RANGE, "vrt_write_materials: %u+%u > 256", first, n);
     if (n == 0) return VRT_OK;
+    c->view_gen++;
     memcpy(c->h_mats + first, mats, (size_t)n * sizeof(vrt_material));
     memset(c->liquid_mask, 0, sizeof c->liquid_mask);
     int lo = -1, hi = -1, n_liquid = 0;
@@ -1018,15 +1023,7 @@ int vrt_write_materials(vrt_ctx *c, uint32_t first, const vrt_material *mats, ui
 int vrt_set_camera(vrt_ctx *c, const vrt_cam_data *cam) {
     GRP_EACH(c, vrt_set_camera(d, cam));
     if (!c || !cam) return fail(c, VRT_ERR_INVALID_ARG, "vrt_set_camera: null argument");
-    // a cut — the eye more than four voxels away or the view turned by more than ~6 degrees since the last frame — makes the
-    // tile order of a one-frame-at-a-time context stale at once: the next frame notes its tiles' trips again
-    if (c->tile_order_valid) {
-        float moved = 0.f, turned = 0.f;
-        for (int i = 0; i < 3; i++) moved = std::max(moved, std::fabs(cam->pos[i] - c->cam.pos[i]));
-        for (int col = 0; col < 3; col++)   // (the rotation part of the column-major matrix; its fourth column is the eye again)
-            for (int row = 0; row < 3; row++) turned = std::max(turned, std::fabs(cam->inv_view_mat[col * 4 + row] - c->cam.inv_view_mat[col * 4 + row]));
-        if (!(moved <= 4.0f) || !(turned <= 0.1f)) c->tile_frames = c->tile_every;
-    }
+    if (memcmp(&c->cam, cam, sizeof *cam) != 0) c->view_gen++;
     c->cam = *cam;
     return VRT_OK;
 }
@@ -1034,6 +1031,7 @@ int vrt_set_camera(vrt_ctx *c, const vrt_cam_data *cam) {
 int vrt_set_settings(vrt_ctx *c, const vrt_settings *s) {
     GRP_EACH(c, vrt_set_settings(d, s));
     if (!c || !s) return fail(c, VRT_ERR_INVALID_ARG, "vrt_set_settings: null argument");
+    if (memcmp(&c->settings, s, sizeof *s) != 0) c->view_gen++;
     c->settings = *s;
     return VRT_OK;
 }
@@ -1041,6 +1039,7 @@ int vrt_set_settings(vrt_ctx *c, const vrt_settings *s) {
 int vrt_set_world(vrt_ctx *c, const vrt_world_data *w) {
     GRP_EACH(c, vrt_set_world(d, w));
     if (!c || !w) return fail(c, VRT_ERR_INVALID_ARG, "vrt_set_world: null argument");
+    if (memcmp(&c->world, w, sizeof *w) != 0) c->view_gen++;
     c->world = *w;
     return VRT_OK;
 }
@@ -1581,12 +1580,13 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
             HIP_TRY(c, hipMalloc(&c->d_tile_scratch, (size_t)64u * (chunks + 1u) * sizeof(uint32_t)));
             c->tile_buf_tiles = c->tiles_local;
             c->tile_order_valid = false;
-            c->tile_frames = 0;
         }
+        if (c->order_view_gen != c->view_gen) c->tile_order_valid = false;   // the order of another view: worse than none
         if (c->tile_order_valid) P.tile_order = c->d_tile_order;
-        tile_sort = !c->tile_order_valid || ++c->tile_frames >= c->tile_every;
+        tile_sort = !c->tile_order_valid && c->frame_view_gen == c->view_gen;   // the view has come to rest: this frame notes its trips
         if (tile_sort) P.tile_cost = c->d_tile_cost;
     }
+    c->frame_view_gen = c->view_gen;
     // the counters feed stats frames and the path trace's segment cursors; a plain primary(+shadow) frame reads none
     if (kstats || o.mode == VRT_MODE_PATH) HIP_TRY(c, hipMemsetAsync(f.counters, 0, kCounterBytes, f.st));
     if (o.mode == VRT_MODE_PATH) rc = launch_path_frame(c, P, f, o, kstats, air_liquid, *ev, *ev_kind);
@@ -1596,7 +1596,7 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
         vrt::launch_tile_order(c->d_tile_cost, c->tiles_local, 1u, c->d_tile_scratch, c->d_tile_order, f.st);   // classes of two trips
         HIP_TRY(c, hipGetLastError());
         c->tile_order_valid = true;
-        c->tile_frames = 0;
+        c->order_view_gen = c->view_gen;
     }
     c->rendered = true;
     c->last_stats = o.stats == 1u;
