@@ -95,7 +95,9 @@ typedef struct {
 typedef struct {
     uint32_t max_nodes;          /* NodeBuffer capacity in nodes (shader.rs:9-16; forced even) */
     uint32_t world_size_chunks;  /* S: chunk_roots holds S^3 entries (shader.rs:59,67) */
-    uint32_t width, height;      /* result texture size; multiples of 8 (main.rs:452) */
+    uint32_t width, height;      /* result texture size, any non-zero size (main.rs:257-262: 1080 rows at the window's
+                                  * aspect).  As in the reference, width/8 x height/8 tiles of 8x8 pixels are traced
+                                  * (main.rs:452, integer division); the pixels beyond them stay zero, alpha included */
     int32_t device;              /* HIP device ordinal; -1 = current */
     uint32_t shard_rank, shard_count;
     uint32_t flags;              /* VRT_FLAG_* */

@@ -357,7 +357,14 @@ void orc_present(const float *rgb, uint32_t w, uint32_t h, uint32_t screen_w, ui
                 const float top = c00 * (1.0f - a) + c10 * a, bot = c01 * (1.0f - a) + c11 * a;
                 texel[k] = top * (1.0f - b) + bot * b;
             }
-            texel[3] = 1.0f * (1.0f - b) + 1.0f * b;   /* alpha 1 through the same expression (it is exactly 1 for b in [0,1)) */
+            {   /* alpha: 1 where the compute pass stored a texel, 0 (the fresh texture) beyond its workgroups (main.rs:452);
+                 * through the same expression — exactly 1 when all four are 1 */
+                const uint32_t cw = w & ~7u, chh = h & ~7u;
+                const float a00 = ((uint32_t)x0 < cw && (uint32_t)y0 < chh) ? 1.0f : 0.0f, a10 = ((uint32_t)x1 < cw && (uint32_t)y0 < chh) ? 1.0f : 0.0f;
+                const float a01 = ((uint32_t)x0 < cw && (uint32_t)y1 < chh) ? 1.0f : 0.0f, a11 = ((uint32_t)x1 < cw && (uint32_t)y1 < chh) ? 1.0f : 0.0f;
+                const float top = a00 * (1.0f - a) + a10 * a, bot = a01 * (1.0f - a) + a11 * a;
+                texel[3] = top * (1.0f - b) + bot * b;
+            }
             const float cc[4] = {ch->color[0], ch->color[1], ch->color[2], 1.0f};
             uint8_t *o = rgba8 + ((size_t)sy * screen_w + sx) * 4;
             for (int k = 0; k < 4; k++) o[k] = (uint8_t)orc_unorm8(texel[k] * (1.0f - mask) + cc[k] * mask);  /* :60-63 */
@@ -636,6 +643,14 @@ void orc_render(const orc_scene *scene, int mode, uint32_t w, uint32_t h,
 #else
     (void)threads;
 #endif
+    /* main.rs:452 dispatches result_tex_size / 8 workgroups of 8x8 invocations per axis (integer division) with no bounds
+     * test in the shader: the pixels beyond the last whole 8x8 tile are never invoked and keep the fresh texture's zeros
+     * (the result texture is 1080 rows at the window's aspect, main.rs:257-262 — any width).  The caller passes zeroed
+     * arrays; NDC still comes from the full w x h (cam.proj_size). */
+    if (x1 > (w & ~7u)) x1 = w & ~7u;
+    if (y1 > (h & ~7u)) y1 = h & ~7u;
+    if (x0 > x1) x0 = x1;
+    if (y0 > y1) y0 = y1;
     /* 8-row bands, dynamic schedule. */
     int32_t nbands = (int32_t)((y1 - y0 + 7u) / 8u);
 #pragma omp parallel for schedule(dynamic, 1) reduction(+ : t_prim, t_sec, t_hits, t_steps, t_visits, t_psteps, t_pvisits)

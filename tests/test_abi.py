@@ -54,7 +54,7 @@ def test_missing_library_fails_loudly(tmp_path, monkeypatch):
 def test_create_validates_arguments_without_touching_the_gpu():
     lib = _ffi.vrt()
     h = C.c_void_p()
-    for cfg in (_ffi.Config(1024, 2, 60, 64, -1, 0, 1, 0),   # width not a multiple of 8 (main.rs:452)
+    for cfg in (_ffi.Config(1024, 2, 0, 64, -1, 0, 1, 0),    # an empty result texture
                 _ffi.Config(1, 2, 64, 64, -1, 0, 1, 0),      # max_nodes < 2
                 _ffi.Config(1024, 2, 64, 64, -1, 3, 2, 0)):  # shard_rank >= shard_count
         assert lib.vrt_create(C.byref(cfg), C.byref(h)) == -1

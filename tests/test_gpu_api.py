@@ -5,7 +5,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from voxelraytracing_amd import Gpu, MODE_PRIMARY, MODE_PRIMARY_SHADOW, VrtError, graphics as g, scenes
+from voxelraytracing_amd import Gpu, MODE_PATH, MODE_PRIMARY, MODE_PRIMARY_SHADOW, VrtError, graphics as g, scenes
 
 from util import assert_frame_parity, gpu_for_scene
 
@@ -31,7 +31,7 @@ def test_state_and_range_errors():
         gpu.write_materials(g.std_materials(), first=10, n=250)
     assert e.value.code == -2
     with pytest.raises(VrtError) as e:
-        gpu.resize_result_texture((100, 64))
+        gpu.resize_result_texture((0, 64))
     assert e.value.code == -1
     with pytest.raises(VrtError) as e:
         gpu.render(MODE_PRIMARY, variant=99)
@@ -99,6 +99,69 @@ def test_resize_output_and_rgba8_readback(orc):
     r_rgb, r_ids, _, _ = o.render(orc.MODE_PRIMARY_SHADOW, 256, 144)
     assert b_ids.shape == (144, 256) and np.array_equal(b_ids, r_ids)
     assert float(np.abs(b_rgb - r_rgb).max()) <= 1e-4
+
+
+@pytest.mark.parametrize("size", [(203, 77), (128, 75), (131, 72), (7, 40), (40, 5)])
+def test_result_textures_of_any_size(orc, size):
+    """The reference's result texture is 1080 rows at the window's aspect — any width (main.rs:257-262) — and its compute
+    pass dispatches tex_size / 8 workgroups per axis (main.rs:452, no bounds test in the shader): whole 8x8 tiles are traced
+    with the NDC of the full size, the columns and rows beyond them keep the fresh texture's zeros, alpha included.  Frames,
+    step counts, the rgba8 texture and the presented image against the oracle; primary + shadow and the path trace; one
+    and two frames in flight; a context created at that size and one resized to it."""
+    w, h = size
+    sc = scenes.c2((w, h))
+    o = orc.from_package_scene(sc)
+    r_rgb, r_ids, r_steps, _ = o.render(orc.MODE_PRIMARY_SHADOW, w, h, want_steps=True)
+    cw, chh = w & ~7, h & ~7
+    assert not r_ids[:, cw:].any() and not r_ids[chh:, :].any() and not r_rgb[:, cw:].any() and not r_rgb[chh:, :].any()
+    made = gpu_for_scene(sc)
+    resized = gpu_for_scene(scenes.c2((64, 64)))
+    resized.resize_result_texture((w, h))
+    resized.write_cam_data(sc.cam)
+    for gpu in (made, resized):
+        for _ in range(3):                                 # (every frame set of the frames in flight)
+            gpu.render(MODE_PRIMARY_SHADOW)
+        a_rgb, a_ids, a_q = gpu.read_output(rgba8=True)
+        assert a_ids.shape == (h, w)
+        assert_frame_parity(a_rgb, a_ids, r_rgb, r_ids, f"{w}x{h}")
+        assert not a_rgb[:, cw:].any() and not a_rgb[chh:, :].any()
+        want = np.zeros((h, w, 4), dtype=np.uint8)
+        want[..., :3] = np.rint(np.clip(a_rgb, 0.0, 1.0) * np.float32(255.0)).astype(np.uint8)
+        want[:chh, :cw, 3] = 255
+        assert np.array_equal(a_q, want)
+        for screen in ((w, h), (2 * w + 1, h + 3), (max(w // 2, 1), max(h // 2, 1))):
+            assert np.array_equal(gpu.present(screen), orc.present(a_rgb, screen)), screen
+        gpu.render(MODE_PRIMARY_SHADOW, stats=True)
+        assert np.array_equal(gpu.read_steps(), r_steps)
+        st = gpu.stats()
+        assert st.primary_rays == cw * chh
+    # tile shards and one context over two (here: the same) devices cover the same whole tiles
+    acc_rgb, acc_ids = np.zeros_like(r_rgb), np.zeros_like(r_ids)
+    for r in range(3):
+        sh = gpu_for_scene(sc, shard_rank=r, shard_count=3)
+        sh.render(MODE_PRIMARY_SHADOW)
+        s_rgb, s_ids, _ = sh.read_output()
+        acc_rgb += s_rgb
+        acc_ids |= s_ids
+        sh.close()
+    assert_frame_parity(acc_rgb, acc_ids, r_rgb, r_ids, f"{w}x{h} in three shards")
+    both = gpu_for_scene(sc, devices=[0, 0])
+    both.render(MODE_PRIMARY_SHADOW)
+    d_rgb, d_ids, _ = both.read_output()
+    assert_frame_parity(d_rgb, d_ids, r_rgb, r_ids, f"{w}x{h} over two devices")
+    both.close()
+    settings = g.make_settings(sun_pos=scenes.SUN_POS, max_ray_bounces=2)
+    made.write_settings(settings)
+    o.set_settings(settings)
+    for spp in (1, 3):
+        p_rgb, p_ids, _, _ = o.render(orc.MODE_PATH, w, h, spp=spp, seed=5)
+        for _ in range(2):
+            made.render(MODE_PATH, spp=spp, seed=5)
+        g_rgb, g_ids, _ = made.read_output()
+        assert np.array_equal(g_ids, p_ids) and float(np.abs(g_rgb - p_rgb).max()) <= 1e-4, spp
+        assert not g_rgb[:, cw:].any() and not g_rgb[chh:, :].any()
+    made.close()
+    resized.close()
 
 
 def test_two_contexts_are_independent():

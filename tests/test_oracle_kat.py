@@ -291,17 +291,29 @@ def test_present_known_answers(orc):
     dot = orc.present(rgb, (16, 8), style=1, size=1.0, color=(0.0, 0.0, 0.0, 1.0))
     assert (dot[3:5, 7:9] == np.array([0, 0, 0, 255], dtype=np.uint8)).all() and (dot != plain).any(axis=2).sum() == 4   # distance sqrt(0.5) < 1
     # textureSample through the reference's sampler: its lod clamp [1, 1] (texture.rs:39-40) selects the min filter, Linear,
-    # at every size.  A 2 x 1 texture {0, 1} on a 4-pixel row: the sample points sit at texel coordinates u W - 1/2 =
-    # -0.25, 0.25, 0.75, 1.25 -> ClampToEdge gives 0, a blend of 0.25, of 0.75, and 1: 0, 63.75 -> 64, 191.25 -> 191, 255
-    ramp = np.zeros((1, 2, 3), dtype=np.float32)
-    ramp[0, 1, 0] = 1.0
-    row = orc.present(ramp, (4, 1), style=0)
-    assert row[0, :, 0].tolist() == [0, 64, 191, 255] and (row[..., 3] == 255).all()
+    # at every size.  An 8 x 8 texture, left half 0, right half 1, on a 16-pixel row: the sample points sit at texel
+    # coordinates u W - 1/2 = -0.25, 0.25, ... 7.25; between texels 3 and 4 that is 3.25 and 3.75 -> blends of 0.25 and
+    # 0.75: 63.75 -> 64, 191.25 -> 191; ClampToEdge at both ends
+    ramp = np.zeros((8, 8, 3), dtype=np.float32)
+    ramp[:, 4:, 0] = 1.0
+    row = orc.present(ramp, (16, 1), style=0)
+    assert row[0, :, 0].tolist() == [0] * 7 + [64, 191] + [255] * 7 and (row[..., 3] == 255).all()
     # minified 2:1 the sample point falls on the corner shared by four texels: their mean (here 0, 1, 0, 0 -> 63.75 -> 64)
-    quad = np.zeros((2, 2, 3), dtype=np.float32)
+    quad = np.zeros((8, 8, 3), dtype=np.float32)
     quad[0, 1, 1] = 1.0
-    assert orc.present(quad, (1, 1), style=0)[0, 0].tolist() == [0, 64, 0, 255]
+    assert orc.present(quad, (4, 4), style=0)[0, 0].tolist() == [0, 64, 0, 255]
     # at 1:1 the weights are (1, 0): the texture itself
-    chk = np.zeros((4, 4, 3), dtype=np.float32)
+    chk = np.zeros((8, 8, 3), dtype=np.float32)
     chk[::2, 1::2, 2] = 1.0
-    assert np.array_equal(orc.present(chk, (4, 4), style=0)[..., 2], (chk[..., 2] * 255).astype(np.uint8))
+    assert np.array_equal(orc.present(chk, (8, 8), style=0)[..., 2], (chk[..., 2] * 255).astype(np.uint8))
+    # a texture that is not whole 8x8 tiles: main.rs:452 dispatches tex_size / 8 workgroups, the texels beyond them are never
+    # stored to and keep the fresh texture's (0, 0, 0, 0).  12 x 8: columns 8..11 are transparent black whatever the frame
+    # array holds there (orc_render leaves them zero), and the sampler blends alpha like any channel (column 7.5 -> 0.5)
+    ragged = np.ones((8, 12, 3), dtype=np.float32)
+    ragged[:, 8:, :] = 0.0
+    out = orc.present(ragged, (12, 8), style=0)
+    assert (out[:, :8] == 255).all() and (out[:, 8:] == 0).all()
+    half = orc.present(ragged, (6, 8), style=0)       # sample points at texel coordinates 0.5, 2.5, ..., 10.5
+    assert half[0, :, 3].tolist() == [255, 255, 255, 255, 0, 0] and half[0, :, 0].tolist() == [255, 255, 255, 255, 0, 0]
+    wide = orc.present(ragged, (24, 8), style=0)      # sx / 2 - 0.25: 7.25 and 7.75 blend texels 7 and 8 -> 191, 64
+    assert wide[0, :, 3].tolist() == [255] * 15 + [191, 64] + [0] * 7 and np.array_equal(wide[..., 0], wide[..., 3])

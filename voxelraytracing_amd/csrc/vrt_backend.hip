@@ -39,7 +39,7 @@ void launch_path_finish(Texel *out, uint32_t n, uint32_t spp, hipStream_t st);
 void launch_tile_order(const uint32_t *cost, uint32_t n, uint32_t shift, uint32_t *scratch, uint32_t *order, hipStream_t st);
 void launch_path_chain_finish(Texel *out, const Texel *acc, uint32_t n, uint32_t chain, bool first, bool last, uint32_t spp, hipStream_t st);
 void launch_path_persistent(const FrameParams &P, uint32_t *heads, uint32_t n_cus, hipStream_t st);
-void launch_quantize(const Texel *out, uint8_t *rgba8, uint32_t n, hipStream_t st);
+void launch_quantize(const Texel *out, uint8_t *rgba8, uint32_t w, uint32_t h, hipStream_t st);
 void launch_assemble(const Texel *gathered, Texel *dst, uint32_t width, uint32_t tiles_x, uint32_t tiles_total,
                      uint32_t root_weight, uint32_t period, bool skip_root, uint64_t rank_stride, hipStream_t st);
 void launch_present(const Texel *out, uint32_t w, uint32_t h, uint32_t screen_w, uint32_t screen_h, const vrt_crosshair &ch,
@@ -290,6 +290,15 @@ static int quiesce(vrt_ctx *c) {
         const int q_ = quiesce(c);     \
         if (q_) return q_;             \
     } while (0)
+
+// The reference dispatches tex_size / 8 workgroups per axis (main.rs:452) over a result texture of any size
+// (main.rs:257-262: 1080 rows, the window's aspect): the columns and rows beyond the last whole 8x8 tile are never stored to
+// and keep the fresh texture's zeros.  Buffers that are read as whole frames start out zero for such a size.
+static bool ragged_output(const vrt_ctx *c) { return ((c->width | c->height) & 7u) != 0u; }
+static hipError_t zero_now(vrt_ctx *c, void *p, size_t bytes) {
+    const hipError_t e = hipMemsetAsync(p, 0, bytes, c->stream);
+    return e != hipSuccess ? e : hipStreamSynchronize(c->stream);   // (done before a launch on any other stream can follow)
+}
 
 static void layout_tiles(vrt_ctx *c) {
     c->tiles_x = c->width / 8u;
@@ -809,10 +818,8 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     if (cfg->n_devices > 1u) return grp_create(cfg, out);
     if (cfg->max_nodes < 2 || cfg->max_nodes > 0x7FFFFFFEu)
         return fail(nullptr, VRT_ERR_INVALID_ARG, "max_nodes must be in [2, 2^31 - 2] (the pool is addressed through a 32-bit byte offset)");
-    if (cfg->width == 0 || cfg->height == 0 || (cfg->width % 8u) || (cfg->height % 8u))
-        return fail(nullptr, VRT_ERR_INVALID_ARG,
-                    "output %ux%u: dimensions must be non-zero multiples of 8 (the reference dispatches "
-                    "tex_size/8 workgroups with no bounds check, main.rs:452)", cfg->width, cfg->height);
+    if (cfg->width == 0 || cfg->height == 0)
+        return fail(nullptr, VRT_ERR_INVALID_ARG, "output %ux%u: dimensions must be non-zero", cfg->width, cfg->height);
     if ((uint64_t)cfg->width * cfg->height > (1ull << 28))
         return fail(nullptr, VRT_ERR_INVALID_ARG, "output too large");
     const uint32_t sc = cfg->shard_count ? cfg->shard_count : 1u;
@@ -1047,8 +1054,8 @@ int vrt_set_world(vrt_ctx *c, const vrt_world_data *w) {
 int vrt_resize_output(vrt_ctx *c, uint32_t width, uint32_t height) {
     if (c && c->grp) return grp_resize_output(c, width, height);
     if (!c) return VRT_ERR_INVALID_ARG;
-    if (width == 0 || height == 0 || (width % 8u) || (height % 8u) || (uint64_t)width * height > (1ull << 28))
-        return fail(c, VRT_ERR_INVALID_ARG, "output %ux%u: dimensions must be non-zero multiples of 8", width, height);
+    if (width == 0 || height == 0 || (uint64_t)width * height > (1ull << 28))
+        return fail(c, VRT_ERR_INVALID_ARG, "output %ux%u: dimensions must be non-zero, at most 2^28 pixels", width, height);
     HIP_TRY(c, hipSetDevice(c->device));
     QUIESCE(c);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1211,7 +1218,11 @@ static int pick_frame_set(vrt_ctx *c, const vrt_render_opts &o, uint32_t variant
             f.path_buf = &c->extra_path[k];
         }
         if (!c->extra_stream[k]) HIP_TRY(c, hipStreamCreateWithFlags(&c->extra_stream[k], hipStreamNonBlocking));
-        if (!bound && !c->extra_out[k]) HIP_TRY(c, hipMalloc(&c->extra_out[k], (size_t)(c->slots ? c->slots : 1) * sizeof(vrt::Texel)));
+        if (!bound && !c->extra_out[k]) {
+            const size_t bytes = (size_t)(c->slots ? c->slots : 1) * sizeof(vrt::Texel);
+            HIP_TRY(c, hipMalloc(&c->extra_out[k], bytes));
+            if (ragged_output(c)) HIP_TRY(c, zero_now(c, c->extra_out[k], bytes));   // texels no workgroup covers stay zero (main.rs:452)
+        }
         if (!c->extra_blk[k]) HIP_TRY(c, hipMalloc(&c->extra_blk[k], (size_t)(c->tiles_local ? c->tiles_local : 1) * sizeof(uint32_t)));
         f.st = c->extra_stream[k];
         f.blk = c->extra_blk[k];
@@ -1295,6 +1306,7 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
         (void)hipFree(c->path_acc[f.slot]);
         c->path_acc[f.slot] = nullptr; c->path_acc_texels[f.slot] = 0;
         HIP_TRY(c, hipMalloc(&c->path_acc[f.slot], (size_t)samples * c->slots * sizeof(vrt::Texel)));
+        if (ragged_output(c)) HIP_TRY(c, zero_now(c, c->path_acc[f.slot], (size_t)samples * c->slots * sizeof(vrt::Texel)));
         c->path_acc_texels[f.slot] = (size_t)samples * c->slots;
     }
     vrt::Texel *const frame_out = P.out;
@@ -1468,7 +1480,10 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     if (c->compact && (o.mode == VRT_MODE_PATH || (o.variant != 0u && o.variant != 2u) || c->settings.show_step_count == 1u))
         return fail(c, VRT_ERR_STATE, "vrt_render: a VRT_FLAG_COMPACT context renders primary(+shadow) frames with the default march "
                     "only (no path trace, step-count view, literal or two-launch variants)");
-    if (o.stats == 1u && !c->d_steps) HIP_TRY(c, hipMalloc(&c->d_steps, (size_t)(c->slots ? c->slots : 1) * sizeof(uint32_t)));
+    if (o.stats == 1u && !c->d_steps) {
+        HIP_TRY(c, hipMalloc(&c->d_steps, (size_t)(c->slots ? c->slots : 1) * sizeof(uint32_t)));
+        if (ragged_output(c)) HIP_TRY(c, zero_now(c, c->d_steps, (size_t)(c->slots ? c->slots : 1) * sizeof(uint32_t)));
+    }
     if (o.stats == 2u && !c->d_clock) {
         HIP_TRY(c, hipMalloc(&c->d_clock, 2 * sizeof(unsigned long long)));
         HIP_TRY(c, hipMemsetAsync(c->d_clock, 0, 2 * sizeof(unsigned long long), c->stream));
@@ -1629,7 +1644,7 @@ int vrt_read_output(vrt_ctx *c, float *rgb, uint32_t *ids, uint8_t *rgba8) {
     if (rgba8) {
         if (c->tile_major) return fail(c, VRT_ERR_STATE, "vrt_read_output: rgba8 readback needs the row-major (unsharded) layout");
         if (!c->d_rgba8) HIP_TRY(c, hipMalloc(&c->d_rgba8, npix * 4));
-        vrt::launch_quantize(c->last_out, c->d_rgba8, (uint32_t)npix, c->stream);
+        vrt::launch_quantize(c->last_out, c->d_rgba8, c->width, c->height, c->stream);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipMemcpyAsync(rgba8, c->d_rgba8, npix * 4, hipMemcpyDeviceToHost, c->stream));
     }

@@ -392,13 +392,15 @@ void launch_tile_order(const uint32_t *cost, uint32_t n, uint32_t shift, uint32_
 // Output helpers
 // ------------------------------------------------------------------------------------------------
 
-// textureStore to rgba8unorm (ray_tracer.wgsl:179): clamp to [0,1], scale by 255, round to nearest.
-__global__ void quantize_rgba8_kernel(const Texel *out, uint8_t *rgba8, uint32_t n) {
+// textureStore to rgba8unorm (ray_tracer.wgsl:179): clamp to [0,1], scale by 255, round to nearest.  Texels beyond the
+// dispatched workgroups (main.rs:452: tex_size / 8 of them per axis) are never stored to: they keep the fresh texture's zeros,
+// alpha included.
+__global__ void quantize_rgba8_kernel(const Texel *out, uint8_t *rgba8, uint32_t n, uint32_t w, uint32_t cov_w, uint32_t cov_h) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const Texel t = out[i];
     const float c[3] = {__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z)};
-    uint32_t q = 0xFF000000u;
+    uint32_t q = (i % w < cov_w && i / w < cov_h) ? 0xFF000000u : 0u;
 #pragma unroll
     for (int k = 0; k < 3; k++) q |= ((uint32_t)rintf(vclamp(c[k], 0.0f, 1.0f) * 255.0f) & 0xFFu) << (8 * k);
     reinterpret_cast<uint32_t *>(rgba8)[i] = q;
@@ -408,8 +410,8 @@ __global__ void quantize_rgba8_kernel(const Texel *out, uint8_t *rgba8, uint32_t
 // per screen pixel: the sampler's (bilinear) sample of the texture at the pixel centre, crosshair mask, blend, unorm8 store.
 __device__ __forceinline__ uint32_t unorm8(float x) { return (uint32_t)rintf(vclamp(x, 0.0f, 1.0f) * 255.0f) & 0xFFu; }
 
-__global__ void present_kernel(const Texel *out, uint32_t w, uint32_t h, uint32_t screen_w, uint32_t screen_h, vrt_crosshair ch,
-                               uint8_t *rgba8) {
+__global__ void present_kernel(const Texel *out, uint32_t w, uint32_t h, uint32_t cov_w, uint32_t cov_h, uint32_t screen_w, uint32_t screen_h,
+                               vrt_crosshair ch, uint8_t *rgba8) {
     const uint32_t sx = blockIdx.x * blockDim.x + threadIdx.x, sy = blockIdx.y;
     if (sx >= screen_w) return;
     const float ssx = (float)screen_w, ssy = (float)screen_h;
@@ -443,7 +445,12 @@ __global__ void present_kernel(const Texel *out, uint32_t w, uint32_t h, uint32_
         const float top = v00 * (1.0f - a) + v10 * a, bot = v01 * (1.0f - a) + v11 * a;
         texel[k] = top * (1.0f - b) + bot * b;
     }
-    texel[3] = 1.0f * (1.0f - b) + 1.0f * b;
+    {   // alpha: 1 where the compute pass stored a texel, 0 beyond its workgroups (all of it when w and h are multiples of 8)
+        const float a00 = ((uint32_t)x0 < cov_w && (uint32_t)y0 < cov_h) ? 1.0f : 0.0f, a10 = ((uint32_t)x1 < cov_w && (uint32_t)y0 < cov_h) ? 1.0f : 0.0f;
+        const float a01 = ((uint32_t)x0 < cov_w && (uint32_t)y1 < cov_h) ? 1.0f : 0.0f, a11 = ((uint32_t)x1 < cov_w && (uint32_t)y1 < cov_h) ? 1.0f : 0.0f;
+        const float top = a00 * (1.0f - a) + a10 * a, bot = a01 * (1.0f - a) + a11 * a;
+        texel[3] = top * (1.0f - b) + bot * b;
+    }
     const float cc[4] = {ch.color[0], ch.color[1], ch.color[2], 1.0f};
     uint32_t q = 0u;
 #pragma unroll
@@ -604,9 +611,10 @@ void launch_shadow(const FrameParams &P, uint32_t variant, bool stats, hipStream
     }
 }
 
-void launch_quantize(const Texel *out, uint8_t *rgba8, uint32_t n, hipStream_t st) {
+void launch_quantize(const Texel *out, uint8_t *rgba8, uint32_t w, uint32_t h, hipStream_t st) {
+    const uint32_t n = w * h;
     if (!n) return;
-    hipLaunchKernelGGL(quantize_rgba8_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, out, rgba8, n);
+    hipLaunchKernelGGL(quantize_rgba8_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, out, rgba8, n, w, w & ~7u, h & ~7u);
 }
 
 void launch_assemble_shade(const FrameParams &P, const void *gathered, Texel *dst, uint32_t root_weight, uint32_t period,
@@ -618,8 +626,8 @@ void launch_assemble_shade(const FrameParams &P, const void *gathered, Texel *ds
 
 void launch_present(const Texel *out, uint32_t w, uint32_t h, uint32_t screen_w, uint32_t screen_h, const vrt_crosshair &ch,
                     uint8_t *rgba8, hipStream_t st) {
-    hipLaunchKernelGGL(present_kernel, dim3((screen_w + 255u) / 256u, screen_h), dim3(256), 0, st, out, w, h, screen_w, screen_h, ch,
-                       rgba8);
+    hipLaunchKernelGGL(present_kernel, dim3((screen_w + 255u) / 256u, screen_h), dim3(256), 0, st, out, w, h, w & ~7u, h & ~7u, screen_w,
+                       screen_h, ch, rgba8);
 }
 
 void launch_assemble(const Texel *gathered, Texel *dst, uint32_t width, uint32_t tiles_x, uint32_t tiles_total,
