@@ -10,8 +10,9 @@
  * PARITY STATUS: "parity unpinned" by the reference — the reference has no tests, golden vectors or
  * fixtures for this path and cannot be built here (Rust + WGSL via wgpu; no
  * cargo/rustc/naga in the image).  The oracle is pinned instead by hand-derived known-answer tests
- * from the shader text (tests/test_oracle_kat.py) and by golden vectors it generated itself
- * (tests/golden/, generator script committed).
+ * from the shader text (tests/test_oracle_kat.py), by golden vectors it generated itself
+ * (tests/golden/, generator script committed), and by a second restatement of the live shader written
+ * separately in numpy (tests/wgsl_numpy.py) that it agrees with bit for bit on ids and iteration counts.
  *
  * Every function cites the reference file:line it follows (paths relative to /root/reference).
  */
