@@ -138,13 +138,21 @@ def main():
         # the inner loop (DESIGN.md §3 m) IS the fast path: the steps in which no lane of the wave has anything to decide
         loop = [b for b in bl if b[2] == h]
         per_block = {b[0]: count(b[1]) for b in loop}
+        # the bit-pattern minimum a wave falls back to when some lane's smallest distance is zero or NaN (vrt_march.h (p)):
+        # the block behind `v_cmp_nlt_f32 vcc, 0, <min>; s_cbranch_vccz <over it>` is skipped on (practically) every
+        # step — listed, not counted into the fast path
+        rare = [loop[i + 1][0] for i in range(len(loop) - 1)
+                if len(loop[i][1]) >= 2 and loop[i][1][-1].startswith("s_cbranch_vccz") and loop[i][1][-2].startswith("v_cmp_nlt_f32")
+                and " 0, " in loop[i][1][-2]]
         fp = {}
         for lab in per_block:
-            fp = add(fp, per_block[lab])
-        res["loops"][name] = {"header": h, "fast_path_blocks": [b[0] for b in loop], "fast_path": fp, "per_block": per_block}
+            if lab not in rare:
+                fp = add(fp, per_block[lab])
+        res["loops"][name] = {"header": h, "fast_path_blocks": [b[0] for b in loop if b[0] not in rare], "fast_path": fp, "per_block": per_block,
+                              "rarely_executed_blocks": rare}
         listing.append(f"==== {name} ray: inner march loop (header {h}) = the fast path, one trip per step ====")
         for b in loop:
-            listing.append(f"{b[0]}:   {per_block[b[0]]}")
+            listing.append(f"{b[0]}:   {per_block[b[0]]}" + ("   (not in the fast path: only when some lane's smallest distance is zero or NaN)" if b[0] in rare else ""))
             listing += ["    " + t for t in b[1]]
     try:
         from voxelraytracing_amd import _ffi

@@ -466,6 +466,12 @@ __device__ __forceinline__ int flr2i(float x) {
     asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
     return r;
 }
+// v_min3_f32 as the instruction (fminf would add a canonicalising v_max per operand); a quiet NaN operand is ignored
+__device__ __forceinline__ float min3_f32(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ uint32_t min3_u32(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t r;
     asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
@@ -508,6 +514,12 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
     float ux = fabsf(unit.x), uy = fabsf(unit.y), uz = fabsf(unit.z);
     asm("" : "+v"(ux), "+v"(uy), "+v"(uz));   // (held in registers: the compiler would otherwise redo the three |.| on every step)
     const uint32_t mxm = mx ? ~0u : 0u, mym = my ? ~0u : 0u, mzm = mz ? ~0u : 0u;
+    // (q) the exit plane as a float without a conversion: plane + 0x4B000000 is the bit pattern of 2^23 + plane for
+    // 0 <= plane < 2^23, and (2^23 + plane) - 2^23 is exact — two full-rate instructions for v_cvt_f32_i32's half-rate one
+    // (the bias rides on the subtraction of the direction mask that is there anyway)
+    constexpr uint32_t kTwo23 = 0x4B000000u;
+    uint32_t mxb = mxm - kTwo23, myb = mym - kTwo23, mzb = mzm - kTwo23;
+    asm("" : "+v"(mxb), "+v"(myb), "+v"(mzb));   // (held in registers)
 
     const uint32_t wsize = P.world.size;
     const TableBuf gb = table_buffer(P.grid, P.grid_bytes), bb = table_buffer(P.bricks, P.brick_bytes);
@@ -539,9 +551,9 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
     // ---- the step to the leaf's exit face (:243-283), for a leaf of size lo + 1 ----
     auto take_step = [&](uint32_t lo) __attribute__((always_inline)) {
         // (h) the exit plane: low = v & ~lo, high = (v | lo) + 1; the direction mask is 0 or ~0 = -1, so "+ 1" is "- mask"
-        const float tx = (float)(int)(bfi(lo, mxm, (uint32_t)vx) - mxm) - pos.x;
-        const float ty = (float)(int)(bfi(lo, mym, (uint32_t)vy) - mym) - pos.y;
-        const float tz = (float)(int)(bfi(lo, mzm, (uint32_t)vz) - mzm) - pos.z;
+        const float tx = (__uint_as_float(bfi(lo, mxm, (uint32_t)vx) - mxb) - 8388608.0f) - pos.x;
+        const float ty = (__uint_as_float(bfi(lo, mym, (uint32_t)vy) - myb) - 8388608.0f) - pos.y;
+        const float tz = (__uint_as_float(bfi(lo, mzm, (uint32_t)vz) - mzb) - 8388608.0f) - pos.z;
         // (b'') |t| * |unit| has the bits of (mask ? t : -t) * unit, except that a zero is always +0 (never observed)
         adx = abs_mul(tx, ux);
         ady = abs_mul(ty, uy);
@@ -549,7 +561,12 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
         // (c') the minimum over the non-zero distances, on bit patterns: non-negative floats order like unsigned integers,
         // NaNs above every number, and bits - 1 sends +0 to the very top, so one unsigned min3 replaces the shader's
         // branch tree (:247-270): the smallest non-zero number; a NaN only if nothing else is non-zero; +0 if all are zero
-        step = __uint_as_float(min3_u32(__float_as_uint(adx) - 1u, __float_as_uint(ady) - 1u, __float_as_uint(adz) - 1u) + 1u);
+        // (p) ... and when every lane's three distances are above zero (or NaN beside a number above zero) the plain float
+        // minimum is that same number: one v_min3_f32 and one compare instead of three decrements, the unsigned minimum
+        // and an increment.  A wave in which some lane's minimum is zero or NaN takes the bit-pattern form.
+        step = min3_f32(adx, ady, adz);
+        if (__ballot(!(step > 0.0f)) != 0ull)
+            step = __uint_as_float(min3_u32(__float_as_uint(adx) - 1u, __float_as_uint(ady) - 1u, __float_as_uint(adz) - 1u) + 1u);
         total_len += step;
         const float sp = step + 0.001f;
         pos.x += dir.x * (step == adx ? sp : step);

@@ -374,7 +374,9 @@ __device__ __forceinline__ bool segment_trip(const FrameParams &P, const uint32_
     m.adx = abs_mul(tx, m.ux);
     m.ady = abs_mul(ty, m.uy);
     m.adz = abs_mul(tz, m.uz);
-    m.step = __uint_as_float(min3_u32(__float_as_uint(m.adx) - 1u, __float_as_uint(m.ady) - 1u, __float_as_uint(m.adz) - 1u) + 1u);
+    m.step = min3_f32(m.adx, m.ady, m.adz);   // (p) of vrt_march.h: the float minimum when no lane's is zero or NaN
+    if (__ballot(!(m.step > 0.0f)) != 0ull)
+        m.step = __uint_as_float(min3_u32(__float_as_uint(m.adx) - 1u, __float_as_uint(m.ady) - 1u, __float_as_uint(m.adz) - 1u) + 1u);
     m.total_len += m.step;
     const float sp = m.step + 0.001f;
     m.pos.x += m.dir.x * (m.step == m.adx ? sp : m.step);
@@ -594,7 +596,9 @@ __global__ void __launch_bounds__(256) path_bounce_pool_kernel(FrameParams P, ui
                 q.adx = abs_mul(tx, q.ux);
                 q.ady = abs_mul(ty, q.uy);
                 q.adz = abs_mul(tz, q.uz);
-                q.step = __uint_as_float(min3_u32(__float_as_uint(q.adx) - 1u, __float_as_uint(q.ady) - 1u, __float_as_uint(q.adz) - 1u) + 1u);
+                q.step = min3_f32(q.adx, q.ady, q.adz);   // (p) of vrt_march.h
+                if (__ballot(!(q.step > 0.0f)) != 0ull)
+                    q.step = __uint_as_float(min3_u32(__float_as_uint(q.adx) - 1u, __float_as_uint(q.ady) - 1u, __float_as_uint(q.adz) - 1u) + 1u);
                 const float sp = q.step + 0.001f;
                 q.pos.x += q.dir.x * (q.step == q.adx ? sp : q.step);
                 q.pos.y += q.dir.y * (q.step == q.ady ? sp : q.step);
