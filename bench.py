@@ -274,6 +274,14 @@ def main():
         dt = time.perf_counter() - t0
         return float(all_reduce(torch.tensor([dt], dtype=torch.float64, device="cuda"), dist.ReduceOp.MAX if world > 1 else None)[0])
 
+    # The interpreter's cyclic garbage collector is off from here (the share tuning's trials included) to the end of the
+    # measurements, as `timeit` runs its statements: with torch loaded a full collection is a 40 ms pause of the submitting
+    # thread, it comes every ~600 frames of the gather pipeline, and after the settling frames it used to fall into a
+    # 20-step timed region — 2.5 ms per frame instead of 0.15 (found with `--force-gather --steps 20 --warmup 5`;
+    # `--warmup 50` moved it out of the region).
+    import gc
+    gc.collect()
+    gc.disable()
     # ---- N > 1 (one process per GPU): how much of the frame the gather root should trace itself (off the clock) ----
     root_weight, batch, tuning, batch_tuning = 1, 1, None, None
     if world > 1:
