@@ -4,6 +4,8 @@ behind it, the same with an edit in front, and the frame period of a pipelined l
 import os
 import sys
 import time
+import gc
+gc.disable()   # (a full collection would be a 30-40 ms pause inside a measurement)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from voxelraytracing_amd import Gpu, MODE_PRIMARY_SHADOW, scenes
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 8     # world size in chunks (8 = C2, 32 = C5's world)

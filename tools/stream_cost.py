@@ -25,7 +25,9 @@ def frames(n, per_frame):
         gpu.write_chunk_roots(sc.world.chunk_roots())
         gpu.render(MODE_PRIMARY_SHADOW)
 
-frames(300, 1); gpu.synchronize(); frames(300, 0); gpu.synchronize()   # (a host that runs hundreds of frames ahead of the device hits a one-off stall of ~30 ms around its 500th frame, whatever the frames do; it stays out of the figures)
+import gc
+gc.collect(); gc.disable()   # (a full collection is a ~30-40 ms pause of this thread around its 500th frame: the interpreter's, not the library's)
+frames(300, 1); gpu.synchronize(); frames(300, 0); gpu.synchronize()
 for per_frame in (0, 1, 2, 3, 4, 8, 16):
     t0 = time.perf_counter()
     frames(300, per_frame)
