@@ -150,6 +150,13 @@ def test_result_textures_of_any_size(orc, size):
     d_rgb, d_ids, _ = both.read_output()
     assert_frame_parity(d_rgb, d_ids, r_rgb, r_ids, f"{w}x{h} over two devices")
     both.close()
+    # one frame at a time: the view rests, so from the third frame on the tiles are launched longest first (>= 128 tiles)
+    made.set_frames_in_flight(1)
+    for _ in range(4):
+        made.render(MODE_PRIMARY_SHADOW)
+    l_rgb, l_ids, _ = made.read_output()
+    assert_frame_parity(l_rgb, l_ids, r_rgb, r_ids, f"{w}x{h} one frame at a time")
+    made.set_frames_in_flight(2)
     settings = g.make_settings(sun_pos=scenes.SUN_POS, max_ray_bounces=2)
     made.write_settings(settings)
     o.set_settings(settings)
