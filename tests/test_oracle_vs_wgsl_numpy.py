@@ -49,3 +49,14 @@ def test_other_views_and_the_step_count_view(orc):
         agree(*both(orc, sc, 64, 40), f"rot {rot} eye {eye}")
     sc.settings = g.make_settings(sun_pos=scenes.SUN_POS, show_step_count=1)
     agree(*both(orc, sc, 64, 40), "step-count view")
+
+
+def test_presentation(orc):
+    """screen_shader.wgsl over the result texture: the oracle's orc_present against the numpy restatement, byte for byte —
+    windows at 1:1, magnified, minified, squeezed; a texture that is not whole tiles; every crosshair style."""
+    for size in ((64, 40), (75, 43)):
+        sc = scenes.c2(size)
+        rgb, _, _, _ = orc.from_package_scene(sc).render(orc.MODE_PRIMARY, *size)
+        for kw in (dict(), dict(style=1, size=9.5, color=(1.0, 0.2, 0.1, 0.75)), dict(style=0)):
+            for screen in (size, (2 * size[0] + 1, size[1] + 3), (size[0] // 2, size[1] // 2), (33, 7)):
+                assert np.array_equal(orc.present(rgb, screen, **kw), wgsl_numpy.present(rgb, screen, **kw)), (size, screen, kw)

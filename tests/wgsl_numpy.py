@@ -215,3 +215,45 @@ def render_primary(nodes_u16, chunk_roots, materials, cam, settings, world, w, h
     out_ids[:chh, :cw] = ids.reshape(chh, cw)
     out_it[:chh, :cw] = iters.reshape(chh, cw)
     return out_rgb, out_ids, out_it
+
+
+def present(rgb, screen_size, color=(1.0, 1.0, 1.0, 0.33), style=2, size=5.0):
+    """fs_main of clientdesktop/src/graphics/screen_shader.wgsl:43-65 over the rgba8unorm result texture, vectorised over the
+    window's pixels: -> rgba8 [screen_h, screen_w, 4].  The texture is what `update` stored (ray_tracer.wgsl:179: clamp,
+    x 255, round to nearest even; alpha 1) where the compute pass ran (main.rs:452: tex_size / 8 workgroups per axis) and
+    the fresh texture's zeros elsewhere.  The sampler (texture.rs:31-44: ClampToEdge, mag Nearest, min Linear, lod clamped
+    to [1, 1] on a one-level texture) samples with its minification filter at every size — the reading DESIGN.md section 2
+    argues — i.e. bilinear on unnormalised coordinates u W - 1/2."""
+    rgb = np.asarray(rgb, dtype=F)
+    h, w, _ = rgb.shape
+    sw, sh = screen_size
+    cw, chh = (w // 8) * 8, (h // 8) * 8
+    tex = np.zeros((h, w, 4), dtype=F)
+    q = np.rint(np.clip(np.nan_to_num(rgb, nan=0.0), 0.0, 1.0) * F(255.0)).astype(F) / F(255.0)
+    tex[:chh, :cw, :3] = q[:chh, :cw]
+    tex[:chh, :cw, 3] = F(1.0)
+    ssx, ssy = F(sw), F(sh)
+    sy, sx = np.meshgrid(np.arange(sh), np.arange(sw), indexing="ij")
+    u = (sx.astype(F) + F(0.5)) / ssx                               # tex_coord at the pixel centre (:33-40)
+    v = (sy.astype(F) + F(0.5)) / ssy
+    px, py = u * ssx, v * ssy                                        # :44
+    cx, cy = ssx * F(0.5), ssy * F(0.5)                              # :45
+    mask = np.zeros((sh, sw), dtype=F)
+    if style == 1:                                                   # :48-50
+        dx, dy = cx - px, cy - py
+        mask = (np.sqrt(dx * dx + dy * dy) < F(size)).astype(F) * F(color[3])
+    if style == 2:                                                   # :51-59
+        dx, dy = np.abs(cx - px), np.abs(cy - py)
+        wd = F(size) * F(0.25)
+        mask = (((dx < F(size)) & (dy < wd)) | ((dy < F(size)) & (dx < wd))).astype(F) * F(color[3])
+    ut, vt = u * F(w) - F(0.5), v * F(h) - F(0.5)
+    fu, fv = np.floor(ut), np.floor(vt)
+    a, b = (ut - fu)[..., None], (vt - fv)[..., None]
+    x0 = np.clip(fu.astype(np.int64), 0, w - 1); x1 = np.clip(fu.astype(np.int64) + 1, 0, w - 1)
+    y0 = np.clip(fv.astype(np.int64), 0, h - 1); y1 = np.clip(fv.astype(np.int64) + 1, 0, h - 1)
+    top = tex[y0, x0] * (F(1.0) - a) + tex[y0, x1] * a
+    bot = tex[y1, x0] * (F(1.0) - a) + tex[y1, x1] * a
+    texel = top * (F(1.0) - b) + bot * b                             # :61
+    cc = np.array([color[0], color[1], color[2], 1.0], dtype=F)
+    out = texel * (F(1.0) - mask[..., None]) + cc * mask[..., None]  # :60-63
+    return np.rint(np.clip(out, 0.0, 1.0) * F(255.0)).astype(np.uint8)
