@@ -317,7 +317,9 @@ int vrt_set_stream(vrt_ctx *ctx, void *hip_stream);
 
 /* Render into caller-owned device memory (e.g. a torch tensor handed to an RCCL gather) instead of the
  * context's own buffer: `texels` must hold the byte count vrt_device_output reports and be 16-byte
- * aligned.  NULL restores the context's buffer; vrt_resize_output drops the binding. */
+ * aligned.  NULL restores the context's buffer; vrt_resize_output drops the binding.  With a result size that is
+ * not whole 8x8 tiles the frame's last columns / rows are never written (vrt_config.width): a row-major caller buffer
+ * should start out zero, as the context's own buffers do, and the same goes for the dst of vrt_assemble*. */
 int vrt_bind_output(vrt_ctx *ctx, void *texels);
 
 /* Device pointer and size in bytes of the buffer frames are currently written to. */
