@@ -93,6 +93,11 @@ void vrth_gen_dense_superflat(const int32_t chunk_pos[3], uint16_t *dense);
 /* Generate every chunk of the world's grid and create_chunk it. kind 0 = procedural (seed),
  * 1 = superflat built by set_node (config C1). threads <= 0: all cores. Returns 0 or a SetVoxelErr. */
 int vrth_world_generate(vrth_world *w, uint32_t kind, uint32_t seed, int threads);
+/* The same for the grid's EMPTY cells only — what arrives after request_missing_chunks (client/src/lib.rs:80-108) once
+ * center_chunks moved the grid: ranges[2 i], ranges[2 i + 1] = (root, node count) of the i-th chunk created (grid order;
+ * at most cap pairs are written), *n_ranges = how many were created — the ranges to hand to vrt_write_nodes
+ * (main.rs:289-295).  All-air chunks stay empty cells. */
+int vrth_world_generate_missing(vrth_world *w, uint32_t kind, uint32_t seed, int threads, uint32_t *ranges, uint32_t cap, uint32_t *n_ranges);
 
 /* ---- region files of the reference server (servercli/src/main.rs:25-73; format in csrc/host/regionfile.hpp) ---- */
 /* Parse one `regions/r_X_Y_Z_.data` image and create_chunk every chunk of it that lies inside the world's grid.

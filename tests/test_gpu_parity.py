@@ -427,7 +427,8 @@ def test_path_trace_mirror_materials_and_sharding(orc):
 
 def test_large_world_uses_global_chunk_table(orc):
     """24^3 chunks = 13 824 chunk roots: more than the 8 192 entries staged in LDS, so the kernels read the
-    table from global memory (LDS_ROOTS = false); also a world.min away from the origin."""
+    table from global memory (LDS_ROOTS = false).  (ClientWorld((12,12,12), ., 24) has min chunk (0,0,0): world.min is the
+    origin here; worlds whose min is not are tests/test_gpu_operating_point.py.)"""
     from voxelraytracing_amd.world import ClientWorld, gen_height
     w = ClientWorld((12, 12, 12), 1 << 25, 24)
     w.generate(0, 1)

@@ -202,6 +202,7 @@ VRTH_SYMBOLS = {
     "vrth_gen_dense": (C.c_int, [C.c_uint32, _I32P, _P]),
     "vrth_gen_dense_superflat": (None, [_I32P, _P]),
     "vrth_world_generate": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_int]),
+    "vrth_world_generate_missing": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_int, _P, C.c_uint32, _U32P]),
     "vrth_region_load_into_world": (C.c_int, [_P, _P, C.c_uint64, _I32P, _U32P]),
     "vrth_region_save_from_world": (C.c_uint64, [_P, _I32P, _P, C.c_uint64]),
     "vrth_chunk_msg_ingest": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(C.c_uint64), _I32P, _U32P, _U32P]),

@@ -175,10 +175,22 @@ int vrth_gen_dense(uint32_t seed, const int32_t chunk_pos[3], uint16_t *dense) {
 
 void vrth_gen_dense_superflat(const int32_t chunk_pos[3], uint16_t *dense) { fill_dense_superflat(cp3(chunk_pos), dense); }
 
-int vrth_world_generate(vrth_world *w, uint32_t kind, uint32_t seed, int threads) {
+// Shared by vrth_world_generate (every cell of the grid) and vrth_world_generate_missing (the empty cells only: what the
+// server sends back for request_missing_chunks, client/src/lib.rs:80-108, after the grid moved).  `ranges`: (root, count)
+// of every chunk created, in grid order — the ranges GameState::process_cmd hands to NodeBuffer::write (main.rs:289-295).
+static int generate_impl(vrth_world *w, uint32_t kind, uint32_t seed, int threads, bool only_missing, uint32_t *ranges, uint32_t cap,
+                         uint32_t *n_ranges) {
     const uint32_t S = w->w.size_in_chunks();
     const size_t total = (size_t)S * S * S;
     std::vector<std::vector<Node>> built(total);
+    std::vector<uint8_t> skip(total, 0);
+    if (only_missing) {
+        const ChunkPos mn0 = w->w.min_chunk();
+        for (size_t i = 0; i < total; i++) {
+            const ChunkPos cp{mn0.x + (int32_t)(i % S), mn0.y + (int32_t)((i / S) % S), mn0.z + (int32_t)(i / ((size_t)S * S))};
+            skip[i] = w->w.get_chunk(cp) != nullptr;
+        }
+    }
     std::atomic<size_t> next{0};
     std::atomic<int> failed{0};
     // (at most 16 workers unless asked for more: a chunk is ~0.1 ms of work, and a host with hundreds of hardware threads —
@@ -194,6 +206,7 @@ int vrth_world_generate(vrth_world *w, uint32_t kind, uint32_t seed, int threads
         for (;;) {
             const size_t i = next.fetch_add(1);
             if (i >= total) return;
+            if (skip[i]) continue;
             const ChunkPos cp{mn.x + (int32_t)(i % S), mn.y + (int32_t)((i / S) % S), mn.z + (int32_t)(i / ((size_t)S * S))};
             if (kind == 1) {
                 fill_dense_superflat(cp, dense.data());
@@ -218,15 +231,27 @@ int vrth_world_generate(vrth_world *w, uint32_t kind, uint32_t seed, int threads
     for (auto &t : pool) t.join();
     if (failed) return failed;
     // create_chunk in grid order (x fastest), so pool layout is deterministic regardless of threads
+    uint32_t count = 0;
     for (size_t i = 0; i < total; i++) {
         const ChunkPos cp{mn.x + (int32_t)(i % S), mn.y + (int32_t)((i / S) % S), mn.z + (int32_t)(i / ((size_t)S * S))};
         // an all-air chunk needs no storage: leaving the cell empty resolves to pool[0] (world.rs:154-159)
-        if (built[i].size() == 1 && built[i][0].w == 0) continue;
+        if (skip[i] || (built[i].size() == 1 && built[i][0].w == 0)) continue;
         SetVoxelErr err;
-        w->w.create_chunk(cp, built[i].data(), (uint32_t)built[i].size(), err);
+        const NodeAddr root = w->w.create_chunk(cp, built[i].data(), (uint32_t)built[i].size(), err);
         if (err != SetVoxelErr::Ok) return (int)err;
+        if (ranges && count < cap) { ranges[2 * count] = root; ranges[2 * count + 1] = (uint32_t)built[i].size(); }
+        count++;
     }
+    if (n_ranges) *n_ranges = count;
     return 0;
+}
+
+int vrth_world_generate(vrth_world *w, uint32_t kind, uint32_t seed, int threads) {
+    return generate_impl(w, kind, seed, threads, false, nullptr, 0, nullptr);
+}
+
+int vrth_world_generate_missing(vrth_world *w, uint32_t kind, uint32_t seed, int threads, uint32_t *ranges, uint32_t cap, uint32_t *n_ranges) {
+    return generate_impl(w, kind, seed, threads, true, ranges, cap, n_ranges);
 }
 
 

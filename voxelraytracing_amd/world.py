@@ -120,6 +120,17 @@ class ClientWorld:
         if rc:
             raise SetVoxelErr(rc)
 
+    def generate_missing(self, kind: int = 0, seed: int = 1, threads: int = 0) -> np.ndarray:
+        """Fill the grid's empty cells (what the server answers request_missing_chunks with, client/src/lib.rs:80-108).
+        -> u32[n, 2] of (root, node count): the ranges to upload, as GameState::process_cmd returns them."""
+        cap = self.size_in_chunks() ** 3
+        out = np.zeros((cap, 2), dtype=np.uint32)
+        n = C.c_uint32()
+        rc = self._lib.vrth_world_generate_missing(self._h, kind, seed, threads, out.ctypes.data_as(C.c_void_p), cap, C.byref(n))
+        if rc:
+            raise SetVoxelErr(rc)
+        return out[:n.value].copy()
+
     # --- views ---
     def nodes(self) -> np.ndarray:
         """The whole flat pool as a zero-copy u16 view (client/src/world.rs:292-294)."""
