@@ -181,7 +181,7 @@ class _Client:
         return ids
 
 
-def _session(orc, gpu, size, path_frames=True):
+def _session(orc, gpu, size, path_frames=True, max_in_flight=3):
     world = ClientWorld(PLAYER_CHUNK, MAX_NODES, S)
     cl = _Client(gpu, world, size, g.std_materials())
     # ---- join: the whole grid is missing; the server's chunks arrive over many frames (a 30^3 join is 27 000 messages) ----
@@ -202,7 +202,7 @@ def _session(orc, gpu, size, path_frames=True):
     steps = [((px + 1, py, pz), 1), ((px + 1, py - 1, pz), 2), ((px + 1, py - 1, pz + 1), 3), ((px, py - 1, pz + 1), 2),
              ((px, py, pz + 1), 1), ((px, py, pz), 3)]
     for k, (chunk, in_flight) in enumerate(steps):
-        gpu.set_frames_in_flight(in_flight)
+        gpu.set_frames_in_flight(min(in_flight, max_in_flight))
         removed, added = cl.move_to(chunk)
         assert removed + added > 0      # (a layer of open sky leaves or enters as empty cells)
         cl.look((20.0 - 3 * k, 35.0 + 50 * k, 0.0))
@@ -233,7 +233,7 @@ def _session(orc, gpu, size, path_frames=True):
     far = [(px + S + 1, py, pz), (px + S + 1, py, pz - S - 3), (px + S + 1, py + S + 2, pz - S - 3), (px + S + 1, py, pz - S - 3),
            (px + S + 1, py - S - 1, pz - S - 3), (px, py, pz)]
     for k, chunk in enumerate(far):
-        gpu.set_frames_in_flight(1 + k % 3)
+        gpu.set_frames_in_flight(min(1 + k % 3, max_in_flight))
         populated = world.populated_count()
         removed, added = cl.move_to(chunk)
         assert removed == populated       # nothing of the old grid is inside the new one
@@ -277,7 +277,7 @@ def test_session_join_recentre_stream_and_edit_three_devices(orc):
     """The same session through ONE context over three devices (device_ids = {0, 0, 0}: the rehearsal of a multi-GPU host)."""
     size = (256, 144)
     gpu = Gpu(MAX_NODES, S, size, devices=[0, 0, 0], texel_messages=True)
-    _session(orc, gpu, size)
+    _session(orc, gpu, size, max_in_flight=2)      # (two message slots: a multi-device context keeps at most two frames in flight)
     gpu.close()
 
 

@@ -17,6 +17,15 @@
 //   brick pool  u16[bricks][64], index (x&3) | (y&3) << 2 | (z&3) << 4 inside the cell:
 //               air leaf -> lo (1 at depth 4, 0 at depth 5); other leaf -> voxel << 1 | lo
 //
+//   march cells uint4[8S][8S+1][8S+1], same indexing and border (worlds of S <= kMarchCellsMaxS; the path trace's bounce
+//               launches, vrt_path.hip): everything a march step has to know about a cell in ONE 16-byte load, so that a
+//               split cell costs no second, dependent load —
+//               .x  the cell grid's entry (lo of a leaf in its low 5 bits, 0x80000000 | brick * 64 for a split cell)
+//               .y  split cell: bit (x>>1&1) | (y>>1&1) << 2 | (z>>1&1) << 4 set <=> that 2^3 sub-block is one depth-4 leaf
+//               .z .w  64 bits, bit (x&3) | (y&3) << 2 | (z&3) << 4: the voxel there stops a ray (not air, not a liquid of the
+//                   material table the tables were built with); a leaf cell is all ones or all zeros
+//               The voxel a ray stopped on is read from the brick afterwards, at full width, not inside the loop.
+//
 // Every entry is exactly what find_node would return for any position inside it (same node word, same depth;
 // a node read past the end of the pool is 0, a missing chunk is root 0), so the march visits the same leaves
 // and produces the same frame bit for bit; variant 1 (the literal walk) and variant 2 (ancestor cache) still
@@ -41,6 +50,30 @@ __device__ __forceinline__ size_t cell_index(uint32_t S, uint32_t chunk, uint32_
 
 // A leaf's grid entry: air -> lo, anything else -> voxel << 16 | lo  (lo = leaf size - 1).
 __device__ __forceinline__ uint32_t leaf_entry(uint32_t node, uint32_t lo) { return ((node & 0x7FFFu) << 16) | lo; }
+
+// voxel_mats[voxel].is_liquid == 1 with ids >= 256 clamped to material 255 (ray_tracer.wgsl:226), as a 256-bit mask
+struct LiquidMask { uint32_t w[8]; };
+__device__ __forceinline__ bool stops_a_ray(const LiquidMask &lq, uint32_t voxel) {
+    const uint32_t v = min(voxel, 255u);
+    return voxel != 0u && !((lq.w[v >> 5] >> (v & 31u)) & 1u);
+}
+// The march-cell entry of a leaf cell: all of it stops a ray, or none of it.
+__device__ __forceinline__ uint4 leaf_march_cell(const LiquidMask &lq, uint32_t node, uint32_t lo) {
+    const uint32_t m = stops_a_ray(lq, node & 0x7FFFu) ? 0xFFFFFFFFu : 0u;
+    return make_uint4(leaf_entry(node, lo), 0u, m, m);
+}
+// ... of a split cell, from its brick's 64 entries (voxel << 1 | lo) packed two per word
+__device__ __forceinline__ uint4 split_march_cell(const LiquidMask &lq, uint32_t brick, const uint32_t w[32]) {
+    uint32_t occ[2] = {0u, 0u}, size2 = 0u;
+#pragma unroll
+    for (uint32_t e = 0; e < 64u; e++) {
+        const uint32_t b = (w[e >> 1] >> ((e & 1u) * 16u)) & 0xFFFFu;
+        if (stops_a_ray(lq, b >> 1)) occ[e >> 5] |= 1u << (e & 31u);
+        // (every voxel of a depth-4 leaf carries lo = 1; the mask is indexed by the sub-block's corner)
+        if ((b & 1u) && !(e & 0x15u)) size2 |= 1u << (e >> 1);
+    }
+    return make_uint4(0x80000000u | (brick * 64u), size2, occ[0], occ[1]);
+}
 
 // Walks the three levels above a cell. Returns the node word at the stop depth (<= 3) and that depth.
 __device__ __forceinline__ uint32_t descend3(const uint16_t *nodes, uint32_t n_nodes, uint32_t root, uint32_t cx, uint32_t cy,
@@ -71,26 +104,39 @@ __device__ __forceinline__ uint32_t rank_split_cells(bool split, uint32_t *s_wav
     return before + (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
 }
 
-// The 64 entries of one split cell's brick: 8 depth-4 children x 8 depth-5 grandchildren.
-__device__ __forceinline__ void fill_brick(const uint16_t *nodes, uint32_t n_nodes, uint32_t root, uint32_t n3, uint16_t *b) {
+// The 64 entries of one split cell's brick — 8 depth-4 children x 8 depth-5 grandchildren — assembled in registers, two
+// entries per word.  node_at(i): node i of the chunk, relative to its root.
+template <typename NodeAt>
+__device__ __forceinline__ void assemble_brick(const NodeAt &node_at, uint32_t n3, uint32_t w[32]) {
+#pragma unroll
+    for (uint32_t k = 0; k < 32u; k++) w[k] = 0u;
+#pragma unroll
     for (uint32_t c = 0; c < 8u; c++) {
-        const uint32_t n4 = pool_node(nodes, n_nodes, root + (n3 & 0x7FFFu) + c);
+        const uint32_t n4 = node_at((n3 & 0x7FFFu) + c);
         const uint32_t x1 = (c & 1u) * 2u, y1 = ((c >> 1) & 1u) * 2u, z1 = ((c >> 2) & 1u) * 2u;
+#pragma unroll
         for (uint32_t g = 0; g < 8u; g++) {
             const uint32_t x = x1 + (g & 1u), y = y1 + ((g >> 1) & 1u), z = z1 + ((g >> 2) & 1u);
             uint32_t word;
-            if (n4 & 0x8000u) word = (pool_node(nodes, n_nodes, root + (n4 & 0x7FFFu) + g) & 0x7FFFu) << 1;  // depth 5: the walk stops here, size 1
-            else word = ((n4 & 0x7FFFu) << 1) | 1u;                                                          // depth-4 leaf, size 2
-            b[x | (y << 2) | (z << 4)] = (uint16_t)word;
+            if (n4 & 0x8000u) word = (node_at((n4 & 0x7FFFu) + g) & 0x7FFFu) << 1;  // depth 5: the walk stops here, size 1
+            else word = ((n4 & 0x7FFFu) << 1) | 1u;                                 // depth-4 leaf, size 2
+            const uint32_t e = x | (y << 2) | (z << 4);
+            w[e >> 1] |= word << ((e & 1u) * 16u);
         }
     }
+}
+// ... and stored as eight 16-byte vectors (a brick is 128-byte aligned: hipMalloc + brick * 128)
+__device__ __forceinline__ void store_brick(uint16_t *bricks, uint32_t brick, const uint32_t w[32]) {
+    uint4 *dst = reinterpret_cast<uint4 *>(bricks + (size_t)brick * 64u);
+#pragma unroll
+    for (uint32_t k = 0; k < 8u; k++) dst[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
 }
 
 // Whole-world build, pass 1.  One workgroup per chunk slot, one thread per depth-3 cell: writes leaf entries, ranks the
 // split cells inside the chunk (their bricks are laid out contiguously per chunk, cells in x-major order) and the
 // chunk's brick count.
 __global__ void __launch_bounds__(512) accel_cells_kernel(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots,
-                                                          uint32_t S, uint32_t *grid, uint32_t *chunk_bricks) {
+                                                          uint32_t S, uint32_t *grid, uint32_t *chunk_bricks, uint4 *mcells, LiquidMask lq) {
     __shared__ uint32_t s_wave[8];
     const uint32_t chunk = blockIdx.x;
     const uint32_t t = threadIdx.x, cx = t & 7u, cy = (t >> 3) & 7u, cz = t >> 6;
@@ -100,7 +146,9 @@ __global__ void __launch_bounds__(512) accel_cells_kernel(const uint16_t *nodes,
     const bool split = (node & 0x8000u) != 0u;  // only possible at depth 3
     uint32_t total;
     const uint32_t rank = rank_split_cells(split, s_wave, total);
-    grid[cell_index(S, chunk, cx, cy, cz)] = split ? (0x80000000u | rank) : leaf_entry(node, (32u >> depth) - 1u);
+    const size_t cell = cell_index(S, chunk, cx, cy, cz);
+    grid[cell] = split ? (0x80000000u | rank) : leaf_entry(node, (32u >> depth) - 1u);
+    if (mcells && !split) mcells[cell] = leaf_march_cell(lq, node, (32u >> depth) - 1u);   // (split cells: pass 3)
     if (t == 0) chunk_bricks[chunk] = total;
 }
 
@@ -140,7 +188,7 @@ __global__ void __launch_bounds__(1024) accel_scan_kernel(const uint32_t *counts
 // Pass 3: fills the bricks of the split cells and replaces their in-chunk rank by the pool position.
 __global__ void __launch_bounds__(512) accel_bricks_kernel(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots,
                                                            uint32_t S, uint32_t *grid, const uint32_t *chunk_bases,
-                                                           uint16_t *bricks, uint32_t brick_cap) {
+                                                           uint16_t *bricks, uint32_t brick_cap, uint4 *mcells, LiquidMask lq) {
     const uint32_t chunk = blockIdx.x;
     const uint32_t t = threadIdx.x, cx = t & 7u, cy = (t >> 3) & 7u, cz = t >> 6;
     const size_t cell = cell_index(S, chunk, cx, cy, cz);
@@ -151,8 +199,11 @@ __global__ void __launch_bounds__(512) accel_bricks_kernel(const uint16_t *nodes
     const uint32_t root = roots[chunk];
     uint32_t depth;
     const uint32_t n3 = descend3(nodes, n_nodes, root, cx, cy, cz, depth);
-    fill_brick(nodes, n_nodes, root, n3, bricks + (size_t)brick * 64u);
+    uint32_t w[32];
+    assemble_brick([&](uint32_t i) { return pool_node(nodes, n_nodes, root + i); }, n3, w);
+    store_brick(bricks, brick, w);
     grid[cell] = 0x80000000u | (brick * 64u);
+    if (mcells) mcells[cell] = split_march_cell(lq, brick, w);
 }
 
 // Rebuild of single chunks (a voxel edit, a chunk that arrived): one workgroup per listed chunk does all three passes
@@ -185,7 +236,7 @@ struct ChunkNodes {
 __global__ void __launch_bounds__(512) accel_chunks_kernel(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S,
                                                            uint32_t *grid, uint32_t *chunk_bricks, uint32_t *chunk_bases,
                                                            uint32_t *chunk_caps, uint32_t *tail, uint16_t *bricks, uint32_t brick_cap,
-                                                           ChunkList list) {
+                                                           uint4 *mcells, LiquidMask lq, ChunkList list) {
     extern __shared__ __attribute__((aligned(16))) uint16_t s_raw[];  // the chunk's node words from the 16-byte boundary at or below its root
     __shared__ uint32_t s_wave[8];
     __shared__ uint32_t s_base;
@@ -236,33 +287,17 @@ __global__ void __launch_bounds__(512) accel_chunks_kernel(const uint16_t *nodes
     const size_t cell = cell_index(S, chunk, cx, cy, cz);
     if (!split) {
         grid[cell] = leaf_entry(node, (32u >> depth) - 1u);
+        if (mcells) mcells[cell] = leaf_march_cell(lq, node, (32u >> depth) - 1u);
         return;
     }
     const uint32_t brick = s_base + rank;
     if (brick >= brick_cap) return;  // cannot happen: the host accounts for every possible move
-    // the brick, assembled in registers (64 entries = 32 words) and stored as eight 16-byte vectors
     uint32_t w[32];
-#pragma unroll
-    for (uint32_t k = 0; k < 32u; k++) w[k] = 0u;
-#pragma unroll
-    for (uint32_t c = 0; c < 8u; c++) {
-        const uint32_t n4 = lds_node((node & 0x7FFFu) + c);
-        const uint32_t x1 = (c & 1u) * 2u, y1 = ((c >> 1) & 1u) * 2u, z1 = ((c >> 2) & 1u) * 2u;
-#pragma unroll
-        for (uint32_t g = 0; g < 8u; g++) {
-            const uint32_t x = x1 + (g & 1u), y = y1 + ((g >> 1) & 1u), z = z1 + ((g >> 2) & 1u);
-            uint32_t word;
-            if (n4 & 0x8000u) word = (lds_node((n4 & 0x7FFFu) + g) & 0x7FFFu) << 1;  // depth 5: the walk stops here, size 1
-            else word = ((n4 & 0x7FFFu) << 1) | 1u;                                            // depth-4 leaf, size 2
-            const uint32_t e = x | (y << 2) | (z << 4);
-            w[e >> 1] |= word << ((e & 1u) * 16u);
-        }
-    }
-    uint4 *dst = reinterpret_cast<uint4 *>(bricks + (size_t)brick * 64u);   // 128-byte aligned: hipMalloc + brick * 128
-#pragma unroll
-    for (uint32_t k = 0; k < 8u; k++) dst[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+    assemble_brick(lds_node, node, w);
+    store_brick(bricks, brick, w);
     __threadfence();
     grid[cell] = 0x80000000u | (brick * 64u);
+    if (mcells) mcells[cell] = split_march_cell(lq, brick, w);
 }
 
 // Upload of a staged range: the pinned ring is mapped into the device's address space, so a kernel reads it over PCIe and
@@ -281,23 +316,32 @@ void launch_upload_words(void *dst, const void *pinned_src, uint32_t n_words, hi
                        (const uint32_t *)pinned_src, n_words);
 }
 
+static LiquidMask liquid_mask(const uint32_t liquid[8]) {
+    LiquidMask lq;
+    for (int i = 0; i < 8; i++) lq.w[i] = liquid[i];
+    return lq;
+}
+
+// mcells: the march cells (null: not kept for this world), liquid: the 256-bit is_liquid mask they are built with
 void launch_accel_cells(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S, uint32_t *grid,
                         uint32_t *chunk_bricks, uint32_t *chunk_bases, uint32_t *chunk_caps, uint32_t *total, uint32_t *tail,
-                        hipStream_t st) {
+                        uint4 *mcells, const uint32_t liquid[8], hipStream_t st) {
     const uint32_t n = S * S * S;
-    hipLaunchKernelGGL(accel_cells_kernel, dim3(n), dim3(512), 0, st, nodes, n_nodes, roots, S, grid, chunk_bricks);
+    hipLaunchKernelGGL(accel_cells_kernel, dim3(n), dim3(512), 0, st, nodes, n_nodes, roots, S, grid, chunk_bricks, mcells, liquid_mask(liquid));
     hipLaunchKernelGGL(accel_scan_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t *)chunk_bricks, chunk_bases, chunk_caps, n, total, tail);
 }
 
 void launch_accel_bricks(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S, uint32_t *grid,
-                         const uint32_t *chunk_bases, uint16_t *bricks, uint32_t brick_cap, hipStream_t st) {
+                         const uint32_t *chunk_bases, uint16_t *bricks, uint32_t brick_cap, uint4 *mcells, const uint32_t liquid[8],
+                         hipStream_t st) {
     hipLaunchKernelGGL(accel_bricks_kernel, dim3(S * S * S), dim3(512), 0, st, nodes, n_nodes, roots, S, grid, chunk_bases, bricks,
-                       brick_cap);
+                       brick_cap, mcells, liquid_mask(liquid));
 }
 
 void launch_accel_chunks(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S, uint32_t *grid,
                          uint32_t *chunk_bricks, uint32_t *chunk_bases, uint32_t *chunk_caps, uint32_t *tail, uint16_t *bricks,
-                         uint32_t brick_cap, const uint32_t *chunks, const uint32_t *extents, uint32_t n, hipStream_t st) {
+                         uint32_t brick_cap, uint4 *mcells, const uint32_t liquid[8], const uint32_t *chunks, const uint32_t *extents,
+                         uint32_t n, hipStream_t st) {
     // 64 KiB + of dynamic LDS needs opting in (the CU has 160 KiB); per device, and any thread may be the first
     const size_t lds = (size_t)(kChunkNodesMax + 16u) * sizeof(uint16_t);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(accel_chunks_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -306,7 +350,7 @@ void launch_accel_chunks(const uint16_t *nodes, uint32_t n_nodes, const uint32_t
         const uint32_t m = n - i < 64u ? n - i : 64u;
         for (uint32_t k = 0; k < m; k++) { list.chunk[k] = chunks[i + k]; list.extent[k] = extents[i + k]; }
         hipLaunchKernelGGL(accel_chunks_kernel, dim3(m), dim3(512), lds, st, nodes, n_nodes, roots, S, grid, chunk_bricks, chunk_bases,
-                           chunk_caps, tail, bricks, brick_cap, list);
+                           chunk_caps, tail, bricks, brick_cap, mcells, liquid_mask(liquid), list);
     }
 }
 

@@ -35,6 +35,7 @@ void launch_primary_shadow_persistent(const FrameParams &P, uint32_t *heads, uin
 void launch_path_primary(const FrameParams &P, bool stats, bool literal, hipStream_t st);
 void launch_path_bounce(const FrameParams &P, bool stats, bool literal, hipStream_t st);
 void launch_path_bounce_pool(const FrameParams &P, bool continuations, uint32_t refill_at, uint32_t eject_at, hipStream_t st);
+void launch_path_bounce_cells(const FrameParams &P, uint32_t refill_at, bool sort, hipStream_t st);
 void launch_path_finish(Texel *out, uint32_t n, uint32_t spp, hipStream_t st);
 void launch_tile_order(const uint32_t *cost, uint32_t n, uint32_t shift, uint32_t *scratch, uint32_t *order, hipStream_t st);
 void launch_path_chain_finish(Texel *out, const Texel *acc, uint32_t n, uint32_t chain, bool first, bool last, uint32_t spp, hipStream_t st);
@@ -48,13 +49,15 @@ void launch_assemble_shade(const FrameParams &P, const void *gathered, Texel *ds
                            uint64_t rank_stride, hipStream_t st);
 void launch_accel_cells(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S, uint32_t *grid,
                         uint32_t *chunk_bricks, uint32_t *chunk_bases, uint32_t *chunk_caps, uint32_t *total, uint32_t *tail,
-                        hipStream_t st);
+                        uint4 *mcells, const uint32_t liquid[8], hipStream_t st);
 void launch_accel_bricks(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S, uint32_t *grid,
-                         const uint32_t *chunk_bases, uint16_t *bricks, uint32_t brick_cap, hipStream_t st);
+                         const uint32_t *chunk_bases, uint16_t *bricks, uint32_t brick_cap, uint4 *mcells, const uint32_t liquid[8],
+                         hipStream_t st);
 void launch_upload_words(void *dst, const void *pinned_src, uint32_t n_words, hipStream_t st);
 void launch_accel_chunks(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S, uint32_t *grid,
                          uint32_t *chunk_bricks, uint32_t *chunk_bases, uint32_t *chunk_caps, uint32_t *tail, uint16_t *bricks,
-                         uint32_t brick_cap, const uint32_t *chunks, const uint32_t *extents, uint32_t n, hipStream_t st);
+                         uint32_t brick_cap, uint4 *mcells, const uint32_t liquid[8], const uint32_t *chunks, const uint32_t *extents,
+                         uint32_t n, hipStream_t st);
 }  // namespace vrt
 
 static_assert(sizeof(vrt_material) == 32, "Material layout (mod.rs:20-28)");
@@ -142,6 +145,8 @@ struct vrt_ctx {
         size_t grid_cap = 0;          // entries allocated ([8S][8S+1][8S+1] with the zero border)
         uint16_t *d_bricks = nullptr;
         uint32_t brick_cap = 0;
+        uint4 *d_mcells = nullptr;    // the march cells (vrt_accel.hip), same indexing as the grid; worlds of S <= kMarchCellsMaxS
+        size_t mcells_cap = 0;
         uint32_t *d_chunk_bricks = nullptr, *d_chunk_bases = nullptr, *d_chunk_caps = nullptr, *d_brick_tail = nullptr;
         uint32_t chunk_cap = 0;
         bool live = false;            // a copy of tabs[0] as of the last whole-world build, plus its own chunk updates since
@@ -173,6 +178,8 @@ struct vrt_ctx {
     bool path_persistent = false;  // VRT_PATH_PERSISTENT=1: plain path frames as one persistent launch instead of one launch per bounce
     bool path_pool = true;         // VRT_PATH_POOL=0: bounce launches with lane = path (the round-1 structure) instead of the pool kernel
     bool path_chain = false;       // VRT_PATH_POOL_CHAIN=1: the pool kernel's stragglers go to a chain of launches on a side stream
+    bool path_cells = true;        // VRT_PATH_CELLS=0: the pool kernel over cell grid + bricks instead of the one over the march cells
+    bool path_sort = true;         // VRT_PATH_SORT=0: a wave's rays handed out in record order instead of by direction octant
     uint32_t path_samples = 8;     // VRT_PATH_SAMPLES_PER_CHAIN: samples a launch chain traces at once when spp > 1 (1: one, as round 1 did)
     vrt::Texel *path_acc[kMaxInFlight] = {nullptr, nullptr, nullptr, nullptr};   // ... their accumulation planes, per frame set
     size_t path_acc_texels[kMaxInFlight] = {0, 0, 0, 0}, path_buf_records[kMaxInFlight] = {0, 0, 0, 0}, path_cont_records[kMaxInFlight] = {0, 0, 0, 0};
@@ -192,6 +199,7 @@ struct vrt_ctx {
     uint32_t view_gen = 0;              // counts the changes of anything a tile's trips depend on
     uint32_t frame_view_gen = ~0u;      // ... as of the last frame rendered
     uint32_t order_view_gen = ~0u;      // ... as of the frame the order was made from
+    uint32_t frame_mode = ~0u;          // vrt_mode of the last frame rendered (a change of mode is a change of view)
     uint32_t last_slot = 0, last_tab = 0;   // the frame set and the table set of the last frame
     float accel_last_ms = 0.f;
     std::vector<uint32_t> h_roots;  // what chunk_roots holds, to recognise the reference's per-frame rewrite of the same table
@@ -271,6 +279,13 @@ static int fail(vrt_ctx *ctx, int code, const char *fmt, ...) {
                         hipGetErrorString(e_));                                                     \
     } while (0)
 
+// Multi-device entry points switch the calling thread's current HIP device; the caller gets its own back.
+struct DeviceRestore {
+    int dev = -1;
+    DeviceRestore() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
+    ~DeviceRestore() { if (dev >= 0) (void)hipSetDevice(dev); }
+};
+
 // Wait for the frame that may still be running on the second stream.
 static int quiesce(vrt_ctx *c) {
     if (c->alt_pending) {
@@ -346,6 +361,9 @@ static int alloc_output(vrt_ctx *c) {
     HIP_TRY(c, hipMalloc(&c->d_blk_counts, ncnt * sizeof(uint32_t)));
     HIP_TRY(c, hipMemsetAsync(c->d_blk_counts, 0, ncnt * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->own_out, 0, n * sizeof(vrt::Texel), c->stream));
+    // (c->stream may be the caller's: a VRT_RENDER_OWN_STREAMS frame on own_stream is not ordered behind these memsets, and
+    // result sizes that are not whole tiles rely on the zeros)
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     // the extra (stream, output, counts) sets of frames in flight are created when first used (vrt_render)
     c->d_out = c->own_out;  // a resize drops any caller-bound output (its size no longer matches)
     c->last_out = c->own_out;
@@ -381,6 +399,8 @@ static int alloc_roots(vrt_ctx *c, uint32_t world_size) {
 // Largest world the grid march's tables cover: the cell grid is addressed by a 32-bit byte offset built with signed
 // 24-bit multiplies (8S (8S+1)^2 * 4 B < 2^31, (8S+1)^2 * 4 < 2^23), bricks by brick * 128 B < 2^32.
 static constexpr uint32_t kAccelMaxS = 100;
+// ... the march cells (16 bytes per cell) are addressed the same way: 8S (8S+1)^2 * 16 B < 2^31
+static constexpr uint32_t kMarchCellsMaxS = 63;
 static constexpr uint32_t kAccelMaxBricks = (1u << 25) - 1u;
 // Chunks that can be rebuilt alone between two whole-world builds: each may move, once, into a 512-brick region
 // (64 KiB) at the tail of the brick pool.
@@ -565,9 +585,10 @@ static void mark_node_range_dirty(vrt_ctx *c, uint32_t start, uint32_t end) {
 static int free_tables(vrt_ctx *c, vrt_ctx::Tables &T) {
     (void)c;
     (void)hipFree(T.d_grid); (void)hipFree(T.d_bricks); (void)hipFree(T.d_chunk_bricks); (void)hipFree(T.d_chunk_bases);
-    (void)hipFree(T.d_chunk_caps); (void)hipFree(T.d_brick_tail);
+    (void)hipFree(T.d_chunk_caps); (void)hipFree(T.d_brick_tail); (void)hipFree(T.d_mcells);
     T.d_grid = nullptr; T.d_bricks = nullptr; T.d_chunk_bricks = T.d_chunk_bases = T.d_chunk_caps = T.d_brick_tail = nullptr;
-    T.grid_cap = 0; T.brick_cap = 0; T.chunk_cap = 0;
+    T.d_mcells = nullptr;
+    T.grid_cap = 0; T.brick_cap = 0; T.chunk_cap = 0; T.mcells_cap = 0;
     T.live = false;
     return VRT_OK;
 }
@@ -583,6 +604,11 @@ static int alloc_tables_like_first(vrt_ctx *c, uint32_t k) {
         (void)hipFree(T.d_grid); T.d_grid = nullptr; T.grid_cap = 0;
         HIP_TRY(c, hipMalloc(&T.d_grid, entries * sizeof(uint32_t)));
         T.grid_cap = entries;
+    }
+    if (A.d_mcells && T.mcells_cap < entries) {
+        (void)hipFree(T.d_mcells); T.d_mcells = nullptr; T.mcells_cap = 0;
+        HIP_TRY(c, hipMalloc(&T.d_mcells, entries * sizeof(uint4)));
+        T.mcells_cap = entries;
     }
     if (T.chunk_cap < n_chunks) {
         (void)hipFree(T.d_chunk_bricks); (void)hipFree(T.d_chunk_bases); (void)hipFree(T.d_chunk_caps);
@@ -611,6 +637,7 @@ static int copy_tables_from_first(vrt_ctx *c, uint32_t k) {
         if (rc) return rc;
     }
     HIP_TRY(c, hipMemcpyAsync(T.d_grid, A.d_grid, entries * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    if (A.d_mcells) HIP_TRY(c, hipMemcpyAsync(T.d_mcells, A.d_mcells, entries * sizeof(uint4), hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(T.d_chunk_bricks, A.d_chunk_bricks, (size_t)n_chunks * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(T.d_chunk_bases, A.d_chunk_bases, (size_t)n_chunks * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(T.d_chunk_caps, A.d_chunk_caps, (size_t)n_chunks * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
@@ -671,6 +698,17 @@ static int ensure_accel_world(vrt_ctx *c) {
     }
     // the border rows / entries are never written by the kernels: zero = "outside the world"
     HIP_TRY(c, hipMemsetAsync(A.d_grid, 0, entries * sizeof(uint32_t), c->stream));
+    if (S <= kMarchCellsMaxS) {
+        if (entries > A.mcells_cap) {
+            (void)hipFree(A.d_mcells);
+            A.d_mcells = nullptr; A.mcells_cap = 0;
+            HIP_TRY(c, hipMalloc(&A.d_mcells, entries * sizeof(uint4)));
+            A.mcells_cap = entries;
+        }
+        HIP_TRY(c, hipMemsetAsync(A.d_mcells, 0, entries * sizeof(uint4), c->stream));
+    } else if (A.d_mcells) {   // (a world beyond them: the path trace's bounce launches then read the cell grid and the bricks)
+        for (auto &T : c->tabs) { (void)hipFree(T.d_mcells); T.d_mcells = nullptr; T.mcells_cap = 0; }
+    }
     if (n_chunks > A.chunk_cap) {
         (void)hipFree(A.d_chunk_bricks); (void)hipFree(A.d_chunk_bases); (void)hipFree(A.d_chunk_caps);
         A.d_chunk_bricks = A.d_chunk_bases = A.d_chunk_caps = nullptr; A.chunk_cap = 0;
@@ -687,7 +725,7 @@ static int ensure_accel_world(vrt_ctx *c) {
     auto body = [&]() -> int {
         HIP_TRY(c, hipEventRecord(e0, c->stream));
         vrt::launch_accel_cells(c->d_nodes, c->max_nodes, c->d_roots, S, A.d_grid, A.d_chunk_bricks, A.d_chunk_bases, A.d_chunk_caps,
-                                c->d_brick_total, A.d_brick_tail, c->stream);
+                                c->d_brick_total, A.d_brick_tail, A.d_mcells, c->liquid_mask, c->stream);
         HIP_TRY(c, hipGetLastError());
         uint32_t total = 0;  // bricks in all chunk regions (counts + slack)
         HIP_TRY(c, hipMemcpyAsync(&total, c->d_brick_total, sizeof total, hipMemcpyDeviceToHost, c->stream));
@@ -702,7 +740,8 @@ static int ensure_accel_world(vrt_ctx *c) {
             HIP_TRY(c, hipMalloc(&A.d_bricks, (size_t)cap * 64u * sizeof(uint16_t)));
             A.brick_cap = (uint32_t)cap;
         }
-        vrt::launch_accel_bricks(c->d_nodes, c->max_nodes, c->d_roots, S, A.d_grid, A.d_chunk_bases, A.d_bricks, A.brick_cap, c->stream);
+        vrt::launch_accel_bricks(c->d_nodes, c->max_nodes, c->d_roots, S, A.d_grid, A.d_chunk_bases, A.d_bricks, A.brick_cap, A.d_mcells,
+                                 c->liquid_mask, c->stream);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipEventRecord(e1, c->stream));
         HIP_TRY(c, hipEventSynchronize(e1));
@@ -772,7 +811,8 @@ static int update_tables(vrt_ctx *c, uint32_t k, hipStream_t st) {
         extents[i] = r ? (end > r ? end - r : 0u) : 1u;   // (a missing chunk is node 0 alone: one air leaf)
     }
     vrt::launch_accel_chunks(c->d_nodes, c->max_nodes, c->d_roots, c->accel_S, T.d_grid, T.d_chunk_bricks, T.d_chunk_bases, T.d_chunk_caps,
-                             T.d_brick_tail, T.d_bricks, T.brick_cap, T.dirty_chunks.data(), extents.data(), (uint32_t)T.dirty_chunks.size(), st);
+                             T.d_brick_tail, T.d_bricks, T.brick_cap, T.d_mcells, c->liquid_mask, T.dirty_chunks.data(), extents.data(),
+                             (uint32_t)T.dirty_chunks.size(), st);
     HIP_TRY(c, hipGetLastError());
     // the next upload of nodes or roots waits for this reader
     if (!T.ev_updated) HIP_TRY(c, hipEventCreateWithFlags(&T.ev_updated, hipEventDisableTiming));
@@ -803,7 +843,7 @@ template <typename F> static int grp_each(vrt_ctx *c, F f);
     } while (0)
 #define GRP_ROOT(c, call)                                                   \
     do {                                                                    \
-        if ((c) && (c)->grp) { vrt_ctx *d = grp_root(c); const int rc_ = call; if (rc_) (c)->err = d->err; return rc_; } \
+        if ((c) && (c)->grp) { DeviceRestore restore_; vrt_ctx *d = grp_root(c); const int rc_ = call; if (rc_) (c)->err = d->err; return rc_; } \
     } while (0)
 #define GRP_REFUSE(c, what)                                                 \
     do {                                                                    \
@@ -860,6 +900,8 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     if (const char *e = getenv("VRT_TILE_ORDER")) c->tile_lpt = e[0] != '0';
     if (const char *e = getenv("VRT_PATH_POOL")) c->path_pool = e[0] != '0';
     if (const char *e = getenv("VRT_PATH_POOL_CHAIN")) c->path_chain = e[0] == '1';
+    if (const char *e = getenv("VRT_PATH_CELLS")) c->path_cells = e[0] != '0';
+    if (const char *e = getenv("VRT_PATH_SORT")) c->path_sort = e[0] != '0';
     if (const char *e = getenv("VRT_PATH_SAMPLES_PER_CHAIN")) { const int v = atoi(e); if (v >= 1 && v <= 16) c->path_samples = (uint32_t)v; }
     if (const char *e = getenv("VRT_PATH_POOL_REFILL")) c->path_refill = (uint32_t)atoi(e);
     if (const char *e = getenv("VRT_PATH_POOL_EJECT")) c->path_eject = (uint32_t)atoi(e);
@@ -1010,6 +1052,8 @@ int vrt_write_materials(vrt_ctx *c, uint32_t first, const vrt_material *mats, ui
     if (n == 0) return VRT_OK;
     c->view_gen++;
     memcpy(c->h_mats + first, mats, (size_t)n * sizeof(vrt_material));
+    uint32_t old_mask[8];
+    memcpy(old_mask, c->liquid_mask, sizeof old_mask);
     memset(c->liquid_mask, 0, sizeof c->liquid_mask);
     int lo = -1, hi = -1, n_liquid = 0;
     for (int v = 0; v < 256; v++)
@@ -1023,6 +1067,8 @@ int vrt_write_materials(vrt_ctx *c, uint32_t first, const vrt_material *mats, ui
     c->liquid_is_range = n_liquid == 0 || (hi - lo + 1 == n_liquid && hi < 255);
     c->liquid_lo = n_liquid ? (uint32_t)lo : 0x80000000u;
     c->liquid_span = n_liquid ? (uint32_t)(hi - lo) : 0u;
+    // the march cells say which voxels stop a ray: another set of liquids is another set of tables (a join-time event)
+    if (memcmp(old_mask, c->liquid_mask, sizeof old_mask) != 0) mark_all_dirty(c);
     HIP_TRY(c, hipSetDevice(c->device));
     return stage_upload(c, c->d_mats + first, mats, (size_t)n * sizeof(vrt_material));
 }
@@ -1332,7 +1378,8 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
     // wait for, are off the frame's critical path.  A path is in exactly one of the two chains, so nothing is shared but
     // the record sets' cursors (atomics).  The chains join at the end of every sample.
     const bool pool = !kstats && !literal && P.grid && bounces > 1 && c->path_pool;
-    const bool chain = pool && bounces - 1u <= kContSets && c->path_chain;
+    const bool cells = pool && P.mcells && c->path_cells;
+    const bool chain = pool && !cells && bounces - 1u <= kContSets && c->path_chain;
     uint32_t *cont_seg[kContSets];
     for (uint32_t i = 0; i < kContSets; i++) cont_seg[i] = P.seg_counts + (3 + i) * kSegWords;
     hipStream_t side = nullptr;
@@ -1375,6 +1422,8 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
                 vrt::launch_path_primary(P, kstats, literal, f.st);
             } else if (!pool) {
                 vrt::launch_path_bounce(P, kstats, literal, f.st);
+            } else if (cells) {
+                vrt::launch_path_bounce_cells(P, c->path_refill, c->path_sort, f.st);
             } else {
                 if (chain) {
                     P.cont_out = cont + (size_t)(b - 1u) * 4 * cap;
@@ -1558,6 +1607,8 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
         const size_t G = (size_t)c->accel_S * 8u;
         P.grid_bytes = (uint32_t)(G * (G + 1u) * (G + 1u) * sizeof(uint32_t));  // [8S][8S+1][8S+1]: the zero border
         P.brick_bytes = (uint32_t)((size_t)T.brick_cap * 64u * sizeof(uint16_t));
+        P.mcells = T.d_mcells;
+        P.mcells_bytes = T.d_mcells ? (uint32_t)(G * (G + 1u) * (G + 1u) * sizeof(uint4)) : 0u;
     }
     // a march that walks the octree reads the node pool and chunk_roots: uploads then wait for the frames in flight
     if (!P.grid || variant == 1u || variant == 2u) c->walkers_in_flight = true;
@@ -1587,6 +1638,9 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     const bool lpt = c->tile_lpt && c->in_flight == 1u && f.st == c->stream && (o.mode == VRT_MODE_PRIMARY_SHADOW || o.mode == VRT_MODE_PRIMARY) && variant == 0u && !kstats &&
                      o.stats == 0u && P.grid && c->tiles_local >= 128u;
     bool tile_sort = false;
+    // (a tile's trips depend on the mode too — a primary-only frame has no shadow march: an order made from the other
+    // mode's frame is a stale order, and the frame before a sort must be of the same kind)
+    if (c->frame_mode != o.mode) c->view_gen++;
     if (lpt) {
         if (c->tile_buf_tiles != c->tiles_local) {
             const uint32_t chunks = (c->tiles_local + 63u) / 64u;
@@ -1602,6 +1656,7 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
         if (tile_sort) P.tile_cost = c->d_tile_cost;
     }
     c->frame_view_gen = c->view_gen;
+    c->frame_mode = o.mode;
     // the counters feed stats frames and the path trace's segment cursors; a plain primary(+shadow) frame reads none
     if (kstats || o.mode == VRT_MODE_PATH) HIP_TRY(c, hipMemsetAsync(f.counters, 0, kCounterBytes, f.st));
     if (o.mode == VRT_MODE_PATH) rc = launch_path_frame(c, P, f, o, kstats, air_liquid, *ev, *ev_kind);
@@ -1869,6 +1924,14 @@ int vrt_set_frames_in_flight(vrt_ctx *c, uint32_t n) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->in_flight = n;
     c->flip = 0;
+    // the table sets of frame slots that no longer render go stale: nobody brings them up to date, so their dirty lists
+    // would only grow (and, full, force whole-world builds on a context whose active sets are fine)
+    for (uint32_t k = n; k < vrt_ctx::kMaxInFlight; k++) {
+        auto &T = c->tabs[k];
+        for (uint32_t ch : T.dirty_chunks) T.chunk_is_dirty[ch] = 0;
+        T.dirty_chunks.clear();
+        T.live = false;
+    }
     return VRT_OK;
 }
 
@@ -2033,6 +2096,7 @@ static vrt_ctx *grp_root(vrt_ctx *c) { return c->grp->dev[0]; }
 
 template <typename F>
 static int grp_each(vrt_ctx *c, F f) {
+    DeviceRestore restore;
     for (vrt_ctx *d : c->grp->dev) {
         const int rc = f(d);
         if (rc) { c->err = d->err; return rc; }
@@ -2069,6 +2133,7 @@ static int grp_create(const vrt_config *cfg, vrt_ctx **out) {
     g->texels = (cfg->flags & VRT_FLAG_TEXEL_MESSAGES) != 0u;
     // the root's own tiles never cross a link, so it takes more of the frame; measured defaults
     const uint32_t w0 = cfg->shard_root_weight ? cfg->shard_root_weight : (n == 2u ? 4u : n <= 4u ? 3u : 2u);
+    DeviceRestore restore;
     auto body = [&]() -> int {
         for (uint32_t r = 0; r < n; r++) {
             vrt_config sub = *cfg;
@@ -2126,6 +2191,7 @@ static int grp_create(const vrt_config *cfg, vrt_ctx **out) {
 
 static void grp_destroy(vrt_ctx *c) {
     vrt_group *g = c->grp;
+    DeviceRestore restore;
     for (auto &w : g->workers) w->stop();
     for (vrt_ctx *d : g->dev) {
         (void)hipSetDevice(d->device);
@@ -2154,6 +2220,7 @@ static int grp_set_frames_in_flight(vrt_ctx *c, uint32_t n) {
 }
 
 static int grp_resize_output(vrt_ctx *c, uint32_t w, uint32_t h) {
+    DeviceRestore restore;
     int rc = grp_synchronize(c);
     if (rc) return rc;
     rc = grp_each(c, [&](vrt_ctx *d) { return vrt_resize_output(d, w, h); });
@@ -2195,6 +2262,7 @@ static int grp_render(vrt_ctx *c, const vrt_render_opts *opts) {
             return fail(d, VRT_ERR_DEVICE, "hipEventRecord failed on device %d", d->device);
         return VRT_OK;
     };
+    DeviceRestore restore;
     if (!g->workers.empty()) {
         for (uint32_t r = 1; r < n; r++) g->workers[r - 1]->post([issue, r] { return issue(r); });
     } else {
@@ -2203,9 +2271,10 @@ static int grp_render(vrt_ctx *c, const vrt_render_opts *opts) {
             if (rc) { c->err = g->dev[r]->err; return rc; }
         }
     }
-    HIP_TRY(c, hipSetDevice(root->device));
-    int rc = vrt_render(root, &o);
-    // the workers have *enqueued* their frames (their done events are recorded) before the root's stream is told to wait
+    int rc = hipSetDevice(root->device) == hipSuccess ? VRT_OK : fail(root, VRT_ERR_DEVICE, "hipSetDevice(%d) failed", root->device);
+    if (!rc) rc = vrt_render(root, &o);
+    // the workers have *enqueued* their frames (their done events are recorded) before the root's stream is told to wait —
+    // and they are joined on every path out of here: nothing of a context is ever touched by two threads
     int wrc = VRT_OK;
     for (uint32_t r = 1; r < n && !g->workers.empty(); r++) {
         const int one = g->workers[r - 1]->join();
@@ -2236,6 +2305,7 @@ static int grp_render(vrt_ctx *c, const vrt_render_opts *opts) {
 
 static int grp_get_stats(vrt_ctx *c, vrt_stats *out) {
     if (!out) return fail(c, VRT_ERR_INVALID_ARG, "vrt_get_stats: null argument");
+    DeviceRestore restore;
     int rc = grp_synchronize(c);
     if (rc) return rc;
     vrt_stats acc;

@@ -866,6 +866,313 @@ extern "C" void vrt_exp_pool_dbg(unsigned long long *out) {   // read (16384 x 8
 }
 #endif
 
+// ------------------------------------------------------------------------------------------------
+// Bounce b >= 1 over the MARCH CELLS (vrt_accel.hip; the default for plain frames of worlds that have them): the pool
+// kernel above with a march loop that has ONE load per step and no dependent load at all.
+//
+// What held the pool kernel at a quarter of its issue rate was the pair of dependent loads of a step in a split cell —
+// cell entry, then the voxel's brick entry: 290 + 515 cycles of a 2 200-cycle wave-step, half of them L1 misses
+// (profiles/r02_path_pmc_summary.txt) — on the critical path of every ray, and a launch lasts as long as its longest
+// chain of steps.  A march cell answers both questions of a step from one 16-byte entry: the leaf's size (a leaf
+// cell's lo, or the split cell's size-2 mask) and whether the voxel stops the ray (64 bits; liquids are transparent to
+// a path segment, so they count as air — the tables are built with the material table's liquid set).  Which voxel it
+// stopped on is only asked after the march, at full width, from the brick (phase C).
+// Also new here: the wave hands its rays out sorted by direction octant (rays that march together then walk the same
+// way through the same neighbourhood: they share the lines of the cells they read), phase C takes the rays that hit and
+// the rays that missed in separate batches (a wave executes both sides of that branch otherwise: ~510 + ~130 vector
+// instructions per ray), and on the last bounce the rays that hit are not shaded at all (their bounce would be dropped).
+// Every ray executes the arithmetic the other kernels execute for it: bit-identical frames (tests).
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kCellsPoolBytesPerWave = kPoolWords * 4u + kPoolEntries * 2u;   // the pool + a u16 order per entry
+
+template <bool SORT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) path_bounce_cells_kernel(FrameParams P, uint32_t refill_at) {
+    extern __shared__ uint32_t smem[];
+    uint32_t *s_liquid = smem;
+    if (threadIdx.x < 8) s_liquid[threadIdx.x] = P.liquid[threadIdx.x];
+    if (blockIdx.x == 0 && P.seg_clear) P.seg_clear[threadIdx.x * kSegStride] = 0u;   // kHitSegments == blockDim.x cursors
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    constexpr uint32_t E = kPoolEntries;
+    float *pool = reinterpret_cast<float *>(smem + 8) + wave * kPoolWords;
+    uint16_t *order = reinterpret_cast<uint16_t *>(smem + 8 + 4u * kPoolWords) + wave * E;
+
+    // this wave's paths: the workgroup takes up to 4 E records of its segment, split evenly over its waves
+    const uint32_t seg = blockIdx.x % kHitSegments, part = blockIdx.x / kHitSegments;
+    const uint32_t count = P.seg_in[seg * kSegStride];
+    const uint32_t wg_begin = part * 4u * E;
+    if (wg_begin >= count) return;
+    const uint32_t n_wg = min(4u * E, count - wg_begin), per = (n_wg + 3u) / 4u;
+    if (wave * per >= n_wg) return;
+    const uint32_t n = min(per, n_wg - wave * per);   // <= E
+    const uint32_t base = seg * P.in_seg_cap + wg_begin + wave * per;
+    const float world_max = 0.0f + (float)P.world.size;
+    const unsigned long long below = (1ull << lane) - 1ull;
+
+    // ---- A: the unit steps of every ray (nine divides, three square roots), full width; the order they are handed out in ----
+    {
+        uint32_t key[kPoolBatches];
+#pragma unroll
+        for (uint32_t k = 0; k < kPoolBatches; k++) {
+            const uint32_t i = k * 64u + lane;
+            key[k] = 8u;   // (no ray)
+            if (i < n) {
+                const uint4 b = P.path_in[P.in_cap + base + i];
+                const V3 dir{__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z)};
+                const V3 unit = unit_steps(dir);
+                pool[0u * E + i] = unit.x; pool[1u * E + i] = unit.y; pool[2u * E + i] = unit.z;
+                key[k] = (dir.x >= 0.0f ? 1u : 0u) | (dir.y >= 0.0f ? 2u : 0u) | (dir.z >= 0.0f ? 4u : 0u);
+            }
+        }
+        if (SORT) {   // a stable counting sort of the wave's rays by direction octant (ballots: a few dozen scalar instructions)
+            uint32_t start = 0u;
+#pragma unroll
+            for (uint32_t o = 0; o < 8u; o++) {
+#pragma unroll
+                for (uint32_t k = 0; k < kPoolBatches; k++) {
+                    const unsigned long long m = __ballot(key[k] == o);
+                    if (key[k] == o) order[start + (uint32_t)__popcll(m & below)] = (uint16_t)(k * 64u + lane);
+                    start += (uint32_t)__popcll(m);
+                }
+            }
+        } else {
+#pragma unroll
+            for (uint32_t k = 0; k < kPoolBatches; k++) order[k * 64u + lane] = (uint16_t)(k * 64u + lane);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- B: the marches, lanes refilled from the pool; a ray that has stopped keeps its end state in its registers until
+    // the wave's next refill parks it.  Water is not tracked (no output of a path segment depends on it). ----
+    {
+        const TableBuf mb = table_buffer(P.mcells, P.mcells_bytes);
+        const TableBuf gb = table_buffer(P.grid, P.grid_bytes), bb = table_buffer(P.bricks, P.brick_bytes);
+        const uint32_t row16 = (P.grid_dim + 1u) * 16u, slab16 = (P.grid_dim + 1u) * row16;   // < 2^23: S <= 63
+        const uint32_t row_bytes = (P.grid_dim + 1u) * 4u, slab_bytes = (P.grid_dim + 1u) * row_bytes;
+        const uint32_t wsize = P.world.size;
+        V3 pos{0.f, 0.f, 0.f}, dir{0.f, 0.f, 0.f};
+        float ux = 0.f, uy = 0.f, uz = 0.f, step = -1.f, adx = 0.f, ady = 0.f, adz = 0.f;
+        uint32_t mxm = 0u, mym = 0u, mzm = 0u, ref = 0u, iter = 0u, idx = 0u;
+        int vx = 0, vy = 0, vz = 0;
+        bool marching = false, parked = true, not_finite = false;
+        uint32_t next = 0u;   // wave-uniform: the pool's first ray not handed out yet
+
+        // the end state phase C needs: where, through which faces, on what (bit 3: `what` is the split cell's brick)
+        auto park = [&]() __attribute__((always_inline)) {
+            uint32_t packed = (int)ref < 0 ? (8u | ((ref & 0x7FFFFFC0u) >> 2)) : ((ref >> 16) << 4);
+            if (step != -1.0f) packed |= (step == adx ? 1u : 0u) | (step == ady ? 2u : 0u) | (step == adz ? 4u : 0u);
+            pool[0u * E + idx] = pos.x; pool[1u * E + idx] = pos.y; pool[2u * E + idx] = pos.z;
+            pool[3u * E + idx] = __uint_as_float(packed);
+            parked = true;
+        };
+        auto take = [&](uint32_t at) __attribute__((always_inline)) {
+            idx = order[at];
+            const uint32_t rec = base + idx;
+            const uint4 a = P.path_in[rec], b = P.path_in[P.in_cap + rec];
+            const V3 origin{__uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w)};
+            dir = V3{__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z)};
+            not_finite = !(finite3(origin) && finite3(dir));
+            ux = pool[0u * E + idx]; uy = pool[1u * E + idx]; uz = pool[2u * E + idx];
+            mxm = dir.x >= 0.0f ? ~0u : 0u; mym = dir.y >= 0.0f ? ~0u : 0u; mzm = dir.z >= 0.0f ? ~0u : 0u;
+            ref = 0u;
+            marching = true;
+            parked = false;
+            pos = nudged(origin, dir);
+            step = -1.0f; adx = ady = adz = 0.0f;
+            iter = 0u;
+            if ((pos.x <= 0.0f || pos.y <= 0.0f || pos.z <= 0.0f) || (pos.x >= world_max || pos.y >= world_max || pos.z >= world_max)) {
+                // starts outside the world: a miss before any lookup.  Its end state says so (a position outside), and is
+                // parked right here: the wave may find nothing left to march and never come back to the refill
+                marching = false;
+                pos = V3{-1.0f, -1.0f, -1.0f};
+                park();
+            }
+            vx = trunc2i(pos.x); vy = trunc2i(pos.y); vz = trunc2i(pos.z);
+        };
+        // the step to the leaf's exit face for a leaf of size lo + 1 (take_step of march_grid)
+        auto take_step = [&](uint32_t lo) __attribute__((always_inline)) {
+            const float tx = (float)(int)(bfi(lo, mxm, (uint32_t)vx) - mxm) - pos.x;
+            const float ty = (float)(int)(bfi(lo, mym, (uint32_t)vy) - mym) - pos.y;
+            const float tz = (float)(int)(bfi(lo, mzm, (uint32_t)vz) - mzm) - pos.z;
+            adx = abs_mul(tx, ux);
+            ady = abs_mul(ty, uy);
+            adz = abs_mul(tz, uz);
+            step = min3_f32(adx, ady, adz);   // (p) of vrt_march.h
+            if (__ballot(!(step > 0.0f)) != 0ull)
+                step = __uint_as_float(min3_u32(__float_as_uint(adx) - 1u, __float_as_uint(ady) - 1u, __float_as_uint(adz) - 1u) + 1u);
+            const float sp = step + 0.001f;
+            pos.x += dir.x * (step == adx ? sp : step);
+            pos.y += dir.y * (step == ady ? sp : step);
+            pos.z += dir.z * (step == adz ? sp : step);
+            vx = flr2i(pos.x);
+            vy = flr2i(pos.y);
+            vz = flr2i(pos.z);
+        };
+        // (l) of vrt_march.h: the general step as march_grid has it for a wave with a ray that is not finite — the shader's
+        // own bounds test, its lookup at i32(f32) coordinates; over the cell grid and the bricks (rare: NaN cameras)
+        auto careful_step = [&]() __attribute__((always_inline)) {
+            iter += 1u;
+            vx = trunc2i(pos.x);
+            vy = trunc2i(pos.y);
+            vz = trunc2i(pos.z);
+            uint32_t e = 0u;
+            if (!(min3_nan_ignoring(pos.x, pos.y, pos.z) < 0.0f || max(max((uint32_t)vx, (uint32_t)vy), (uint32_t)vz) >= wsize))
+                e = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(gb, mad_i24(vz >> 2, slab_bytes, mad_i24(vy >> 2, row_bytes, (uint32_t)vx & ~3u)), 0, 0);
+            uint32_t lo = e, voxel = 0u;
+            bool stop = e == 0u;   // border, or past either end of the grid: the position is outside the world
+            if (!stop) {
+                if ((int)e < 0) {
+                    const uint32_t u = ((uint32_t)vx & 3u) | (((uint32_t)vy & 3u) << 2) | (((uint32_t)vz & 3u) << 4);
+                    const uint32_t b = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(bb, (e + u) << 1, 0, 0);
+                    lo = b & 1u;
+                    voxel = b >> 1;
+                } else if (e > 31u) {
+                    lo = e & 31u;
+                    voxel = e >> 16;
+                }
+                stop = voxel != 0u && !is_liquid_ranged(P, s_liquid, voxel);   // solid: the hit
+            }
+            ref = voxel << 16;   // (the voxel itself, as a leaf cell's entry has it)
+            if (!stop) {
+                take_step(lo);
+                stop = iter >= kMaxSteps;
+            }
+            marching = !stop;
+        };
+        for (;;) {
+            // ---- refill: park what has stopped, hand out the pool's next rays ----
+            if (!marching && !parked) park();
+            {
+                const unsigned long long idle = __ballot(!marching);
+                const uint32_t at = next + (uint32_t)__popcll(idle & below);
+                if (!marching && at < n) take(at);
+                next = min(n, next + (uint32_t)__popcll(idle));
+            }
+            if (__ballot(marching) == 0ull) {
+                if (next >= n) break;   // the pool is empty and nobody marches (every ray is parked: take() parks the ones that start outside)
+                continue;
+            }
+            const bool careful = __ballot(marching && not_finite) != 0ull;   // per refill round
+            for (;;) {
+                if (careful) {   // wave-uniform, rare
+                    if (marching) careful_step();
+                } else if (marching) {
+                    // one 16-byte load answers the step: c.x the cell's entry, c.y the size-2 mask of a split cell, c.z / c.w
+                    // the voxels that stop a ray
+                    const uint32_t off = mad_i24(vz >> 2, slab16, mad_i24(vy >> 2, row16, ((uint32_t)vx & ~3u) << 2));
+                    const uint4 c = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(mb, off, 0, 0));
+                    iter += 1u;
+                    const uint32_t u = ((uint32_t)vx & 3u) | (((uint32_t)vy & 3u) << 2) | (((uint32_t)vz & 3u) << 4);
+                    const uint32_t occ = (u & 32u) ? c.w : c.z;
+                    const uint32_t lo = (c.x & 31u) | ((c.y >> ((u >> 1) & 0x15u)) & 1u);
+                    bool stop = (((occ >> (u & 31u)) & 1u) != 0u) | (c.x == 0u);
+                    ref = c.x;
+                    if (!stop) {
+                        take_step(lo);
+                        if (iter >= kMaxSteps) {
+                            // out of lookups in air or in a liquid (:220, :293): the segment ends as a hit on the voxel of the last
+                            // lookup — which for a split cell is in its brick, at the position that was looked up
+                            stop = true;
+                            ref = (int)c.x < 0 ? ((uint32_t)__builtin_amdgcn_raw_buffer_load_b16(bb, ((c.x & 0x7FFFFFFFu) + u) << 1, 0, 0) >> 1) << 16 : c.x;
+                        }
+                    }
+                    marching = !stop;
+                }
+                const uint32_t n_march = (uint32_t)__popcll(__ballot(marching));
+                if (n_march == 0u || (next < n && 64u - n_march >= refill_at)) break;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- between B and C: the rays that hit first, then the rays that missed (their end position is outside the world) ----
+    uint32_t n_hit = 0u;
+    {
+        bool hit[kPoolBatches];
+        uint32_t cnt[kPoolBatches];
+#pragma unroll
+        for (uint32_t k = 0; k < kPoolBatches; k++) {
+            const uint32_t i = k * 64u + lane;
+            hit[k] = false;
+            if (i < n) {
+                const V3 pos{pool[0u * E + i], pool[1u * E + i], pool[2u * E + i]};
+                hit[k] = !(min3_nan_ignoring(pos.x, pos.y, pos.z) < 0.0f ||
+                           max(max((uint32_t)trunc2i(pos.x), (uint32_t)trunc2i(pos.y)), (uint32_t)trunc2i(pos.z)) >= P.world.size);
+            }
+            cnt[k] = (uint32_t)__popcll(__ballot(hit[k]));
+            n_hit += cnt[k];
+        }
+        uint32_t at_hit = 0u, at_miss = n_hit;
+#pragma unroll
+        for (uint32_t k = 0; k < kPoolBatches; k++) {
+            const uint32_t i = k * 64u + lane;
+            const unsigned long long mh = __ballot(hit[k]), mm = __ballot(i < n && !hit[k]);
+            if (hit[k]) order[at_hit + (uint32_t)__popcll(mh & below)] = (uint16_t)i;
+            else if (i < n) order[at_miss + (uint32_t)__popcll(mm & below)] = (uint16_t)i;
+            at_hit += (uint32_t)__popcll(mh);
+            at_miss += (uint32_t)__popcll(mm);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- C: what follows the march, full width.  On the last bounce a ray that hit has nothing left to do: its bounce
+    // would be dropped and only a miss adds light ----
+    const TableBuf bb = table_buffer(P.bricks, P.brick_bytes);
+    for (uint32_t j0 = P.last_bounce ? n_hit & ~63u : 0u; j0 < n; j0 += 64u) {
+        const uint32_t j = j0 + lane;
+        bool alive = false;
+        PathState st;
+        st.slot = 0; st.rng = 0;
+        st.origin = st.dir = st.thr = V3{0.f, 0.f, 0.f};
+        if (j < n && !(P.last_bounce && j < n_hit)) {
+            const uint32_t i = order[j];
+            const uint32_t rec = base + i;
+            const uint4 a = P.path_in[rec], b = P.path_in[P.in_cap + rec], c = P.path_in[2u * P.in_cap + rec];
+            st.slot = a.x;
+            st.origin = V3{__uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w)};
+            st.dir = V3{__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z)};
+            st.rng = b.w;
+            st.thr = V3{__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z)};
+            // segment_end on the parked end state (a path segment's water is nobody's business: DESIGN.md, path trace)
+            const V3 pos{pool[0u * E + i], pool[1u * E + i], pool[2u * E + i]};
+            const uint32_t packed = __float_as_uint(pool[3u * E + i]);
+            MarchResult R;
+            R.hit = false;
+            R.pos = V3{0.f, 0.f, 0.f};
+            R.norm = V3{0.f, 0.f, 0.f};
+            R.water_dist = 0.0f;
+            R.voxel = 0u;
+            R.iters = 0u;
+            R.visits = 0u;
+            if (j < n_hit) {
+                R.hit = true;
+                R.pos = pos;
+                R.norm = V3{((packed & 1u) ? 1.0f : 0.0f) * -vsign(st.dir.x), ((packed & 2u) ? 1.0f : 0.0f) * -vsign(st.dir.y),
+                            ((packed & 4u) ? 1.0f : 0.0f) * -vsign(st.dir.z)};
+                R.voxel = packed >> 4;
+                if (packed & 8u) {   // stopped in a split cell: the voxel is in the cell's brick, at the end position
+                    const uint32_t u = ((uint32_t)trunc2i(pos.x) & 3u) | (((uint32_t)trunc2i(pos.y) & 3u) << 2) | (((uint32_t)trunc2i(pos.z) & 3u) << 4);
+                    R.voxel = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(bb, (((packed >> 4) << 6) + u) << 1, 0, 0) >> 1;
+                }
+            }
+            V3 light{0.f, 0.f, 0.f};
+            bool missed;
+            alive = path_after_march(P, st, R, light, missed) && !P.last_bounce;
+            if (missed) {
+                uint4 t = P.out[st.slot];
+                t.x = __float_as_uint(__uint_as_float(t.x) + light.x);
+                t.y = __float_as_uint(__uint_as_float(t.y) + light.y);
+                t.z = __float_as_uint(__uint_as_float(t.z) + light.z);
+                P.out[st.slot] = t;
+            }
+        }
+        append_paths(P, alive, st, lane);
+    }
+}
+
 __device__ __forceinline__ uint32_t path_xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u; }
 
 // Next tile of the frame for this wave: its own XCD's queue first, then the others (tile i of queue x = x + 8 i).
@@ -1112,6 +1419,17 @@ void launch_path_bounce_pool(const FrameParams &P, bool continuations, uint32_t 
     const size_t sh = (8u + 4u * kPoolWords) * 4u;
     if (continuations) hipLaunchKernelGGL(path_bounce_pool_kernel<true>, grid, block, sh, st, P, refill, 0u);
     else hipLaunchKernelGGL(path_bounce_pool_kernel<false>, grid, block, sh, st, P, refill, P.cont_out ? eject : 0u);
+}
+
+// the pool kernel over the march cells (P.mcells): sort = hand the wave's rays out by direction octant
+void launch_path_bounce_cells(const FrameParams &P, uint32_t refill_at, bool sort, hipStream_t st) {
+    if (P.tiles_local == 0) return;
+    const uint32_t refill = refill_at >= 1u && refill_at <= 64u ? refill_at : kPoolRefillAt;
+    const uint32_t parts = (P.in_seg_cap + 4u * kPoolEntries - 1u) / (4u * kPoolEntries);
+    const dim3 grid(kHitSegments * parts), block(256);
+    const size_t sh = 8u * 4u + 4u * kCellsPoolBytesPerWave;
+    if (sort) hipLaunchKernelGGL(path_bounce_cells_kernel<true>, grid, block, sh, st, P, refill);
+    else hipLaunchKernelGGL(path_bounce_cells_kernel<false>, grid, block, sh, st, P, refill);
 }
 
 void launch_path_bounce(const FrameParams &P, bool stats, bool literal, hipStream_t st) {
