@@ -21,9 +21,11 @@
 //               launches, vrt_path.hip): everything a march step has to know about a cell in ONE 16-byte load, so that a
 //               split cell costs no second, dependent load —
 //               .x  the cell grid's entry (lo of a leaf in its low 5 bits, 0x80000000 | brick * 64 for a split cell)
-//               .y  split cell: bit (x>>1&1) | (y>>1&1) << 2 | (z>>1&1) << 4 set <=> that 2^3 sub-block is one depth-4 leaf
-//               .z .w  64 bits, bit (x&3) | (y&3) << 2 | (z&3) << 4: the voxel there stops a ray (not air, not a liquid of the
-//                   material table the tables were built with); a leaf cell is all ones or all zeros
+//               .y  split cell: bit (u >> 1) & 31, u = (x&3) | (y&3) << 2 | (z&3) << 4, set <=> the voxel's 2^3 sub-block is
+//                   one depth-4 leaf (the index is what a shift of u gives: every sub-block owns four of the 32 bits)
+//               .z .w  64 bits, bit u set <=> a ray PASSES the voxel: it is air, or a liquid of the material table the tables
+//                   were built with; a leaf cell is all ones or all zeros.  Zero — the border, a load past either end of
+//                   the buffer — stops the ray: "outside the world" needs no test of its own
 //               The voxel a ray stopped on is read from the brick afterwards, at full width, not inside the loop.
 //
 // Every entry is exactly what find_node would return for any position inside it (same node word, same depth;
@@ -57,22 +59,21 @@ __device__ __forceinline__ bool stops_a_ray(const LiquidMask &lq, uint32_t voxel
     const uint32_t v = min(voxel, 255u);
     return voxel != 0u && !((lq.w[v >> 5] >> (v & 31u)) & 1u);
 }
-// The march-cell entry of a leaf cell: all of it stops a ray, or none of it.
+// The march-cell entry of a leaf cell: a ray passes all of it, or none of it.
 __device__ __forceinline__ uint4 leaf_march_cell(const LiquidMask &lq, uint32_t node, uint32_t lo) {
-    const uint32_t m = stops_a_ray(lq, node & 0x7FFFu) ? 0xFFFFFFFFu : 0u;
+    const uint32_t m = stops_a_ray(lq, node & 0x7FFFu) ? 0u : 0xFFFFFFFFu;
     return make_uint4(leaf_entry(node, lo), 0u, m, m);
 }
 // ... of a split cell, from its brick's 64 entries (voxel << 1 | lo) packed two per word
 __device__ __forceinline__ uint4 split_march_cell(const LiquidMask &lq, uint32_t brick, const uint32_t w[32]) {
-    uint32_t occ[2] = {0u, 0u}, size2 = 0u;
+    uint32_t pass[2] = {0u, 0u}, size2 = 0u;
 #pragma unroll
     for (uint32_t e = 0; e < 64u; e++) {
         const uint32_t b = (w[e >> 1] >> ((e & 1u) * 16u)) & 0xFFFFu;
-        if (stops_a_ray(lq, b >> 1)) occ[e >> 5] |= 1u << (e & 31u);
-        // (every voxel of a depth-4 leaf carries lo = 1; the mask is indexed by the sub-block's corner)
-        if ((b & 1u) && !(e & 0x15u)) size2 |= 1u << (e >> 1);
+        if (!stops_a_ray(lq, b >> 1)) pass[e >> 5] |= 1u << (e & 31u);
+        if (b & 1u) size2 |= 1u << (e >> 1);   // (every voxel of a depth-4 leaf carries lo = 1)
     }
-    return make_uint4(0x80000000u | (brick * 64u), size2, occ[0], occ[1]);
+    return make_uint4(0x80000000u | (brick * 64u), size2, pass[0], pass[1]);
 }
 
 // Walks the three levels above a cell. Returns the node word at the stop depth (<= 3) and that depth.

@@ -886,7 +886,10 @@ extern "C" void vrt_exp_pool_dbg(unsigned long long *out) {   // read (16384 x 8
 constexpr uint32_t kCellsPoolBytesPerWave = kPoolWords * 4u + kPoolEntries * 2u;   // the pool + a u16 order per entry
 
 template <bool SORT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) path_bounce_cells_kernel(FrameParams P, uint32_t refill_at) {
+#ifndef VRT_CELLS_NO_WAVES_ATTR
+__attribute__((amdgpu_waves_per_eu(8, 8)))
+#endif
+__global__ void __launch_bounds__(256) path_bounce_cells_kernel(FrameParams P, uint32_t refill_at) {
     extern __shared__ uint32_t smem[];
     uint32_t *s_liquid = smem;
     if (threadIdx.x < 8) s_liquid[threadIdx.x] = P.liquid[threadIdx.x];
@@ -1059,14 +1062,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                     if (marching) careful_step();
                 } else if (marching) {
                     // one 16-byte load answers the step: c.x the cell's entry, c.y the size-2 mask of a split cell, c.z / c.w
-                    // the voxels that stop a ray
+                    // the voxels a ray passes (zero — the border, beyond the buffer — stops it: outside the world)
                     const uint32_t off = mad_i24(vz >> 2, slab16, mad_i24(vy >> 2, row16, ((uint32_t)vx & ~3u) << 2));
                     const uint4 c = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(mb, off, 0, 0));
                     iter += 1u;
-                    const uint32_t u = ((uint32_t)vx & 3u) | (((uint32_t)vy & 3u) << 2) | (((uint32_t)vz & 3u) << 4);
-                    const uint32_t occ = (u & 32u) ? c.w : c.z;
-                    const uint32_t lo = (c.x & 31u) | ((c.y >> ((u >> 1) & 0x15u)) & 1u);
-                    bool stop = (((occ >> (u & 31u)) & 1u) != 0u) | (c.x == 0u);
+                    // u = (x&3) | (y&3) << 2 | (z&3) << 4, with z's upper bits left on top: the shifts below use the low bits only
+                    const uint32_t u = ((((uint32_t)vz << 2) | ((uint32_t)vy & 3u)) << 2) | ((uint32_t)vx & 3u);
+                    const uint32_t passes = (uint32_t)((((unsigned long long)c.w << 32) | c.z) >> (u & 63u)) & 1u;
+                    const uint32_t lo = (c.x & 31u) | __builtin_amdgcn_ubfe(c.y, (u >> 1) & 31u, 1u);
+                    bool stop = passes == 0u;
                     ref = c.x;
                     if (!stop) {
                         take_step(lo);
