@@ -17,7 +17,8 @@
 //   brick pool  u16[bricks][64], index (x&3) | (y&3) << 2 | (z&3) << 4 inside the cell:
 //               air leaf -> lo (1 at depth 4, 0 at depth 5); other leaf -> voxel << 1 | lo
 //
-//   march cells uint4[8S][8S+1][8S+1], same indexing and border (worlds of S <= kMarchCellsMaxS; the path trace's bounce
+//   march cells uint4[4S][4S+1][4S+1][2][2][2]: blocks of 2 x 2 x 2 cells, one 128-byte line each, the blocks x-major with a
+//               border block per row and a border row of blocks per slab (worlds of S <= kMarchCellsMaxS; the path trace's bounce
 //               launches, vrt_path.hip): everything a march step has to know about a cell in ONE 16-byte load, so that a
 //               split cell costs no second, dependent load —
 //               .x  the cell grid's entry (lo of a leaf in its low 5 bits, 0x80000000 | brick * 64 for a split cell)
@@ -48,6 +49,19 @@ __device__ __forceinline__ size_t cell_index(uint32_t S, uint32_t chunk, uint32_
     const uint32_t G = S * 8u, G1 = G + 1u;
     const uint32_t chx = chunk % S, chy = (chunk / S) % S, chz = chunk / (S * S);
     return ((size_t)(chz * 8u + cz) * G1 + (chy * 8u + cy)) * G1 + (chx * 8u + cx);
+}
+
+// Position of the same cell among the march cells: blocks of 2 x 2 x 2 cells (8^3 voxels, 128 bytes: one cache line), the
+// blocks x-major with one border block per row and one border row of blocks per z slab:
+// [4S][4S+1][4S+1] blocks of [2][2][2] cells.  A ray reads the cells it walks through; a line that is a cube holds two or
+// three of them, a line that is a row of eight cells along x hardly ever two.
+__host__ __device__ __forceinline__ size_t march_cell_index(uint32_t S, uint32_t gx, uint32_t gy, uint32_t gz) {
+    const uint32_t B1 = S * 4u + 1u;
+    return (((size_t)(gz >> 1) * B1 + (gy >> 1)) * B1 + (gx >> 1)) * 8u + ((gx & 1u) | ((gy & 1u) << 1) | ((gz & 1u) << 2));
+}
+__device__ __forceinline__ size_t march_cell_index(uint32_t S, uint32_t chunk, uint32_t cx, uint32_t cy, uint32_t cz) {
+    const uint32_t chx = chunk % S, chy = (chunk / S) % S, chz = chunk / (S * S);
+    return march_cell_index(S, chx * 8u + cx, chy * 8u + cy, chz * 8u + cz);
 }
 
 // A leaf's grid entry: air -> lo, anything else -> voxel << 16 | lo  (lo = leaf size - 1).
@@ -149,7 +163,7 @@ __global__ void __launch_bounds__(512) accel_cells_kernel(const uint16_t *nodes,
     const uint32_t rank = rank_split_cells(split, s_wave, total);
     const size_t cell = cell_index(S, chunk, cx, cy, cz);
     grid[cell] = split ? (0x80000000u | rank) : leaf_entry(node, (32u >> depth) - 1u);
-    if (mcells && !split) mcells[cell] = leaf_march_cell(lq, node, (32u >> depth) - 1u);   // (split cells: pass 3)
+    if (mcells && !split) mcells[march_cell_index(S, chunk, cx, cy, cz)] = leaf_march_cell(lq, node, (32u >> depth) - 1u);   // (split cells: pass 3)
     if (t == 0) chunk_bricks[chunk] = total;
 }
 
@@ -204,7 +218,7 @@ __global__ void __launch_bounds__(512) accel_bricks_kernel(const uint16_t *nodes
     assemble_brick([&](uint32_t i) { return pool_node(nodes, n_nodes, root + i); }, n3, w);
     store_brick(bricks, brick, w);
     grid[cell] = 0x80000000u | (brick * 64u);
-    if (mcells) mcells[cell] = split_march_cell(lq, brick, w);
+    if (mcells) mcells[march_cell_index(S, chunk, cx, cy, cz)] = split_march_cell(lq, brick, w);
 }
 
 // Rebuild of single chunks (a voxel edit, a chunk that arrived): one workgroup per listed chunk does all three passes
@@ -288,7 +302,7 @@ __global__ void __launch_bounds__(512) accel_chunks_kernel(const uint16_t *nodes
     const size_t cell = cell_index(S, chunk, cx, cy, cz);
     if (!split) {
         grid[cell] = leaf_entry(node, (32u >> depth) - 1u);
-        if (mcells) mcells[cell] = leaf_march_cell(lq, node, (32u >> depth) - 1u);
+        if (mcells) mcells[march_cell_index(S, chunk, cx, cy, cz)] = leaf_march_cell(lq, node, (32u >> depth) - 1u);
         return;
     }
     const uint32_t brick = s_base + rank;
@@ -298,7 +312,7 @@ __global__ void __launch_bounds__(512) accel_chunks_kernel(const uint16_t *nodes
     store_brick(bricks, brick, w);
     __threadfence();
     grid[cell] = 0x80000000u | (brick * 64u);
-    if (mcells) mcells[cell] = split_march_cell(lq, brick, w);
+    if (mcells) mcells[march_cell_index(S, chunk, cx, cy, cz)] = split_march_cell(lq, brick, w);
 }
 
 // Upload of a staged range: the pinned ring is mapped into the device's address space, so a kernel reads it over PCIe and

@@ -401,6 +401,8 @@ static int alloc_roots(vrt_ctx *c, uint32_t world_size) {
 static constexpr uint32_t kAccelMaxS = 100;
 // ... the march cells (16 bytes per cell) are addressed the same way: 8S (8S+1)^2 * 16 B < 2^31
 static constexpr uint32_t kMarchCellsMaxS = 63;
+// [4S][4S+1][4S+1] blocks of 2 x 2 x 2 cells (vrt_accel.hip: march_cell_index)
+static size_t march_cell_entries(uint32_t S) { const size_t B = (size_t)S * 4u; return B * (B + 1u) * (B + 1u) * 8u; }
 static constexpr uint32_t kAccelMaxBricks = (1u << 25) - 1u;
 // Chunks that can be rebuilt alone between two whole-world builds: each may move, once, into a 512-brick region
 // (64 KiB) at the tail of the brick pool.
@@ -605,10 +607,11 @@ static int alloc_tables_like_first(vrt_ctx *c, uint32_t k) {
         HIP_TRY(c, hipMalloc(&T.d_grid, entries * sizeof(uint32_t)));
         T.grid_cap = entries;
     }
-    if (A.d_mcells && T.mcells_cap < entries) {
+    const size_t m_entries = march_cell_entries(S);
+    if (A.d_mcells && T.mcells_cap < m_entries) {
         (void)hipFree(T.d_mcells); T.d_mcells = nullptr; T.mcells_cap = 0;
-        HIP_TRY(c, hipMalloc(&T.d_mcells, entries * sizeof(uint4)));
-        T.mcells_cap = entries;
+        HIP_TRY(c, hipMalloc(&T.d_mcells, m_entries * sizeof(uint4)));
+        T.mcells_cap = m_entries;
     }
     if (T.chunk_cap < n_chunks) {
         (void)hipFree(T.d_chunk_bricks); (void)hipFree(T.d_chunk_bases); (void)hipFree(T.d_chunk_caps);
@@ -637,7 +640,7 @@ static int copy_tables_from_first(vrt_ctx *c, uint32_t k) {
         if (rc) return rc;
     }
     HIP_TRY(c, hipMemcpyAsync(T.d_grid, A.d_grid, entries * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
-    if (A.d_mcells) HIP_TRY(c, hipMemcpyAsync(T.d_mcells, A.d_mcells, entries * sizeof(uint4), hipMemcpyDeviceToDevice, c->stream));
+    if (A.d_mcells) HIP_TRY(c, hipMemcpyAsync(T.d_mcells, A.d_mcells, march_cell_entries(S) * sizeof(uint4), hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(T.d_chunk_bricks, A.d_chunk_bricks, (size_t)n_chunks * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(T.d_chunk_bases, A.d_chunk_bases, (size_t)n_chunks * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(T.d_chunk_caps, A.d_chunk_caps, (size_t)n_chunks * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
@@ -699,13 +702,14 @@ static int ensure_accel_world(vrt_ctx *c) {
     // the border rows / entries are never written by the kernels: zero = "outside the world"
     HIP_TRY(c, hipMemsetAsync(A.d_grid, 0, entries * sizeof(uint32_t), c->stream));
     if (S <= kMarchCellsMaxS) {
-        if (entries > A.mcells_cap) {
+        const size_t m_entries = march_cell_entries(S);
+        if (m_entries > A.mcells_cap) {
             (void)hipFree(A.d_mcells);
             A.d_mcells = nullptr; A.mcells_cap = 0;
-            HIP_TRY(c, hipMalloc(&A.d_mcells, entries * sizeof(uint4)));
-            A.mcells_cap = entries;
+            HIP_TRY(c, hipMalloc(&A.d_mcells, m_entries * sizeof(uint4)));
+            A.mcells_cap = m_entries;
         }
-        HIP_TRY(c, hipMemsetAsync(A.d_mcells, 0, entries * sizeof(uint4), c->stream));
+        HIP_TRY(c, hipMemsetAsync(A.d_mcells, 0, m_entries * sizeof(uint4), c->stream));
     } else if (A.d_mcells) {   // (a world beyond them: the path trace's bounce launches then read the cell grid and the bricks)
         for (auto &T : c->tabs) { (void)hipFree(T.d_mcells); T.d_mcells = nullptr; T.mcells_cap = 0; }
     }
@@ -1608,7 +1612,7 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
         P.grid_bytes = (uint32_t)(G * (G + 1u) * (G + 1u) * sizeof(uint32_t));  // [8S][8S+1][8S+1]: the zero border
         P.brick_bytes = (uint32_t)((size_t)T.brick_cap * 64u * sizeof(uint16_t));
         P.mcells = T.d_mcells;
-        P.mcells_bytes = T.d_mcells ? (uint32_t)(G * (G + 1u) * (G + 1u) * sizeof(uint4)) : 0u;
+        P.mcells_bytes = T.d_mcells ? (uint32_t)(march_cell_entries(c->accel_S) * sizeof(uint4)) : 0u;
     }
     // a march that walks the octree reads the node pool and chunk_roots: uploads then wait for the frames in flight
     if (!P.grid || variant == 1u || variant == 2u) c->walkers_in_flight = true;

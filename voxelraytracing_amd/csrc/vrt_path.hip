@@ -951,7 +951,8 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(FrameParams P, u
     {
         const TableBuf mb = table_buffer(P.mcells, P.mcells_bytes);
         const TableBuf gb = table_buffer(P.grid, P.grid_bytes), bb = table_buffer(P.bricks, P.brick_bytes);
-        const uint32_t row16 = (P.grid_dim + 1u) * 16u, slab16 = (P.grid_dim + 1u) * row16;   // < 2^23: S <= 63
+        // the march cells: [4S][4S+1][4S+1] blocks of 2 x 2 x 2 cells, 128 bytes a block; both strides < 2^23 for S <= 63
+        const uint32_t row128 = (P.grid_dim / 2u + 1u) * 128u, slab128 = (P.grid_dim / 2u + 1u) * row128;
         const uint32_t row_bytes = (P.grid_dim + 1u) * 4u, slab_bytes = (P.grid_dim + 1u) * row_bytes;
         const uint32_t wsize = P.world.size;
         V3 pos{0.f, 0.f, 0.f}, dir{0.f, 0.f, 0.f};
@@ -1063,7 +1064,9 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(FrameParams P, u
                 } else if (marching) {
                     // one 16-byte load answers the step: c.x the cell's entry, c.y the size-2 mask of a split cell, c.z / c.w
                     // the voxels a ray passes (zero — the border, beyond the buffer — stops it: outside the world)
-                    const uint32_t off = mad_i24(vz >> 2, slab16, mad_i24(vy >> 2, row16, ((uint32_t)vx & ~3u) << 2));
+                    // (block: bits 3.. of the coordinates; the cell inside it: their bits 2)
+                    const uint32_t sub = ((((uint32_t)vz >> 2) & 1u) << 2) | ((((uint32_t)vy >> 2) & 1u) << 1) | (((uint32_t)vx >> 2) & 1u);
+                    const uint32_t off = mad_i24(vz >> 3, slab128, mad_i24(vy >> 3, row128, ((uint32_t)(vx >> 3) << 7) + (sub << 4)));
                     const uint4 c = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(mb, off, 0, 0));
                     iter += 1u;
                     // u = (x&3) | (y&3) << 2 | (z&3) << 4, with z's upper bits left on top: the shifts below use the low bits only
