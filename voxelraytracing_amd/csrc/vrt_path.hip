@@ -993,6 +993,9 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(FrameParams P, u
                 park();
             }
             vx = trunc2i(pos.x); vy = trunc2i(pos.y); vz = trunc2i(pos.z);
+#ifdef VRT_EXP_NOMARCH   // counting experiment: every ray ends where it starts
+            if (marching) { marching = false; park(); }
+#endif
         };
         // the step to the leaf's exit face for a leaf of size lo + 1 (take_step of march_grid)
         auto take_step = [&](uint32_t lo) __attribute__((always_inline)) {
@@ -1057,11 +1060,18 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(FrameParams P, u
                 if (next >= n) break;   // the pool is empty and nobody marches (every ray is parked: take() parks the ones that start outside)
                 continue;
             }
-            const bool careful = __ballot(marching && not_finite) != 0ull;   // per refill round
-            for (;;) {
-                if (careful) {   // wave-uniform, rare
+            // (two loops, chosen per refill round: one loop with both bodies costs a register move per loop-carried value and
+            // body on every trip — 22 of them, a quarter of the step)
+            if (__ballot(marching && not_finite) != 0ull) {   // wave-uniform, rare
+                for (;;) {
                     if (marching) careful_step();
-                } else if (marching) {
+                    const uint32_t n_march = (uint32_t)__popcll(__ballot(marching));
+                    if (n_march == 0u || (next < n && 64u - n_march >= refill_at)) break;
+                }
+                continue;
+            }
+            for (;;) {
+                if (marching) {
                     // one 16-byte load answers the step: c.x the cell's entry, c.y the size-2 mask of a split cell, c.z / c.w
                     // the voxels a ray passes (zero — the border, beyond the buffer — stops it: outside the world)
                     // (block: bits 3.. of the coordinates; the cell inside it: their bits 2)
@@ -1081,7 +1091,7 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(FrameParams P, u
                             // out of lookups in air or in a liquid (:220, :293): the segment ends as a hit on the voxel of the last
                             // lookup — which for a split cell is in its brick, at the position that was looked up
                             stop = true;
-                            ref = (int)c.x < 0 ? ((uint32_t)__builtin_amdgcn_raw_buffer_load_b16(bb, ((c.x & 0x7FFFFFFFu) + u) << 1, 0, 0) >> 1) << 16 : c.x;
+                            ref = (int)c.x < 0 ? ((uint32_t)__builtin_amdgcn_raw_buffer_load_b16(bb, ((c.x & 0x7FFFFFFFu) + (u & 63u)) << 1, 0, 0) >> 1) << 16 : c.x;
                         }
                     }
                     marching = !stop;
