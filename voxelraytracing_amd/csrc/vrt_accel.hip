@@ -17,17 +17,23 @@
 //   brick pool  u16[bricks][64], index (x&3) | (y&3) << 2 | (z&3) << 4 inside the cell:
 //               air leaf -> lo (1 at depth 4, 0 at depth 5); other leaf -> voxel << 1 | lo
 //
-//   march cells uint4[4S][4S+1][4S+1][2][2][2]: blocks of 2 x 2 x 2 cells, one 128-byte line each, the blocks x-major with a
-//               border block per row and a border row of blocks per slab (worlds of S <= kMarchCellsMaxS; the path trace's bounce
-//               launches, vrt_path.hip): everything a march step has to know about a cell in ONE 16-byte load, so that a
-//               split cell costs no second, dependent load —
+//   march cells (the path trace's bounce launches, vrt_path.hip): everything a march step has to know about a cell in ONE
+//               16-byte load, so that a split cell costs no second, dependent load —
 //               .x  the cell grid's entry (lo of a leaf in its low 5 bits, 0x80000000 | brick * 64 for a split cell)
 //               .y  split cell: bit (u >> 1) & 31, u = (x&3) | (y&3) << 2 | (z&3) << 4, set <=> the voxel's 2^3 sub-block is
 //                   one depth-4 leaf (the index is what a shift of u gives: every sub-block owns four of the 32 bits)
 //               .z .w  64 bits, bit u set <=> a ray PASSES the voxel: it is air, or a liquid of the material table the tables
-//                   were built with; a leaf cell is all ones or all zeros.  Zero — the border, a load past either end of
-//                   the buffer — stops the ray: "outside the world" needs no test of its own
+//                   were built with; a leaf cell is all ones or all zeros.  Zero stops the ray.
 //               The voxel a ray stopped on is read from the brick afterwards, at full width, not inside the loop.
+//               Sixteen bytes for every cell of the world would be 273 MB for a 32^3-chunk world — beyond the 256 MB
+//               memory-side cache, where the 67 MB cell grid sits inside it — and nine chunks in ten are one leaf.  So the
+//               cells come in BLOCKS of one chunk (512 cells x-major, 8 KiB), found through a chunk directory
+//               u32[S][S+1][S+1] (zero border like the grid's) that a ray re-reads only when it enters another chunk:
+//               0 = outside the world -> block 0, all zeros: every cell stops the ray, "outside" needs no test;
+//               1 = a chunk that is one air leaf (or missing) -> block 1, shared: 512 x {lo 31, passes};
+//               b >= 2 = the chunk's own block.  23 MB instead of 273 for that world.  Inside a block the cells stand in lines
+//               of 2 x 2 x 2 (a 128-byte cache line is a cube of 8^3 voxels).  Worlds of S <= 16 skip the directory: the same
+//               lines, x-major over the whole world with a zero border ("direct": 4.5 MB for 8^3 chunks, 35 MB for 16^3).
 //
 // Every entry is exactly what find_node would return for any position inside it (same node word, same depth;
 // a node read past the end of the pool is 0, a missing chunk is root 0), so the march visits the same leaves
@@ -51,18 +57,33 @@ __device__ __forceinline__ size_t cell_index(uint32_t S, uint32_t chunk, uint32_
     return ((size_t)(chz * 8u + cz) * G1 + (chy * 8u + cy)) * G1 + (chx * 8u + cx);
 }
 
-// Position of the same cell among the march cells: blocks of 2 x 2 x 2 cells (8^3 voxels, 128 bytes: one cache line), the
-// blocks x-major with one border block per row and one border row of blocks per z slab:
-// [4S][4S+1][4S+1] blocks of [2][2][2] cells.  A ray reads the cells it walks through; a line that is a cube holds two or
-// three of them, a line that is a row of eight cells along x hardly ever two.
-__host__ __device__ __forceinline__ size_t march_cell_index(uint32_t S, uint32_t gx, uint32_t gy, uint32_t gz) {
-    const uint32_t B1 = S * 4u + 1u;
+// What the kernels below need of the march cells (null blocks: not kept for this world).
+struct MarchCells {
+    uint32_t *dir;      // the chunk directory, [S][S+1][S+1] (null: direct)
+    uint4 *blocks;      // [cap][512]; direct: [4S][4S+1][4S+1][8]
+    uint32_t *tail;     // the first block not handed out yet (single-chunk rebuilds take theirs from here)
+    uint32_t cap;
+    uint32_t direct;    // small worlds: no directory, the cells of the whole world in lines of 2 x 2 x 2 cells, the lines x-major
+                        // over the world with one border line per row and one border row of lines per slab
+};
+// A cell inside its chunk's block: lines of 2 x 2 x 2 cells (8^3 voxels, 128 bytes: one cache line), the lines x-major.  A ray
+// reads the cells it walks through: a line that is a cube holds two or three of them, a row of eight cells along x hardly
+// ever two (measured on C4: 17.5 Grays/s against 15.4).
+__host__ __device__ __forceinline__ uint32_t cell_in_block(uint32_t cx, uint32_t cy, uint32_t cz) {
+    return ((((cz >> 1) << 2 | (cy >> 1)) << 2 | (cx >> 1)) << 3) | (cx & 1u) | ((cy & 1u) << 1) | ((cz & 1u) << 2);
+}
+// ... and in a direct world
+__device__ __forceinline__ size_t direct_cell_index(uint32_t S, uint32_t chunk, uint32_t cx, uint32_t cy, uint32_t cz) {
+    const uint32_t chx = chunk % S, chy = (chunk / S) % S, chz = chunk / (S * S);
+    const uint32_t gx = chx * 8u + cx, gy = chy * 8u + cy, gz = chz * 8u + cz, B1 = S * 4u + 1u;
     return (((size_t)(gz >> 1) * B1 + (gy >> 1)) * B1 + (gx >> 1)) * 8u + ((gx & 1u) | ((gy & 1u) << 1) | ((gz & 1u) << 2));
 }
-__device__ __forceinline__ size_t march_cell_index(uint32_t S, uint32_t chunk, uint32_t cx, uint32_t cy, uint32_t cz) {
+__device__ __forceinline__ size_t chunk_dir_index(uint32_t S, uint32_t chunk) {
     const uint32_t chx = chunk % S, chy = (chunk / S) % S, chz = chunk / (S * S);
-    return march_cell_index(S, chx * 8u + cx, chy * 8u + cy, chz * 8u + cz);
+    return ((size_t)chz * (S + 1u) + chy) * (S + 1u) + chx;
 }
+// does a chunk with this root node need a block of its own?  (one air leaf — a missing chunk is node 0 — shares block 1)
+__device__ __forceinline__ bool chunk_needs_block(uint32_t root_node) { return (root_node & 0x8000u) != 0u || (root_node & 0x7FFFu) != 0u; }
 
 // A leaf's grid entry: air -> lo, anything else -> voxel << 16 | lo  (lo = leaf size - 1).
 __device__ __forceinline__ uint32_t leaf_entry(uint32_t node, uint32_t lo) { return ((node & 0x7FFFu) << 16) | lo; }
@@ -151,7 +172,7 @@ __device__ __forceinline__ void store_brick(uint16_t *bricks, uint32_t brick, co
 // split cells inside the chunk (their bricks are laid out contiguously per chunk, cells in x-major order) and the
 // chunk's brick count.
 __global__ void __launch_bounds__(512) accel_cells_kernel(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots,
-                                                          uint32_t S, uint32_t *grid, uint32_t *chunk_bricks, uint4 *mcells, LiquidMask lq) {
+                                                          uint32_t S, uint32_t *grid, uint32_t *chunk_bricks, uint32_t *chunk_needs) {
     __shared__ uint32_t s_wave[8];
     const uint32_t chunk = blockIdx.x;
     const uint32_t t = threadIdx.x, cx = t & 7u, cy = (t >> 3) & 7u, cz = t >> 6;
@@ -163,8 +184,36 @@ __global__ void __launch_bounds__(512) accel_cells_kernel(const uint16_t *nodes,
     const uint32_t rank = rank_split_cells(split, s_wave, total);
     const size_t cell = cell_index(S, chunk, cx, cy, cz);
     grid[cell] = split ? (0x80000000u | rank) : leaf_entry(node, (32u >> depth) - 1u);
-    if (mcells && !split) mcells[march_cell_index(S, chunk, cx, cy, cz)] = leaf_march_cell(lq, node, (32u >> depth) - 1u);   // (split cells: pass 3)
-    if (t == 0) chunk_bricks[chunk] = total;
+    if (t == 0) {
+        chunk_bricks[chunk] = total;
+        if (chunk_needs) chunk_needs[chunk] = chunk_needs_block(pool_node(nodes, n_nodes, root)) ? 1u : 0u;
+    }
+}
+
+// Pass 2b: the chunk directory.  Chunks that need a block of their own get 2, 3, ... in chunk order; block 1 is shared by the
+// chunks that are one air leaf, block 0 (outside the world: the directory's zero border) stays all zeros.  One workgroup.
+__global__ void __launch_bounds__(1024) accel_dir_kernel(const uint32_t *needs, uint32_t S, MarchCells mc, uint32_t *total_blocks) {
+    __shared__ uint32_t s_part[1024];
+    const uint32_t t = threadIdx.x, n = S * S * S;
+    const uint32_t per = (n + 1023u) / 1024u;
+    const uint32_t lo = min(t * per, n), hi = min(lo + per, n);
+
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += needs[i];
+    s_part[t] = sum;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024u; o <<= 1) {
+        const uint32_t v = t >= o ? s_part[t - o] : 0u;
+        __syncthreads();
+        s_part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = 2u + s_part[t] - sum;
+    for (uint32_t i = lo; i < hi; i++) {
+        mc.dir[chunk_dir_index(S, i)] = needs[i] ? run : 1u;
+        run += needs[i];
+    }
+    if (t == 1023u) { *total_blocks = s_part[1023]; *mc.tail = 2u + s_part[1023]; }
 }
 
 // How many bricks a chunk's region of the pool holds beyond what it needs now: room for the cells an edit splits, so
@@ -203,22 +252,35 @@ __global__ void __launch_bounds__(1024) accel_scan_kernel(const uint32_t *counts
 // Pass 3: fills the bricks of the split cells and replaces their in-chunk rank by the pool position.
 __global__ void __launch_bounds__(512) accel_bricks_kernel(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots,
                                                            uint32_t S, uint32_t *grid, const uint32_t *chunk_bases,
-                                                           uint16_t *bricks, uint32_t brick_cap, uint4 *mcells, LiquidMask lq) {
+                                                           uint16_t *bricks, uint32_t brick_cap, MarchCells mc, LiquidMask lq) {
     const uint32_t chunk = blockIdx.x;
     const uint32_t t = threadIdx.x, cx = t & 7u, cy = (t >> 3) & 7u, cz = t >> 6;
     const size_t cell = cell_index(S, chunk, cx, cy, cz);
     const uint32_t e = grid[cell];
-    if (!(e & 0x80000000u)) return;
+    uint4 *mcell = nullptr;
+    if (mc.blocks && mc.direct) {
+        mcell = mc.blocks + direct_cell_index(S, chunk, cx, cy, cz);
+    } else if (mc.blocks) {
+        const uint32_t blk = mc.dir[chunk_dir_index(S, chunk)];
+        if (blk >= 2u && blk < mc.cap) mcell = mc.blocks + (size_t)blk * 512u + cell_in_block(cx, cy, cz);
+    }
+    const uint32_t root = roots[chunk];
+    if (!(e & 0x80000000u)) {
+        if (!mcell) return;
+        uint32_t depth;
+        const uint32_t node = descend3(nodes, n_nodes, root, cx, cy, cz, depth);
+        *mcell = leaf_march_cell(lq, node, (32u >> depth) - 1u);
+        return;
+    }
     const uint32_t brick = chunk_bases[chunk] + (e & 0x7FFFFFFFu);
     if (brick >= brick_cap) return;  // cannot happen: the pool was sized from the scan's total
-    const uint32_t root = roots[chunk];
     uint32_t depth;
     const uint32_t n3 = descend3(nodes, n_nodes, root, cx, cy, cz, depth);
     uint32_t w[32];
     assemble_brick([&](uint32_t i) { return pool_node(nodes, n_nodes, root + i); }, n3, w);
     store_brick(bricks, brick, w);
     grid[cell] = 0x80000000u | (brick * 64u);
-    if (mcells) mcells[march_cell_index(S, chunk, cx, cy, cz)] = split_march_cell(lq, brick, w);
+    if (mcell) *mcell = split_march_cell(lq, brick, w);
 }
 
 // Rebuild of single chunks (a voxel edit, a chunk that arrived): one workgroup per listed chunk does all three passes
@@ -251,10 +313,10 @@ struct ChunkNodes {
 __global__ void __launch_bounds__(512) accel_chunks_kernel(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S,
                                                            uint32_t *grid, uint32_t *chunk_bricks, uint32_t *chunk_bases,
                                                            uint32_t *chunk_caps, uint32_t *tail, uint16_t *bricks, uint32_t brick_cap,
-                                                           uint4 *mcells, LiquidMask lq, ChunkList list) {
+                                                           MarchCells mc, LiquidMask lq, ChunkList list) {
     extern __shared__ __attribute__((aligned(16))) uint16_t s_raw[];  // the chunk's node words from the 16-byte boundary at or below its root
     __shared__ uint32_t s_wave[8];
-    __shared__ uint32_t s_base;
+    __shared__ uint32_t s_base, s_blk;
     const uint32_t chunk = list.chunk[blockIdx.x];
     const uint32_t t = threadIdx.x, cx = t & 7u, cy = (t >> 3) & 7u, cz = t >> 6;
     const uint32_t root = roots[chunk];
@@ -297,12 +359,26 @@ __global__ void __launch_bounds__(512) accel_chunks_kernel(const uint16_t *nodes
         }
         chunk_bricks[chunk] = total;
         s_base = base;
+        // the chunk's block of march cells: its own if it has one (it keeps it, whatever the chunk turns into), a new one
+        // from the tail when a chunk that was one air leaf is that no longer
+        uint32_t blk = 0u;
+        if (mc.blocks && !mc.direct) {
+            const size_t d = chunk_dir_index(S, chunk);
+            blk = mc.dir[d];
+            if (blk < 2u && chunk_needs_block(lds_node(0u))) {
+                blk = atomicAdd(mc.tail, 1u);
+                mc.dir[d] = blk < mc.cap ? blk : 1u;   // (cannot overflow: the host accounts for every possible new block)
+            }
+        }
+        s_blk = blk;
     }
     __syncthreads();
+    uint4 *mcell = s_blk >= 2u && s_blk < mc.cap ? mc.blocks + (size_t)s_blk * 512u + cell_in_block(cx, cy, cz) : nullptr;
+    if (mc.blocks && mc.direct) mcell = mc.blocks + direct_cell_index(S, chunk, cx, cy, cz);
     const size_t cell = cell_index(S, chunk, cx, cy, cz);
     if (!split) {
         grid[cell] = leaf_entry(node, (32u >> depth) - 1u);
-        if (mcells) mcells[march_cell_index(S, chunk, cx, cy, cz)] = leaf_march_cell(lq, node, (32u >> depth) - 1u);
+        if (mcell) *mcell = leaf_march_cell(lq, node, (32u >> depth) - 1u);
         return;
     }
     const uint32_t brick = s_base + rank;
@@ -312,7 +388,7 @@ __global__ void __launch_bounds__(512) accel_chunks_kernel(const uint16_t *nodes
     store_brick(bricks, brick, w);
     __threadfence();
     grid[cell] = 0x80000000u | (brick * 64u);
-    if (mcells) mcells[march_cell_index(S, chunk, cx, cy, cz)] = split_march_cell(lq, brick, w);
+    if (mcell) *mcell = split_march_cell(lq, brick, w);
 }
 
 // Upload of a staged range: the pinned ring is mapped into the device's address space, so a kernel reads it over PCIe and
@@ -337,35 +413,47 @@ static LiquidMask liquid_mask(const uint32_t liquid[8]) {
     return lq;
 }
 
-// mcells: the march cells (null: not kept for this world), liquid: the 256-bit is_liquid mask they are built with
+// march cells: dir / blocks / tail / cap (blocks null: not kept for this world; dir null: a direct world), liquid: the 256-bit is_liquid mask they are
+// built with.  launch_accel_cells leaves the number of blocks the chunks need in *total_blocks (+ 2: blocks 0 and 1).
 void launch_accel_cells(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S, uint32_t *grid,
                         uint32_t *chunk_bricks, uint32_t *chunk_bases, uint32_t *chunk_caps, uint32_t *total, uint32_t *tail,
-                        uint4 *mcells, const uint32_t liquid[8], hipStream_t st) {
+                        uint32_t *chunk_needs, uint32_t *dir, uint32_t *block_tail, uint32_t *total_blocks, hipStream_t st) {
     const uint32_t n = S * S * S;
-    hipLaunchKernelGGL(accel_cells_kernel, dim3(n), dim3(512), 0, st, nodes, n_nodes, roots, S, grid, chunk_bricks, mcells, liquid_mask(liquid));
+    hipLaunchKernelGGL(accel_cells_kernel, dim3(n), dim3(512), 0, st, nodes, n_nodes, roots, S, grid, chunk_bricks, chunk_needs);
     hipLaunchKernelGGL(accel_scan_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t *)chunk_bricks, chunk_bases, chunk_caps, n, total, tail);
+    if (chunk_needs) {   // (the directory: block 1 is filled by the bricks pass' launcher once the blocks exist)
+        const MarchCells mc{dir, nullptr, block_tail, 0u, 0u};
+        hipLaunchKernelGGL(accel_dir_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t *)chunk_needs, S, mc, total_blocks);
+    }
+}
+
+__global__ void __launch_bounds__(512) accel_air_block_kernel(uint4 *blocks) {
+    blocks[512u + threadIdx.x] = make_uint4(31u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu);   // block 1: one air leaf
 }
 
 void launch_accel_bricks(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S, uint32_t *grid,
-                         const uint32_t *chunk_bases, uint16_t *bricks, uint32_t brick_cap, uint4 *mcells, const uint32_t liquid[8],
-                         hipStream_t st) {
+                         const uint32_t *chunk_bases, uint16_t *bricks, uint32_t brick_cap, uint32_t *dir, uint4 *blocks, uint32_t *block_tail,
+                         uint32_t block_cap, const uint32_t liquid[8], hipStream_t st) {
+    if (blocks && dir) hipLaunchKernelGGL(accel_air_block_kernel, dim3(1), dim3(512), 0, st, blocks);
+    const MarchCells mc{dir, blocks, block_tail, block_cap, dir ? 0u : 1u};
     hipLaunchKernelGGL(accel_bricks_kernel, dim3(S * S * S), dim3(512), 0, st, nodes, n_nodes, roots, S, grid, chunk_bases, bricks,
-                       brick_cap, mcells, liquid_mask(liquid));
+                       brick_cap, mc, liquid_mask(liquid));
 }
 
 void launch_accel_chunks(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S, uint32_t *grid,
                          uint32_t *chunk_bricks, uint32_t *chunk_bases, uint32_t *chunk_caps, uint32_t *tail, uint16_t *bricks,
-                         uint32_t brick_cap, uint4 *mcells, const uint32_t liquid[8], const uint32_t *chunks, const uint32_t *extents,
-                         uint32_t n, hipStream_t st) {
+                         uint32_t brick_cap, uint32_t *dir, uint4 *blocks, uint32_t *block_tail, uint32_t block_cap, const uint32_t liquid[8],
+                         const uint32_t *chunks, const uint32_t *extents, uint32_t n, hipStream_t st) {
     // 64 KiB + of dynamic LDS needs opting in (the CU has 160 KiB); per device, and any thread may be the first
     const size_t lds = (size_t)(kChunkNodesMax + 16u) * sizeof(uint16_t);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(accel_chunks_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const MarchCells mc{dir, blocks, block_tail, block_cap, dir ? 0u : 1u};
     for (uint32_t i = 0; i < n; i += 64u) {
         ChunkList list;
         const uint32_t m = n - i < 64u ? n - i : 64u;
         for (uint32_t k = 0; k < m; k++) { list.chunk[k] = chunks[i + k]; list.extent[k] = extents[i + k]; }
         hipLaunchKernelGGL(accel_chunks_kernel, dim3(m), dim3(512), lds, st, nodes, n_nodes, roots, S, grid, chunk_bricks, chunk_bases,
-                           chunk_caps, tail, bricks, brick_cap, mcells, liquid_mask(liquid), list);
+                           chunk_caps, tail, bricks, brick_cap, mc, liquid_mask(liquid), list);
     }
 }
 

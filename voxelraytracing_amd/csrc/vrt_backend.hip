@@ -35,7 +35,7 @@ void launch_primary_shadow_persistent(const FrameParams &P, uint32_t *heads, uin
 void launch_path_primary(const FrameParams &P, bool stats, bool literal, hipStream_t st);
 void launch_path_bounce(const FrameParams &P, bool stats, bool literal, hipStream_t st);
 void launch_path_bounce_pool(const FrameParams &P, bool continuations, uint32_t refill_at, uint32_t eject_at, hipStream_t st);
-void launch_path_bounce_cells(const FrameParams &P, uint32_t refill_at, bool sort, hipStream_t st);
+void launch_path_bounce_cells(const FrameParams &P, uint32_t refill_at, hipStream_t st);
 void launch_path_finish(Texel *out, uint32_t n, uint32_t spp, hipStream_t st);
 void launch_tile_order(const uint32_t *cost, uint32_t n, uint32_t shift, uint32_t *scratch, uint32_t *order, hipStream_t st);
 void launch_path_chain_finish(Texel *out, const Texel *acc, uint32_t n, uint32_t chain, bool first, bool last, uint32_t spp, hipStream_t st);
@@ -49,15 +49,15 @@ void launch_assemble_shade(const FrameParams &P, const void *gathered, Texel *ds
                            uint64_t rank_stride, hipStream_t st);
 void launch_accel_cells(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S, uint32_t *grid,
                         uint32_t *chunk_bricks, uint32_t *chunk_bases, uint32_t *chunk_caps, uint32_t *total, uint32_t *tail,
-                        uint4 *mcells, const uint32_t liquid[8], hipStream_t st);
+                        uint32_t *chunk_needs, uint32_t *dir, uint32_t *block_tail, uint32_t *total_blocks, hipStream_t st);
 void launch_accel_bricks(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S, uint32_t *grid,
-                         const uint32_t *chunk_bases, uint16_t *bricks, uint32_t brick_cap, uint4 *mcells, const uint32_t liquid[8],
-                         hipStream_t st);
+                         const uint32_t *chunk_bases, uint16_t *bricks, uint32_t brick_cap, uint32_t *dir, uint4 *blocks, uint32_t *block_tail,
+                         uint32_t block_cap, const uint32_t liquid[8], hipStream_t st);
 void launch_upload_words(void *dst, const void *pinned_src, uint32_t n_words, hipStream_t st);
 void launch_accel_chunks(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S, uint32_t *grid,
                          uint32_t *chunk_bricks, uint32_t *chunk_bases, uint32_t *chunk_caps, uint32_t *tail, uint16_t *bricks,
-                         uint32_t brick_cap, uint4 *mcells, const uint32_t liquid[8], const uint32_t *chunks, const uint32_t *extents,
-                         uint32_t n, hipStream_t st);
+                         uint32_t brick_cap, uint32_t *dir, uint4 *blocks, uint32_t *block_tail, uint32_t block_cap, const uint32_t liquid[8],
+                         const uint32_t *chunks, const uint32_t *extents, uint32_t n, hipStream_t st);
 }  // namespace vrt
 
 static_assert(sizeof(vrt_material) == 32, "Material layout (mod.rs:20-28)");
@@ -145,8 +145,13 @@ struct vrt_ctx {
         size_t grid_cap = 0;          // entries allocated ([8S][8S+1][8S+1] with the zero border)
         uint16_t *d_bricks = nullptr;
         uint32_t brick_cap = 0;
-        uint4 *d_mcells = nullptr;    // the march cells (vrt_accel.hip), same indexing as the grid; worlds of S <= kMarchCellsMaxS
-        size_t mcells_cap = 0;
+        // the march cells (vrt_accel.hip): a chunk directory [S][S+1][S+1] and 8-KiB blocks of 512 cells (0: outside the world,
+        // 1: shared by the chunks that are one air leaf, the rest: one chunk each; the tail takes chunks that stop being air)
+        uint32_t *d_cdir = nullptr;
+        size_t cdir_cap = 0;
+        uint4 *d_mblk = nullptr;
+        uint32_t mblk_cap = 0;        // blocks
+        uint32_t *d_mblk_tail = nullptr;
         uint32_t *d_chunk_bricks = nullptr, *d_chunk_bases = nullptr, *d_chunk_caps = nullptr, *d_brick_tail = nullptr;
         uint32_t chunk_cap = 0;
         bool live = false;            // a copy of tabs[0] as of the last whole-world build, plus its own chunk updates since
@@ -166,6 +171,9 @@ struct vrt_ctx {
     uint32_t quiet_frames = 0;
     bool shared_readers_in_flight = false;   // a frame on another frame set is reading tabs[0] (cleared with the frames in flight)
     uint32_t *d_brick_total = nullptr;
+    uint32_t *d_chunk_needs = nullptr;   // whole-world build scratch: which chunks need a block of march cells
+    bool march_direct = false;           // the blocks of the march cells are addressed by chunk position (kMarchDirectMaxS)
+    uint32_t chunk_needs_cap = 0;
     uint32_t n_bricks = 0;        // bricks inside the chunks' regions after the last whole-world build
     uint32_t accel_S = 0;         // world size the tables were built for
     bool accel_dirty = true;
@@ -179,7 +187,6 @@ struct vrt_ctx {
     bool path_pool = true;         // VRT_PATH_POOL=0: bounce launches with lane = path (the round-1 structure) instead of the pool kernel
     bool path_chain = false;       // VRT_PATH_POOL_CHAIN=1: the pool kernel's stragglers go to a chain of launches on a side stream
     bool path_cells = true;        // VRT_PATH_CELLS=0: the pool kernel over cell grid + bricks instead of the one over the march cells
-    bool path_sort = true;         // VRT_PATH_SORT=0: a wave's rays handed out in record order instead of by direction octant
     uint32_t path_samples = 8;     // VRT_PATH_SAMPLES_PER_CHAIN: samples a launch chain traces at once when spp > 1 (1: one, as round 1 did)
     vrt::Texel *path_acc[kMaxInFlight] = {nullptr, nullptr, nullptr, nullptr};   // ... their accumulation planes, per frame set
     size_t path_acc_texels[kMaxInFlight] = {0, 0, 0, 0}, path_buf_records[kMaxInFlight] = {0, 0, 0, 0}, path_cont_records[kMaxInFlight] = {0, 0, 0, 0};
@@ -400,9 +407,13 @@ static int alloc_roots(vrt_ctx *c, uint32_t world_size) {
 // 24-bit multiplies (8S (8S+1)^2 * 4 B < 2^31, (8S+1)^2 * 4 < 2^23), bricks by brick * 128 B < 2^32.
 static constexpr uint32_t kAccelMaxS = 100;
 // ... the march cells (16 bytes per cell) are addressed the same way: 8S (8S+1)^2 * 16 B < 2^31
-static constexpr uint32_t kMarchCellsMaxS = 63;
-// [4S][4S+1][4S+1] blocks of 2 x 2 x 2 cells (vrt_accel.hip: march_cell_index)
-static size_t march_cell_entries(uint32_t S) { const size_t B = (size_t)S * 4u; return B * (B + 1u) * (B + 1u) * 8u; }
+static constexpr uint32_t kMarchBlocksMax = 1u << 18;   // 2 GiB of march-cell blocks (byte offsets stay below 2^31)
+static size_t chunk_dir_entries(uint32_t S) { return (size_t)S * (S + 1u) * (S + 1u); }
+// Small worlds skip the directory: the cells of the whole world, [4S][4S+1][4S+1] lines of 2 x 2 x 2 cells (one dependent
+// load and a divergent branch less per change of chunk: 17.5 against 16.1 Grays/s on C4).  16^3 chunks: 35 MB; larger
+// worlds go through the directory (32^3: 23 MB instead of 273).
+static constexpr uint32_t kMarchDirectMaxS = 16;
+static size_t direct_cell_entries(uint32_t S) { const size_t B = (size_t)S * 4u; return B * (B + 1u) * (B + 1u) * 8u; }
 static constexpr uint32_t kAccelMaxBricks = (1u << 25) - 1u;
 // Chunks that can be rebuilt alone between two whole-world builds: each may move, once, into a 512-brick region
 // (64 KiB) at the tail of the brick pool.
@@ -587,10 +598,10 @@ static void mark_node_range_dirty(vrt_ctx *c, uint32_t start, uint32_t end) {
 static int free_tables(vrt_ctx *c, vrt_ctx::Tables &T) {
     (void)c;
     (void)hipFree(T.d_grid); (void)hipFree(T.d_bricks); (void)hipFree(T.d_chunk_bricks); (void)hipFree(T.d_chunk_bases);
-    (void)hipFree(T.d_chunk_caps); (void)hipFree(T.d_brick_tail); (void)hipFree(T.d_mcells);
+    (void)hipFree(T.d_chunk_caps); (void)hipFree(T.d_brick_tail); (void)hipFree(T.d_cdir); (void)hipFree(T.d_mblk); (void)hipFree(T.d_mblk_tail);
     T.d_grid = nullptr; T.d_bricks = nullptr; T.d_chunk_bricks = T.d_chunk_bases = T.d_chunk_caps = T.d_brick_tail = nullptr;
-    T.d_mcells = nullptr;
-    T.grid_cap = 0; T.brick_cap = 0; T.chunk_cap = 0; T.mcells_cap = 0;
+    T.d_cdir = nullptr; T.d_mblk = nullptr; T.d_mblk_tail = nullptr;
+    T.grid_cap = 0; T.brick_cap = 0; T.chunk_cap = 0; T.cdir_cap = 0; T.mblk_cap = 0;
     T.live = false;
     return VRT_OK;
 }
@@ -607,11 +618,20 @@ static int alloc_tables_like_first(vrt_ctx *c, uint32_t k) {
         HIP_TRY(c, hipMalloc(&T.d_grid, entries * sizeof(uint32_t)));
         T.grid_cap = entries;
     }
-    const size_t m_entries = march_cell_entries(S);
-    if (A.d_mcells && T.mcells_cap < m_entries) {
-        (void)hipFree(T.d_mcells); T.d_mcells = nullptr; T.mcells_cap = 0;
-        HIP_TRY(c, hipMalloc(&T.d_mcells, m_entries * sizeof(uint4)));
-        T.mcells_cap = m_entries;
+    if (A.d_mblk) {
+        if (T.cdir_cap < chunk_dir_entries(S)) {
+            (void)hipFree(T.d_cdir); T.d_cdir = nullptr; T.cdir_cap = 0;
+            HIP_TRY(c, hipMalloc(&T.d_cdir, chunk_dir_entries(S) * sizeof(uint32_t)));
+            T.cdir_cap = chunk_dir_entries(S);
+        }
+        if (T.mblk_cap != A.mblk_cap || !T.d_mblk) {
+            (void)hipFree(T.d_mblk); T.d_mblk = nullptr; T.mblk_cap = 0;
+            HIP_TRY(c, hipMalloc(&T.d_mblk, (size_t)A.mblk_cap * 512u * sizeof(uint4)));
+            T.mblk_cap = A.mblk_cap;
+        }
+        if (!T.d_mblk_tail) HIP_TRY(c, hipMalloc(&T.d_mblk_tail, sizeof(uint32_t)));
+    } else if (T.d_mblk) {
+        (void)hipFree(T.d_mblk); T.d_mblk = nullptr; T.mblk_cap = 0;
     }
     if (T.chunk_cap < n_chunks) {
         (void)hipFree(T.d_chunk_bricks); (void)hipFree(T.d_chunk_bases); (void)hipFree(T.d_chunk_caps);
@@ -640,7 +660,11 @@ static int copy_tables_from_first(vrt_ctx *c, uint32_t k) {
         if (rc) return rc;
     }
     HIP_TRY(c, hipMemcpyAsync(T.d_grid, A.d_grid, entries * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
-    if (A.d_mcells) HIP_TRY(c, hipMemcpyAsync(T.d_mcells, A.d_mcells, march_cell_entries(S) * sizeof(uint4), hipMemcpyDeviceToDevice, c->stream));
+    if (A.d_mblk) {
+        HIP_TRY(c, hipMemcpyAsync(T.d_cdir, A.d_cdir, chunk_dir_entries(S) * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(T.d_mblk, A.d_mblk, (size_t)A.mblk_cap * 512u * sizeof(uint4), hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(T.d_mblk_tail, A.d_mblk_tail, sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    }
     HIP_TRY(c, hipMemcpyAsync(T.d_chunk_bricks, A.d_chunk_bricks, (size_t)n_chunks * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(T.d_chunk_bases, A.d_chunk_bases, (size_t)n_chunks * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(T.d_chunk_caps, A.d_chunk_caps, (size_t)n_chunks * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
@@ -701,17 +725,19 @@ static int ensure_accel_world(vrt_ctx *c) {
     }
     // the border rows / entries are never written by the kernels: zero = "outside the world"
     HIP_TRY(c, hipMemsetAsync(A.d_grid, 0, entries * sizeof(uint32_t), c->stream));
-    if (S <= kMarchCellsMaxS) {
-        const size_t m_entries = march_cell_entries(S);
-        if (m_entries > A.mcells_cap) {
-            (void)hipFree(A.d_mcells);
-            A.d_mcells = nullptr; A.mcells_cap = 0;
-            HIP_TRY(c, hipMalloc(&A.d_mcells, m_entries * sizeof(uint4)));
-            A.mcells_cap = m_entries;
-        }
-        HIP_TRY(c, hipMemsetAsync(A.d_mcells, 0, m_entries * sizeof(uint4), c->stream));
-    } else if (A.d_mcells) {   // (a world beyond them: the path trace's bounce launches then read the cell grid and the bricks)
-        for (auto &T : c->tabs) { (void)hipFree(T.d_mcells); T.d_mcells = nullptr; T.mcells_cap = 0; }
+    if (chunk_dir_entries(S) > A.cdir_cap) {
+        (void)hipFree(A.d_cdir);
+        A.d_cdir = nullptr; A.cdir_cap = 0;
+        HIP_TRY(c, hipMalloc(&A.d_cdir, chunk_dir_entries(S) * sizeof(uint32_t)));
+        A.cdir_cap = chunk_dir_entries(S);
+    }
+    HIP_TRY(c, hipMemsetAsync(A.d_cdir, 0, chunk_dir_entries(S) * sizeof(uint32_t), c->stream));   // the border: outside the world
+    if (!A.d_mblk_tail) HIP_TRY(c, hipMalloc(&A.d_mblk_tail, sizeof(uint32_t)));
+    if (n_chunks > c->chunk_needs_cap) {
+        (void)hipFree(c->d_chunk_needs);
+        c->d_chunk_needs = nullptr; c->chunk_needs_cap = 0;
+        HIP_TRY(c, hipMalloc(&c->d_chunk_needs, (size_t)n_chunks * sizeof(uint32_t)));
+        c->chunk_needs_cap = n_chunks;
     }
     if (n_chunks > A.chunk_cap) {
         (void)hipFree(A.d_chunk_bricks); (void)hipFree(A.d_chunk_bases); (void)hipFree(A.d_chunk_caps);
@@ -721,19 +747,39 @@ static int ensure_accel_world(vrt_ctx *c) {
         HIP_TRY(c, hipMalloc(&A.d_chunk_caps, (size_t)n_chunks * sizeof(uint32_t)));
         A.chunk_cap = n_chunks;
     }
-    if (!c->d_brick_total) HIP_TRY(c, hipMalloc(&c->d_brick_total, sizeof(uint32_t)));
+    if (!c->d_brick_total) HIP_TRY(c, hipMalloc(&c->d_brick_total, 2 * sizeof(uint32_t)));   // [0] bricks, [1] march-cell blocks
     if (!A.d_brick_tail) HIP_TRY(c, hipMalloc(&A.d_brick_tail, sizeof(uint32_t)));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     HIP_TRY(c, hipEventCreate(&e0));
     HIP_TRY(c, hipEventCreate(&e1));
+    const bool direct = S <= kMarchDirectMaxS;
+    c->march_direct = direct;
     auto body = [&]() -> int {
         HIP_TRY(c, hipEventRecord(e0, c->stream));
         vrt::launch_accel_cells(c->d_nodes, c->max_nodes, c->d_roots, S, A.d_grid, A.d_chunk_bricks, A.d_chunk_bases, A.d_chunk_caps,
-                                c->d_brick_total, A.d_brick_tail, A.d_mcells, c->liquid_mask, c->stream);
+                                c->d_brick_total, A.d_brick_tail, direct ? nullptr : c->d_chunk_needs, A.d_cdir, A.d_mblk_tail, c->d_brick_total + 1, c->stream);
         HIP_TRY(c, hipGetLastError());
-        uint32_t total = 0;  // bricks in all chunk regions (counts + slack)
-        HIP_TRY(c, hipMemcpyAsync(&total, c->d_brick_total, sizeof total, hipMemcpyDeviceToHost, c->stream));
+        uint32_t totals[2] = {0, 0};  // bricks in all chunk regions (counts + slack); chunks that need a block of march cells
+        HIP_TRY(c, hipMemcpyAsync(totals, c->d_brick_total, sizeof totals, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
+        const uint32_t total = totals[0];
+        // the march cells: blocks 0 and 1, one per chunk that needs its own, and room for the chunks that may come to need one
+        // before the next whole-world build (every one of them is a chunk rebuilt alone: at most kTailChunks)
+        const uint64_t want_blocks = direct ? (direct_cell_entries(S) + 511u) / 512u : 2ull + totals[1] + kTailChunks;
+        if (want_blocks > kMarchBlocksMax) {
+            for (auto &T : c->tabs) { (void)hipFree(T.d_mblk); T.d_mblk = nullptr; T.mblk_cap = 0; }
+        } else {
+            if (want_blocks > A.mblk_cap || !A.d_mblk) {
+                (void)hipFree(A.d_mblk);
+                A.d_mblk = nullptr; A.mblk_cap = 0;
+                uint64_t cap = want_blocks + (direct ? 0u : totals[1] / 8u);
+                if (cap > kMarchBlocksMax) cap = kMarchBlocksMax;
+                HIP_TRY(c, hipMalloc(&A.d_mblk, (size_t)cap * 512u * sizeof(uint4)));
+                A.mblk_cap = (uint32_t)cap;
+            }
+            // block 0: every cell stops the ray (direct: so do the blocks of the directory's border)
+            HIP_TRY(c, hipMemsetAsync(A.d_mblk, 0, (direct ? (size_t)want_blocks : (size_t)1) * 512u * sizeof(uint4), c->stream));
+        }
         const uint64_t want = (uint64_t)total + (uint64_t)kTailChunks * 512u;
         if (want > kAccelMaxBricks) return VRT_OK;  // accel_ok stays false
         if (want > A.brick_cap || !A.d_bricks) {
@@ -744,8 +790,8 @@ static int ensure_accel_world(vrt_ctx *c) {
             HIP_TRY(c, hipMalloc(&A.d_bricks, (size_t)cap * 64u * sizeof(uint16_t)));
             A.brick_cap = (uint32_t)cap;
         }
-        vrt::launch_accel_bricks(c->d_nodes, c->max_nodes, c->d_roots, S, A.d_grid, A.d_chunk_bases, A.d_bricks, A.brick_cap, A.d_mcells,
-                                 c->liquid_mask, c->stream);
+        vrt::launch_accel_bricks(c->d_nodes, c->max_nodes, c->d_roots, S, A.d_grid, A.d_chunk_bases, A.d_bricks, A.brick_cap, direct ? nullptr : A.d_cdir, A.d_mblk,
+                                 A.d_mblk_tail, A.mblk_cap, c->liquid_mask, c->stream);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipEventRecord(e1, c->stream));
         HIP_TRY(c, hipEventSynchronize(e1));
@@ -815,8 +861,8 @@ static int update_tables(vrt_ctx *c, uint32_t k, hipStream_t st) {
         extents[i] = r ? (end > r ? end - r : 0u) : 1u;   // (a missing chunk is node 0 alone: one air leaf)
     }
     vrt::launch_accel_chunks(c->d_nodes, c->max_nodes, c->d_roots, c->accel_S, T.d_grid, T.d_chunk_bricks, T.d_chunk_bases, T.d_chunk_caps,
-                             T.d_brick_tail, T.d_bricks, T.brick_cap, T.d_mcells, c->liquid_mask, T.dirty_chunks.data(), extents.data(),
-                             (uint32_t)T.dirty_chunks.size(), st);
+                             T.d_brick_tail, T.d_bricks, T.brick_cap, c->march_direct ? nullptr : T.d_cdir, T.d_mblk, T.d_mblk_tail, T.mblk_cap, c->liquid_mask,
+                             T.dirty_chunks.data(), extents.data(), (uint32_t)T.dirty_chunks.size(), st);
     HIP_TRY(c, hipGetLastError());
     // the next upload of nodes or roots waits for this reader
     if (!T.ev_updated) HIP_TRY(c, hipEventCreateWithFlags(&T.ev_updated, hipEventDisableTiming));
@@ -905,7 +951,6 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     if (const char *e = getenv("VRT_PATH_POOL")) c->path_pool = e[0] != '0';
     if (const char *e = getenv("VRT_PATH_POOL_CHAIN")) c->path_chain = e[0] == '1';
     if (const char *e = getenv("VRT_PATH_CELLS")) c->path_cells = e[0] != '0';
-    if (const char *e = getenv("VRT_PATH_SORT")) c->path_sort = e[0] != '0';
     if (const char *e = getenv("VRT_PATH_SAMPLES_PER_CHAIN")) { const int v = atoi(e); if (v >= 1 && v <= 16) c->path_samples = (uint32_t)v; }
     if (const char *e = getenv("VRT_PATH_POOL_REFILL")) c->path_refill = (uint32_t)atoi(e);
     if (const char *e = getenv("VRT_PATH_POOL_EJECT")) c->path_eject = (uint32_t)atoi(e);
@@ -978,7 +1023,7 @@ void vrt_destroy(vrt_ctx *c) {
         (void)free_tables(c, T);
         if (T.ev_updated) (void)hipEventDestroy(T.ev_updated);
     }
-    (void)hipFree(c->d_brick_total);
+    (void)hipFree(c->d_brick_total); (void)hipFree(c->d_chunk_needs);
     if (c->up_stream) { (void)hipStreamSynchronize(c->up_stream); (void)hipStreamDestroy(c->up_stream); }
     if (c->ev_pool_upload) (void)hipEventDestroy(c->ev_pool_upload);
     if (c->ev_walkers) (void)hipEventDestroy(c->ev_walkers);
@@ -1382,7 +1427,7 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
     // wait for, are off the frame's critical path.  A path is in exactly one of the two chains, so nothing is shared but
     // the record sets' cursors (atomics).  The chains join at the end of every sample.
     const bool pool = !kstats && !literal && P.grid && bounces > 1 && c->path_pool;
-    const bool cells = pool && P.mcells && c->path_cells;
+    const bool cells = pool && P.mblk && c->path_cells;
     const bool chain = pool && !cells && bounces - 1u <= kContSets && c->path_chain;
     uint32_t *cont_seg[kContSets];
     for (uint32_t i = 0; i < kContSets; i++) cont_seg[i] = P.seg_counts + (3 + i) * kSegWords;
@@ -1427,7 +1472,7 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
             } else if (!pool) {
                 vrt::launch_path_bounce(P, kstats, literal, f.st);
             } else if (cells) {
-                vrt::launch_path_bounce_cells(P, c->path_refill, c->path_sort, f.st);
+                vrt::launch_path_bounce_cells(P, c->path_refill, f.st);
             } else {
                 if (chain) {
                     P.cont_out = cont + (size_t)(b - 1u) * 4 * cap;
@@ -1611,8 +1656,14 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
         const size_t G = (size_t)c->accel_S * 8u;
         P.grid_bytes = (uint32_t)(G * (G + 1u) * (G + 1u) * sizeof(uint32_t));  // [8S][8S+1][8S+1]: the zero border
         P.brick_bytes = (uint32_t)((size_t)T.brick_cap * 64u * sizeof(uint16_t));
-        P.mcells = T.d_mcells;
-        P.mcells_bytes = T.d_mcells ? (uint32_t)(march_cell_entries(c->accel_S) * sizeof(uint4)) : 0u;
+        if (T.d_mblk) {
+            P.cdir = T.d_cdir;
+            P.cdir_bytes = (uint32_t)(chunk_dir_entries(c->accel_S) * sizeof(uint32_t));
+            P.mblk = T.d_mblk;
+            // (a direct world: exactly its lines — a position beyond the last slab must be out of range, it reads as zeros)
+            P.mblk_bytes = (uint32_t)(c->march_direct ? direct_cell_entries(c->accel_S) * sizeof(uint4) : (size_t)T.mblk_cap * 512u * sizeof(uint4));
+            P.march_direct = c->march_direct ? 1u : 0u;
+        }
     }
     // a march that walks the octree reads the node pool and chunk_roots: uploads then wait for the frames in flight
     if (!P.grid || variant == 1u || variant == 2u) c->walkers_in_flight = true;

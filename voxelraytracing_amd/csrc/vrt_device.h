@@ -33,10 +33,12 @@ struct FrameParams {
     const uint16_t *bricks;
     uint32_t grid_dim;       // cells per world axis = 8 * size_in_chunks
     uint32_t grid_bytes, brick_bytes;
-    // the march cells (vrt_accel.hip): 16 bytes per cell, indexed like the grid — the cell's entry, which of its 2^3 sub-blocks are
-    // depth-4 leaves and which of its 64 voxels stop a ray; null for worlds beyond them (S > 63)
-    const uint4 *mcells;
-    uint32_t mcells_bytes;
+    // the march cells (vrt_accel.hip): a chunk directory u32[S][S+1][S+1] -> 8-KiB blocks of 512 cells x 16 bytes (the cell's
+    // entry, which of its 2^3 sub-blocks are depth-4 leaves, which of its 64 voxels a ray passes); null when not kept
+    const uint32_t *cdir;
+    const uint4 *mblk;
+    uint32_t cdir_bytes, mblk_bytes;
+    uint32_t march_direct;   // 1: the block of directory position i is 2 + i (small worlds; no directory load in the march)
     Texel *out;              // one texel per pixel slot
     uint4 *hits;             // hit buffer {slot, origin.xyz bits}: 256 records per primary workgroup, compacted per workgroup
     uint32_t *blk_counts;    // records appended by primary workgroup b

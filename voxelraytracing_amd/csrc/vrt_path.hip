@@ -877,15 +877,13 @@ extern "C" void vrt_exp_pool_dbg(unsigned long long *out) {   // read (16384 x 8
 // cell's lo, or the split cell's size-2 mask) and whether the voxel stops the ray (64 bits; liquids are transparent to
 // a path segment, so they count as air — the tables are built with the material table's liquid set).  Which voxel it
 // stopped on is only asked after the march, at full width, from the brick (phase C).
-// Also new here: the wave hands its rays out sorted by direction octant (rays that march together then walk the same
-// way through the same neighbourhood: they share the lines of the cells they read), phase C takes the rays that hit and
-// the rays that missed in separate batches (a wave executes both sides of that branch otherwise: ~510 + ~130 vector
+// Also new here: phase C takes the rays that hit and the rays that missed in separate batches (a wave executes both sides of that branch otherwise: ~510 + ~130 vector
 // instructions per ray), and on the last bounce the rays that hit are not shaded at all (their bounce would be dropped).
 // Every ray executes the arithmetic the other kernels execute for it: bit-identical frames (tests).
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t kCellsPoolBytesPerWave = kPoolWords * 4u + kPoolEntries * 2u;   // the pool + a u16 order per entry
 
-template <bool SORT>
+template <bool DIRECT>
 #ifndef VRT_CELLS_NO_WAVES_ATTR
 __attribute__((amdgpu_waves_per_eu(8, 8)))
 #endif
@@ -912,35 +910,14 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(FrameParams P, u
     const float world_max = 0.0f + (float)P.world.size;
     const unsigned long long below = (1ull << lane) - 1ull;
 
-    // ---- A: the unit steps of every ray (nine divides, three square roots), full width; the order they are handed out in ----
-    {
-        uint32_t key[kPoolBatches];
+    // ---- A: the unit steps of every ray (nine divides, three square roots), full width ----
 #pragma unroll
-        for (uint32_t k = 0; k < kPoolBatches; k++) {
-            const uint32_t i = k * 64u + lane;
-            key[k] = 8u;   // (no ray)
-            if (i < n) {
-                const uint4 b = P.path_in[P.in_cap + base + i];
-                const V3 dir{__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z)};
-                const V3 unit = unit_steps(dir);
-                pool[0u * E + i] = unit.x; pool[1u * E + i] = unit.y; pool[2u * E + i] = unit.z;
-                key[k] = (dir.x >= 0.0f ? 1u : 0u) | (dir.y >= 0.0f ? 2u : 0u) | (dir.z >= 0.0f ? 4u : 0u);
-            }
-        }
-        if (SORT) {   // a stable counting sort of the wave's rays by direction octant (ballots: a few dozen scalar instructions)
-            uint32_t start = 0u;
-#pragma unroll
-            for (uint32_t o = 0; o < 8u; o++) {
-#pragma unroll
-                for (uint32_t k = 0; k < kPoolBatches; k++) {
-                    const unsigned long long m = __ballot(key[k] == o);
-                    if (key[k] == o) order[start + (uint32_t)__popcll(m & below)] = (uint16_t)(k * 64u + lane);
-                    start += (uint32_t)__popcll(m);
-                }
-            }
-        } else {
-#pragma unroll
-            for (uint32_t k = 0; k < kPoolBatches; k++) order[k * 64u + lane] = (uint16_t)(k * 64u + lane);
+    for (uint32_t k = 0; k < kPoolBatches; k++) {
+        const uint32_t i = k * 64u + lane;
+        if (i < n) {
+            const uint4 b = P.path_in[P.in_cap + base + i];
+            const V3 unit = unit_steps(V3{__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z)});
+            pool[0u * E + i] = unit.x; pool[1u * E + i] = unit.y; pool[2u * E + i] = unit.z;
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -949,16 +926,20 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(FrameParams P, u
     // ---- B: the marches, lanes refilled from the pool; a ray that has stopped keeps its end state in its registers until
     // the wave's next refill parks it.  Water is not tracked (no output of a path segment depends on it). ----
     {
-        const TableBuf mb = table_buffer(P.mcells, P.mcells_bytes);
+        const TableBuf mb = table_buffer(P.mblk, P.mblk_bytes), db = table_buffer(P.cdir, P.cdir_bytes);
         const TableBuf gb = table_buffer(P.grid, P.grid_bytes), bb = table_buffer(P.bricks, P.brick_bytes);
-        // the march cells: [4S][4S+1][4S+1] blocks of 2 x 2 x 2 cells, 128 bytes a block; both strides < 2^23 for S <= 63
-        const uint32_t row128 = (P.grid_dim / 2u + 1u) * 128u, slab128 = (P.grid_dim / 2u + 1u) * row128;
+        // the chunk directory: [S][S+1][S+1] with a zero border; a direct world: [4S][4S+1][4S+1] lines of 128 bytes
+        const uint32_t drow = (P.grid_dim / 8u + 1u) * 4u, dslab = (P.grid_dim / 8u + 1u) * drow;
+        const uint32_t row128 = (P.grid_dim / 2u + 1u) * 128u, slab128 = (P.grid_dim / 2u + 1u) * row128;   // < 2^23: S <= 16
         const uint32_t row_bytes = (P.grid_dim + 1u) * 4u, slab_bytes = (P.grid_dim + 1u) * row_bytes;
         const uint32_t wsize = P.world.size;
         V3 pos{0.f, 0.f, 0.f}, dir{0.f, 0.f, 0.f};
         float ux = 0.f, uy = 0.f, uz = 0.f, step = -1.f, adx = 0.f, ady = 0.f, adz = 0.f;
         uint32_t mxm = 0u, mym = 0u, mzm = 0u, ref = 0u, iter = 0u, idx = 0u;
         int vx = 0, vy = 0, vz = 0;
+        // the chunk the ray is in — its coordinates as one number — and where that chunk's block of march cells begins
+        constexpr uint32_t kNoChunk = 0x7FFFFFFFu;
+        uint32_t ckey = kNoChunk, cblock = 0u;
         bool marching = false, parked = true, not_finite = false;
         uint32_t next = 0u;   // wave-uniform: the pool's first ray not handed out yet
 
@@ -971,7 +952,7 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(FrameParams P, u
             parked = true;
         };
         auto take = [&](uint32_t at) __attribute__((always_inline)) {
-            idx = order[at];
+            idx = at;
             const uint32_t rec = base + idx;
             const uint4 a = P.path_in[rec], b = P.path_in[P.in_cap + rec];
             const V3 origin{__uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w)};
@@ -980,6 +961,7 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(FrameParams P, u
             ux = pool[0u * E + idx]; uy = pool[1u * E + idx]; uz = pool[2u * E + idx];
             mxm = dir.x >= 0.0f ? ~0u : 0u; mym = dir.y >= 0.0f ? ~0u : 0u; mzm = dir.z >= 0.0f ? ~0u : 0u;
             ref = 0u;
+            ckey = kNoChunk;
             marching = true;
             parked = false;
             pos = nudged(origin, dir);
@@ -1072,11 +1054,26 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(FrameParams P, u
             }
             for (;;) {
                 if (marching) {
-                    // one 16-byte load answers the step: c.x the cell's entry, c.y the size-2 mask of a split cell, c.z / c.w
-                    // the voxels a ray passes (zero — the border, beyond the buffer — stops it: outside the world)
-                    // (block: bits 3.. of the coordinates; the cell inside it: their bits 2)
+                    // the chunk's block of march cells: looked up in the chunk directory when the ray has entered another chunk
+                    // (coordinates -1 .. S: one voxel beyond the world at most; they make one number, base 128).  Outside the
+                    // world the directory's border — or a load past either end of it — says block 0, whose cells are all zeros
+                    // The cell inside its line of 2 x 2 x 2 (bits 2 of the coordinates), the line inside the chunk's block (bits 3, 4) —
+                    // or, in a direct world, among the lines of the whole world (bits 3 and up; the border lines stay zero)
                     const uint32_t sub = ((((uint32_t)vz >> 2) & 1u) << 2) | ((((uint32_t)vy >> 2) & 1u) << 1) | (((uint32_t)vx >> 2) & 1u);
-                    const uint32_t off = mad_i24(vz >> 3, slab128, mad_i24(vy >> 3, row128, ((uint32_t)(vx >> 3) << 7) + (sub << 4)));
+                    uint32_t off;
+                    if (DIRECT) {
+                        off = mad_i24(vz >> 3, slab128, mad_i24(vy >> 3, row128, ((uint32_t)(vx >> 3) << 7) + (sub << 4)));
+                    } else {
+                        const uint32_t key = (uint32_t)((((vz >> 5) << 7) + (vy >> 5)) << 7) + (uint32_t)(vx >> 5);
+                        if (key != ckey) {
+                            ckey = key;
+                            cblock = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(db, mad_i24(vz >> 5, dslab, mad_i24(vy >> 5, drow, (uint32_t)(vx >> 5) << 2)), 0, 0) << 13;
+                        }
+                        const uint32_t line = (((((uint32_t)vz >> 3) & 3u) << 2 | (((uint32_t)vy >> 3) & 3u)) << 2) | (((uint32_t)vx >> 3) & 3u);
+                        off = cblock + (((line << 3) | sub) << 4);
+                    }
+                    // one 16-byte load answers the step: c.x the cell's entry, c.y the size-2 mask of a split cell, c.z / c.w
+                    // the voxels a ray passes (zero stops it)
                     const uint4 c = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(mb, off, 0, 0));
                     iter += 1u;
                     // u = (x&3) | (y&3) << 2 | (z&3) << 4, with z's upper bits left on top: the shifts below use the low bits only
@@ -1438,14 +1435,14 @@ void launch_path_bounce_pool(const FrameParams &P, bool continuations, uint32_t 
     else hipLaunchKernelGGL(path_bounce_pool_kernel<false>, grid, block, sh, st, P, refill, P.cont_out ? eject : 0u);
 }
 
-// the pool kernel over the march cells (P.mcells): sort = hand the wave's rays out by direction octant
-void launch_path_bounce_cells(const FrameParams &P, uint32_t refill_at, bool sort, hipStream_t st) {
+// the pool kernel over the march cells (P.mblk)
+void launch_path_bounce_cells(const FrameParams &P, uint32_t refill_at, hipStream_t st) {
     if (P.tiles_local == 0) return;
     const uint32_t refill = refill_at >= 1u && refill_at <= 64u ? refill_at : kPoolRefillAt;
     const uint32_t parts = (P.in_seg_cap + 4u * kPoolEntries - 1u) / (4u * kPoolEntries);
     const dim3 grid(kHitSegments * parts), block(256);
     const size_t sh = 8u * 4u + 4u * kCellsPoolBytesPerWave;
-    if (sort) hipLaunchKernelGGL(path_bounce_cells_kernel<true>, grid, block, sh, st, P, refill);
+    if (P.march_direct) hipLaunchKernelGGL(path_bounce_cells_kernel<true>, grid, block, sh, st, P, refill);
     else hipLaunchKernelGGL(path_bounce_cells_kernel<false>, grid, block, sh, st, P, refill);
 }
 
