@@ -177,6 +177,7 @@ extern "C" {
     pub fn vrt_get_stats(ctx: *mut vrt_ctx, out: *mut vrt_stats) -> c_int;
     pub fn vrt_get_accel_info(ctx: *mut vrt_ctx, out: *mut vrt_accel_info) -> c_int;
     pub fn vrt_read_accel(ctx: *mut vrt_ctx, grid: *mut u32, bricks: *mut u16) -> c_int;
+    pub fn vrt_read_march_cells(ctx: *mut vrt_ctx, cells: *mut u32, direct: *mut u32) -> c_int;
     pub fn vrt_read_steps(ctx: *mut vrt_ctx, steps: *mut u32) -> c_int;
     pub fn vrt_set_stream(ctx: *mut vrt_ctx, hip_stream: *mut c_void) -> c_int;
     pub fn vrt_bind_output(ctx: *mut vrt_ctx, texels: *mut c_void) -> c_int;

@@ -299,6 +299,13 @@ int vrt_get_accel_info(vrt_ctx *ctx, vrt_accel_info *out);
  * leaf).  Either pointer may be NULL. */
 int vrt_read_accel(vrt_ctx *ctx, uint32_t *grid, uint16_t *bricks);
 
+/* The march cells the path trace's bounce launches read (one 16-byte entry per depth-3 cell: the cell grid's entry, the
+ * size-2 mask of a split cell — bit (u >> 1) & 31, u = (x&3) | (y&3) << 2 | (z&3) << 4 —, and 64 bits "a ray passes voxel
+ * u": air, or a liquid of the material table they were built with), gathered through their chunk directory and blocks
+ * into cells[(8S)^3][4], x-major over the whole world, for inspection (synchronises).  *direct = 1 when the world is small
+ * enough to be kept without a directory.  VRT_ERR_STATE when the tables are not up to date or this world keeps none. */
+int vrt_read_march_cells(vrt_ctx *ctx, uint32_t *cells, uint32_t *direct);
+
 /* Per-pixel march-loop iteration counts of the last frame (primary | shadow << 16); the frame must
  * have been rendered with opts.stats = 1.  Numeric twin of the reference's F2 step-count heat-map
  * (main.rs:368-370, ray_tracer.wgsl:311-314). */

@@ -108,6 +108,7 @@ VRT_SYMBOLS = {
     "vrt_get_stats": (C.c_int, [_P, C.POINTER(Stats)]),
     "vrt_get_accel_info": (C.c_int, [_P, C.POINTER(AccelInfo)]),
     "vrt_read_accel": (C.c_int, [_P, _P, _P]),
+    "vrt_read_march_cells": (C.c_int, [_P, _P, _P]),
     "vrt_read_steps": (C.c_int, [_P, _P]),
     "vrt_set_stream": (C.c_int, [_P, _P]),
     "vrt_bind_output": (C.c_int, [_P, _P]),

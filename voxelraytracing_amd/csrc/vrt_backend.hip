@@ -172,7 +172,8 @@ struct vrt_ctx {
     bool shared_readers_in_flight = false;   // a frame on another frame set is reading tabs[0] (cleared with the frames in flight)
     uint32_t *d_brick_total = nullptr;
     uint32_t *d_chunk_needs = nullptr;   // whole-world build scratch: which chunks need a block of march cells
-    bool march_direct = false;           // the blocks of the march cells are addressed by chunk position (kMarchDirectMaxS)
+    bool march_direct = false;           // the march cells of the whole world, no chunk directory (worlds up to march_direct_max_s)
+    uint32_t march_direct_max_s = 0;     // kMarchDirectMaxS, or VRT_MARCH_DIRECT_MAX_S (tests: the directory on a small world)
     uint32_t chunk_needs_cap = 0;
     uint32_t n_bricks = 0;        // bricks inside the chunks' regions after the last whole-world build
     uint32_t accel_S = 0;         // world size the tables were built for
@@ -752,7 +753,7 @@ static int ensure_accel_world(vrt_ctx *c) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     HIP_TRY(c, hipEventCreate(&e0));
     HIP_TRY(c, hipEventCreate(&e1));
-    const bool direct = S <= kMarchDirectMaxS;
+    const bool direct = S <= c->march_direct_max_s;
     c->march_direct = direct;
     auto body = [&]() -> int {
         HIP_TRY(c, hipEventRecord(e0, c->stream));
@@ -945,6 +946,11 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     if (const char *e = getenv("VRT_ACCEL_MAX_S")) {
         const long v = strtol(e, nullptr, 10);
         if (v >= 0 && v < (long)kAccelMaxS) c->accel_max_s = (uint32_t)v;
+    }
+    c->march_direct_max_s = kMarchDirectMaxS;
+    if (const char *e = getenv("VRT_MARCH_DIRECT_MAX_S")) {
+        const long v = strtol(e, nullptr, 10);
+        if (v >= 0 && v <= (long)kMarchDirectMaxS) c->march_direct_max_s = (uint32_t)v;
     }
     if (const char *e = getenv("VRT_PATH_PERSISTENT")) c->path_persistent = e[0] == '1';
     if (const char *e = getenv("VRT_TILE_ORDER")) c->tile_lpt = e[0] != '0';
@@ -1967,6 +1973,44 @@ int vrt_read_accel(vrt_ctx *c, uint32_t *grid, uint16_t *bricks) {
     if (bricks && used)
         HIP_TRY(c, hipMemcpyAsync(bricks, c->tabs[0].d_bricks, (size_t)used * 64u * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VRT_OK;
+}
+
+int vrt_read_march_cells(vrt_ctx *c, uint32_t *cells, uint32_t *direct) {
+    GRP_ROOT(c, vrt_read_march_cells(d, cells, direct));
+    if (!c || !cells) return fail(c, VRT_ERR_INVALID_ARG, "vrt_read_march_cells: null argument");
+    if (!c->accel_ok || c->accel_dirty || !c->tabs[0].d_mblk)
+        return fail(c, VRT_ERR_STATE, "vrt_read_march_cells: no march cells, or not up to date (render a frame first)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    {
+        const int rc = first_tables_up_to_date(c);   // (the last frame may have used another frame set's tables)
+        if (rc) return rc;
+    }
+    const auto &T = c->tabs[0];
+    const uint32_t S = c->accel_S;
+    const size_t G = (size_t)S * 8u;
+    if (direct) *direct = c->march_direct ? 1u : 0u;
+    std::vector<uint4> blocks(c->march_direct ? direct_cell_entries(S) : (size_t)T.mblk_cap * 512u);
+    std::vector<uint32_t> dir(chunk_dir_entries(S));
+    HIP_TRY(c, hipMemcpyAsync(blocks.data(), T.d_mblk, blocks.size() * sizeof(uint4), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(dir.data(), T.d_cdir, dir.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const size_t B1 = (size_t)S * 4u + 1u;
+    for (size_t z = 0; z < G; z++)
+        for (size_t y = 0; y < G; y++)
+            for (size_t x = 0; x < G; x++) {
+                const size_t sub = (x & 1u) | ((y & 1u) << 1) | ((z & 1u) << 2);
+                size_t at;
+                if (c->march_direct) {
+                    at = (((z >> 1) * B1 + (y >> 1)) * B1 + (x >> 1)) * 8u + sub;
+                } else {
+                    const uint32_t blk = dir[((z >> 3) * (S + 1u) + (y >> 3)) * (S + 1u) + (x >> 3)];
+                    if (blk >= T.mblk_cap) return fail(c, VRT_ERR_DEVICE, "vrt_read_march_cells: the directory names block %u of %u", blk, T.mblk_cap);
+                    const size_t line = ((((z >> 1) & 3u) << 2 | ((y >> 1) & 3u)) << 2) | ((x >> 1) & 3u);
+                    at = (size_t)blk * 512u + line * 8u + sub;
+                }
+                memcpy(cells + ((z * G + y) * G + x) * 4u, &blocks[at], sizeof(uint4));
+            }
     return VRT_OK;
 }
 

@@ -201,6 +201,14 @@ class Gpu:
         self._ck(self._lib.vrt_read_accel(self._h, grid.ctypes.data_as(C.c_void_p), bricks.ctypes.data_as(C.c_void_p)))
         return grid, bricks
 
+    def read_march_cells(self):
+        """(cells[G,G,G,4] indexed [z,y,x], direct) — see vrt_read_march_cells in include/vrt.h."""
+        g = self.accel_info().world_size_chunks * 8
+        cells = np.empty((g, g, g, 4), dtype=np.uint32)
+        direct = C.c_uint32()
+        self._ck(self._lib.vrt_read_march_cells(self._h, cells.ctypes.data_as(C.c_void_p), C.byref(direct)))
+        return cells, bool(direct.value)
+
     # --- device plumbing for torch / RCCL ---
     def set_stream(self, hip_stream: int):
         self._ck(self._lib.vrt_set_stream(self._h, C.c_void_p(hip_stream)))
