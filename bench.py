@@ -231,7 +231,7 @@ def main():
         frame_no[0] += 1
         gp.write_settings(sc.settings)
         gp.write_cam_data(g.cam_data_create(rot, eye, 70.0, (float(args.width), float(args.height))))
-        gp.write_chunk_roots(sc.world.chunk_roots())     # a fresh S^3 table every frame, as the reference does (world.rs:154-159)
+        gp.write_chunk_roots(sc.world.chunk_roots(), tag=sc.world.roots_generation())   # a fresh S^3 table every frame, as the reference does (world.rs:154-159)
         gp.write_world_data(world_data)
 
     def run_frames(gp, f, n, fixed=False):

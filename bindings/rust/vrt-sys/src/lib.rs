@@ -161,6 +161,7 @@ extern "C" {
     pub fn vrt_last_error(ctx: *const vrt_ctx) -> *const c_char;
     pub fn vrt_write_nodes(ctx: *mut vrt_ctx, pool: *const u16, start: u32, end: u32) -> c_int;
     pub fn vrt_write_chunk_roots(ctx: *mut vrt_ctx, offset: u32, roots: *const u32, n: u32) -> c_int;
+    pub fn vrt_write_chunk_roots_tagged(ctx: *mut vrt_ctx, offset: u32, roots: *const u32, n: u32, tag: u64) -> c_int;
     pub fn vrt_resize_world(ctx: *mut vrt_ctx, world_size_chunks: u32) -> c_int;
     pub fn vrt_write_materials(ctx: *mut vrt_ctx, first: u32, mats: *const vrt_material, n: u32) -> c_int;
     pub fn vrt_set_camera(ctx: *mut vrt_ctx, cam: *const vrt_cam_data) -> c_int;

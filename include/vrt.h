@@ -208,6 +208,13 @@ int vrt_write_nodes(vrt_ctx *ctx, const uint16_t *pool, uint32_t start, uint32_t
  * buffer's capacity like the reference. */
 int vrt_write_chunk_roots(vrt_ctx *ctx, uint32_t offset, const uint32_t *roots, uint32_t n);
 
+/* The same with the caller's word for "which table this is": the reference rewrites the table every frame (main.rs:446),
+ * nearly always unchanged, and at 32^3 chunks the backend's compare of 128 KB is half a frame's host time.  tag != 0 that
+ * equals the tag of the previous call (same offset and n) returns at once — the caller vouches that the contents are
+ * the same — any other value is an ordinary write that remembers the tag (a host world's generation counter, bumped by
+ * create_chunk / center_chunks / resize; include/vrt_host.h: vrth_world_chunk_roots_generation).  tag 0 = no tag. */
+int vrt_write_chunk_roots_tagged(vrt_ctx *ctx, uint32_t offset, const uint32_t *roots, uint32_t n, uint64_t tag);
+
 /* Buffers::resize_chunk_buffer(world_size) + recreate_bind_group — shader.rs:74-80, main.rs:441-445.
  * Contents are undefined afterwards (a fresh buffer in the reference). */
 int vrt_resize_world(vrt_ctx *ctx, uint32_t world_size_chunks);

@@ -53,6 +53,11 @@ uint32_t vrth_world_max_nodes(const vrth_world *w);
 
 /* ChunkGrid::chunk_roots — world.rs:154-159. Writes min(cap, S^3) entries, returns S^3. */
 uint32_t vrth_world_chunk_roots(const vrth_world *w, uint32_t *out, uint32_t cap);
+/* The table itself (S^3 entries; valid until the grid next changes) and a number that changes whenever its contents may
+ * have: the tag of vrt_write_chunk_roots_tagged, which lets the per-frame rewrite of an unchanged table (main.rs:446) cost
+ * nothing.  (The mirror keeps the table; the reference builds a fresh Vec per frame.) */
+const uint32_t *vrth_world_chunk_roots_ptr(const vrth_world *w);
+uint64_t vrth_world_chunk_roots_generation(const vrth_world *w);
 
 /* min_voxel, size_in_voxels, size_in_chunks, populated_count */
 void vrth_world_info(const vrth_world *w, int32_t min_voxel[3], uint32_t *size_in_voxels, uint32_t *size_in_chunks, uint32_t *populated);

@@ -39,6 +39,14 @@ for k in range(200):
     try: edits.append(sc.world.set_voxel(p, 5 if k%2 else 0) and p)
     except Exception: pass
 gpu.synchronize()
+# the per-frame seam's table rewrite alone (main.rs:446), table unchanged: a fresh copy + the backend's compare, and tagged
+seam=[]
+for tagged in (False, True):
+    t0=time.perf_counter()
+    for _ in range(300):
+        gpu.write_chunk_roots(sc.world.chunk_roots(), tag=sc.world.roots_generation() if tagged else 0)
+    seam.append((time.perf_counter()-t0)/300*1e6)
+print("unchanged-table rewrite, host us per frame: chunk_roots() + vrt_write_chunk_roots %.1f; + tagged with the world's generation %.1f" % tuple(seam))
 n_pipe=0; host=[0.0,0.0,0.0,0.0]
 t0=time.perf_counter()
 for k in range(200):   # an edit before every frame, nothing waits for the device
@@ -49,7 +57,7 @@ for k in range(200):   # an edit before every frame, nothing waits for the devic
     h1=time.perf_counter()
     gpu.write_nodes(sc.world.nodes_ptr(), start, start+n)
     h2=time.perf_counter()
-    gpu.write_chunk_roots(sc.world.chunk_roots())
+    gpu.write_chunk_roots(sc.world.chunk_roots(), tag=sc.world.roots_generation())
     h3=time.perf_counter()
     gpu.render(MODE_PRIMARY_SHADOW); n_pipe+=1
     h4=time.perf_counter()

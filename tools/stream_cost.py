@@ -22,7 +22,7 @@ def frames(n, per_frame):
         for _ in range(per_frame):
             a, b = ranges[k % len(ranges)]; k += 7
             gpu.write_nodes(sc.world.nodes_ptr(), a, b)
-        gpu.write_chunk_roots(sc.world.chunk_roots())
+        gpu.write_chunk_roots(sc.world.chunk_roots(), tag=sc.world.roots_generation())
         gpu.render(MODE_PRIMARY_SHADOW)
 
 import gc

@@ -92,6 +92,7 @@ VRT_SYMBOLS = {
     "vrt_last_error": (C.c_char_p, [_P]),
     "vrt_write_nodes": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32]),
     "vrt_write_chunk_roots": (C.c_int, [_P, C.c_uint32, _P, C.c_uint32]),
+    "vrt_write_chunk_roots_tagged": (C.c_int, [_P, C.c_uint32, _P, C.c_uint32, C.c_uint64]),
     "vrt_resize_world": (C.c_int, [_P, C.c_uint32]),
     "vrt_write_materials": (C.c_int, [_P, C.c_uint32, _P, C.c_uint32]),
     "vrt_set_camera": (C.c_int, [_P, C.POINTER(CamData)]),
@@ -187,6 +188,8 @@ VRTH_SYMBOLS = {
     "vrth_world_nodes": (_P, [_P]),
     "vrth_world_max_nodes": (C.c_uint32, [_P]),
     "vrth_world_chunk_roots": (C.c_uint32, [_P, _P, C.c_uint32]),
+    "vrth_world_chunk_roots_ptr": (C.c_void_p, [_P]),
+    "vrth_world_chunk_roots_generation": (C.c_uint64, [_P]),
     "vrth_world_info": (None, [_P, _I32P, _U32P, _U32P, _U32P]),
     "vrth_world_alloc_status": (None, [_P, _U32P, _U32P]),
     "vrth_world_chunk_state": (C.c_int, [_P, _I32P, _U32P, _U32P, _U32P, _P, C.c_uint32]),

@@ -71,7 +71,7 @@ int main(int argc, char **argv) {
         auto draw_frame = [&](const PixelShader &shader) {  // main.rs:426-453
             res.buffers.write_settings(gpu, settings);
             res.buffers.write_cam_data(gpu, CamData::create(player.rot, player.cam_pos(), player.fov, {(float)W, (float)H}));
-            res.buffers.chunk_roots.write(gpu, 0, world.chunk_roots());
+            res.buffers.chunk_roots.write(gpu, 0, world.chunk_roots(), world.roots_generation());
             res.buffers.write_world_data(gpu, WorldData::from(world));
             shader.encode_pass(gpu, {W / 8, H / 8});
         };

@@ -143,8 +143,9 @@ struct NodeBuffer {
 struct ChunkRootsBuffer {
     uint32_t size_;
     uint32_t size() const { return size_; }
-    void write(const Gpu &gpu, uint64_t offset, const std::vector<NodeAddr> &items) const {
-        gpu.check(vrt_write_chunk_roots(gpu.ctx(), (uint32_t)offset, items.data(), (uint32_t)items.size()));
+    // tag: ChunkGrid::roots_generation() — an unchanged table is then not even compared (vrt_write_chunk_roots_tagged)
+    void write(const Gpu &gpu, uint64_t offset, const std::vector<NodeAddr> &items, uint64_t tag = 0) const {
+        gpu.check(vrt_write_chunk_roots_tagged(gpu.ctx(), (uint32_t)offset, items.data(), (uint32_t)items.size(), tag));
     }
 };
 

@@ -74,10 +74,14 @@ const uint16_t *vrth_world_nodes(const vrth_world *w) { return reinterpret_cast<
 uint32_t vrth_world_max_nodes(const vrth_world *w) { return w->w.max_nodes(); }
 
 uint32_t vrth_world_chunk_roots(const vrth_world *w, uint32_t *out, uint32_t cap) {
-    const std::vector<NodeAddr> r = w->w.chunk_roots();
-    if (out) std::copy_n(r.begin(), std::min<size_t>(cap, r.size()), out);
+    if (!out) return (uint32_t)w->w.chunk_count();
+    const std::vector<NodeAddr> &r = w->w.chunk_roots();
+    std::copy_n(r.begin(), std::min<size_t>(cap, r.size()), out);
     return (uint32_t)r.size();
 }
+
+const uint32_t *vrth_world_chunk_roots_ptr(const vrth_world *w) { return w->w.chunk_roots().data(); }
+uint64_t vrth_world_chunk_roots_generation(const vrth_world *w) { return w->w.roots_generation(); }
 
 void vrth_world_info(const vrth_world *w, int32_t min_voxel[3], uint32_t *size_in_voxels, uint32_t *size_in_chunks, uint32_t *populated) {
     const VoxelPos m = w->w.min_voxel();

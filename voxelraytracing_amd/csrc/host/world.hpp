@@ -12,6 +12,7 @@
 #pragma once
 
 #include <array>
+#include <atomic>
 #include <cstdint>
 #include <cstring>
 #include <optional>
@@ -284,14 +285,21 @@ public:
                     nc[local_pos_to_idx({(uint32_t)dx, (uint32_t)dy, (uint32_t)dz}, size_)] = std::move(src);
                 }
         chunks_ = std::move(nc);
+        touch_roots();
     }
 
-    // chunk_roots, :154-159: root of every cell, 0 (the permanent air leaf) for a missing chunk
-    std::vector<NodeAddr> chunk_roots() const {
-        std::vector<NodeAddr> r(chunks_.size());
-        for (size_t i = 0; i < chunks_.size(); i++) r[i] = chunks_[i] ? chunks_[i]->range.start : 0u;
-        return r;
+    // chunk_roots, :154-159: root of every cell, 0 (the permanent air leaf) for a missing chunk.  The reference builds a
+    // fresh Vec every frame (main.rs:446: 27 000 entries at its 30^3 chunks); here the table is kept and rebuilt only after
+    // the grid changed, and roots_generation() says whether it did — the tag of vrt_write_chunk_roots_tagged.
+    const std::vector<NodeAddr> &chunk_roots() const {
+        if (roots_stale_) {
+            roots_.resize(chunks_.size());
+            for (size_t i = 0; i < chunks_.size(); i++) roots_[i] = chunks_[i] ? chunks_[i]->range.start : 0u;
+            roots_stale_ = false;
+        }
+        return roots_;
     }
+    uint64_t roots_generation() const { return roots_gen_; }
     size_t populated_count() const { size_t r = 0; for (auto &c : chunks_) r += c.has_value(); return r; }
     std::vector<ChunkPos> empty_chunks() const {  // :169-183
         std::vector<ChunkPos> out;
@@ -305,6 +313,7 @@ public:
         auto lp = local_pos_for(p);
         if (!lp) return false;
         chunks_[local_pos_to_idx(*lp, size_)] = std::move(c);
+        touch_roots();
         return true;
     }
     const Chunk *get_chunk(ChunkPos p) const {
@@ -317,9 +326,15 @@ public:
 
 protected:
     friend class ClientWorld;
+    // (values never repeat, whichever grid object hands them out: resize() replaces the grid by a new one)
+    static uint64_t next_generation() { static std::atomic<uint64_t> g{1}; return g.fetch_add(1) + 1; }
+    void touch_roots() { roots_stale_ = true; roots_gen_ = next_generation(); }
     ChunkPos min_;
     std::vector<std::optional<Chunk>> chunks_;
     uint32_t size_;
+    mutable std::vector<NodeAddr> roots_;
+    mutable bool roots_stale_ = true;
+    uint64_t roots_gen_ = next_generation();
 };
 
 // ChunkAlloc, client/src/world.rs:203-257: first-fit over spans of the flat pool; slot 0 is reserved.

@@ -398,7 +398,22 @@ __global__ void __launch_bounds__(256) upload_words_kernel(uint32_t *dst, const 
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
+// A batch of staged ranges — everything vrt_write_nodes / vrt_write_chunk_roots staged since the last frame — in ONE launch:
+// a workgroup per piece of at most kUploadPieceWords words (the host cuts the ranges up; the pieces ride in the kernarg).
+__global__ void __launch_bounds__(256) upload_batch_kernel(uint32_t *dst0, uint32_t *dst1, const uint32_t *ring, UploadBatch batch) {
+    const UploadPiece p = batch.piece[blockIdx.x];
+    uint32_t *dst = ((p.n_words >> 31) ? dst1 : dst0) + p.dst_word;
+    const uint32_t *src = ring + p.src_word;
+    const uint32_t n = p.n_words & 0x7FFFFFFFu;
+    for (uint32_t i = threadIdx.x; i < n; i += 256u) dst[i] = src[i];
+}
+
 }  // namespace
+
+void launch_upload_batch(void *dst0, void *dst1, const void *pinned_ring, const UploadBatch &batch, uint32_t n_pieces, hipStream_t st) {
+    if (!n_pieces) return;
+    hipLaunchKernelGGL(upload_batch_kernel, dim3(n_pieces), dim3(256), 0, st, (uint32_t *)dst0, (uint32_t *)dst1, (const uint32_t *)pinned_ring, batch);
+}
 
 void launch_upload_words(void *dst, const void *pinned_src, uint32_t n_words, hipStream_t st) {
     if (!n_words) return;

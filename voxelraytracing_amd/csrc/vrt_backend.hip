@@ -54,6 +54,7 @@ void launch_accel_bricks(const uint16_t *nodes, uint32_t n_nodes, const uint32_t
                          const uint32_t *chunk_bases, uint16_t *bricks, uint32_t brick_cap, uint32_t *dir, uint4 *blocks, uint32_t *block_tail,
                          uint32_t block_cap, const uint32_t liquid[8], hipStream_t st);
 void launch_upload_words(void *dst, const void *pinned_src, uint32_t n_words, hipStream_t st);
+void launch_upload_batch(void *dst0, void *dst1, const void *pinned_ring, const UploadBatch &batch, uint32_t n_pieces, hipStream_t st);
 void launch_accel_chunks(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S, uint32_t *grid,
                          uint32_t *chunk_bricks, uint32_t *chunk_bases, uint32_t *chunk_caps, uint32_t *tail, uint16_t *bricks,
                          uint32_t brick_cap, uint32_t *dir, uint4 *blocks, uint32_t *block_tail, uint32_t block_cap, const uint32_t liquid[8],
@@ -210,6 +211,8 @@ struct vrt_ctx {
     uint32_t frame_mode = ~0u;          // vrt_mode of the last frame rendered (a change of mode is a change of view)
     uint32_t last_slot = 0, last_tab = 0;   // the frame set and the table set of the last frame
     float accel_last_ms = 0.f;
+    uint64_t roots_tag = 0;         // vrt_write_chunk_roots_tagged: the caller's tag of the table as last written (0: none)
+    uint32_t roots_tag_offset = 0, roots_tag_n = 0;
     std::vector<uint32_t> h_roots;  // what chunk_roots holds, to recognise the reference's per-frame rewrite of the same table
     std::vector<std::pair<uint32_t, uint32_t>> roots_index;  // (root, chunk slot) sorted by root, roots != 0: which chunk owns a node
     bool roots_index_stale = true;
@@ -222,6 +225,14 @@ struct vrt_ctx {
     bool ring_ev_used[kRingSegs][2] = {};
     uint32_t ring_seg = 0;
     size_t ring_off = 0;
+    // node-pool / chunk_roots uploads staged since the last flush: copied into the ring at call time, launched together — one
+    // copy kernel for all of them — before the next thing that reads those buffers (a frame's table update, a whole-world
+    // build, a synchronise).  The reference drains every pending GiveChunkData per frame (main.rs:289-295): a launch per
+    // range made the frame loop host-bound beyond two uploads per frame (27 us each).
+    struct Staged { uint32_t buf, dst_word, n_words; size_t ring_at; };
+    std::vector<Staged> staged;
+    size_t staged_bytes = 0;
+    bool staged_seg[kRingSegs] = {};  // ring segments the staged ranges lie in (their events are recorded at the flush)
     hipEvent_t ev_frames = nullptr;   // scratch: "everything enqueued on that frame stream so far"
     hipEvent_t ev_upload = nullptr;   // the last upload / table rebuild on c->stream
     // Node-pool and chunk_roots uploads have a stream of their own: frame set 0 runs on c->stream, and an upload queued
@@ -380,10 +391,16 @@ static int alloc_output(vrt_ctx *c) {
     return VRT_OK;
 }
 
+static int flush_staged(vrt_ctx *c);
 static int alloc_roots(vrt_ctx *c, uint32_t world_size) {
     const uint64_t n = (uint64_t)world_size * world_size * world_size;
     if (world_size == 0 || n > (1ull << 28)) return fail(c, VRT_ERR_INVALID_ARG, "world_size_chunks %u out of range", world_size);
-    if (c->up_stream) HIP_TRY(c, hipStreamSynchronize(c->up_stream));   // uploads into the table that goes away
+    {   // uploads into the table that goes away: launched, then waited for
+        const int rc = flush_staged(c);
+        if (rc) return rc;
+    }
+    if (c->up_stream) HIP_TRY(c, hipStreamSynchronize(c->up_stream));
+    c->roots_tag = 0;
     (void)hipFree(c->d_roots);
     c->d_roots = nullptr;
     HIP_TRY(c, hipMalloc(&c->d_roots, n * sizeof(uint32_t)));
@@ -453,7 +470,12 @@ static int publish_upload(vrt_ctx *c) {
 }
 
 // `st` (a frame stream's slot, or kMaxInFlight for c->stream) waits for the node-pool / chunk_roots uploads so far.
+static int flush_staged(vrt_ctx *c);
 static int wait_for_pool_uploads(vrt_ctx *c, hipStream_t st, uint32_t slot) {
+    {
+        const int rc = flush_staged(c);   // (what vrt_write_nodes / vrt_write_chunk_roots staged since the last flush: one launch)
+        if (rc) return rc;
+    }
     if (!c->ev_pool_upload || c->seen_pool_gen[slot] == c->pool_gen) return VRT_OK;
     HIP_TRY(c, hipStreamWaitEvent(st, c->ev_pool_upload, 0));
     c->seen_pool_gen[slot] = c->pool_gen;
@@ -476,6 +498,96 @@ static int frame_waits_for_uploads(vrt_ctx *c, hipStream_t st, uint32_t slot) {
 // the copy runs on the upload stream behind the readers of those two buffers (the table updates; every frame only if one
 // that walks the octree is in flight); otherwise on c->stream behind the frames in flight.  Transfers larger than a ring
 // segment (the initial pool upload) take the synchronous route.
+// `bytes` of the pinned ring (64-byte aligned), valid until the segment comes round again (eight segments on)
+static int ring_place(vrt_ctx *c, size_t bytes, size_t *at) {
+    if (!c->h_ring) {
+        HIP_TRY(c, hipHostMalloc((void **)&c->h_ring, vrt_ctx::kRingSegBytes * vrt_ctx::kRingSegs, hipHostMallocMapped));
+        HIP_TRY(c, hipHostGetDevicePointer((void **)&c->d_ring, c->h_ring, 0));
+    }
+    const size_t need = (bytes + 63u) & ~(size_t)63u;
+    if (c->ring_off + need > vrt_ctx::kRingSegBytes) {
+        c->ring_seg = (c->ring_seg + 1u) % vrt_ctx::kRingSegs;
+        c->ring_off = 0;
+        // the segment's previous copies must have left it (seven segments ago: practically always long done)
+        for (int k = 0; k < 2; k++)
+            if (c->ring_ev_used[c->ring_seg][k]) HIP_TRY(c, hipEventSynchronize(c->ring_ev[c->ring_seg][k]));
+    }
+    *at = (size_t)c->ring_seg * vrt_ctx::kRingSegBytes + c->ring_off;
+    c->ring_off += need;
+    return VRT_OK;
+}
+
+// The node-pool / chunk_roots uploads staged so far, as one launch on the upload stream: behind the readers of those two
+// buffers (whole-world builds and the other uploads so far, every table set's last update — those that are not over yet: a
+// wait is a barrier packet on the stream, a query is a load; every frame only if one that walks the octree is in flight).
+static int order_after_frames(vrt_ctx *c, hipStream_t target);
+static int flush_staged(vrt_ctx *c) {
+    if (c->staged.empty()) return VRT_OK;
+    hipStream_t st = c->up_stream;
+    if (c->ev_upload && hipEventQuery(c->ev_upload) != hipSuccess) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_upload, 0));
+    for (auto &T : c->tabs)
+        if (T.update_pending) {
+            if (hipEventQuery(T.ev_updated) == hipSuccess) T.update_pending = false;
+            else HIP_TRY(c, hipStreamWaitEvent(st, T.ev_updated, 0));
+        }
+    (void)hipGetLastError();   // (hipErrorNotReady from the queries is not an error)
+    if (c->walkers_in_flight) {
+        const int rc = order_after_frames(c, st);
+        if (rc) return rc;
+    }
+    vrt::UploadBatch batch;
+    uint32_t n = 0;
+    auto launch = [&]() -> int {
+        vrt::launch_upload_batch(c->d_nodes, c->d_roots, c->d_ring, batch, n, st);
+        HIP_TRY(c, hipGetLastError());
+        n = 0;
+        return VRT_OK;
+    };
+    for (const auto &s : c->staged)
+        for (uint32_t done = 0; done < s.n_words; done += vrt::kUploadPieceWords) {
+            const uint32_t words = s.n_words - done < vrt::kUploadPieceWords ? s.n_words - done : vrt::kUploadPieceWords;
+            batch.piece[n++] = vrt::UploadPiece{s.dst_word + done, (uint32_t)(s.ring_at / 4u) + done, words | (s.buf ? 0x80000000u : 0u)};
+            if (n == vrt::kUploadBatchPieces) { const int rc = launch(); if (rc) return rc; }
+        }
+    if (n) { const int rc = launch(); if (rc) return rc; }
+    for (uint32_t k = 0; k < vrt_ctx::kRingSegs; k++)
+        if (c->staged_seg[k]) {
+            hipEvent_t &rev = c->ring_ev[k][1];
+            if (!rev) HIP_TRY(c, hipEventCreateWithFlags(&rev, hipEventDisableTiming));
+            HIP_TRY(c, hipEventRecord(rev, st));
+            c->ring_ev_used[k][1] = true;
+            c->staged_seg[k] = false;
+        }
+    c->staged.clear();
+    c->staged_bytes = 0;
+    HIP_TRY(c, hipEventRecord(c->ev_pool_upload, st));
+    c->pool_gen += 1;
+    return VRT_OK;
+}
+
+// Stage `bytes` for words [dst_word, ...) of the node pool (buf 0) or chunk_roots (buf 1): copied now, launched at the flush.
+static int stage_pool_upload(vrt_ctx *c, uint32_t buf, uint32_t dst_word, const void *src, size_t bytes) {
+    // a range that overlaps one staged earlier must land after it: the batch's pieces run side by side
+    for (const auto &s : c->staged)
+        if (s.buf == buf && dst_word < s.dst_word + s.n_words && s.dst_word < dst_word + (uint32_t)(bytes / 4u)) {
+            const int rc = flush_staged(c);
+            if (rc) return rc;
+            break;
+        }
+    if (c->staged_bytes + bytes > 4u * vrt_ctx::kRingSegBytes) {   // (half the ring: staged data is never overwritten by what follows)
+        const int rc = flush_staged(c);
+        if (rc) return rc;
+    }
+    size_t at = 0;
+    const int rc = ring_place(c, bytes, &at);
+    if (rc) return rc;
+    memcpy(c->h_ring + at, src, bytes);
+    c->staged.push_back({buf, dst_word, (uint32_t)(bytes / 4u), at});
+    c->staged_bytes += bytes;
+    c->staged_seg[at / vrt_ctx::kRingSegBytes] = true;
+    return VRT_OK;
+}
+
 static int stage_upload(vrt_ctx *c, void *dst, const void *src, size_t bytes, bool pool = false) {
     if (bytes == 0) return VRT_OK;
     hipStream_t st = c->stream;
@@ -483,6 +595,14 @@ static int stage_upload(vrt_ctx *c, void *dst, const void *src, size_t bytes, bo
         if (!c->up_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
         if (!c->ev_pool_upload) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_pool_upload, hipEventDisableTiming));
         st = c->up_stream;
+        const bool is_roots = dst >= (void *)c->d_roots && dst < (void *)(c->d_roots + c->n_roots);
+        if (bytes <= vrt_ctx::kRingSegBytes && !(bytes & 3u) && !((uintptr_t)dst & 3u))
+            return stage_pool_upload(c, is_roots ? 1u : 0u,
+                                     (uint32_t)(((uintptr_t)dst - (uintptr_t)(is_roots ? (void *)c->d_roots : (void *)c->d_nodes)) / 4u), src, bytes);
+        {   // (the whole pool at join time: the synchronous route below, behind what is staged)
+            const int rc = flush_staged(c);
+            if (rc) return rc;
+        }
         // whole-world builds and the other uploads so far, every set's last update — those that are not over yet (a wait is
         // a barrier packet on the stream, a query is a load)
         if (c->ev_upload && hipEventQuery(c->ev_upload) != hipSuccess) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_upload, 0));
@@ -511,27 +631,19 @@ static int stage_upload(vrt_ctx *c, void *dst, const void *src, size_t bytes, bo
         HIP_TRY(c, hipStreamSynchronize(st));
         return publish();
     }
-    if (!c->h_ring) {
-        HIP_TRY(c, hipHostMalloc((void **)&c->h_ring, vrt_ctx::kRingSegBytes * vrt_ctx::kRingSegs, hipHostMallocMapped));
-        HIP_TRY(c, hipHostGetDevicePointer((void **)&c->d_ring, c->h_ring, 0));
+    size_t at = 0;
+    {
+        const int rc = ring_place(c, bytes, &at);
+        if (rc) return rc;
     }
-    const size_t need = (bytes + 63u) & ~(size_t)63u;
-    if (c->ring_off + need > vrt_ctx::kRingSegBytes) {
-        c->ring_seg = (c->ring_seg + 1u) % vrt_ctx::kRingSegs;
-        c->ring_off = 0;
-        // the segment's previous copies must have left it (seven segments ago: practically always long done)
-        for (int k = 0; k < 2; k++)
-            if (c->ring_ev_used[c->ring_seg][k]) HIP_TRY(c, hipEventSynchronize(c->ring_ev[c->ring_seg][k]));
-    }
-    const size_t at = (size_t)c->ring_seg * vrt_ctx::kRingSegBytes + c->ring_off;
     memcpy(c->h_ring + at, src, bytes);
-    c->ring_off += need;
     vrt::launch_upload_words(dst, c->d_ring + at, (uint32_t)(bytes / 4u), st);
     HIP_TRY(c, hipGetLastError());
-    hipEvent_t &rev = c->ring_ev[c->ring_seg][pool ? 1 : 0];
+    const size_t seg = at / vrt_ctx::kRingSegBytes;
+    hipEvent_t &rev = c->ring_ev[seg][pool ? 1 : 0];
     if (!rev) HIP_TRY(c, hipEventCreateWithFlags(&rev, hipEventDisableTiming));
     HIP_TRY(c, hipEventRecord(rev, st));
-    c->ring_ev_used[c->ring_seg][pool ? 1 : 0] = true;
+    c->ring_ev_used[seg][pool ? 1 : 0] = true;
     return publish();
 }
 
@@ -1070,15 +1182,22 @@ int vrt_write_nodes(vrt_ctx *c, const uint16_t *pool, uint32_t start, uint32_t e
     return VRT_OK;
 }
 
-int vrt_write_chunk_roots(vrt_ctx *c, uint32_t offset, const uint32_t *roots, uint32_t n) {
-    GRP_EACH(c, vrt_write_chunk_roots(d, offset, roots, n));
+int vrt_write_chunk_roots(vrt_ctx *c, uint32_t offset, const uint32_t *roots, uint32_t n) { return vrt_write_chunk_roots_tagged(c, offset, roots, n, 0); }
+
+int vrt_write_chunk_roots_tagged(vrt_ctx *c, uint32_t offset, const uint32_t *roots, uint32_t n, uint64_t tag) {
+    GRP_EACH(c, vrt_write_chunk_roots_tagged(d, offset, roots, n, tag));
     if (!c || (!roots && n)) return fail(c, VRT_ERR_INVALID_ARG, "vrt_write_chunk_roots: null argument");
+    // the reference rewrites the whole table every frame (main.rs:446).  A caller that can say "nothing changed since the
+    // write I tagged like this" is believed: the 128 KB compare of a 32^3 table is half a frame's host time
+    if (tag != 0 && tag == c->roots_tag && offset == c->roots_tag_offset && n == c->roots_tag_n) return VRT_OK;
+    c->roots_tag = 0;
     if (offset > c->n_roots) return fail(c, VRT_ERR_OUT_OF_RANGE, "vrt_write_chunk_roots: offset %u > %u", offset, c->n_roots);
     // ArrayBuffer::write truncates to capacity (shader.rs:134-135)
     const uint32_t cut = n < c->n_roots - offset ? n : c->n_roots - offset;
     if (cut == 0) return VRT_OK;
-    // the reference rewrites the whole table every frame (main.rs:446); an identical rewrite changes nothing
-    if (memcmp(c->h_roots.data() + offset, roots, (size_t)cut * sizeof(uint32_t)) == 0) return VRT_OK;
+    auto remember = [&]() { c->roots_tag = tag; c->roots_tag_offset = offset; c->roots_tag_n = n; };
+    // ... an identical rewrite changes nothing
+    if (memcmp(c->h_roots.data() + offset, roots, (size_t)cut * sizeof(uint32_t)) == 0) { remember(); return VRT_OK; }
     HIP_TRY(c, hipSetDevice(c->device));
     const int rc = stage_upload(c, c->d_roots + offset, roots, (size_t)cut * sizeof(uint32_t), true);
     if (rc) return rc;
@@ -1088,6 +1207,7 @@ int vrt_write_chunk_roots(vrt_ctx *c, uint32_t offset, const uint32_t *roots, ui
         if (c->h_roots[offset + i] != roots[i]) mark_chunk_dirty(c, offset + i);
     memcpy(c->h_roots.data() + offset, roots, (size_t)cut * sizeof(uint32_t));
     c->roots_index_stale = true;
+    remember();
     return VRT_OK;
 }
 
@@ -1741,6 +1861,10 @@ int vrt_synchronize(vrt_ctx *c) {
     if (!c) return VRT_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     QUIESCE(c);
+    {
+        const int rc = flush_staged(c);
+        if (rc) return rc;
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->up_stream) HIP_TRY(c, hipStreamSynchronize(c->up_stream));
     c->walkers_in_flight = false;   // nothing is in flight any more

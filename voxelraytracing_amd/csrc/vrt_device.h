@@ -119,6 +119,12 @@ __host__ __device__ __forceinline__ uint32_t shard_tile(uint32_t t_local, uint32
     return run == 1u ? t_local * period + first : (t_local / run) * period + first + t_local % run;
 }
 
+// Pieces of staged uploads (vrt_accel.hip: upload_batch_kernel): words of the pinned ring -> words of destination 0 (the node
+// pool) or, with bit 31 of n_words set, destination 1 (chunk_roots)
+constexpr uint32_t kUploadPieceWords = 4096, kUploadBatchPieces = 128;
+struct UploadPiece { uint32_t dst_word, src_word, n_words; };
+struct UploadBatch { UploadPiece piece[kUploadBatchPieces]; };
+
 struct V3 { float x, y, z; };
 
 // WGSL min() with a NaN operand is implementation-defined; choice: a NaN operand is ignored, ties

@@ -107,9 +107,10 @@ class Gpu:
         ptr = pool if isinstance(pool, int) else pool.ctypes.data
         self._ck(self._lib.vrt_write_nodes(self._h, C.c_void_p(ptr), start, end))
 
-    def write_chunk_roots(self, roots: np.ndarray, offset: int = 0):
+    def write_chunk_roots(self, roots: np.ndarray, offset: int = 0, tag: int = 0):
+        """ArrayBuffer::write (shader.rs:133-142).  tag: vrt_write_chunk_roots_tagged — e.g. ClientWorld.roots_generation()."""
         roots = np.ascontiguousarray(roots, dtype=np.uint32)
-        self._ck(self._lib.vrt_write_chunk_roots(self._h, offset, roots.ctypes.data_as(C.c_void_p), roots.size))
+        self._ck(self._lib.vrt_write_chunk_roots_tagged(self._h, offset, roots.ctypes.data, roots.size, tag))
 
     def resize_chunk_buffer(self, world_size: int):
         self._ck(self._lib.vrt_resize_world(self._h, world_size))

@@ -147,10 +147,22 @@ class ClientWorld:
         return self._lib.vrth_world_max_nodes(self._h)
 
     def chunk_roots(self) -> np.ndarray:
+        """ChunkGrid::chunk_roots (world.rs:154-159): a fresh array, as the reference's fresh Vec."""
         n = self._lib.vrth_world_chunk_roots(self._h, None, 0)
-        out = np.zeros(n, dtype=np.uint32)
+        out = np.empty(n, dtype=np.uint32)
         self._lib.vrth_world_chunk_roots(self._h, out.ctypes.data_as(C.c_void_p), n)
         return out
+
+    def chunk_roots_view(self) -> np.ndarray:
+        """The mirror's own table, zero-copy and read-only; valid until the grid next changes."""
+        n = self._lib.vrth_world_chunk_roots(self._h, None, 0)
+        a = np.frombuffer((C.c_uint32 * n).from_address(self._lib.vrth_world_chunk_roots_ptr(self._h)), dtype=np.uint32)
+        a.flags.writeable = False
+        return a
+
+    def roots_generation(self) -> int:
+        """Changes whenever chunk_roots() may have: the tag of Gpu.write_chunk_roots(..., tag=)."""
+        return self._lib.vrth_world_chunk_roots_generation(self._h)
 
     def _info(self):
         mn = (C.c_int32 * 3)()
