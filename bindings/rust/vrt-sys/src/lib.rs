@@ -91,6 +91,8 @@ pub const VRT_FLAG_TILE_MAJOR: u32 = 1;
 pub const VRT_FLAG_ROW_MAJOR: u32 = 2;
 pub const VRT_FLAG_COMPACT: u32 = 4;
 pub const VRT_FLAG_TEXEL_MESSAGES: u32 = 8;
+pub const VRT_FLAG_STAGED_MESSAGES: u32 = 16;
+pub const VRT_FLAG_POISON_MESSAGES: u32 = 32;
 
 pub const VRT_MODE_PRIMARY: u32 = 0;
 pub const VRT_MODE_PRIMARY_SHADOW: u32 = 1;

@@ -109,7 +109,8 @@ typedef struct {
      * row-major frame, the others as 8-byte records stored over xGMI directly into device_ids[0]'s memory
      * (hipDeviceEnablePeerAccess; no collective library, no second process) — and device_ids[0] shades those records into the
      * frame.  The frame, read-backs, vrt_present and vrt_device_output are device_ids[0]'s.  shard_rank / shard_count must be
-     * 0 / 0-1; of the flags only VRT_FLAG_TEXEL_MESSAGES applies.  n_devices 0 or 1: `device` alone, as before. */
+     * 0 / 0-1; of the flags VRT_FLAG_TEXEL_MESSAGES, VRT_FLAG_STAGED_MESSAGES and VRT_FLAG_POISON_MESSAGES apply.  n_devices
+     * 0 or 1: `device` alone, as before. */
     uint32_t n_devices;
     int32_t device_ids[VRT_MAX_DEVICES];
 } vrt_config;
@@ -129,6 +130,14 @@ typedef struct {
  * records: twice the bytes over every link, but every kind of frame — also the path trace and the non-default marches,
  * whose pixels the root cannot re-shade from an id word. */
 #define VRT_FLAG_TEXEL_MESSAGES 8u
+/* A multi-device context whose other devices render their messages into a buffer of their own and copy it to device_ids[0]
+ * afterwards (hipMemcpyPeerAsync on the sender's stream) instead of storing into device_ids[0]'s memory directly.  Taken
+ * by itself for every device whose peer access to device_ids[0] is refused (hipDeviceEnablePeerAccess); the flag forces
+ * it for all of them (tests, and hosts on which peer stores are slower than a copy engine). */
+#define VRT_FLAG_STAGED_MESSAGES 16u
+/* Testing: device_ids[0] overwrites a message slot with 0xFF bytes as soon as it has assembled the slot's frame, so a frame
+ * assembled from a slot that its senders have not written again yet — a missing wait, a stale read — is visibly wrong. */
+#define VRT_FLAG_POISON_MESSAGES 32u
 
 typedef enum {
     VRT_MODE_PRIMARY = 0,        /* the reference's live shader (ray_tracer.wgsl) */

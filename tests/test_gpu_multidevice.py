@@ -169,3 +169,60 @@ def test_bench_starts_its_own_ranks_and_prints_one_line(extra):
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == int(extra[1]) and d["value"] > 0 and d["steps"] == 12 and d["scaling"] == "strong"
+
+
+@pytest.mark.parametrize("texels", [False, True])
+@pytest.mark.parametrize("n", [2, 3])
+def test_staged_messages_when_peer_stores_are_refused(c2_small, n, texels):
+    """VRT_FLAG_STAGED_MESSAGES forces what a refused hipDeviceEnablePeerAccess falls back to: a device renders its message
+    into a buffer of its own and copies it to device 0 (hipMemcpyPeerAsync on its own stream) before signalling `done`.
+    With VRT_FLAG_POISON_MESSAGES on top — device 0 fills a slot with 0xFF once it has assembled it — a frame that read a
+    slot before its senders had written it again could not equal the single-device frame."""
+    w, h = c2_small.size
+    cams = [g.cam_data_create((20.0 + 5 * k, 40.0 + 29 * k, 0.0), (c2_small.eye[0] - k, c2_small.eye[1] + 0.5 * k, c2_small.eye[2] + k), 70.0,
+                              (float(w), float(h))) for k in range(6)]
+    want, _ = reference_frames(c2_small, cams, MODE_PRIMARY_SHADOW)
+    grp = gpu_for_scene(c2_small, devices=[0] * n, staged_messages=True, poison_messages=True, texel_messages=texels)
+    for upto in (1, 2, 3, 6):
+        for cam in cams[:upto]:
+            grp.write_cam_data(cam)
+            grp.render(MODE_PRIMARY_SHADOW)
+        rgb, ids, _ = grp.read_output()
+        assert np.array_equal(ids, want[upto - 1][1]) and np.array_equal(rgb, want[upto - 1][0]), f"{n} devices, after {upto} frames"
+    grp.set_frames_in_flight(1)
+    for cam in cams[:3]:
+        grp.write_cam_data(cam)
+        grp.render(MODE_PRIMARY_SHADOW)
+    rgb, ids, _ = grp.read_output()
+    assert np.array_equal(ids, want[2][1]) and np.array_equal(rgb, want[2][0])
+    if texels:   # the path trace travels as texels
+        sc = scenes.c4((320, 184), bounces=3)
+        one = gpu_for_scene(sc)
+        one.render(MODE_PATH, spp=2, seed=11)
+        r1, i1, _ = one.read_output()
+        one.close()
+        pg = gpu_for_scene(sc, devices=[0] * n, staged_messages=True, poison_messages=True, texel_messages=True)
+        for _ in range(3):
+            pg.render(MODE_PATH, spp=2, seed=11)
+        r2, i2, _ = pg.read_output()
+        assert np.array_equal(i2, i1) and np.array_equal(r2, r1)
+        pg.close()
+    grp.close()
+
+
+@pytest.mark.parametrize("n", [2, 8])
+def test_poisoned_message_slots_never_reach_a_frame(c2_small, n):
+    """Peer stores (the default), two frames in flight, a different camera every frame: device 0 poisons every slot it has
+    consumed; every frame read back equals the single-device frame of its camera."""
+    w, h = c2_small.size
+    cams = [g.cam_data_create((15.0 + 3 * k, 11.0 * k, 0.0), (c2_small.eye[0] + 2 * k, c2_small.eye[1], c2_small.eye[2] - k), 70.0,
+                              (float(w), float(h))) for k in range(8)]
+    want, _ = reference_frames(c2_small, cams, MODE_PRIMARY_SHADOW)
+    grp = gpu_for_scene(c2_small, devices=[0] * n, poison_messages=True)
+    for k, cam in enumerate(cams):
+        grp.write_cam_data(cam)
+        grp.render(MODE_PRIMARY_SHADOW)
+        if k % 3 == 2 or k == len(cams) - 1:
+            rgb, ids, _ = grp.read_output()
+            assert np.array_equal(ids, want[k][1]) and np.array_equal(rgb, want[k][0]), f"frame {k}"
+    grp.close()

@@ -2305,6 +2305,11 @@ struct vrt_group {
     std::vector<vrt_ctx *> dev;      // dev[0] = the root
     std::vector<std::unique_ptr<GrpWorker>> workers;   // [r - 1] issues for dev[r]; empty: the calling thread issues for all (VRT_GROUP_THREADS=0)
     bool texels = false;             // VRT_FLAG_TEXEL_MESSAGES
+    bool poison = false;             // VRT_FLAG_POISON_MESSAGES
+    // [r] device r cannot store into device 0's memory (peer access refused), or VRT_FLAG_STAGED_MESSAGES: it renders into
+    // stage[r][slot], a buffer of its own, and copies the message over afterwards (hipMemcpyPeerAsync, its own stream)
+    std::vector<uint8_t> staged;
+    std::vector<std::array<void *, 2>> stage;
     static constexpr uint32_t kSlots = 2;
     void *recv[kSlots] = {nullptr, nullptr};               // on device 0: [n_devices][tiles_padded * 64] records or texels
     size_t rank_stride = 0;                                // bytes between two devices' messages
@@ -2337,6 +2342,16 @@ static int grp_alloc_messages(vrt_ctx *c) {
         HIP_TRY(c, hipMalloc(&p, g->rank_stride * g->dev.size()));
         HIP_TRY(c, hipMemset(p, 0, g->rank_stride * g->dev.size()));
     }
+    for (size_t r = 1; r < g->dev.size(); r++) {
+        if (!g->staged[r]) continue;
+        HIP_TRY(c, hipSetDevice(g->dev[r]->device));
+        for (auto &p : g->stage[r]) {
+            (void)hipFree(p); p = nullptr;
+            HIP_TRY(c, hipMalloc(&p, g->rank_stride));
+            HIP_TRY(c, hipMemset(p, 0, g->rank_stride));
+        }
+    }
+    HIP_TRY(c, hipSetDevice(root->device));
     g->slot = 0;
     g->consumed_used[0] = g->consumed_used[1] = false;
     return VRT_OK;
@@ -2347,13 +2362,16 @@ static int grp_create(const vrt_config *cfg, vrt_ctx **out) {
     if (n > VRT_MAX_DEVICES) return fail(nullptr, VRT_ERR_INVALID_ARG, "n_devices %u > VRT_MAX_DEVICES", n);
     if (cfg->shard_rank != 0u || cfg->shard_count > 1u)
         return fail(nullptr, VRT_ERR_INVALID_ARG, "a multi-device context shards by itself: shard_rank / shard_count must be 0");
-    if (cfg->flags & ~VRT_FLAG_TEXEL_MESSAGES)
-        return fail(nullptr, VRT_ERR_INVALID_ARG, "a multi-device context takes VRT_FLAG_TEXEL_MESSAGES only");
+    if (cfg->flags & ~(VRT_FLAG_TEXEL_MESSAGES | VRT_FLAG_STAGED_MESSAGES | VRT_FLAG_POISON_MESSAGES))
+        return fail(nullptr, VRT_ERR_INVALID_ARG, "a multi-device context takes VRT_FLAG_TEXEL_MESSAGES, _STAGED_MESSAGES and _POISON_MESSAGES only");
     vrt_ctx *c = new (std::nothrow) vrt_ctx();
     vrt_group *g = new (std::nothrow) vrt_group();
     if (!c || !g) { delete c; delete g; return fail(nullptr, VRT_ERR_OOM, "host allocation failed"); }
     c->grp = g;
     g->texels = (cfg->flags & VRT_FLAG_TEXEL_MESSAGES) != 0u;
+    g->poison = (cfg->flags & VRT_FLAG_POISON_MESSAGES) != 0u;
+    g->staged.assign(n, (cfg->flags & VRT_FLAG_STAGED_MESSAGES) ? 1 : 0);
+    g->stage.assign(n, {nullptr, nullptr});
     // the root's own tiles never cross a link, so it takes more of the frame; measured defaults
     const uint32_t w0 = cfg->shard_root_weight ? cfg->shard_root_weight : (n == 2u ? 4u : n <= 4u ? 3u : 2u);
     DeviceRestore restore;
@@ -2365,7 +2383,7 @@ static int grp_create(const vrt_config *cfg, vrt_ctx **out) {
             sub.shard_rank = r;
             sub.shard_count = n;
             sub.shard_root_weight = w0;
-            sub.flags = r == 0u ? VRT_FLAG_ROW_MAJOR : (g->texels ? 0u : VRT_FLAG_COMPACT);
+            sub.flags = r == 0u ? VRT_FLAG_ROW_MAJOR : (g->texels ? 0u : VRT_FLAG_COMPACT);   // (the group's own flags stay here)
             vrt_ctx *d = nullptr;
             const int rc = vrt_create(&sub, &d);
             if (rc) { c->err = g_create_err; return rc; }
@@ -2375,11 +2393,10 @@ static int grp_create(const vrt_config *cfg, vrt_ctx **out) {
         g->done.resize(n);
         for (uint32_t r = 1; r < n; r++) {
             HIP_TRY(c, hipSetDevice(g->dev[r]->device));
-            if (g->dev[r]->device != g->dev[0]->device) {
+            if (g->dev[r]->device != g->dev[0]->device && !g->staged[r]) {
+                // no peer access: the message is rendered at home and copied over (a copy between two devices needs none)
                 const hipError_t e = hipDeviceEnablePeerAccess(g->dev[0]->device, 0);
-                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
-                    return fail(c, VRT_ERR_DEVICE, "device %d cannot store into device %d's memory (hipDeviceEnablePeerAccess: %s)",
-                                g->dev[r]->device, g->dev[0]->device, hipGetErrorString(e));
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) g->staged[r] = 1;
                 (void)hipGetLastError();
             }
             for (auto &ev : g->done[r]) HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -2419,6 +2436,10 @@ static void grp_destroy(vrt_ctx *c) {
     for (vrt_ctx *d : g->dev) {
         (void)hipSetDevice(d->device);
         (void)vrt_synchronize(d);
+    }
+    for (size_t r = 1; r < g->dev.size() && r < g->stage.size(); r++) {
+        (void)hipSetDevice(g->dev[r]->device);
+        for (auto p : g->stage[r]) (void)hipFree(p);
     }
     if (!g->dev.empty()) (void)hipSetDevice(g->dev[0]->device);
     for (auto p : g->recv) (void)hipFree(p);
@@ -2472,15 +2493,20 @@ static int grp_render(vrt_ctx *c, const vrt_render_opts *opts) {
     g->slot = (g->slot + 1u) % (g->in_flight > 1u ? vrt_group::kSlots : 1u);
     o.flags |= VRT_RENDER_OWN_STREAMS;   // every device's frame runs on that context's in-flight streams, into the buffer bound here
     // what is issued to device r >= 1 for this frame — by its worker thread, or here
-    auto issue = [g, k, o](uint32_t r) -> int {
+    auto issue = [g, k, o, root](uint32_t r) -> int {
         vrt_ctx *d = g->dev[r];
         if (hipSetDevice(d->device) != hipSuccess) return fail(d, VRT_ERR_DEVICE, "hipSetDevice(%d) failed", d->device);
-        int rc = vrt_bind_output(d, (uint8_t *)g->recv[k] + (size_t)r * g->rank_stride);
+        void *slot = (uint8_t *)g->recv[k] + (size_t)r * g->rank_stride;
+        int rc = vrt_bind_output(d, g->staged[r] ? g->stage[r][k] : slot);
         // the slot's previous message must have been consumed by device 0 before this frame overwrites it
         d->wait_before_frame = g->consumed_used[k] ? g->consumed[k] : nullptr;
         if (!rc) rc = vrt_render(d, &o);
         d->wait_before_frame = nullptr;
         if (rc) return rc;
+        // (a staged message: behind the frame on its stream — which waited for the slot to be consumed — over to device 0)
+        if (d->tiles_local && g->staged[r] &&
+            hipMemcpyPeerAsync(slot, root->device, g->stage[r][k], d->device, g->rank_stride, d->last_stream) != hipSuccess)
+            return fail(d, VRT_ERR_DEVICE, "hipMemcpyPeerAsync from device %d to device %d failed", d->device, root->device);
         if (d->tiles_local && hipEventRecord(g->done[r][k], d->last_stream) != hipSuccess)
             return fail(d, VRT_ERR_DEVICE, "hipEventRecord failed on device %d", d->device);
         return VRT_OK;
@@ -2521,6 +2547,8 @@ static int grp_render(vrt_ctx *c, const vrt_render_opts *opts) {
         vrt::launch_assemble_shade(P, g->recv[k], frame, root->shard_w0, root->shard_period, g->rank_stride / 8u, X);
     }
     HIP_TRY(c, hipGetLastError());
+    // (testing: a consumed slot holds nothing a later frame could pass for its own)
+    if (g->poison) HIP_TRY(c, hipMemsetAsync((uint8_t *)g->recv[k] + g->rank_stride, 0xFF, g->rank_stride * (n - 1u), X));
     HIP_TRY(c, hipEventRecord(g->consumed[k], X));
     g->consumed_used[k] = true;
     return VRT_OK;

@@ -72,11 +72,13 @@ class Gpu:
 
     def __init__(self, max_nodes: int, world_size: int, result_size, device: int = -1,
                  shard_rank: int = 0, shard_count: int = 1, tile_major: bool = False, root_weight: int = 1,
-                 row_major: bool = False, compact: bool = False, devices=None, texel_messages: bool = False):
+                 row_major: bool = False, compact: bool = False, devices=None, texel_messages: bool = False,
+                 staged_messages: bool = False, poison_messages: bool = False):
         """devices: a list of HIP device ordinals makes this ONE context over several devices (vrt_config.device_ids)."""
         self._lib = _ffi.vrt()
         cfg = _ffi.Config(max_nodes, world_size, result_size[0], result_size[1], device, shard_rank, shard_count,
-                          (1 if tile_major else 0) | (2 if row_major else 0) | (4 if compact else 0) | (8 if texel_messages else 0),
+                          (1 if tile_major else 0) | (2 if row_major else 0) | (4 if compact else 0) | (8 if texel_messages else 0) |
+                          (16 if staged_messages else 0) | (32 if poison_messages else 0),
                           root_weight)
         if devices:
             cfg.n_devices = len(devices)
