@@ -24,6 +24,8 @@ import os
 import socket
 import subprocess
 import sys
+import tempfile
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -62,6 +64,12 @@ def parse_args():
                     help="N > 1: one process, N devices behind one vrt context (vrt_config.device_ids; peer stores over xGMI)")
     ap.add_argument("--force-gather", action="store_true",
                     help="development only: with --gpus 1, still run the pipelined RCCL gather + assemble path (one-rank group)")
+    ap.add_argument("--init-timeout", type=float, default=120.0,
+                    help="N > 1: seconds the process group's rendezvous and the first collective may take before the rank gives "
+                         "up (exit status 3, the failing rank named on stderr)")
+    ap.add_argument("--launch-retries", type=int, default=1,
+                    help="N > 1 started by this script: how often ranks that never got through the rendezvous / first collective "
+                         "(exit status 3) are started again — always as fresh processes")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development only: run the N > 1 code path with every rank / device on cuda:0 (multi-process: a gloo "
                          "gather staged through host memory, RCCL refuses two ranks on one device); never for reported numbers")
@@ -72,31 +80,50 @@ def parse_args():
 # N > 1 without a launcher: start one process per GPU ourselves — before anything touches torch or the GPU
 # ---------------------------------------------------------------------------------------------------------------------
 def self_launch(args) -> int:
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # rank 0's stdout carries the JSON line; the other ranks' stdout joins stderr
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode]
-    for p in procs[1:]:
-        try:
-            rcs.append(p.wait(timeout=600))
-        except subprocess.TimeoutExpired:
-            p.kill()
-            rcs.append(-9)
-    sys.stdout.write(out.decode())
-    sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
-        print(f"bench.py: ranks failed: {bad}", file=sys.stderr)
-        return 1
-    return 0
+    """One process per GPU, started here (the parent never touches torch or the GPU).  A rank that dies takes the others
+    with it and is named; ranks that never got through the rendezvous or the first collective (exit status 3) are started
+    again, as fresh processes on a fresh port, --launch-retries times."""
+    for attempt in range(args.launch_retries + 1):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        procs = []
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            # rank 0's stdout carries the JSON line (into a file: nothing here blocks on a pipe); the other ranks' stdout joins stderr
+            out_f = tempfile.TemporaryFile() if r == 0 else None
+            procs.append((subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                           stdout=out_f if r == 0 else sys.stderr), out_f))
+        rcs = [None] * args.gpus
+        deadline = time.time() + 3300.0
+        while any(rc is None for rc in rcs):
+            for r, (pr, _) in enumerate(procs):
+                if rcs[r] is None:
+                    rcs[r] = pr.poll()
+            failed = [r for r, rc in enumerate(rcs) if rc not in (None, 0)]
+            if failed or time.time() > deadline:
+                time.sleep(2.0)   # (the others may be on their way out with a status of their own)
+                for r, (pr, _) in enumerate(procs):
+                    if rcs[r] is None:
+                        rcs[r] = pr.poll()
+                    if rcs[r] is None:   # a rank that lost its peers would wait for them for ever: ended here, by its own PID
+                        pr.kill()
+                        rcs[r] = pr.wait()
+                        rcs[r] = "killed (a peer failed)" if failed else "killed (overall time limit)"
+                break
+            time.sleep(0.05)
+        bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+        if not bad:
+            procs[0][1].seek(0)
+            sys.stdout.write(procs[0][1].read().decode())
+            sys.stdout.flush()
+            return 0
+        print(f"bench.py: attempt {attempt + 1}: ranks failed (rank, exit status): {bad}", file=sys.stderr)
+        if not any(rc == 3 for _, rc in bad) or attempt == args.launch_retries:
+            return 1
+        print("bench.py: the rendezvous / first collective did not complete: starting fresh processes", file=sys.stderr)
+    return 1
 
 
 def algorithmic_bytes(st):
@@ -147,10 +174,26 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29577")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        if args.rehearse_on_one_gpu:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # the rendezvous and the first collective under a clock: a rank that cannot reach its peers says so and leaves with
+        # status 3 instead of waiting for ever (the launcher — this script's, or torch's — then ends the others)
+        import datetime
+
+        def give_up(what):
+            print(f"bench.py: rank {rank} of {world}: {what} did not complete within {args.init_timeout:.0f} s "
+                  f"(MASTER {os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}, device {local_rank})", file=sys.stderr, flush=True)
+            os._exit(3)
+        watchdog = threading.Timer(args.init_timeout, give_up, ("the process group's rendezvous",))
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            if args.rehearse_on_one_gpu:
+                dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=args.init_timeout))
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=args.init_timeout))
+        except Exception as e:
+            print(f"bench.py: rank {rank} of {world}: init_process_group failed: {e}", file=sys.stderr, flush=True)
+            os._exit(3)
+        watchdog.cancel()
 
     def all_reduce(t, op=None):
         """all_reduce of a small cuda tensor (through the host when rehearsing over gloo)."""
@@ -163,6 +206,25 @@ def main():
             return c.to(t.device)
         dist.all_reduce(t, **kw)
         return t
+
+    # ---- who is here: every rank adds a one (RCCL's first collective, under the same clock), and what the devices can reach ----
+    ranks_seen = 1
+    if sharded:
+        watchdog = threading.Timer(args.init_timeout, give_up, ("the first collective (an all-reduce of ones)",))
+        watchdog.daemon = True
+        watchdog.start()
+        ranks_seen = int(all_reduce(torch.ones(1, dtype=torch.int64, device="cuda"))[0])
+        torch.cuda.synchronize()
+        watchdog.cancel()
+        if ranks_seen != world:
+            print(f"bench.py: rank {rank}: the all-reduce of ones gave {ranks_seen}, WORLD_SIZE is {world}", file=sys.stderr, flush=True)
+            os._exit(3)
+    n_vis = torch.cuda.device_count()
+    peer = [[bool(torch.cuda.can_device_access_peer(i, j)) for j in range(n_vis)] for i in range(n_vis)] if n_vis > 1 else []
+    links = {"devices_visible": n_vis,   # hipDeviceCanAccessPeer over every ordered pair of the devices this process sees
+             "peer_access_pairs": sum(peer[i][j] for i in range(n_vis) for j in range(n_vis) if i != j) if n_vis > 1 else 0,
+             "of_pairs": n_vis * (n_vis - 1),
+             "to_device_0": [i for i in range(1, n_vis) if peer[i][0]] if n_vis > 1 else []}
 
     # ---- scene (deterministic, built by every rank) and upload: off the clock ----
     MODE = {"shadow": MODE_PRIMARY_SHADOW, "primary": MODE_PRIMARY, "path": MODE_PATH}[args.mode]
@@ -377,6 +439,16 @@ def main():
             extras["value_1_in_flight"] = rays_fixed * args.steps / d1 / 1e6
             extras["ms_per_step_1_in_flight"] = d1 / args.steps * 1e3
             extras["avg_launch_ms_1_in_flight"] = k1.sum_ms_primary / max(k1.frames, 1)
+            if not fixed:
+                # ... and what a host that renders one moving-camera frame at a time gets: the orbit, the whole seam per frame,
+                # screen order (a tile order made for another view is worse than none)
+                frame_no[0] = 0
+                run_frames(gpu, fg, 50, False)
+                frame_no[0] = 0
+                d1o = timed(gpu, fg, args.steps, False)
+                gpu.stats()
+                extras["value_1_in_flight_orbit"] = rays_total / d1o / 1e6
+                extras["ms_per_step_1_in_flight_orbit"] = d1o / args.steps * 1e3
             gpu.set_frames_in_flight(args.frames_in_flight)
         if MODE == MODE_PRIMARY_SHADOW and args.variant == 0:
             # the clock: right behind the timed load, frames of the probe build (the same kernel + two stamps per wave)
@@ -468,21 +540,43 @@ def main():
     if pmc and world == 1 and not sharded and not devices:
         n_valu, n_salu = pmc["valu_wave_instructions"], pmc.get("salu_wave_instructions")
         period_fixed = (extras.get("ms_per_step_fixed_camera", period_s * 1e3) if not fixed else period_s * 1e3) * 1e-3
-        roof["achieved"] = n_valu / period_fixed / 1e9          # the counters are of the fixed-camera frame: its period
+        # the headline leg's own period (ms_per_step); the counters are of the standing camera's frame, whose period gives the
+        # second figure (an orbit frame launches 0.5 % more rays on average: config.rays_per_frame_*)
+        roof["achieved"] = n_valu / period_s / 1e9
         roof["frac"] = roof["achieved"] / roof["peak"]
+        roof["achieved_fixed_camera"] = n_valu / period_fixed / 1e9
+        roof["frac_fixed_camera"] = roof["achieved_fixed_camera"] / roof["peak"]
         roof["frac_note"] = ("instructions per second over the peak at 2 cycles per wave-instruction: removing instructions lowers it; "
                              "class_weighted.frac (each class at its issue time) says how full the VALU pipes are")
         roof["traffic"] = pmc["hbm_bytes"]
         roof["valu_wave_instructions_per_launch"] = n_valu
         roof["salu_wave_instructions_per_launch"] = n_salu
-        roof["period_used_ms"] = period_fixed * 1e3
+        roof["period_used_ms"] = period_s * 1e3
+        roof["period_fixed_camera_ms"] = period_fixed * 1e3
         # the same with every class at its measured issue cost (tools/valu_rates.hip): SIMD cycles the launch's
         # instructions need / SIMD cycles the frame period offers
         nominal, cls = pmc.get("valu_issue_cycles_by_class_nominal"), pmc.get("issue_cycles_by_class")
         if nominal and cls:
-            avail = N_SIMD * peak_clock * 1e9 * period_fixed
+            avail = N_SIMD * peak_clock * 1e9 * period_s
             valu_measured = sum(v for k, v in cls.items() if k.startswith("valu"))
+            # the model against the launch's own class counters (tools/pmc.sh group 3): f32 add / mul / fma are full rate (2
+            # cycles), conversions half rate (4), transcendentals 8; the integer class and what no counter names (compares,
+            # selects, min / max, moves) hold full- and half-rate instructions alike: priced at 2 and at 4 they bracket the truth
+            cnt = pmc.get("counters", {})
+            check = None
+            if all(k in cnt for k in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32",
+                                      "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_CVT")):
+                full = cnt["SQ_INSTS_VALU_ADD_F32"] + cnt["SQ_INSTS_VALU_MUL_F32"] + cnt["SQ_INSTS_VALU_FMA_F32"]
+                known = 2.0 * full + 4.0 * cnt["SQ_INSTS_VALU_CVT"] + 8.0 * cnt["SQ_INSTS_VALU_TRANS_F32"]
+                rest = n_valu - full - cnt["SQ_INSTS_VALU_CVT"] - cnt["SQ_INSTS_VALU_TRANS_F32"]
+                lo_c, hi_c, model_c = known + 2.0 * rest, known + 4.0 * rest, sum(nominal.values())
+                check = {"cycles_lower": lo_c, "cycles_upper": hi_c, "cycles_model": model_c,
+                         "model_inside_bracket": bool(lo_c <= model_c <= hi_c),
+                         "residual_vs_bracket_midpoint": model_c / (0.5 * (lo_c + hi_c)) - 1.0,
+                         "instructions_no_counter_classifies": rest,
+                         "note": "whole-launch class counters; the model prices the whole launch at the march loop's class mix"}
             roof["class_weighted"] = {
+                "counter_check": check,
                 # VALU wave-instructions x their class's architectural issue time on a SIMD-32 (2 / 4 / 8 cycles for full rate /
                 # half rate + packed / transcendental), classes in the proportions of the march loop's fast path (profiles/*isa_mix*)
                 "valu_issue_cycles_per_launch_nominal": nominal, "simd_cycles_available": avail,
@@ -514,6 +608,8 @@ def main():
         "value": rays_total / dt / 1e6,
         "unit": "Mrays/s",
         "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+        "ranks_seen": ranks_seen,   # an all-reduce of ones over the process group (1: no group)
+        "links": links,
         "ms_per_step": period_s * 1e3,
         "host_submit_ms_per_step": host_submit_ms,   # time until the loop's last call returned / steps: the host's share of a step
         "higher_is_better": True,
