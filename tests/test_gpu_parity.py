@@ -13,6 +13,14 @@ from util import assert_frame_parity, gpu_for_scene
 pytestmark = pytest.mark.gpu
 
 
+def needs_experiments():
+    """The structures that were measured and not chosen compile into tools/ab/libvrt_exp.so only (make -C
+    voxelraytracing_amd/csrc experiments; run the tests with VRT_LIB=tools/ab/libvrt_exp.so): their tests skip on the default build."""
+    from voxelraytracing_amd import _ffi
+    if not hasattr(_ffi.vrt(), "vrt_experiments_build"):
+        pytest.skip("the experiments build only (VRT_LIB=tools/ab/libvrt_exp.so)")
+
+
 @pytest.fixture(scope="module")
 def c1():
     return scenes.c1_flat()
@@ -298,6 +306,7 @@ def test_batched_gather_frames_stay_apart(c2_small, orc):
 def test_persistent_grid_variant_gives_the_same_frames(c1, c2_small):
     """Variant 4 — the default kernel's work pulled from per-XCD tile queues by a grid that just fills the chip — against
     variant 0, whole and sharded (tile-major), several frames in a row (the queue heads are reset per frame)."""
+    needs_experiments()
     for sc in (c1, c2_small):
         gpu = gpu_for_scene(sc)
         gpu.render(MODE_PRIMARY_SHADOW)
@@ -806,6 +815,7 @@ def test_compact_shards_without_the_derived_tables_stay_inside_their_records(c2_
 def test_persistent_path_kernel_gives_the_same_frames(orc, monkeypatch):
     """VRT_PATH_PERSISTENT=1: the path trace as one launch of persistent waves whose lanes are refilled in batches (built
     and measured, not the default) — bit for bit the frame of the launch-per-bounce kernels, whole and sharded."""
+    needs_experiments()
     sc = scenes.c4((320, 184), bounces=4)
     ref = gpu_for_scene(sc)
     ref.render(MODE_PATH, spp=3, seed=11)
@@ -829,12 +839,15 @@ def test_persistent_path_kernel_gives_the_same_frames(orc, monkeypatch):
     assert np.array_equal(acc_ids, ids) and np.array_equal(acc_rgb, rgb)
 
 
-@pytest.mark.parametrize("env", [{"VRT_PATH_POOL": "0"}, {"VRT_PATH_POOL_CHAIN": "1"}, {"VRT_PATH_POOL_CHAIN": "1", "VRT_PATH_POOL_EJECT": "40"}])
+@pytest.mark.parametrize("env", [{"VRT_PATH_POOL": "0"}, {"VRT_PATH_CELLS": "0"}, {"VRT_PATH_CELLS": "0", "VRT_PATH_POOL_CHAIN": "1"},
+                                 {"VRT_PATH_CELLS": "0", "VRT_PATH_POOL_CHAIN": "1", "VRT_PATH_POOL_EJECT": "40"}])
 def test_every_form_of_the_bounce_launch_gives_the_same_frames(orc, monkeypatch, env):
-    """The default bounce launch is the pool kernel (a wave refills its lanes from its own LDS pool of rays).  VRT_PATH_POOL=0:
-    lane = path for the whole kernel, the round-1 structure.  VRT_PATH_POOL_CHAIN=1 (built and measured, not the default):
-    rays still marching when a wave's pool runs dry go to a chain of launches on a side stream.  All bit for bit the same
-    frame, with several samples (the chains join per sample), sharded, and with two frames in flight."""
+    """The default bounce launch is the pool kernel over the march cells (a wave refills its lanes from its own LDS pool of
+    rays; one 16-byte load per step).  VRT_PATH_POOL=0: lane = path for the whole kernel, the round-1 structure.
+    VRT_PATH_CELLS=0: the round-2 pool kernel over cell grid + bricks; with VRT_PATH_POOL_CHAIN=1 (built and measured, not the
+    default) its rays still marching when a wave's pool runs dry go to a chain of launches on a side stream.  All bit for
+    bit the same frame, with several samples (the chains join per sample), sharded, and with two frames in flight."""
+    needs_experiments()
     sc = scenes.c4((320, 184), bounces=4)
     ref = gpu_for_scene(sc)
     ref.render(MODE_PATH, spp=3, seed=11)

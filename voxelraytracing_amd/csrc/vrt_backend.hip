@@ -31,15 +31,17 @@ bool variant_supported(uint32_t variant);
 void launch_primary(const FrameParams &P, uint32_t variant, bool stats, bool shadow, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
 void launch_shadow(const FrameParams &P, uint32_t variant, bool stats, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
 void launch_primary_shadow_fused(const FrameParams &P, uint32_t march, bool stats, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
+#ifdef VRT_EXPERIMENTS   // measured and rejected structures, kept for tools/ab (make experiments): DESIGN.md section 5
 void launch_primary_shadow_persistent(const FrameParams &P, uint32_t *heads, uint32_t n_cus, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
+void launch_path_bounce_pool(const FrameParams &P, bool continuations, uint32_t refill_at, uint32_t eject_at, hipStream_t st);
+void launch_path_persistent(const FrameParams &P, uint32_t *heads, uint32_t n_cus, hipStream_t st);
+#endif
 void launch_path_primary(const FrameParams &P, bool stats, bool literal, hipStream_t st);
 void launch_path_bounce(const FrameParams &P, bool stats, bool literal, hipStream_t st);
-void launch_path_bounce_pool(const FrameParams &P, bool continuations, uint32_t refill_at, uint32_t eject_at, hipStream_t st);
 void launch_path_bounce_cells(const FrameParams &P, uint32_t refill_at, hipStream_t st);
 void launch_path_finish(Texel *out, uint32_t n, uint32_t spp, hipStream_t st);
 void launch_tile_order(const uint32_t *cost, uint32_t n, uint32_t shift, uint32_t *scratch, uint32_t *order, hipStream_t st);
 void launch_path_chain_finish(Texel *out, const Texel *acc, uint32_t n, uint32_t chain, bool first, bool last, uint32_t spp, hipStream_t st);
-void launch_path_persistent(const FrameParams &P, uint32_t *heads, uint32_t n_cus, hipStream_t st);
 void launch_quantize(const Texel *out, uint8_t *rgba8, uint32_t w, uint32_t h, hipStream_t st);
 void launch_assemble(const Texel *gathered, Texel *dst, uint32_t width, uint32_t tiles_x, uint32_t tiles_total,
                      uint32_t root_weight, uint32_t period, bool skip_root, uint64_t rank_stride, hipStream_t st);
@@ -1064,14 +1066,16 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         const long v = strtol(e, nullptr, 10);
         if (v >= 0 && v <= (long)kMarchDirectMaxS) c->march_direct_max_s = (uint32_t)v;
     }
-    if (const char *e = getenv("VRT_PATH_PERSISTENT")) c->path_persistent = e[0] == '1';
     if (const char *e = getenv("VRT_TILE_ORDER")) c->tile_lpt = e[0] != '0';
+#ifdef VRT_EXPERIMENTS
+    if (const char *e = getenv("VRT_PATH_PERSISTENT")) c->path_persistent = e[0] == '1';
     if (const char *e = getenv("VRT_PATH_POOL")) c->path_pool = e[0] != '0';
     if (const char *e = getenv("VRT_PATH_POOL_CHAIN")) c->path_chain = e[0] == '1';
     if (const char *e = getenv("VRT_PATH_CELLS")) c->path_cells = e[0] != '0';
-    if (const char *e = getenv("VRT_PATH_SAMPLES_PER_CHAIN")) { const int v = atoi(e); if (v >= 1 && v <= 16) c->path_samples = (uint32_t)v; }
     if (const char *e = getenv("VRT_PATH_POOL_REFILL")) c->path_refill = (uint32_t)atoi(e);
     if (const char *e = getenv("VRT_PATH_POOL_EJECT")) c->path_eject = (uint32_t)atoi(e);
+#endif
+    if (const char *e = getenv("VRT_PATH_SAMPLES_PER_CHAIN")) { const int v = atoi(e); if (v >= 1 && v <= 16) c->path_samples = (uint32_t)v; }
     if (const char *e = getenv("VRT_TIMING_EVERY")) { const long v = strtol(e, nullptr, 10); if (v >= 1 && v <= 1000000) c->timing_every = (uint32_t)v; }
     memset(c->h_mats, 0, sizeof c->h_mats);
     memset(&c->cam, 0, sizeof c->cam);
@@ -1486,6 +1490,7 @@ static int next_events(vrt_ctx *c, std::array<hipEvent_t, 4> **ev, uint8_t **kin
 static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f, const vrt_render_opts &o, bool kstats, bool literal,
                              std::array<hipEvent_t, 4> &ev, uint8_t &ev_kind) {
     const uint32_t spp = o.spp ? o.spp : 1u, bounces = c->settings.max_ray_bounces;
+#ifdef VRT_EXPERIMENTS
     if (bounces > 0 && !kstats && !literal && P.grid && c->path_persistent) {
         // VRT_PATH_PERSISTENT=1 (built and measured, not the default: 10.8 against 13.0 Grays/s on C4):
         // persistent waves whose lanes own pixels and are refilled in batches (vrt_path.hip); one launch per frame
@@ -1509,6 +1514,7 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
         c->last_spp = spp;
         return VRT_OK;
     }
+#endif
     // Several samples per launch chain (plain frames, spp > 1): every launch of the chain carries `samples` times the rays —
     // 2.7 rays per lane are not enough to cover a bounce launch's tail — and a frame of 16 spp is 4 x 4
     // launches instead of 16 x 4.  Each sample accumulates into its own plane; the chain's finishing pass adds the planes
@@ -1554,7 +1560,11 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
     // the record sets' cursors (atomics).  The chains join at the end of every sample.
     const bool pool = !kstats && !literal && P.grid && bounces > 1 && c->path_pool;
     const bool cells = pool && P.mblk && c->path_cells;
+#ifdef VRT_EXPERIMENTS
     const bool chain = pool && !cells && bounces - 1u <= kContSets && c->path_chain;
+#else
+    const bool chain = false;   // (the straggler chain on a side stream: the experiments build)
+#endif
     uint32_t *cont_seg[kContSets];
     for (uint32_t i = 0; i < kContSets; i++) cont_seg[i] = P.seg_counts + (3 + i) * kSegWords;
     hipStream_t side = nullptr;
@@ -1572,6 +1582,7 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
         side = c->side_stream[f.slot];
     }
     uint4 *cont = c->path_cont[f.slot];
+    (void)cont;
     const bool timed = ev[0] != nullptr;
     if (timed) HIP_TRY(c, hipEventRecord(ev[0], f.st));
     if (bounces == 0) HIP_TRY(c, hipMemsetAsync(f.out, 0, (size_t)c->slots * sizeof(vrt::Texel), f.st));
@@ -1600,6 +1611,9 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
             } else if (cells) {
                 vrt::launch_path_bounce_cells(P, c->path_refill, f.st);
             } else {
+#ifndef VRT_EXPERIMENTS
+                vrt::launch_path_bounce(P, kstats, literal, f.st);   // (a world without march cells: lane = path)
+#else
                 if (chain) {
                     P.cont_out = cont + (size_t)(b - 1u) * 4 * cap;
                     P.cont_counts = cont_seg[b - 1u];
@@ -1620,6 +1634,7 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
                     Q.cont_counts = P.last_bounce ? nullptr : cont_seg[b];
                     vrt::launch_path_bounce_pool(Q, true, c->path_refill, 0u, side);
                 }
+#endif
             }
             HIP_TRY(c, hipGetLastError());
             if (first) { if (timed) HIP_TRY(c, hipEventRecord(ev[1], f.st)); first = false; }
@@ -1652,6 +1667,7 @@ static int launch_march_frame(vrt_ctx *c, const vrt::FrameParams &P, const Frame
                               std::array<hipEvent_t, 4> &ev, uint8_t &ev_kind) {
     if (!c->tiles_local) return VRT_OK;  // an empty shard
     const uint32_t march = variant == 3u ? 0u : variant;  // variant 3 = the grid march in two launches
+#ifdef VRT_EXPERIMENTS
     if (variant == 4u) {
         if (!c->d_heads) {
             HIP_TRY(c, hipMalloc(&c->d_heads, 8 * 64));
@@ -1666,6 +1682,7 @@ static int launch_march_frame(vrt_ctx *c, const vrt::FrameParams &P, const Frame
         if (ev[0]) ev_kind = kEvOneKernel;
         return VRT_OK;
     }
+#endif
     // primary + shadow in one launch: the default march, and — on a context whose pixel slots are 8-byte records — the
     // octree walk it falls back to when the world is too large for the derived tables (the two-launch kernels store and
     // re-read 16-byte texels, which such a buffer has no room for)
@@ -2233,6 +2250,10 @@ int vrt_assemble_compact(vrt_ctx *c, const void *gathered, uint64_t rank_stride_
     HIP_TRY(c, hipGetLastError());
     return VRT_OK;
 }
+
+#ifdef VRT_EXPERIMENTS
+int vrt_experiments_build(void) { return 1; }   // (not in include/vrt.h: only `make experiments` exports it)
+#endif
 
 }  // extern "C"
 

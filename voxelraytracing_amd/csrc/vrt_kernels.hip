@@ -266,6 +266,7 @@ __global__ void __launch_bounds__(64 * WAVES) primary_shadow_wave_kernel(FramePa
 }
 
 // ------------------------------------------------------------------------------------------------
+#ifdef VRT_EXPERIMENTS
 // The same work as a persistent grid (variant 4; north_star's "persistent-threads kernel", kept for the measurement):
 // exactly as many workgroups as the chip holds (8 per CU), every wave pulls tiles from the queue of the XCD it runs on
 // until that is empty.  Eight queue heads, one per XCD on its own 64-byte line: a single head saturates at ~88 returning
@@ -303,6 +304,7 @@ __global__ void __launch_bounds__(256) primary_shadow_persistent_kernel(FramePar
         }
     }
 }
+#endif  // VRT_EXPERIMENTS
 
 // ------------------------------------------------------------------------------------------------
 // Longest tiles first.  The dispatcher hands out workgroups in index order, and a launch ends when its slowest late
@@ -554,17 +556,24 @@ static void launch_shadow_t(const FrameParams &P, bool stats, hipStream_t st, hi
 // 1: literal octree walk; 2: ancestor-cache octree walk; 3: grid march, shadow rays as a second launch from a hit buffer
 // in HBM (the wavefront form the path trace is built from); 4: variant 0's work as a persistent grid pulling tiles from
 // per-XCD queues (primary + shadow frames only)
+#ifdef VRT_EXPERIMENTS
 bool variant_supported(uint32_t variant) { return variant <= 4u; }
+#else
+bool variant_supported(uint32_t variant) { return variant <= 3u; }   // (4, the persistent grid: the experiments build)
+#endif
 
 // Variant 4: `heads` = 8 queue heads 64 bytes apart, zeroed by the caller on the same stream.
+#ifdef VRT_EXPERIMENTS
 void launch_primary_shadow_persistent(const FrameParams &P, uint32_t *heads, uint32_t n_cus, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
     hipExtLaunchKernelGGL((primary_shadow_persistent_kernel<0, false>), dim3(n_cus * 8u), dim3(256), 24u * 4u, st, e0, e1, 0, P, heads,
                           (P.tiles_local + 7u) / 8u + 1u);
 }
+#endif
 
 // One launch for primary + shadow; blk_counts gets one launched-ray count per tile.  march 0 = the grid march (variant 0);
 // march 2 = the ancestor-cache octree walk, for contexts whose pixels are 8-byte records (VRT_FLAG_COMPACT: the
 // two-launch kernels store and re-read whole texels) when the world is too large for the derived tables.
+
 template <int MARCH, bool LDS_ROOTS>
 static void launch_fused_t(const FrameParams &P, bool stats, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
     constexpr int WAVES = 4;

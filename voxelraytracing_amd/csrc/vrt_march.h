@@ -544,9 +544,6 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
     float total_len = 0.0f;
     uint32_t iter = 0u;      // wave-uniform trip count (loop control)
     uint32_t looked_up = 0u; // STATS: node lookups of this lane (:221) — one less than its trips if it left through the border
-#ifdef VRT_EXP_VALU
-    uint32_t exp_acc = 0u;
-#endif
 
     // ---- the step to the leaf's exit face (:243-283), for a leaf of size lo + 1 ----
     auto take_step = [&](uint32_t lo) __attribute__((always_inline)) {
@@ -641,10 +638,6 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
             R.visits += (uint32_t)__clz((int)(lo + 1u)) - 25u;  // depth + 1 node words on the reference's walk
         }
         if (stop) break;
-#ifdef VRT_EXP_VALU   // tools/ab experiments only: marginal cost of VRT_EXP_VALU extra simple VALU instructions per step
-#pragma unroll
-        for (int k_ = 0; k_ < VRT_EXP_VALU; k_++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(exp_acc) : "v"(lo));
-#endif
         take_step(lo);
         if (iter >= kMaxSteps) break;  // every lane still here has looked up exactly `iter` nodes
     }
@@ -657,9 +650,6 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
     if (min3_nan_ignoring(pos.x, pos.y, pos.z) < 0.0f ||
         max(max((uint32_t)trunc2i(pos.x), (uint32_t)trunc2i(pos.y)), (uint32_t)trunc2i(pos.z)) >= wsize)
         return R;
-#ifdef VRT_EXP_VALU
-    if (exp_acc == 0x12345u) voxel ^= 1u;
-#endif
     const bool stepped = step != -1.0f;
 
     R.hit = true;

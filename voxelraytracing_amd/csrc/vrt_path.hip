@@ -268,6 +268,27 @@ __global__ void __launch_bounds__(256) path_bounce_kernel(FrameParams P) {
     }
 }
 
+// A wave's pool of rays (the bounce launches below): K batches of 64 paths, 4 words each in the wave's own LDS — unit[3]
+// (phase A -> the hand-out), then pos[3] + the packed end state (the march -> phase C): 4 KiB per wave
+#ifndef VRT_POOL_K
+#define VRT_POOL_K 4
+#endif
+constexpr uint32_t kPoolBatches = VRT_POOL_K;            // K
+constexpr uint32_t kPoolEntries = kPoolBatches * 64u;
+constexpr uint32_t kPoolWords = 4u * kPoolEntries;
+constexpr uint32_t kPoolRefillAt = 16u;                  // idle lanes (of 64) that send the wave back to the pool
+
+// the nudge off a voxel face at the start of a march (ray_tracer.wgsl:204-207)
+__device__ __forceinline__ V3 nudged(V3 pos, V3 dir) {
+    if (pos.x - floorf(pos.x) < 0.001f || pos.y - floorf(pos.y) < 0.001f || pos.z - floorf(pos.z) < 0.001f) {
+        pos.x += 0.001f * dir.x;
+        pos.y += 0.001f * dir.y;
+        pos.z += 0.001f * dir.z;
+    }
+    return pos;
+}
+
+#ifdef VRT_EXPERIMENTS
 // ------------------------------------------------------------------------------------------------
 // The path trace as ONE launch (VRT_PATH_PERSISTENT=1; built and measured, not the default): persistent waves, lanes
 // refilled in batches.
@@ -432,31 +453,15 @@ __device__ __forceinline__ MarchResult segment_end(const FrameParams &P, const S
 // Every ray executes the instructions the other kernels execute for it: bit-identical frames (tests).  The pool is
 // wave-local: no barriers between the phases, a wave that has nothing left leaves.
 // ------------------------------------------------------------------------------------------------
-#ifndef VRT_POOL_K
-#define VRT_POOL_K 4
-#endif
-constexpr uint32_t kPoolBatches = VRT_POOL_K;            // K
-constexpr uint32_t kPoolEntries = kPoolBatches * 64u;
-constexpr uint32_t kPoolWords = 4u * kPoolEntries;       // per wave, field-major: unit[3] (A -> B), then pos[3] + the packed end state (B -> C): 4 KiB
 #ifndef VRT_POOL_RAYS
 #define VRT_POOL_RAYS 1
 #endif
 // rays a lane marches at once.  2 and 3 were measured (their loads in flight together, their arithmetic interleaved): 117 and
 // more registers instead of 60, half the waves per SIMD, 12.4 and 10.4 Grays/s on C4 against 14.5 — profiles/r02_path_pool_sweeps.txt
 constexpr uint32_t kPoolRays = VRT_POOL_RAYS;
-constexpr uint32_t kPoolRefillAt = 16u * kPoolRays;       // idle ray slots (of 64 x kPoolRays) that send the wave back to the pool
 constexpr uint32_t kPoolEjectAt = 16;
 constexpr uint32_t kPoolEjected = 0xFFFFFFFFu;   // a pool entry's packed end state: the ray went on to the continuation launch
 
-// segment_begin's nudge off a voxel face (ray_tracer.wgsl:204-207)
-__device__ __forceinline__ V3 nudged(V3 pos, V3 dir) {
-    if (pos.x - floorf(pos.x) < 0.001f || pos.y - floorf(pos.y) < 0.001f || pos.z - floorf(pos.z) < 0.001f) {
-        pos.x += 0.001f * dir.x;
-        pos.y += 0.001f * dir.y;
-        pos.z += 0.001f * dir.z;
-    }
-    return pos;
-}
 
 #ifdef VRT_EXP_POOLDBG
 __device__ unsigned long long g_pool_dbg[16384 * 8];   // experiment: per wave {n, A, B, C cycles, wave-steps, refills, start, end (100 MHz)}
@@ -865,6 +870,7 @@ extern "C" void vrt_exp_pool_dbg(unsigned long long *out) {   // read (16384 x 8
     (void)hipMemset(p, 0, sizeof(unsigned long long) * 16384 * 8);
 }
 #endif
+#endif  // VRT_EXPERIMENTS
 
 // ------------------------------------------------------------------------------------------------
 // Bounce b >= 1 over the MARCH CELLS (vrt_accel.hip; the default for plain frames of worlds that have them): the pool
@@ -1187,6 +1193,7 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(FrameParams P, u
     }
 }
 
+#ifdef VRT_EXPERIMENTS
 __device__ __forceinline__ uint32_t path_xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u; }
 
 // Next tile of the frame for this wave: its own XCD's queue first, then the others (tile i of queue x = x + 8 i).
@@ -1348,6 +1355,7 @@ void launch_path_persistent(const FrameParams &P, uint32_t *heads, uint32_t n_cu
     }
     hipLaunchKernelGGL(path_persistent_kernel, dim3((waves + 3u) / 4u), dim3(256), 8u * 4u, st, P, heads, refill_at);
 }
+#endif  // VRT_EXPERIMENTS
 
 // The end of a launch chain of several samples: the frame's running sum plus the chain's planes, in sample order — the
 // order the one-sample-per-chain launches add them in and the oracle's — and the division once the last chain is in.
@@ -1420,6 +1428,7 @@ void launch_path_primary(const FrameParams &P, bool stats, bool literal, hipStre
     VRT_PATH_LAUNCH(path_primary_kernel);
 }
 
+#ifdef VRT_EXPERIMENTS
 // `continuations`: a launch of the straggler chain (P.path_in = four-plane records: rays a bounce launch handed on and the
 // next segments of the chain's own survivors), which marches every ray to its end.
 void launch_path_bounce_pool(const FrameParams &P, bool continuations, uint32_t refill_at, uint32_t eject_at, hipStream_t st) {
@@ -1434,6 +1443,7 @@ void launch_path_bounce_pool(const FrameParams &P, bool continuations, uint32_t 
     if (continuations) hipLaunchKernelGGL(path_bounce_pool_kernel<true>, grid, block, sh, st, P, refill, 0u);
     else hipLaunchKernelGGL(path_bounce_pool_kernel<false>, grid, block, sh, st, P, refill, P.cont_out ? eject : 0u);
 }
+#endif
 
 // the pool kernel over the march cells (P.mblk)
 void launch_path_bounce_cells(const FrameParams &P, uint32_t refill_at, hipStream_t st) {
