@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(512) accel_bricks_kernel(const uint16_t *nodes
 // reads LDS.  The bricks go back into the chunk's own region when they fit (they do, unless an edit burst outgrew the
 // slack); otherwise the chunk moves to a fresh 512-brick region — the most a chunk can ever need — taken from the tail of
 // the pool with one atomic.  The host keeps the tail from overflowing: it counts the chunks that may have moved since
-// the last whole-world build and asks for one of those instead when the tail could run out (vrt_backend.hip).
+// the last whole-world build and asks for one of those instead when the tail could run out (vrt_uploads.hip).
 struct ChunkList { uint32_t chunk[64]; uint32_t extent[64]; };   // extent: nodes from the chunk's root up to the next chunk's (host's estimate)
 
 constexpr uint32_t kChunkNodesMax = 0x7FFFu + 8u;  // child_idx <= 0x7FFF, + 8 children

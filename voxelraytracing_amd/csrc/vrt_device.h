@@ -88,7 +88,7 @@ struct FrameParams {
     // lava 2, water 3 — or empty): the march then asks with a subtract and a compare instead of the mask lookup in LDS
     uint32_t liquid_is_range, liquid_lo, liquid_span;
     // frame-uniform subexpressions of the shader, evaluated once on the host in the same IEEE binary32 operations
-    // (the host half of vrt_backend.hip is built with -ffp-contract=off like the kernels):
+    // (the host half of vrt_frames.hip is built with -ffp-contract=off like the kernels):
     const float *ndc_x;      // [width]  ((float)px * 2) / proj_size.x - 1        (create_ray_from_screen :160)
     const float *ndc_y;      // [height] ((float)py * 2) / proj_size.y - 1        (:161)
     float cam_sun_dir[3];    // normalize(sun_pos - world.min - (cam.pos - world.min)): ray_sky's sun_dir for primary rays (:149)

@@ -526,7 +526,7 @@ __global__ void assemble_shade_kernel(FrameParams P, const uint2 *gathered, Texe
 }
 
 // ------------------------------------------------------------------------------------------------
-// Launchers (called from vrt_backend.hip)
+// Launchers (called from vrt_frames.hip, vrt_present.hip, vrt_group.hip)
 // ------------------------------------------------------------------------------------------------
 
 static size_t lds_bytes(const FrameParams &P, bool lds_roots) { return (24u + (lds_roots ? P.n_roots : 0u)) * 4u; }

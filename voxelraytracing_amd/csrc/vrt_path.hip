@@ -1398,7 +1398,7 @@ __global__ void path_finish_kernel(Texel *out, uint32_t n, float spp) {
 static size_t lds_bytes_path(const FrameParams &P, bool lds_roots) { return (24u + (lds_roots ? P.n_roots : 0u)) * 4u; }
 
 // The path trace marches with the grid march when the derived tables exist (P.grid), else with the ancestor-cache walk;
-// `literal` (air flagged liquid, vrt_backend.hip) with the shader's text.
+// `literal` (air flagged liquid, vrt_frames.hip) with the shader's text.
 #define VRT_PATH_LAUNCH(kernel)                                                                                           \
     do {                                                                                                                  \
         const bool lds = (!P.grid || literal) && P.n_roots <= kLdsRootsMax;                                               \
@@ -1421,7 +1421,7 @@ static size_t lds_bytes_path(const FrameParams &P, bool lds_roots) { return (24u
 void launch_path_primary(const FrameParams &P, bool stats, bool literal, hipStream_t st) {
     if (P.tiles_local == 0) return;
     const dim3 grid((P.tiles_local + 3u) / 4u), block(256);
-    if (P.acc) {   // several samples per launch chain: plain frames over the derived tables only (vrt_backend.hip)
+    if (P.acc) {   // several samples per launch chain: plain frames over the derived tables only (vrt_frames.hip)
         hipLaunchKernelGGL((path_primary_kernel<0, false, false, true>), grid, block, lds_bytes_path(P, false), st, P);
         return;
     }

@@ -1,0 +1,88 @@
+// vrt_present.hip — ScreenShader::encode_pass (shader.rs:273-293, main.rs:454) and the gather root's assembly of
+// tile-major messages into the row-major frame.
+#include "vrt_ctx.h"
+
+// ScreenShader::encode_pass into the context's screen buffer on the device; asynchronous on c->stream.
+static int present_on_device(vrt_ctx *c, const vrt_crosshair *crosshair, uint32_t screen_w, uint32_t screen_h, const char *who) {
+    if (!c->rendered) return fail(c, VRT_ERR_STATE, "%s: nothing rendered yet", who);
+    if (c->tile_major || (c->shard_count > 1u && !c->whole_frame_owner))
+        return fail(c, VRT_ERR_STATE, "%s: needs the whole row-major frame", who);
+    if (screen_w == 0u || screen_h == 0u || (uint64_t)screen_w * screen_h > (1ull << 28))
+        return fail(c, VRT_ERR_INVALID_ARG, "%s: screen %ux%u out of range", who, screen_w, screen_h);
+    HIP_TRY(c, hipSetDevice(c->device));
+    QUIESCE(c);
+    const size_t bytes = (size_t)screen_w * screen_h * 4u;
+    if (bytes > c->screen_cap) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));   // an earlier present may still be writing the old buffer
+        (void)hipFree(c->d_screen);
+        c->d_screen = nullptr; c->screen_cap = 0;
+        HIP_TRY(c, hipMalloc(&c->d_screen, bytes));
+        c->screen_cap = bytes;
+    }
+    vrt::launch_present(c->last_out, c->width, c->height, screen_w, screen_h, *crosshair, c->d_screen, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    return VRT_OK;
+}
+
+extern "C" {
+
+int vrt_present(vrt_ctx *c, const vrt_crosshair *crosshair, uint32_t screen_w, uint32_t screen_h, uint8_t *rgba8) {
+    if (c && c->grp) { const int rc_ = grp_synchronize(c); if (rc_) return rc_; }
+    GRP_ROOT(c, vrt_present(d, crosshair, screen_w, screen_h, rgba8));
+    if (!c || !crosshair || !rgba8) return fail(c, VRT_ERR_INVALID_ARG, "vrt_present: null argument");
+    const int rc = present_on_device(c, crosshair, screen_w, screen_h, "vrt_present");
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(rgba8, c->d_screen, (size_t)screen_w * screen_h * 4u, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VRT_OK;
+}
+
+int vrt_present_device(vrt_ctx *c, const vrt_crosshair *crosshair, uint32_t screen_w, uint32_t screen_h, void **rgba8_device, uint64_t *bytes) {
+    if (c && c->grp) { const int rc_ = grp_synchronize(c); if (rc_) return rc_; }
+    GRP_ROOT(c, vrt_present_device(d, crosshair, screen_w, screen_h, rgba8_device, bytes));
+    if (!c || !crosshair || !rgba8_device) return fail(c, VRT_ERR_INVALID_ARG, "vrt_present_device: null argument");
+    const int rc = present_on_device(c, crosshair, screen_w, screen_h, "vrt_present_device");
+    if (rc) return rc;
+    *rgba8_device = c->d_screen;
+    if (bytes) *bytes = (uint64_t)screen_w * screen_h * 4u;
+    return VRT_OK;
+}
+
+int vrt_assemble(vrt_ctx *c, const void *gathered, uint64_t rank_stride_bytes, void *dst) {
+    GRP_REFUSE(c, "vrt_assemble");
+    if (!c) return VRT_ERR_INVALID_ARG;
+    if (!gathered || !dst) return fail(c, VRT_ERR_INVALID_ARG, "vrt_assemble: null argument");
+    if (rank_stride_bytes % 16u) return fail(c, VRT_ERR_INVALID_ARG, "vrt_assemble: rank stride must be a multiple of 16 bytes");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint64_t stride = rank_stride_bytes ? rank_stride_bytes / 16u : (uint64_t)c->tiles_padded * 64u;
+    const bool in_place = c->shard_count > 1u && !c->tile_major;  // VRT_FLAG_ROW_MAJOR root: its tiles are already in dst
+    vrt::launch_assemble((const vrt::Texel *)gathered, (vrt::Texel *)dst, c->width, c->tiles_x, c->tiles_total, c->shard_w0,
+                         c->shard_period, in_place, stride, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    return VRT_OK;
+}
+
+int vrt_assemble_compact(vrt_ctx *c, const void *gathered, uint64_t rank_stride_bytes, void *dst) {
+    GRP_REFUSE(c, "vrt_assemble_compact");
+    if (!c) return VRT_ERR_INVALID_ARG;
+    if (!gathered || !dst) return fail(c, VRT_ERR_INVALID_ARG, "vrt_assemble_compact: null argument");
+    if (rank_stride_bytes % 8u) return fail(c, VRT_ERR_INVALID_ARG, "vrt_assemble_compact: rank stride must be a multiple of 8 bytes");
+    if (!(c->shard_count > 1u && !c->tile_major))
+        return fail(c, VRT_ERR_STATE, "vrt_assemble_compact: the gather root must be a VRT_FLAG_ROW_MAJOR shard context (it shades the "
+                    "other ranks' records with its own uniforms and has its own tiles in the frame already)");
+    int rc = validate_frame(c);
+    if (rc) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    rc = ensure_ndc(c);
+    if (rc) return rc;
+    vrt::FrameParams P;
+    memset(&P, 0, sizeof P);
+    P.mats = c->d_mats;
+    fill_uniforms(c, P);
+    const uint64_t stride = rank_stride_bytes ? rank_stride_bytes / 8u : (uint64_t)c->tiles_padded * 64u;
+    vrt::launch_assemble_shade(P, gathered, (vrt::Texel *)dst, c->shard_w0, c->shard_period, stride, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    return VRT_OK;
+}
+
+}  // extern "C"
