@@ -922,6 +922,11 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(FrameParams P, u
         const uint32_t i = k * 64u + lane;
         if (i < n) {
             const uint4 b = P.path_in[P.in_cap + base + i];
+            {   // the origin plane is touched too: the hand-outs then find both planes of the record in L2 (the previous launch
+                // wrote them, 69 MB ago; + 1 %.  Touching the next hand-outs' records at every refill instead: - 2 %)
+                const uint4 a_ = P.path_in[base + i];
+                asm volatile("" :: "v"(a_.x));
+            }
             const V3 unit = unit_steps(V3{__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z)});
             pool[0u * E + i] = unit.x; pool[1u * E + i] = unit.y; pool[2u * E + i] = unit.z;
         }
