@@ -80,3 +80,14 @@ def test_rust_sys_crate_declares_the_same_abi():
     assert sizes == {k: C.sizeof(v) for k, v in want.items()}
     for flag, val in (("VRT_FLAG_TILE_MAJOR", 1), ("VRT_FLAG_ROW_MAJOR", 2), ("VRT_FLAG_COMPACT", 4)):
         assert re.search(rf"#define {flag} {val}u", hdr) and re.search(rf"pub const {flag}: u32 = {val};", src)
+
+
+def test_no_kernel_of_the_library_spills_registers():
+    """Every gfx950 kernel of libvrt.so: no scratch, no spilled SGPRs or VGPRs (code-object metadata; _ffi.kernel_registers says
+    why a spill is an error here), and the path trace's bounce kernel within the 64 VGPRs of eight waves a SIMD."""
+    regs = _ffi.kernel_registers()
+    assert len(regs) >= 40, f"only {len(regs)} kernels found in libvrt.so's fat binary"
+    bad = {k: v for k, v in regs.items() if v["scratch_bytes"] or v["sgpr_spills"] or v["vgpr_spills"]}
+    assert not bad, f"kernels that spill: {bad}"
+    bounce = {k: v for k, v in regs.items() if "path_bounce_cells_kernel" in k}
+    assert len(bounce) == 2 and all(v["vgprs"] <= 64 for v in bounce.values()), bounce

@@ -156,6 +156,50 @@ def code_object_sha256(path: str | None = None) -> str:
     return hashlib.sha256(data).hexdigest()
 
 
+def kernel_registers(path: str | None = None) -> dict:
+    """{kernel symbol: {"vgprs", "sgprs", "vgpr_spills", "sgpr_spills", "scratch_bytes"}} of the gfx950 kernels in libvrt.so,
+    read from the code objects' metadata (llvm-readelf; no GPU).  tests/test_abi.py holds every kernel to no spills and no
+    scratch: a bounce kernel that spilled (SGPRs into VGPR lanes, three VGPRs into scratch) faulted on the card in round 3
+    while the same source without the spills was bit-exact, so a spill is a build error here, not a slowdown."""
+    import re
+    import struct
+    import subprocess
+    import tempfile
+    path = path or os.environ.get("VRT_LIB") or os.path.join(_HERE, "libvrt.so")
+    data = open(path, "rb").read()
+    shoff, = struct.unpack_from("<Q", data, 0x28)
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", data, 0x3A)
+    sec = [struct.unpack_from("<IIQQQQIIQQ", data, shoff + i * shentsize) for i in range(shnum)]
+    names = sec[shstrndx]
+    fat = b""
+    for s in sec:
+        if data[names[4] + s[0]:data.index(b"\0", names[4] + s[0])] == b".hip_fatbin":
+            fat = data[s[4]:s[4] + s[5]]
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"   # one bundle per translation unit: {count, {offset, size, triple}...}
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    found = {}
+    at = fat.find(magic)
+    while at >= 0:
+        count, = struct.unpack_from("<Q", fat, at + 24)
+        q = at + 32
+        for _ in range(count):
+            off, size, tl = struct.unpack_from("<QQQ", fat, q)
+            triple = fat[q + 24:q + 24 + tl].decode()
+            q += 24 + tl
+            if "gfx950" not in triple or not size:
+                continue
+            with tempfile.NamedTemporaryFile(suffix=".co") as f:
+                f.write(fat[at + off:at + off + size])
+                f.flush()
+                notes = subprocess.run([readelf, "--notes", f.name], capture_output=True, text=True, check=True).stdout
+            for m in re.finditer(r"\.private_segment_fixed_size:\s+(\d+)\s+\.sgpr_count:\s+(\d+)\s+\.sgpr_spill_count:\s+(\d+)\s+"
+                                 r"\.symbol:\s+(\S+?)\.kd\s.*?\.vgpr_count:\s+(\d+)\s+\.vgpr_spill_count:\s+(\d+)", notes, re.S):
+                found[m.group(4)] = {"scratch_bytes": int(m.group(1)), "sgprs": int(m.group(2)), "sgpr_spills": int(m.group(3)),
+                                     "vgprs": int(m.group(5)), "vgpr_spills": int(m.group(6))}
+        at = fat.find(magic, at + 24)
+    return found
+
+
 _vrt = None
 
 

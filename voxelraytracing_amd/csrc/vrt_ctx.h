@@ -44,7 +44,7 @@ void launch_path_persistent(const FrameParams &P, uint32_t *heads, uint32_t n_cu
 #endif
 void launch_path_primary(const FrameParams &P, bool stats, bool literal, hipStream_t st);
 void launch_path_bounce(const FrameParams &P, bool stats, bool literal, hipStream_t st);
-void launch_path_bounce_cells(const FrameParams &P, uint32_t refill_at, hipStream_t st);
+void launch_path_bounce_cells(const FrameParams &P, uint32_t refill_at, uint32_t segments, hipStream_t st);
 void launch_path_finish(Texel *out, uint32_t n, uint32_t spp, hipStream_t st);
 void launch_tile_order(const uint32_t *cost, uint32_t n, uint32_t shift, uint32_t *scratch, uint32_t *order, hipStream_t st);
 void launch_path_chain_finish(Texel *out, const Texel *acc, uint32_t n, uint32_t chain, bool first, bool last, uint32_t spp, hipStream_t st);

@@ -417,7 +417,12 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
             } else if (!pool) {
                 vrt::launch_path_bounce(P, kstats, literal, f.st);
             } else if (cells) {
-                vrt::launch_path_bounce_cells(P, c->path_refill, f.st);
+                // every bounce segment that is left in ONE launch: the waves carry their own survivors from one to the next
+                // (one cursor set, one swap of the path buffers per LAUNCH: g counts launches)
+                const uint32_t segments = bounces - b;
+                P.last_bounce = 1u;
+                vrt::launch_path_bounce_cells(P, c->path_refill, segments, f.st);
+                b += segments - 1u;
             } else {
 #ifndef VRT_EXPERIMENTS
                 vrt::launch_path_bounce(P, kstats, literal, f.st);   // (a world without march cells: lane = path)

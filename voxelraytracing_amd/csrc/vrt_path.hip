@@ -889,42 +889,76 @@ extern "C" void vrt_exp_pool_dbg(unsigned long long *out) {   // read (16384 x 8
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t kCellsPoolBytesPerWave = kPoolWords * 4u + kPoolEntries * 2u;   // the pool + a u16 order per entry
 
+// what a launch of path_bounce_cells_kernel is given (one argument: the kernel reads it again for every segment)
+struct CellsLaunch {
+    FrameParams P;
+    uint32_t refill_at;   // a wave takes rays from its pool when this many of its lanes are idle
+    uint32_t segments;    // bounce segments in this launch: all that the frame's paths have left
+};
+
+// how many lanes of the mask are below this one (two instructions over the mask's halves; no per-lane mask to keep)
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
 template <bool DIRECT>
 #ifndef VRT_CELLS_NO_WAVES_ATTR
 __attribute__((amdgpu_waves_per_eu(8, 8)))
 #endif
-__global__ void __launch_bounds__(256) path_bounce_cells_kernel(FrameParams P, uint32_t refill_at) {
+__global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
+    const FrameParams &K = L.P;
     extern __shared__ uint32_t smem[];
     uint32_t *s_liquid = smem;
-    if (threadIdx.x < 8) s_liquid[threadIdx.x] = P.liquid[threadIdx.x];
-    if (blockIdx.x == 0 && P.seg_clear) P.seg_clear[threadIdx.x * kSegStride] = 0u;   // kHitSegments == blockDim.x cursors
+    if (threadIdx.x < 8) s_liquid[threadIdx.x] = K.liquid[threadIdx.x];
+    if (blockIdx.x == 0 && K.seg_clear) K.seg_clear[threadIdx.x * kSegStride] = 0u;   // kHitSegments == blockDim.x cursors
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr uint32_t E = kPoolEntries;
-    float *pool = reinterpret_cast<float *>(smem + 8) + wave * kPoolWords;
-    uint16_t *order = reinterpret_cast<uint16_t *>(smem + 8 + 4u * kPoolWords) + wave * E;
 
     // this wave's paths: the workgroup takes up to 4 E records of its segment, split evenly over its waves
     const uint32_t seg = blockIdx.x % kHitSegments, part = blockIdx.x / kHitSegments;
-    const uint32_t count = P.seg_in[seg * kSegStride];
+    const uint32_t count = K.seg_in[seg * kSegStride];
     const uint32_t wg_begin = part * 4u * E;
     if (wg_begin >= count) return;
     const uint32_t n_wg = min(4u * E, count - wg_begin), per = (n_wg + 3u) / 4u;
     if (wave * per >= n_wg) return;
-    const uint32_t n = min(per, n_wg - wave * per);   // <= E
-    const uint32_t base = seg * P.in_seg_cap + wg_begin + wave * per;
+    uint32_t n = __builtin_amdgcn_readfirstlane(min(per, n_wg - wave * per));   // <= E
+    const uint32_t base = __builtin_amdgcn_readfirstlane(seg * K.in_seg_cap + wg_begin + wave * per);
+    // The wave keeps its paths for ALL the segments that are left (`segments` of them): the survivors of one segment are
+    // compacted — by the wave alone, no cursor, no atomic — into the same index range of the other path buffer and are the
+    // wave's pool for the next.  A launch per bounce ends when its slowest wave does (221 wave-steps against 81 on average),
+    // three times per frame; here a wave that is done with one segment starts the next, and the launch waits for the slowest
+    // SUM.  (The pools shrink — 256, ~150, ~90 paths — and phases A and C run their last batch partly empty.)
+    // (as offsets from one pointer, so that the address of a record stays "scalar base + lane index")
+    uint4 *const recs = K.path_in < K.path_out ? const_cast<uint4 *>(K.path_in) : K.path_out;
+    uint32_t in_at = __builtin_amdgcn_readfirstlane((uint32_t)(K.path_in - recs));
+    uint32_t out_at = __builtin_amdgcn_readfirstlane((uint32_t)(K.path_out - recs));
+    for (uint32_t left = L.segments;; left--) {   // (left: segments still to do, this one included)
+    // What does not change from one segment to the next is made anew for every one of them — the launch's parameters read
+    // again from the kernel-argument segment (scalar loads), the lane's number and what follows from it computed again —
+    // and not kept in registers around the whole loop: that is 15 VGPRs and 30 SGPRs too many for eight waves a SIMD.
+    typedef const __attribute__((address_space(4))) CellsLaunch *KernArgs;
+    KernArgs kargs = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();   // (L is the kernel's only argument)
+    asm volatile("" : "+s"(kargs));
+    const FrameParams &P = ((const CellsLaunch *)kargs)->P;
+    const uint32_t refill_at = ((const CellsLaunch *)kargs)->refill_at;
+    uint32_t none = 0u;
+    asm volatile("" : "+s"(none));
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, none));
+    float *pool = reinterpret_cast<float *>(smem + 8) + (wave + none) * kPoolWords;
+    uint16_t *order = reinterpret_cast<uint16_t *>(smem + 8 + 4u * kPoolWords) + (wave + none) * E;
     const float world_max = 0.0f + (float)P.world.size;
-    const unsigned long long below = (1ull << lane) - 1ull;
+    const bool last_bounce = left == 1u;   // (the launch's last segment is the paths' last)
 
     // ---- A: the unit steps of every ray (nine divides, three square roots), full width ----
 #pragma unroll
     for (uint32_t k = 0; k < kPoolBatches; k++) {
         const uint32_t i = k * 64u + lane;
         if (i < n) {
-            const uint4 b = P.path_in[P.in_cap + base + i];
+            const uint4 b = recs[in_at + P.in_cap + base + i];
             {   // the origin plane is touched too: the hand-outs then find both planes of the record in L2 (the previous launch
                 // wrote them, 69 MB ago; + 1 %.  Touching the next hand-outs' records at every refill instead: - 2 %)
-                const uint4 a_ = P.path_in[base + i];
+                const uint4 a_ = recs[in_at + base + i];
                 asm volatile("" :: "v"(a_.x));
             }
             const V3 unit = unit_steps(V3{__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z)});
@@ -938,11 +972,10 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(FrameParams P, u
     // the wave's next refill parks it.  Water is not tracked (no output of a path segment depends on it). ----
     {
         const TableBuf mb = table_buffer(P.mblk, P.mblk_bytes), db = table_buffer(P.cdir, P.cdir_bytes);
-        const TableBuf gb = table_buffer(P.grid, P.grid_bytes), bb = table_buffer(P.bricks, P.brick_bytes);
+        const TableBuf bb = table_buffer(P.bricks, P.brick_bytes);
         // the chunk directory: [S][S+1][S+1] with a zero border; a direct world: [4S][4S+1][4S+1] lines of 128 bytes
         const uint32_t drow = (P.grid_dim / 8u + 1u) * 4u, dslab = (P.grid_dim / 8u + 1u) * drow;
         const uint32_t row128 = (P.grid_dim / 2u + 1u) * 128u, slab128 = (P.grid_dim / 2u + 1u) * row128;   // < 2^23: S <= 16
-        const uint32_t row_bytes = (P.grid_dim + 1u) * 4u, slab_bytes = (P.grid_dim + 1u) * row_bytes;
         const uint32_t wsize = P.world.size;
         V3 pos{0.f, 0.f, 0.f}, dir{0.f, 0.f, 0.f};
         float ux = 0.f, uy = 0.f, uz = 0.f, step = -1.f, adx = 0.f, ady = 0.f, adz = 0.f;
@@ -965,7 +998,7 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(FrameParams P, u
         auto take = [&](uint32_t at) __attribute__((always_inline)) {
             idx = at;
             const uint32_t rec = base + idx;
-            const uint4 a = P.path_in[rec], b = P.path_in[P.in_cap + rec];
+            const uint4 a = recs[in_at + rec], b = recs[in_at + P.in_cap + rec];
             const V3 origin{__uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w)};
             dir = V3{__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z)};
             not_finite = !(finite3(origin) && finite3(dir));
@@ -1016,9 +1049,19 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(FrameParams P, u
             vx = trunc2i(pos.x);
             vy = trunc2i(pos.y);
             vz = trunc2i(pos.z);
-            uint32_t e = 0u;
-            if (!(min3_nan_ignoring(pos.x, pos.y, pos.z) < 0.0f || max(max((uint32_t)vx, (uint32_t)vy), (uint32_t)vz) >= wsize))
-                e = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(gb, mad_i24(vz >> 2, slab_bytes, mad_i24(vy >> 2, row_bytes, (uint32_t)vx & ~3u)), 0, 0);
+            uint32_t e = 0u;   // the cell's entry of the cell grid: the march cell's first word
+            if (!(min3_nan_ignoring(pos.x, pos.y, pos.z) < 0.0f || max(max((uint32_t)vx, (uint32_t)vy), (uint32_t)vz) >= wsize)) {
+                const uint32_t sub = ((((uint32_t)vz >> 2) & 1u) << 2) | ((((uint32_t)vy >> 2) & 1u) << 1) | (((uint32_t)vx >> 2) & 1u);
+                uint32_t off;
+                if (DIRECT) {
+                    off = mad_i24(vz >> 3, slab128, mad_i24(vy >> 3, row128, ((uint32_t)(vx >> 3) << 7) + (sub << 4)));
+                } else {   // (inside the world: the chunk has an entry in the directory)
+                    const uint32_t block = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(db, mad_i24(vz >> 5, dslab, mad_i24(vy >> 5, drow, (uint32_t)(vx >> 5) << 2)), 0, 0) << 13;
+                    const uint32_t line = ((((((uint32_t)vz >> 3) & 3u) << 2) | (((uint32_t)vy >> 3) & 3u)) << 2) | (((uint32_t)vx >> 3) & 3u);
+                    off = block + (((line << 3) | sub) << 4);
+                }
+                e = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(mb, off, 0, 0);
+            }
             uint32_t lo = e, voxel = 0u;
             bool stop = e == 0u;   // border, or past either end of the grid: the position is outside the world
             if (!stop) {
@@ -1045,7 +1088,7 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(FrameParams P, u
             if (!marching && !parked) park();
             {
                 const unsigned long long idle = __ballot(!marching);
-                const uint32_t at = next + (uint32_t)__popcll(idle & below);
+                const uint32_t at = next + lanes_below(idle);
                 if (!marching && at < n) take(at);
                 next = min(n, next + (uint32_t)__popcll(idle));
             }
@@ -1134,8 +1177,8 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(FrameParams P, u
         for (uint32_t k = 0; k < kPoolBatches; k++) {
             const uint32_t i = k * 64u + lane;
             const unsigned long long mh = __ballot(hit[k]), mm = __ballot(i < n && !hit[k]);
-            if (hit[k]) order[at_hit + (uint32_t)__popcll(mh & below)] = (uint16_t)i;
-            else if (i < n) order[at_miss + (uint32_t)__popcll(mm & below)] = (uint16_t)i;
+            if (hit[k]) order[at_hit + lanes_below(mh)] = (uint16_t)i;
+            else if (i < n) order[at_miss + lanes_below(mm)] = (uint16_t)i;
             at_hit += (uint32_t)__popcll(mh);
             at_miss += (uint32_t)__popcll(mm);
         }
@@ -1146,16 +1189,17 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(FrameParams P, u
     // ---- C: what follows the march, full width.  On the last bounce a ray that hit has nothing left to do: its bounce
     // would be dropped and only a miss adds light ----
     const TableBuf bb = table_buffer(P.bricks, P.brick_bytes);
-    for (uint32_t j0 = P.last_bounce ? n_hit & ~63u : 0u; j0 < n; j0 += 64u) {
+    uint32_t n_out = 0u;   // survivors so far: the next segment's pool
+    for (uint32_t j0 = last_bounce ? n_hit & ~63u : 0u; j0 < n; j0 += 64u) {
         const uint32_t j = j0 + lane;
         bool alive = false;
         PathState st;
         st.slot = 0; st.rng = 0;
         st.origin = st.dir = st.thr = V3{0.f, 0.f, 0.f};
-        if (j < n && !(P.last_bounce && j < n_hit)) {
+        if (j < n && !(last_bounce && j < n_hit)) {
             const uint32_t i = order[j];
             const uint32_t rec = base + i;
-            const uint4 a = P.path_in[rec], b = P.path_in[P.in_cap + rec], c = P.path_in[2u * P.in_cap + rec];
+            const uint4 a = recs[in_at + rec], b = recs[in_at + P.in_cap + rec], c = recs[in_at + 2u * P.in_cap + rec];
             st.slot = a.x;
             st.origin = V3{__uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w)};
             st.dir = V3{__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z)};
@@ -1185,7 +1229,7 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(FrameParams P, u
             }
             V3 light{0.f, 0.f, 0.f};
             bool missed;
-            alive = path_after_march(P, st, R, light, missed) && !P.last_bounce;
+            alive = path_after_march(P, st, R, light, missed) && !last_bounce;
             if (missed) {
                 uint4 t = P.out[st.slot];
                 t.x = __float_as_uint(__uint_as_float(t.x) + light.x);
@@ -1194,7 +1238,27 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(FrameParams P, u
                 P.out[st.slot] = t;
             }
         }
-        append_paths(P, alive, st, lane);
+        if (left != 1u) {   // the survivors, compacted into this wave's own range of the other buffer
+            const unsigned long long m = __ballot(alive);
+            if (alive) {
+                const uint32_t o = out_at + base + n_out + lanes_below(m);
+                recs[o] = make_uint4(st.slot, __float_as_uint(st.origin.x), __float_as_uint(st.origin.y), __float_as_uint(st.origin.z));
+                recs[P.path_cap + o] = make_uint4(__float_as_uint(st.dir.x), __float_as_uint(st.dir.y), __float_as_uint(st.dir.z), st.rng);
+                recs[2u * P.path_cap + o] = make_uint4(__float_as_uint(st.thr.x), __float_as_uint(st.thr.y), __float_as_uint(st.thr.z), 0u);
+            }
+            n_out += (uint32_t)__popcll(m);
+        }
+    }
+    if (left == 1u || n_out == 0u) break;
+    // the next segment: the records just written are read back by other lanes of this wave (same CU, same L1)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    n = n_out;
+    {
+        const uint32_t t = in_at;
+        in_at = out_at;
+        out_at = t;
+    }
     }
 }
 
@@ -1450,15 +1514,17 @@ void launch_path_bounce_pool(const FrameParams &P, bool continuations, uint32_t 
 }
 #endif
 
-// the pool kernel over the march cells (P.mblk)
-void launch_path_bounce_cells(const FrameParams &P, uint32_t refill_at, hipStream_t st) {
-    if (P.tiles_local == 0) return;
+// the pool kernel over the march cells (P.mblk): `segments` bounce segments in this one launch (every wave carries its own
+// survivors from one to the next; P.path_in / P.path_out are the two buffers it goes back and forth between)
+void launch_path_bounce_cells(const FrameParams &P, uint32_t refill_at, uint32_t segments, hipStream_t st) {
+    if (P.tiles_local == 0 || segments == 0) return;
     const uint32_t refill = refill_at >= 1u && refill_at <= 64u ? refill_at : kPoolRefillAt;
     const uint32_t parts = (P.in_seg_cap + 4u * kPoolEntries - 1u) / (4u * kPoolEntries);
     const dim3 grid(kHitSegments * parts), block(256);
     const size_t sh = 8u * 4u + 4u * kCellsPoolBytesPerWave;
-    if (P.march_direct) hipLaunchKernelGGL(path_bounce_cells_kernel<true>, grid, block, sh, st, P, refill);
-    else hipLaunchKernelGGL(path_bounce_cells_kernel<false>, grid, block, sh, st, P, refill);
+    const CellsLaunch L{P, refill, segments};
+    if (P.march_direct) hipLaunchKernelGGL(path_bounce_cells_kernel<true>, grid, block, sh, st, L);
+    else hipLaunchKernelGGL(path_bounce_cells_kernel<false>, grid, block, sh, st, L);
 }
 
 void launch_path_bounce(const FrameParams &P, bool stats, bool literal, hipStream_t st) {
