@@ -67,6 +67,35 @@ KERNEL(k_nop, "s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop
 // a dependent chain of simple VALU (every instruction needs the one before)
 KERNEL(k_add_dep, "v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n")
 
+// the same loop under a partial EXEC mask: does an instruction cost less when a quarter or a half of the wave has no active lane?
+#define KERNEL_MASKED(name, cond, body)                                           \
+    __global__ void __launch_bounds__(256) name(float *out, int iters, unsigned long long *clk) { \
+        const unsigned long long t0_ = __builtin_amdgcn_s_memtime(), r0_ = __builtin_amdgcn_s_memrealtime(); \
+        float a = threadIdx.x * 0.001f + 1.0f, b = 1.0001f, c = 0.5f, d = 2.0f;   \
+        float e = a + 1.0f, f = a + 2.0f, g = a + 3.0f, h = a + 4.0f;             \
+        int i0 = threadIdx.x, i1 = 7, i2 = 3, i3 = 11;                            \
+        const unsigned lane_ = threadIdx.x & 63u;                                 \
+        if (cond) {                                                               \
+        for (int it = 0; it < iters; it++) {                                      \
+            asm volatile(REP4(body) : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3) : : "vcc", "scc", "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29"); \
+        }                                                                         \
+        }                                                                         \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = a + b + c + d + e + f + g + h + (float)(i0 + i1 + i2 + i3); \
+        if (threadIdx.x == 0) {                                                   \
+            clk[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0_;             \
+            clk[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r0_;     \
+        }                                                                         \
+    }
+#define FMA8 "v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %2, %2, %1, %3\n v_fma_f32 %3, %3, %1, %4\n v_fma_f32 %4, %4, %1, %5\n v_fma_f32 %5, %5, %1, %6\n v_fma_f32 %6, %6, %1, %7\n v_fma_f32 %7, %7, %1, %0\n v_fma_f32 %0, %0, %2, %3\n"
+#define MIN38 "v_min3_f32 %0, %0, %1, %2\n v_min3_f32 %2, %2, %1, %3\n v_min3_f32 %3, %3, %1, %4\n v_min3_f32 %4, %4, %1, %5\n v_min3_f32 %5, %5, %1, %6\n v_min3_f32 %6, %6, %1, %7\n v_min3_f32 %7, %7, %1, %0\n v_min3_f32 %0, %0, %2, %3\n"
+KERNEL_MASKED(k_fma_lanes_0_15, lane_ < 16u, FMA8)
+KERNEL_MASKED(k_fma_lanes_0_31, lane_ < 32u, FMA8)
+KERNEL_MASKED(k_fma_every_4th, (lane_ & 3u) == 0u, FMA8)
+KERNEL_MASKED(k_fma_one_in_16, (lane_ & 15u) == 0u, FMA8)
+KERNEL_MASKED(k_min3_lanes_0_15, lane_ < 16u, MIN38)
+KERNEL_MASKED(k_min3_lanes_0_31, lane_ < 32u, MIN38)
+KERNEL_MASKED(k_min3_every_4th, (lane_ & 3u) == 0u, MIN38)
+
 #include <algorithm>
 
 template <typename K>
@@ -112,5 +141,6 @@ int main() {
     RUN(k_bfi_b32); RUN(k_mad_u24); RUN(k_mad_i24); RUN(k_max3_u32); RUN(k_div_fixup); RUN(k_pk_add_f32);
     RUN(k_sqrt_f32); RUN(k_rcp_f32);
     RUN(k_salu); RUN(k_salu_valu); RUN(k_nop);
+    RUN(k_fma_lanes_0_15); RUN(k_fma_lanes_0_31); RUN(k_fma_every_4th); RUN(k_fma_one_in_16); RUN(k_min3_lanes_0_15); RUN(k_min3_lanes_0_31); RUN(k_min3_every_4th);
     return 0;
 }

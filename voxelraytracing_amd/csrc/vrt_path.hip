@@ -889,6 +889,19 @@ extern "C" void vrt_exp_pool_dbg(unsigned long long *out) {   // read (16384 x 8
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t kCellsPoolBytesPerWave = kPoolWords * 4u + kPoolEntries * 2u;   // the pool + a u16 order per entry
 
+#ifdef VRT_EXP_CELLDBG
+// experiment (tools/ab build, tools/cells_probe.py): per wave of the launch {rays, start, end (100 MHz), wave-steps with rays left
+// in the pool | after it ran dry << 32, lanes marching in them likewise, segments done, -, -}
+__device__ unsigned long long g_cells_dbg[16384 * 8];
+extern "C" void vrt_exp_cells_dbg(unsigned long long *out) {   // read and reset
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cells_dbg), sizeof(unsigned long long) * 16384 * 8);
+    void *p = nullptr;
+    (void)hipGetSymbolAddress(&p, HIP_SYMBOL(g_cells_dbg));
+    (void)hipMemset(p, 0, sizeof(unsigned long long) * 16384 * 8);
+}
+#endif
+
 // what a launch of path_bounce_cells_kernel is given (one argument: the kernel reads it again for every segment)
 struct CellsLaunch {
     FrameParams P;
@@ -901,6 +914,9 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+#ifndef VRT_CELLS_LOAD_AUX
+#define VRT_CELLS_LOAD_AUX 0   // cache policy of the march-cell load (A/B builds: 1 sc0, 2 nt, 16 sc1)
+#endif
 template <bool DIRECT>
 #ifndef VRT_CELLS_NO_WAVES_ATTR
 __attribute__((amdgpu_waves_per_eu(8, 8)))
@@ -923,6 +939,11 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
     const uint32_t n_wg = min(4u * E, count - wg_begin), per = (n_wg + 3u) / 4u;
     if (wave * per >= n_wg) return;
     uint32_t n = __builtin_amdgcn_readfirstlane(min(per, n_wg - wave * per));   // <= E
+#ifdef VRT_EXP_CELLDBG
+    const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
+    const uint32_t dbg_n0 = n;
+    uint32_t dbg_wet = 0, dbg_wet_lanes = 0, dbg_dry = 0, dbg_dry_lanes = 0, dbg_segments = 0;
+#endif
     const uint32_t base = __builtin_amdgcn_readfirstlane(seg * K.in_seg_cap + wg_begin + wave * per);
     // The wave keeps its paths for ALL the segments that are left (`segments` of them): the survivors of one segment are
     // compacted — by the wave alone, no cursor, no atomic — into the same index range of the other path buffer and are the
@@ -1107,6 +1128,12 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
                 continue;
             }
             for (;;) {
+#ifdef VRT_EXP_CELLDBG
+                {
+                    const uint32_t m_ = (uint32_t)__popcll(__ballot(marching));
+                    if (next < n) { dbg_wet++; dbg_wet_lanes += m_; } else { dbg_dry++; dbg_dry_lanes += m_; }
+                }
+#endif
                 if (marching) {
                     // the chunk's block of march cells: looked up in the chunk directory when the ray has entered another chunk
                     // (coordinates -1 .. S: one voxel beyond the world at most; they make one number, base 128).  Outside the
@@ -1128,7 +1155,7 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
                     }
                     // one 16-byte load answers the step: c.x the cell's entry, c.y the size-2 mask of a split cell, c.z / c.w
                     // the voxels a ray passes (zero stops it)
-                    const uint4 c = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(mb, off, 0, 0));
+                    const uint4 c = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(mb, off, 0, VRT_CELLS_LOAD_AUX));
                     iter += 1u;
                     // u = (x&3) | (y&3) << 2 | (z&3) << 4, with z's upper bits left on top: the shifts below use the low bits only
                     const uint32_t u = ((((uint32_t)vz << 2) | ((uint32_t)vy & 3u)) << 2) | ((uint32_t)vx & 3u);
@@ -1249,6 +1276,17 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
             n_out += (uint32_t)__popcll(m);
         }
     }
+#ifdef VRT_EXP_CELLDBG
+    dbg_segments++;
+    if (left == 1u || n_out == 0u) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0 && blockIdx.x * 4u + wave < 16384u) {
+            unsigned long long *d = &g_cells_dbg[(blockIdx.x * 4u + wave) * 8u];
+            d[0] = dbg_n0; d[1] = dbg_t0; d[2] = t1; d[3] = dbg_wet | ((unsigned long long)dbg_dry << 32);
+            d[4] = dbg_wet_lanes | ((unsigned long long)dbg_dry_lanes << 32); d[5] = dbg_segments;
+        }
+    }
+#endif
     if (left == 1u || n_out == 0u) break;
     // the next segment: the records just written are read back by other lanes of this wave (same CU, same L1)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
