@@ -253,6 +253,33 @@ def test_frames_in_flight_keep_frames_apart(orc, in_flight):
         gpu.set_frames_in_flight(5)
 
 
+@pytest.mark.parametrize("in_flight", [2, 3])
+def test_a_frame_stays_announced_when_the_event_pool_is_folded(orc, in_flight, monkeypatch):
+    """A context folds its pool of timing events every 512 timed frames and waits for the frames in flight to do so — between
+    picking the next frame's stream and enqueueing the frame.  The frame must still count as in flight afterwards: a
+    read-back right behind it once copied the slot's previous frame (tools/soak_edits.py, seed 7: once in 180 000 frames).
+    Every frame timed (VRT_TIMING_EVERY=1), the camera alternating, every frame read back."""
+    monkeypatch.setenv("VRT_TIMING_EVERY", "1")
+    sc = scenes.c2((160, 96))
+    gpu = gpu_for_scene(sc)
+    gpu.set_frames_in_flight(in_flight)
+    o = orc.from_package_scene(sc)
+    cams = [g.cam_data_create((20.0 + 30 * k, 35.0 + 120 * k, 0.0), (sc.eye[0] + 3 * k, sc.eye[1] + k, sc.eye[2] - 2 * k), 70.0, (160.0, 96.0))
+            for k in range(2)]
+    refs = []
+    for cam in cams:
+        o.set_cam(cam)
+        refs.append(o.render(orc.MODE_PRIMARY, 160, 96)[1])
+    assert int((refs[0] != refs[1]).sum()) > 5000
+    for i in range(1100):        # two folds
+        k = (i // 2) & 1 if in_flight == 2 else i & 1   # the slot's previous frame (in_flight frames ago) had the other camera
+        gpu.write_cam_data(cams[k])
+        gpu.render(MODE_PRIMARY)
+        if i >= 500:
+            _, ids, _ = gpu.read_output()
+            assert np.array_equal(ids, refs[k]), f"frame {i}: {int((ids != refs[k]).sum())} id words of another frame"
+
+
 def test_render_on_own_streams_with_a_caller_stream_and_bound_outputs(orc):
     """VRT_RENDER_OWN_STREAMS — what the in-place gather root does with its own tiles: the caller has set its stream and
     binds a different buffer per frame, the frames still overlap on the context's streams; after a device-wide

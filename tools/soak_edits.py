@@ -21,12 +21,15 @@ gpu = Gpu(sc.world.max_nodes(), sc.world.size_in_chunks(), sc.size)
 gpu.upload_world(sc.world, sc.materials); gpu.write_settings(sc.settings)
 ex, ey, ez = (float(v) for v in sc.eye)
 cam = sc.cam
+prev_cam = cam
 mode = MODE_PRIMARY_SHADOW
 variant = 0
 frames = checks = edits = recentres = 0
 center0 = tuple(int(v) // 32 + 4 for v in sc.world.min_voxel())   # the grid's centre chunk (8^3 chunks)
 center = center0
 pending = []            # chunk ranges that arrived (generate_missing) and are not uploaded yet: a few per frame
+import collections
+ops = collections.deque(maxlen=80)   # what was done lately, for the report of a mismatch
 t_end = time.time() + seconds
 next_report = time.time() + 20
 while time.time() < t_end:
@@ -45,15 +48,20 @@ while time.time() < t_end:
                         continue
                     start, n = e.range
                 gpu.write_nodes(sc.world.nodes_ptr(), start, start + n)
+                ops.append(f"f{frames} edit {p} nodes [{start},{start + n})")
                 edits += 1
         elif r < 0.55:
             gpu.write_nodes(sc.world.nodes_ptr(), 0, 2)          # node 0: a whole-world rebuild
+            ops.append(f"f{frames} write node 0")
         elif r < 0.6:
-            gpu.set_frames_in_flight(int(rng.integers(1, 4)))
+            nf = int(rng.integers(1, 4))
+            gpu.set_frames_in_flight(nf)
+            ops.append(f"f{frames} frames in flight {nf}")
         elif r < 0.65:
             for _ in range(int(rng.integers(60, 90))):           # a quiet stretch: the table sets merge
                 gpu.render(mode, variant=variant)
                 frames += 1
+            ops.append(f"f{frames} quiet stretch done")
         elif r < 0.69:
             # the player crosses into another chunk (client/src/lib.rs:55-65): the grid follows, within two chunks of where it began
             ax = int(rng.integers(0, 3))
@@ -65,18 +73,23 @@ while time.time() < t_end:
                 sc.world.center_chunks(center)
                 pending.extend(sc.world.generate_missing(0, 1).tolist())
                 gpu.write_world_data(sc.world.world_data())
+                ops.append(f"f{frames} recentre to {center}, {len(pending)} chunk ranges pending")
                 recentres += 1
         for root, n in pending[:6]:                                # main.rs:289-295: the chunk ranges that arrived
             gpu.write_nodes(sc.world.nodes_ptr(), int(root), int(root) + int(n))
+            ops.append(f"f{frames} chunk range [{int(root)},{int(root) + int(n)})")
         del pending[:6]
         if rng.random() < 0.3:
             rot = (float(rng.uniform(-40, 10)), float(rng.uniform(0, 360)), 0.0)
             eye = (ex + float(rng.uniform(-6, 6)), ey + float(rng.uniform(-3, 3)), ez + float(rng.uniform(-6, 6)))
+            prev_cam = cam
             cam = g.cam_data_create(rot, eye, float(rng.uniform(50, 100)), (float(W), float(H)))
             gpu.write_cam_data(cam)
+            ops.append(f"f{frames} camera")
         if rng.random() < 0.1:
             mode = MODE_PRIMARY if rng.random() < 0.3 else MODE_PRIMARY_SHADOW
             variant = 2 if rng.random() < 0.2 else 0
+            ops.append(f"f{frames} mode {mode} variant {variant}")
         gpu.write_chunk_roots(sc.world.chunk_roots(), tag=sc.world.roots_generation())
         gpu.render(mode, variant=variant)
         frames += 1
@@ -93,6 +106,33 @@ while time.time() < t_end:
     checks += 1
     if not np.array_equal(ids, r_ids) or float(np.nanmax(np.abs(rgb - r_rgb))) > 1e-4:
         print(f"MISMATCH at check {checks}, frame {frames}: {int((ids != r_ids).sum())} id words differ (mode {mode}, variant {variant})", flush=True)
+        _, ids_again, _ = gpu.read_output()
+        print(f"the same output read once more, nothing rendered in between: {int((ids_again != r_ids).sum())} id words differ", flush=True)
+        print("the last operations:\n  " + "\n  ".join(list(ops)[-12:]), flush=True)
+        os.makedirs("gpurun_out", exist_ok=True)
+        np.savez_compressed("gpurun_out/soak_mismatch.npz", ids=ids, r_ids=r_ids, rgb=rgb, r_rgb=r_rgb)
+        diff = ids != r_ids
+        ys, xs = np.nonzero(diff)
+        print(f"differing pixels: rows {ys.min()}..{ys.max()}, columns {xs.min()}..{xs.max()}; per 8-row band: {[int(diff[y:y + 8].sum()) for y in range(0, H, 8)]}", flush=True)
+        o.set_cam(prev_cam)
+        _, p_ids, _, _ = o.render(mode, W, H)
+        print(f"of the {int(diff.sum())} differing pixels {int((ids[diff] == p_ids[diff]).sum())} are the oracle's frame of this world through the camera BEFORE the last change", flush=True)
+        vals, cnt = np.unique(ids[diff] & 0x7FFF, return_counts=True)
+        print(f"voxels the frame has there: {dict(zip(vals.tolist()[:8], cnt.tolist()[:8]))}; the oracle: {dict(zip(*[a.tolist()[:8] for a in np.unique(r_ids[diff] & 0x7FFF, return_counts=True)]))}", flush=True)
+        a = gpu.accel_info()
+        print(f"tables: builds {a.builds}, chunk builds {a.chunk_builds}; world min {sc.world.min_voxel()}, generation {sc.world.roots_generation()}", flush=True)
+
+        def again(what):
+            gpu.render(mode, variant=variant)
+            _, ids2, _ = gpu.read_output()
+            print(f"  {what}: {int((ids2 != r_ids).sum())} id words differ", flush=True)
+        again("the same frame once more")
+        gpu.render(mode, variant=2); _, ids2, _ = gpu.read_output()
+        print(f"  through the octree walk (variant 2): {int((ids2 != r_ids).sum())} id words differ", flush=True)
+        gpu.write_cam_data(cam); again("camera written again")
+        gpu.write_world_data(sc.world.world_data()); again("world data written again")
+        gpu.write_chunk_roots(sc.world.chunk_roots()); again("chunk roots written again, untagged")
+        gpu.write_nodes(sc.world.nodes_ptr(), 0, sc.world.max_nodes()); again("every node written again")
         sys.exit(1)
     if checks % 8 == 0:   # and a path-traced frame of the same world: random samples per pixel, seed and bounce count
         from voxelraytracing_amd import MODE_PATH

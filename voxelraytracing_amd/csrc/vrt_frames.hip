@@ -833,6 +833,15 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
         rc = next_events(c, &ev, &ev_kind);
         if (rc) return rc;
     }
+    // The frame is about to be enqueued on its stream: say so again.  pick_frame_set announced it, but what ran since may
+    // have waited for the frames in flight and cleared the announcement with them — next_events folds the event pool every
+    // 512 timed frames and drains for it.  Without this the frame was in flight unannounced: vrt_read_output right behind it
+    // copied the slot's previous frame (tools/soak_edits.py seed 7, check 1161: once in 180 000 frames), and an upload
+    // would not have waited for it.
+    if (f.st != c->stream) {
+        if (f.st == c->own_stream) c->own_pending = true;
+        else c->alt_pending = true;
+    }
     // longest tiles first: the one-launch primary + shadow kernel over the derived tables, plain frames, one frame at a time
     // on the context's own stream (a frame, the sort behind it and the next frame are then ordered by the stream alone)
     const bool lpt = c->tile_lpt && c->in_flight == 1u && f.st == c->stream && (o.mode == VRT_MODE_PRIMARY_SHADOW || o.mode == VRT_MODE_PRIMARY) && variant == 0u && !kstats &&
