@@ -1,8 +1,9 @@
-"""tools/soak_edits.py [seconds] [seed] — a long random session against the oracle: edits (0-3 before a frame), camera moves,
+"""tools/soak_edits.py [seconds] [seed] [devices, e.g. 0,0,0] [texel|staged|poison ...] — a long random session against the oracle: edits (0-3 before a frame), camera moves,
 chunk_roots rewrites, the grid recentred by a chunk (center_chunks: the table shifts, world.min changes, the chunks that came
 into the grid arrive over the next frames), quiet stretches, changes of the number of frames in flight, whole-world rebuilds, the primary and the
 primary + shadow mode, variants 0 and 2 — and every few dozen frames the last frame is compared with the oracle's frame of
-the world as it is.  Exercises the upload stream / per-frame-set table machinery for races that a short
+the world as it is.  With a device list the context is ONE context over those devices (the same device several times
+rehearses it on one GPU): 8-byte records by default — then only the default march's frames — or texel messages.  Exercises the upload stream / per-frame-set table machinery for races that a short
 test would not meet.  Exit status 1 on the first mismatch."""
 import os
 import sys
@@ -17,7 +18,12 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 W, H = 160, 96
 sc = scenes.c2((W, H))
-gpu = Gpu(sc.world.max_nodes(), sc.world.size_in_chunks(), sc.size)
+devices = [int(d) for d in sys.argv[3].split(",")] if len(sys.argv) > 3 and sys.argv[3] else None
+flags = set(sys.argv[4:])
+records_only = devices is not None and "texel" not in flags   # 8-byte records: plain frames of the default march only
+max_in_flight = 2 if devices else 3
+gpu = Gpu(sc.world.max_nodes(), sc.world.size_in_chunks(), sc.size, devices=devices, texel_messages="texel" in flags,
+          staged_messages="staged" in flags, poison_messages="poison" in flags)
 gpu.upload_world(sc.world, sc.materials); gpu.write_settings(sc.settings)
 ex, ey, ez = (float(v) for v in sc.eye)
 cam = sc.cam
@@ -54,7 +60,7 @@ while time.time() < t_end:
             gpu.write_nodes(sc.world.nodes_ptr(), 0, 2)          # node 0: a whole-world rebuild
             ops.append(f"f{frames} write node 0")
         elif r < 0.6:
-            nf = int(rng.integers(1, 4))
+            nf = int(rng.integers(1, max_in_flight + 1))
             gpu.set_frames_in_flight(nf)
             ops.append(f"f{frames} frames in flight {nf}")
         elif r < 0.65:
@@ -88,7 +94,7 @@ while time.time() < t_end:
             ops.append(f"f{frames} camera")
         if rng.random() < 0.1:
             mode = MODE_PRIMARY if rng.random() < 0.3 else MODE_PRIMARY_SHADOW
-            variant = 2 if rng.random() < 0.2 else 0
+            variant = 2 if rng.random() < 0.2 and not records_only else 0
             ops.append(f"f{frames} mode {mode} variant {variant}")
         gpu.write_chunk_roots(sc.world.chunk_roots(), tag=sc.world.roots_generation())
         gpu.render(mode, variant=variant)
@@ -127,14 +133,15 @@ while time.time() < t_end:
             _, ids2, _ = gpu.read_output()
             print(f"  {what}: {int((ids2 != r_ids).sum())} id words differ", flush=True)
         again("the same frame once more")
-        gpu.render(mode, variant=2); _, ids2, _ = gpu.read_output()
-        print(f"  through the octree walk (variant 2): {int((ids2 != r_ids).sum())} id words differ", flush=True)
+        if not records_only:
+            gpu.render(mode, variant=2); _, ids2, _ = gpu.read_output()
+            print(f"  through the octree walk (variant 2): {int((ids2 != r_ids).sum())} id words differ", flush=True)
         gpu.write_cam_data(cam); again("camera written again")
         gpu.write_world_data(sc.world.world_data()); again("world data written again")
         gpu.write_chunk_roots(sc.world.chunk_roots()); again("chunk roots written again, untagged")
         gpu.write_nodes(sc.world.nodes_ptr(), 0, sc.world.max_nodes()); again("every node written again")
         sys.exit(1)
-    if checks % 8 == 0:   # and a path-traced frame of the same world: random samples per pixel, seed and bounce count
+    if checks % 8 == 0 and not records_only:   # and a path-traced frame of the same world: random samples per pixel, seed and bounce count
         from voxelraytracing_amd import MODE_PATH
         spp, pseed = int(rng.integers(1, 7)), int(rng.integers(0, 1000))
         for _ in range(int(rng.integers(1, 4))):
