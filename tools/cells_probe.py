@@ -38,6 +38,8 @@ print(f"launch span {e.max():.1f} us; wave start p50 {np.percentile(s, 50):.1f} 
       f"wave end p10 {np.percentile(e, 10):.1f} p50 {np.percentile(e, 50):.1f} p90 {np.percentile(e, 90):.1f} p99 {np.percentile(e, 99):.1f} max {e.max():.1f}")
 life = e - s
 print(f"us per wave-step (wave life / its wave-steps): mean {(life / (wet + dry)).mean():.3f}, of the 1 % slowest waves {(life / (wet + dry))[e >= np.percentile(e, 99)].mean():.3f}")
+air4, air8, air16 = (raw[:, 6] & lo).astype(float).sum(), (raw[:, 6] >> np.uint64(32)).astype(float).sum(), raw[:, 7].astype(float).sum()
+print(f"lookups {wl.sum() + dl.sum():.0f}: in an air leaf of the cell grid (4 voxels or more) {100 * air4 / (wl.sum() + dl.sum()):.1f} %, of 8 or more {100 * air8 / (wl.sum() + dl.sum()):.1f} %, of 16 or more {100 * air16 / (wl.sum() + dl.sum()):.1f} %")
 for t in np.linspace(0, e.max(), 16):
     alive = (s <= t) & (e > t)
     print(f"  t={t:6.1f} us: {int(alive.sum()):5d} waves alive")

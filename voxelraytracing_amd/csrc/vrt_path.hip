@@ -942,7 +942,7 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
 #ifdef VRT_EXP_CELLDBG
     const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
     const uint32_t dbg_n0 = n;
-    uint32_t dbg_wet = 0, dbg_wet_lanes = 0, dbg_dry = 0, dbg_dry_lanes = 0, dbg_segments = 0;
+    uint32_t dbg_wet = 0, dbg_wet_lanes = 0, dbg_dry = 0, dbg_dry_lanes = 0, dbg_segments = 0, dbg_air4 = 0, dbg_air8 = 0, dbg_air16 = 0;
 #endif
     const uint32_t base = __builtin_amdgcn_readfirstlane(seg * K.in_seg_cap + wg_begin + wave * per);
     // The wave keeps its paths for ALL the segments that are left (`segments` of them): the survivors of one segment are
@@ -1161,6 +1161,11 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
                     const uint32_t u = ((((uint32_t)vz << 2) | ((uint32_t)vy & 3u)) << 2) | ((uint32_t)vx & 3u);
                     const uint32_t passes = (uint32_t)((((unsigned long long)c.w << 32) | c.z) >> (u & 63u)) & 1u;
                     const uint32_t lo = (c.x & 31u) | __builtin_amdgcn_ubfe(c.y, (u >> 1) & 31u, 1u);
+#ifdef VRT_EXP_CELLDBG
+                    dbg_air4 += (uint32_t)__popcll(__ballot(c.x >= 3u && c.x <= 31u));     // lookups answered by an air leaf of the cell grid
+                    dbg_air8 += (uint32_t)__popcll(__ballot(c.x >= 7u && c.x <= 31u));     // ... of 8 voxels or more: a whole line of cells
+                    dbg_air16 += (uint32_t)__popcll(__ballot(c.x >= 15u && c.x <= 31u));
+#endif
                     bool stop = passes == 0u;
                     ref = c.x;
                     if (!stop) {
@@ -1284,6 +1289,7 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
             unsigned long long *d = &g_cells_dbg[(blockIdx.x * 4u + wave) * 8u];
             d[0] = dbg_n0; d[1] = dbg_t0; d[2] = t1; d[3] = dbg_wet | ((unsigned long long)dbg_dry << 32);
             d[4] = dbg_wet_lanes | ((unsigned long long)dbg_dry_lanes << 32); d[5] = dbg_segments;
+            d[6] = dbg_air4 | ((unsigned long long)dbg_air8 << 32); d[7] = dbg_air16;
         }
     }
 #endif
