@@ -99,17 +99,35 @@ while time.time() < t_end:
         gpu.write_chunk_roots(sc.world.chunk_roots(), tag=sc.world.roots_generation())
         gpu.render(mode, variant=variant)
         frames += 1
+        r2 = rng.random()
+        if r2 < 0.02:
+            gpu.stats()                 # folds the timing events: waits for the frames in flight
+        elif r2 < 0.03:
+            gpu.accel_info()            # brings the first table set up to date
+        elif r2 < 0.035:
+            gpu.synchronize()
     if pending:                                                    # the comparison is of the world as the host has it: all of it uploaded
         for root, n in pending:
             gpu.write_nodes(sc.world.nodes_ptr(), int(root), int(root) + int(n))
         pending.clear()
         gpu.render(mode, variant=variant)
         frames += 1
+    r3 = rng.random()
+    if r3 < 0.1:
+        gpu.stats()
+    elif r3 < 0.15:
+        gpu.accel_info()
+    shown = gpu.present((W + 32, H + 18)) if r3 > 0.9 and not devices else None
     rgb, ids, _ = gpu.read_output()
     o = orc.from_package_scene(sc)
     o.set_cam(cam)
     r_rgb, r_ids, _, _ = o.render(mode, W, H)
     checks += 1
+    if shown is not None and np.array_equal(ids, r_ids):
+        want = orc.present(rgb, (W + 32, H + 18))
+        if not np.array_equal(shown, want):
+            print(f"PRESENT MISMATCH at check {checks}: {int((shown != want).any(axis=2).sum())} pixels differ", flush=True)
+            sys.exit(1)
     if not np.array_equal(ids, r_ids) or float(np.nanmax(np.abs(rgb - r_rgb))) > 1e-4:
         print(f"MISMATCH at check {checks}, frame {frames}: {int((ids != r_ids).sum())} id words differ (mode {mode}, variant {variant})", flush=True)
         _, ids_again, _ = gpu.read_output()
