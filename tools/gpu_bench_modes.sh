@@ -18,3 +18,12 @@ import json; d=json.loads(open('gpurun_out/bench_sp_$n.json').readline()); print
 done
 # a rank that cannot reach its peers: WORLD_SIZE says 2, only rank 0 exists -> status 3 within the timeout, the rank named
 RANK=0 LOCAL_RANK=0 WORLD_SIZE=2 MASTER_ADDR=127.0.0.1 MASTER_PORT=29655 timeout -k 10 120 python bench.py --gpus 2 --rehearse-on-one-gpu --init-timeout 8 --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2> gpurun_out/bench_lonely.err; echo "lonely rank exit status $?"; tail -2 gpurun_out/bench_lonely.err
+# the driver's own launch form for N > 1 (one process per rank started by torch.distributed.run), every rank on the one GPU
+for n in 2 4; do
+  timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $((29700 + n)) bench.py --gpus $n --steps 40 --warmup 10 --rehearse-on-one-gpu --no-cpu-baseline > gpurun_out/bench_torchrun_$n.json 2> gpurun_out/bench_torchrun_$n.err || { echo "torchrun $n failed"; tail -8 gpurun_out/bench_torchrun_$n.err; exit 1; }
+  python -c "
+import json
+lines=[l for l in open('gpurun_out/bench_torchrun_$n.json') if l.startswith('{')]
+assert len(lines)==1, lines
+d=json.loads(lines[0]); print('torch.distributed.run N=$n (rehearsal):', round(d['value']), 'n_gpus', d['n_gpus'], 'ranks_seen', d['ranks_seen'], 'scaling', d['scaling'])"
+done
