@@ -949,7 +949,7 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
     // compacted — by the wave alone, no cursor, no atomic — into the same index range of the other path buffer and are the
     // wave's pool for the next.  A launch per bounce ends when its slowest wave does (221 wave-steps against 81 on average),
     // three times per frame; here a wave that is done with one segment starts the next, and the launch waits for the slowest
-    // SUM.  (The pools shrink — 256, ~150, ~90 paths — and phases A and C run their last batch partly empty.)
+    // SUM.  (The pools shrink — C4: 243, 198, 146 paths a wave — and phases A and C run their last batch partly empty.)
     // (as offsets from one pointer, so that the address of a record stays "scalar base + lane index")
     uint4 *const recs = K.path_in < K.path_out ? const_cast<uint4 *>(K.path_in) : K.path_out;
     uint32_t in_at = __builtin_amdgcn_readfirstlane((uint32_t)(K.path_in - recs));
