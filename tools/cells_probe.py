@@ -17,13 +17,17 @@ gpu.set_frames_in_flight(1)
 lib = _ffi.vrt()
 buf = np.zeros((16384, 8), dtype=np.uint64)
 lib.vrt_exp_cells_dbg.argtypes = [C.c_void_p]
+tot = np.zeros(32, dtype=np.uint64)
+lib.vrt_exp_cells_tot.argtypes = [C.c_void_p]
 for _ in range(20):
     gpu.render(MODE_PATH)
 gpu.synchronize()
 lib.vrt_exp_cells_dbg(buf.ctypes.data)
+lib.vrt_exp_cells_tot(tot.ctypes.data)
 gpu.render(MODE_PATH)
 gpu.synchronize()
 lib.vrt_exp_cells_dbg(buf.ctypes.data)
+lib.vrt_exp_cells_tot(tot.ctypes.data)
 raw = buf[buf[:, 0] > 0]
 lo = np.uint64(0xFFFFFFFF)
 n = raw[:, 0].astype(float)
@@ -43,3 +47,17 @@ print(f"lookups {wl.sum() + dl.sum():.0f}: in an air leaf of the cell grid (4 vo
 for t in np.linspace(0, e.max(), 16):
     alive = (s <= t) & (e > t)
     print(f"  t={t:6.1f} us: {int(alive.sum()):5d} waves alive")
+
+# what a lookup finds and whether the lane's previous lookup was in the same line — the misses a ray cannot avoid — under
+# today's layout (16-byte cells, a line = 8^3 voxels) and under denser ones
+t = tot.astype(float)
+L = t[0]
+pc = lambda a, b=None: f"{100 * a / (L if b is None else b):5.1f} %"
+print(f"lookups {L:.0f}; into a line the lane's previous lookup was not in: 8x8x8 {pc(t[1])}, 16x8x8 (8-byte cells) {pc(t[2])}, 16x8x16 (4-byte) {pc(t[3])}")
+print(f"  air leaves of 8 voxels or more {pc(t[4])} of the lookups, new line {pc(t[5], t[4])} of them; a byte per 8^3 voxels in lines of 64x32x32: new line {pc(t[6], t[4])}")
+print(f"  air leaves of 4 voxels {pc(t[7])}, new line {pc(t[8], t[7])}, with 16x8x8 lines {pc(t[9], t[7])}")
+print(f"  split cells {pc(t[10])}, new line {pc(t[11], t[10])}, with 16x8x8 lines {pc(t[12], t[10])}")
+print(f"  other (solid leaves, the border) {pc(t[16])}, new line {pc(t[17], max(t[16], 1))}")
+print(f"  a lane that was in a leaf of 8 or more finds something finer: {pc(t[13])} of the lookups; stays in such leaves {pc(t[18])}, of which into another coarse line {pc(t[19], max(t[18], 1))}")
+print(f"  within 32 voxels of the ray's origin {pc(t[14])}, new line {pc(t[15], max(t[14], 1))} of them")
+print(f"  distinct 128-byte lines per wave-step {t[20] / max(t[21], 1):.1f} (lanes marching {L / max(t[21], 1):.1f})")

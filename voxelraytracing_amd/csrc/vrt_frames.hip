@@ -421,7 +421,7 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
                 // (one cursor set, one swap of the path buffers per LAUNCH: g counts launches)
                 const uint32_t segments = bounces - b;
                 P.last_bounce = 1u;
-                vrt::launch_path_bounce_cells(P, c->path_refill, segments, f.st);
+                vrt::launch_path_bounce_cells(P, c->path_refill, segments, c->path_lds_pad, f.st);
                 b += segments - 1u;
             } else {
 #ifndef VRT_EXPERIMENTS
@@ -573,6 +573,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     if (const char *e = getenv("VRT_PATH_CELLS")) c->path_cells = e[0] != '0';
     if (const char *e = getenv("VRT_PATH_POOL_REFILL")) c->path_refill = (uint32_t)atoi(e);
     if (const char *e = getenv("VRT_PATH_POOL_EJECT")) c->path_eject = (uint32_t)atoi(e);
+    if (const char *e = getenv("VRT_PATH_LDS_PAD")) { const long v = strtol(e, nullptr, 10); if (v >= 0 && v <= 45000) c->path_lds_pad = (uint32_t)v; }
 #endif
     if (const char *e = getenv("VRT_PATH_SAMPLES_PER_CHAIN")) { const int v = atoi(e); if (v >= 1 && v <= 16) c->path_samples = (uint32_t)v; }
     if (const char *e = getenv("VRT_TIMING_EVERY")) { const long v = strtol(e, nullptr, 10); if (v >= 1 && v <= 1000000) c->timing_every = (uint32_t)v; }

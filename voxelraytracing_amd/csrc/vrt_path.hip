@@ -893,6 +893,16 @@ constexpr uint32_t kCellsPoolBytesPerWave = kPoolWords * 4u + kPoolEntries * 2u;
 // experiment (tools/ab build, tools/cells_probe.py): per wave of the launch {rays, start, end (100 MHz), wave-steps with rays left
 // in the pool | after it ran dry << 32, lanes marching in them likewise, segments done, -, -}
 __device__ unsigned long long g_cells_dbg[16384 * 8];
+// launch totals of the lookups by what they find and whether the lane's previous lookup was in the same 128-byte line (the
+// misses a ray cannot avoid), for this layout and for denser ones that are not built: see tools/cells_probe.py
+__device__ unsigned long long g_cells_tot[32];
+extern "C" void vrt_exp_cells_tot(unsigned long long *out) {   // read and reset
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cells_tot), sizeof(unsigned long long) * 32);
+    void *p = nullptr;
+    (void)hipGetSymbolAddress(&p, HIP_SYMBOL(g_cells_tot));
+    (void)hipMemset(p, 0, sizeof(unsigned long long) * 32);
+}
 extern "C" void vrt_exp_cells_dbg(unsigned long long *out) {   // read and reset
     (void)hipDeviceSynchronize();
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cells_dbg), sizeof(unsigned long long) * 16384 * 8);
@@ -943,6 +953,11 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
     const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
     const uint32_t dbg_n0 = n;
     uint32_t dbg_wet = 0, dbg_wet_lanes = 0, dbg_dry = 0, dbg_dry_lanes = 0, dbg_segments = 0, dbg_air4 = 0, dbg_air8 = 0, dbg_air16 = 0;
+    uint32_t dbg_tot[20], dbg_lines = 0, dbg_line_steps = 0;   // (per lane; summed at the wave's end)
+    for (int q = 0; q < 20; q++) dbg_tot[q] = 0;
+    // per lane: the previous lookup's lines under the layouts compared, its class, and the ray's origin voxel
+    uint32_t dbg_l8 = ~0u, dbg_l16 = ~0u, dbg_lc = ~0u, dbg_l4 = ~0u, dbg_prev_big = 0u;
+    int dbg_ox = 0, dbg_oy = 0, dbg_oz = 0;
 #endif
     const uint32_t base = __builtin_amdgcn_readfirstlane(seg * K.in_seg_cap + wg_begin + wave * per);
     // The wave keeps its paths for ALL the segments that are left (`segments` of them): the survivors of one segment are
@@ -1040,6 +1055,9 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
                 park();
             }
             vx = trunc2i(pos.x); vy = trunc2i(pos.y); vz = trunc2i(pos.z);
+#ifdef VRT_EXP_CELLDBG
+            dbg_l8 = dbg_l16 = dbg_lc = dbg_l4 = ~0u; dbg_prev_big = 0u; dbg_ox = vx; dbg_oy = vy; dbg_oz = vz;
+#endif
 #ifdef VRT_EXP_NOMARCH   // counting experiment: every ray ends where it starts
             if (marching) { marching = false; park(); }
 #endif
@@ -1165,6 +1183,38 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
                     dbg_air4 += (uint32_t)__popcll(__ballot(c.x >= 3u && c.x <= 31u));     // lookups answered by an air leaf of the cell grid
                     dbg_air8 += (uint32_t)__popcll(__ballot(c.x >= 7u && c.x <= 31u));     // ... of 8 voxels or more: a whole line of cells
                     dbg_air16 += (uint32_t)__popcll(__ballot(c.x >= 15u && c.x <= 31u));
+                    {
+                        auto cnt = [&](int q, bool b) __attribute__((always_inline)) { dbg_tot[q] += b ? 1u : 0u; };
+                        const uint32_t X = (uint32_t)(vx + 64), Y = (uint32_t)(vy + 64), Z = (uint32_t)(vz + 64);   // (coordinates -1 .. size)
+                        const uint32_t l8 = ((Z >> 3) << 20) | ((Y >> 3) << 10) | (X >> 3);        // today's line: 8 x 8 x 8 voxels
+                        const uint32_t l16 = ((Z >> 3) << 20) | ((Y >> 3) << 10) | (X >> 4);       // 8-byte cells: 16 x 8 x 8
+                        const uint32_t l4 = ((Z >> 4) << 20) | ((Y >> 3) << 10) | (X >> 4);        // (4-byte cells: 16 x 8 x 16)
+                        const uint32_t lc = ((Z >> 5) << 20) | ((Y >> 5) << 10) | (X >> 6);        // a byte per 8^3 voxels: 64 x 32 x 32
+                        const bool big = c.x >= 7u && c.x <= 31u, air4 = c.x == 3u, split = (int)c.x < 0;
+                        const bool n8 = l8 != dbg_l8, n16 = l16 != dbg_l16, n4 = l4 != dbg_l4, nc = lc != dbg_lc;
+                        const bool near = max(max(abs(vx - dbg_ox), abs(vy - dbg_oy)), abs(vz - dbg_oz)) < 32;
+                        cnt(0, true); cnt(1, n8); cnt(2, n16); cnt(3, n4);
+                        cnt(4, big); cnt(5, big && n8); cnt(6, big && nc);
+                        cnt(7, air4); cnt(8, air4 && n8); cnt(9, air4 && n16);
+                        cnt(10, split); cnt(11, split && n8); cnt(12, split && n16);
+                        cnt(13, !big && dbg_prev_big != 0u);            // a lane that was cruising in leaves of 8 or more finds something finer
+                        cnt(14, near); cnt(15, near && n8);
+                        cnt(16, !big && !air4 && !split); cnt(17, !big && !air4 && !split && n8);   // solid leaves of the grid, the border
+                        cnt(18, big && dbg_prev_big != 0u);             // cruising goes on
+                        cnt(19, big && dbg_prev_big != 0u && nc);       // ... into another line of the coarse table
+                        // distinct lines among the wave's marching lanes in this wave-step (a leader loop over the first lanes' lines)
+                        {
+                            unsigned long long todo = __ballot(true);
+                            uint32_t lines = 0;
+                            while (todo) {
+                                const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)l8, (int)__builtin_ctzll(todo));
+                                todo &= ~__ballot(l8 == first);
+                                lines++;
+                            }
+                            dbg_lines += lines; dbg_line_steps += 1u;
+                        }
+                        dbg_l8 = l8; dbg_l16 = l16; dbg_l4 = l4; dbg_lc = lc; dbg_prev_big = big ? 1u : 0u;
+                    }
 #endif
                     bool stop = passes == 0u;
                     ref = c.x;
@@ -1291,6 +1341,12 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
             d[4] = dbg_wet_lanes | ((unsigned long long)dbg_dry_lanes << 32); d[5] = dbg_segments;
             d[6] = dbg_air4 | ((unsigned long long)dbg_air8 << 32); d[7] = dbg_air16;
         }
+#pragma unroll
+        for (int q = 0; q < 20; q++) {
+            const unsigned long long sum = wave_sum((unsigned long long)dbg_tot[q]);
+            if (lane == 0) atomicAdd(&g_cells_tot[q], sum);
+        }
+        if (lane == 0) { atomicAdd(&g_cells_tot[20], (unsigned long long)dbg_lines); atomicAdd(&g_cells_tot[21], (unsigned long long)dbg_line_steps); }
     }
 #endif
     if (left == 1u || n_out == 0u) break;
@@ -1560,12 +1616,12 @@ void launch_path_bounce_pool(const FrameParams &P, bool continuations, uint32_t 
 
 // the pool kernel over the march cells (P.mblk): `segments` bounce segments in this one launch (every wave carries its own
 // survivors from one to the next; P.path_in / P.path_out are the two buffers it goes back and forth between)
-void launch_path_bounce_cells(const FrameParams &P, uint32_t refill_at, uint32_t segments, hipStream_t st) {
+void launch_path_bounce_cells(const FrameParams &P, uint32_t refill_at, uint32_t segments, uint32_t lds_pad, hipStream_t st) {
     if (P.tiles_local == 0 || segments == 0) return;
     const uint32_t refill = refill_at >= 1u && refill_at <= 64u ? refill_at : kPoolRefillAt;
     const uint32_t parts = (P.in_seg_cap + 4u * kPoolEntries - 1u) / (4u * kPoolEntries);
     const dim3 grid(kHitSegments * parts), block(256);
-    const size_t sh = 8u * 4u + 4u * kCellsPoolBytesPerWave;
+    const size_t sh = 8u * 4u + 4u * kCellsPoolBytesPerWave + lds_pad;   // (lds_pad: the occupancy sweep of profiles/r04_path_occupancy_sweep.txt)
     const CellsLaunch L{P, refill, segments};
     if (P.march_direct) hipLaunchKernelGGL(path_bounce_cells_kernel<true>, grid, block, sh, st, L);
     else hipLaunchKernelGGL(path_bounce_cells_kernel<false>, grid, block, sh, st, L);
