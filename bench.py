@@ -439,6 +439,8 @@ def main():
             extras["value_1_in_flight"] = rays_fixed * args.steps / d1 / 1e6
             extras["ms_per_step_1_in_flight"] = d1 / args.steps * 1e3
             extras["avg_launch_ms_1_in_flight"] = k1.sum_ms_primary / max(k1.frames, 1)
+            if MODE == MODE_PATH:   # per frame: the primary launch(es) and the bounce launch(es), each alone on the GPU
+                extras["avg_bounce_launches_ms_1_in_flight"] = k1.sum_ms_secondary / max(k1.frames, 1)
             if not fixed:
                 # ... and what a host that renders one moving-camera frame at a time gets: the orbit, the whole seam per frame,
                 # screen order (a tile order made for another view is worse than none)
@@ -459,6 +461,59 @@ def main():
             cs = gpu.stats()
             if cs.clock_ref_ticks:
                 extras["shader_clock_ghz"] = cs.clock_shader_ticks / cs.clock_ref_ticks * 0.1   # x 100 MHz
+
+    # ---- the client's real frame (main.rs:199, 426-454), off the headline clock: a 30^3-chunk grid around the player with a
+    # world.min of mixed sign, the UNTAGGED chunk_roots rewrite of a fresh table every frame (main.rs:446: 27 000 entries), the
+    # dispatch and the blit into the window's image (vrt_present_device, main.rs:454) — one and two frames in flight ----
+    operating_point = None
+    if world == 1 and not sharded and not devices and not args.no_extras and args.mode == "shadow" and args.variant == 0 and not fixed:
+        from voxelraytracing_amd.world import ClientWorld, gen_height
+        S_OP, player = 30, (7, -3, 11)
+        w_op = ClientWorld(player, 1 << 27, S_OP)
+        w_op.generate(0, 1)
+        px, pz = player[0] * 32 + 16, player[2] * 32 + 16
+        eye_op = (px + 0.5, float(gen_height(1, px, pz)) + 24.5, pz + 0.5)
+        gp = Gpu(w_op.max_nodes(), S_OP, (args.width, args.height), device=local_rank)
+        gp.upload_world(w_op, sc.materials)
+        gp.write_settings(sc.settings)
+        wd_op = w_op.world_data()
+        cams_op = []
+        for k in range(ORBIT):
+            a = 2.0 * math.pi * k / ORBIT
+            cams_op.append(g.cam_data_create((20.0 + 3.0 * math.sin(a), 35.0 + 8.0 * math.sin(a), 0.0),
+                                             (eye_op[0] + 6.0 * math.cos(a), eye_op[1] + 1.5 * math.sin(2 * a), eye_op[2] + 6.0 * math.sin(a)),
+                                             70.0, (float(args.width), float(args.height))))
+        rays_op = []
+        for cam in cams_op:
+            gp.write_cam_data(cam)
+            gp.render(MODE, stats=True)
+            s_ = gp.stats()
+            rays_op.append(s_.primary_rays + s_.secondary_rays)
+
+        def client_frames(n):
+            for i in range(n):
+                gp.write_settings(sc.settings)                       # main.rs:428
+                gp.write_cam_data(cams_op[i % ORBIT])                # :439
+                gp.write_chunk_roots(w_op.chunk_roots())             # :446 — a fresh table, no tag: the backend compares 27 000 roots
+                gp.write_world_data(wd_op)                           # :447-449
+                gp.render(MODE)                                      # :452-453
+                gp.present_device((args.width, args.height))         # :454
+        operating_point = {"world": f"{S_OP}^3 chunks around player chunk {player} (main.rs:199), world.min {tuple(w_op.min_voxel())}, "
+                                    f"{w_op.populated_count()} chunks with nodes", "frames": 400,
+                           "per_frame": "vrt_set_settings, vrt_set_camera, vrt_write_chunk_roots (untagged, a fresh 27 000-entry table), vrt_set_world, "
+                                        "vrt_render (primary + shadow), vrt_present_device at the frame's size"}
+        for nf in (1, 2):
+            gp.set_frames_in_flight(nf)
+            client_frames(100)
+            gp.synchronize()
+            t0 = time.perf_counter()
+            client_frames(400)
+            t_host = time.perf_counter() - t0
+            gp.synchronize()
+            t_all = time.perf_counter() - t0
+            operating_point[f"{nf}_in_flight"] = {"ms_per_frame": t_all / 400 * 1e3, "host_us_per_frame": t_host / 400 * 1e6,
+                                                  "value": sum(rays_op[i % ORBIT] for i in range(400)) / t_all / 1e6, "unit": "Mrays/s"}
+        gp.close()
 
     if sharded and rank == 0 and os.environ.get("VRT_BENCH_VERIFY", "1") == "1":
         # off the clock: the assembled frame must equal an unsharded render of the same frame on this GPU
@@ -505,21 +560,22 @@ def main():
     else:
         dom_name, dom_bytes, dom_ms = ("primary_march", b_primary, ms_p) if ms_p >= ms_s else ("shadow_march", b_shadow, ms_s)
     period_s = dt / args.steps
-    in_flight = args.frames_in_flight if (world == 1 and not sharded and not devices and (fused or args.mode == "primary")) else 1
+    in_flight = args.frames_in_flight if (world == 1 and not sharded and not devices and (fused or args.mode in ("primary", "path"))) else 1
 
     # ---- what bounds the dominant kernel: instruction issue.  Counters come from profiles/traffic_latest.json, which the
     # PMC tool stamps with the code object and the workload it measured; they are printed only for that very build and workload
     code = _ffi.code_object_sha256()
-    workload_key = f"{args.mode}:{args.chunks}:{args.width}x{args.height}:v{args.variant}"
-    pmc, pmc_note = None, None
+    workload_key = f"{args.mode}:{args.chunks}:{args.width}x{args.height}:v{args.variant}" + (f":{args.spp}spp:{args.bounces}b" if args.mode == "path" else "")
+    pmc, pmc_all, pmc_note = None, {}, None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
         if tj.get("code_object_sha256") != code:
             pmc_note = "profiles/traffic_latest.json was collected on another build of the kernels (code-object hash differs): not printed"
-        elif tj.get("workload") != workload_key:
-            pmc_note = f"profiles/traffic_latest.json holds workload {tj.get('workload')}, this run is {workload_key}: not printed"
+        elif workload_key not in tj.get("workloads", {}):
+            pmc_note = f"profiles/traffic_latest.json holds the workloads {sorted(tj.get('workloads', {}))}, this run is {workload_key}: not printed"
         else:
-            pmc = tj.get("kernels", {}).get(dom_name)
+            pmc_all = tj["workloads"][workload_key].get("kernels", {})
+            pmc = pmc_all.get(dom_name)
     except Exception as e:
         pmc_note = f"profiles/traffic_latest.json unreadable: {e}"
     clock_ghz = extras.get("shader_clock_ghz")
@@ -534,42 +590,51 @@ def main():
             "kernels_ms": ({"primary_shadow_march": ms_p} if fused else
                            {"path_primary_march": ms_p, "path_bounce_marches": ms_s} if args.mode == "path" else
                            {"primary_march": ms_p, "shadow_march": ms_s}),
-            "frames_timed": kst.frames, "code_object_sha256": code}
+            "frames_timed": kst.frames, "code_object_sha256": code, "workload_key": workload_key}
     if pmc_note:
         roof["pmc_note"] = pmc_note
-    if pmc and world == 1 and not sharded and not devices:
+
+    def class_bracket(cnt, n_valu):
+        """SIMD cycles a launch's VALU instructions need, bracketed by its own class counters (tools/pmc.sh group 3): f32 add /
+        mul / fma are full rate (2 cycles), conversions half rate (4), transcendentals 8; the integer class and what no counter
+        names (compares, selects, min / max, moves) hold full- and half-rate instructions alike: priced at 2 and at 4."""
+        need = ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_CVT")
+        if not all(k in cnt for k in need):
+            return None
+        full = cnt["SQ_INSTS_VALU_ADD_F32"] + cnt["SQ_INSTS_VALU_MUL_F32"] + cnt["SQ_INSTS_VALU_FMA_F32"]
+        known = 2.0 * full + 4.0 * cnt["SQ_INSTS_VALU_CVT"] + 8.0 * cnt["SQ_INSTS_VALU_TRANS_F32"]
+        rest = n_valu - full - cnt["SQ_INSTS_VALU_CVT"] - cnt["SQ_INSTS_VALU_TRANS_F32"]
+        return known + 2.0 * rest, known + 4.0 * rest, rest
+
+    if pmc and world == 1 and not sharded and not devices and args.mode != "path":
         n_valu, n_salu = pmc["valu_wave_instructions"], pmc.get("salu_wave_instructions")
+        # The counters are of the STANDING camera's frame (tools/pmc.sh), so `achieved` / `frac` divide by that frame's period
+        # when this run measured it (the fixed-camera leg, or --fixed-camera); the headline leg's own period — an orbit frame
+        # launches 0.5 % more rays on average: config.rays_per_frame_* — gives the *_headline_period pair.
         period_fixed = (extras.get("ms_per_step_fixed_camera", period_s * 1e3) if not fixed else period_s * 1e3) * 1e-3
-        # the headline leg's own period (ms_per_step); the counters are of the standing camera's frame, whose period gives the
-        # second figure (an orbit frame launches 0.5 % more rays on average: config.rays_per_frame_*)
-        roof["achieved"] = n_valu / period_s / 1e9
+        roof["achieved"] = n_valu / period_fixed / 1e9
         roof["frac"] = roof["achieved"] / roof["peak"]
-        roof["achieved_fixed_camera"] = n_valu / period_fixed / 1e9
-        roof["frac_fixed_camera"] = roof["achieved_fixed_camera"] / roof["peak"]
-        roof["frac_note"] = ("instructions per second over the peak at 2 cycles per wave-instruction: removing instructions lowers it; "
-                             "class_weighted.frac (each class at its issue time) says how full the VALU pipes are")
+        roof["achieved_headline_period"] = n_valu / period_s / 1e9
+        roof["frac_headline_period"] = roof["achieved_headline_period"] / roof["peak"]
+        roof["frac_note"] = ("instructions per second over the peak at 2 cycles per wave-instruction, on the period of the frame the counters "
+                             "are of (standing camera); removing instructions lowers it; class_weighted.frac (each class at its issue time) "
+                             "says how full the VALU pipes are")
         roof["traffic"] = pmc["hbm_bytes"]
         roof["valu_wave_instructions_per_launch"] = n_valu
         roof["salu_wave_instructions_per_launch"] = n_salu
-        roof["period_used_ms"] = period_s * 1e3
-        roof["period_fixed_camera_ms"] = period_fixed * 1e3
+        roof["period_used_ms"] = period_fixed * 1e3
+        roof["period_headline_ms"] = period_s * 1e3
         # the same with every class at its measured issue cost (tools/valu_rates.hip): SIMD cycles the launch's
         # instructions need / SIMD cycles the frame period offers
         nominal, cls = pmc.get("valu_issue_cycles_by_class_nominal"), pmc.get("issue_cycles_by_class")
         if nominal and cls:
-            avail = N_SIMD * peak_clock * 1e9 * period_s
+            avail = N_SIMD * peak_clock * 1e9 * period_fixed
             valu_measured = sum(v for k, v in cls.items() if k.startswith("valu"))
-            # the model against the launch's own class counters (tools/pmc.sh group 3): f32 add / mul / fma are full rate (2
-            # cycles), conversions half rate (4), transcendentals 8; the integer class and what no counter names (compares,
-            # selects, min / max, moves) hold full- and half-rate instructions alike: priced at 2 and at 4 they bracket the truth
-            cnt = pmc.get("counters", {})
+            br = class_bracket(pmc.get("counters", {}), n_valu)
             check = None
-            if all(k in cnt for k in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32",
-                                      "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_CVT")):
-                full = cnt["SQ_INSTS_VALU_ADD_F32"] + cnt["SQ_INSTS_VALU_MUL_F32"] + cnt["SQ_INSTS_VALU_FMA_F32"]
-                known = 2.0 * full + 4.0 * cnt["SQ_INSTS_VALU_CVT"] + 8.0 * cnt["SQ_INSTS_VALU_TRANS_F32"]
-                rest = n_valu - full - cnt["SQ_INSTS_VALU_CVT"] - cnt["SQ_INSTS_VALU_TRANS_F32"]
-                lo_c, hi_c, model_c = known + 2.0 * rest, known + 4.0 * rest, sum(nominal.values())
+            if br:
+                lo_c, hi_c, rest = br
+                model_c = sum(nominal.values())
                 check = {"cycles_lower": lo_c, "cycles_upper": hi_c, "cycles_model": model_c,
                          "model_inside_bracket": bool(lo_c <= model_c <= hi_c),
                          "residual_vs_bracket_midpoint": model_c / (0.5 * (lo_c + hi_c)) - 1.0,
@@ -585,6 +650,38 @@ def main():
                 "valu_issue_cycles_per_launch_at_measured_costs": valu_measured, "frac_at_measured_costs": valu_measured / avail,
                 "salu_unit_cycles_per_launch_at_measured_cost": cls.get("salu"),
                 "note": "the scalar unit is shared by a CU's four SIMDs and issues beside the VALU; its cycles are not additive"}
+    elif pmc and world == 1 and not sharded and not devices:
+        # The path trace: a frame is the primary launch(es) + the bounce launch(es) (a chain per 8 samples).  `achieved` is the
+        # dominant kernel's VALU wave-instructions of a frame over the time its launches take ALONE on the GPU — the one-frame-
+        # at-a-time leg of this run when it ran (with two frames in flight a launch's own begin-to-end time holds the other
+        # frame's work too) — and `frame` the same for everything a frame launches over the frame period.
+        lone_ms = (extras.get("avg_bounce_launches_ms_1_in_flight") if dom_name == "path_bounce_marches" else extras.get("avg_launch_ms_1_in_flight")) or dom_ms
+        per_frame = lambda k, what: (pmc_all[k][what] or 0.0) * pmc_all[k].get("launches_per_frame", 1.0)   # noqa: E731
+        n_valu = per_frame(dom_name, "valu_wave_instructions")
+        roof["achieved"] = n_valu / (lone_ms * 1e-3) / 1e9
+        roof["frac"] = roof["achieved"] / roof["peak"]
+        roof["lone_launches_ms_per_frame"] = lone_ms
+        roof["lone_launch_source"] = "the one-frame-at-a-time leg of this run" if lone_ms != dom_ms else "the timed frames' own launch durations (no one-at-a-time leg in this run)"
+        roof["launches_per_frame"] = {k: v.get("launches_per_frame", 1.0) for k, v in pmc_all.items()}
+        roof["valu_wave_instructions_per_launch"] = pmc["valu_wave_instructions"]
+        roof["salu_wave_instructions_per_launch"] = pmc.get("salu_wave_instructions")
+        roof["traffic"] = pmc["hbm_bytes"]
+        roof["traffic_per_frame"] = sum(per_frame(k, "hbm_bytes") for k in pmc_all)
+        all_valu = sum(per_frame(k, "valu_wave_instructions") for k in pmc_all)
+        roof["frame"] = {"valu_wave_instructions": all_valu, "achieved": all_valu / period_s / 1e9, "frac": all_valu / period_s / 1e9 / roof["peak"],
+                         "note": "every launch of a frame over the frame period (frames in flight overlap)"}
+        br = class_bracket(pmc.get("counters", {}), pmc["valu_wave_instructions"])
+        if br:
+            avail = N_SIMD * peak_clock * 1e9 * lone_ms * 1e-3 / max(pmc.get("launches_per_frame", 1.0), 1e-9)
+            roof["class_weighted"] = {"cycles_lower": br[0], "cycles_upper": br[1], "simd_cycles_available": avail,
+                                      "frac_lower": br[0] / avail, "frac_upper": br[1] / avail, "frac": 0.5 * (br[0] + br[1]) / avail,
+                                      "note": "the launch's own class counters: f32 add / mul / fma at 2 cycles, conversions 4, transcendentals 8, the rest "
+                                              "(integer class, compares, selects, moves) at 2 and at 4: a bracket, `frac` its midpoint"}
+        c = pmc.get("counters", {})
+        if c.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
+            roof["l1"] = {"line_accesses": c["TCP_TOTAL_CACHE_ACCESSES_sum"], "requests_to_l2": c.get("TCP_TCC_READ_REQ_sum"),
+                          "hit_rate": 1.0 - c.get("TCP_TCC_READ_REQ_sum", 0.0) / c["TCP_TOTAL_CACHE_ACCESSES_sum"],
+                          "lane_utilisation_valu": (c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"] / 64.0) if c.get("SQ_ACTIVE_INST_VALU") else None}
     # §8(d)'s algorithmic bytes stay as a secondary object; a fraction above 1 says the kernel does not move those bytes
     # (the derived tables answer from L1 / L2); `measured_hbm` is what the PMC passes saw
     hbm = {"algorithmic_bytes_per_launch": dom_bytes, "algorithmic_gbs_at_frame_period": dom_bytes / period_s / 1e9,
@@ -620,7 +717,9 @@ def main():
         "config": {"workload": f"{'C2' if (args.chunks, args.width, args.height) == (8, 1920, 1080) else 'C3' if (args.chunks, args.width, args.height) == (16, 1920, 1080) else 'C2-family'}: "
                                f"{args.width}x{args.height} frame, {args.chunks}x{args.chunks}x{args.chunks}-chunk procedural SVO "
                                f"world (seed 1), 1 primary + 1 shadow ray per solid hit",
-                   "camera": "standing" if fixed else f"orbit of {ORBIT} positions (6-voxel circle, +-8 degrees), the whole per-frame seam of main.rs:426-453 issued every frame",
+                   "camera": "standing" if fixed else f"orbit of {ORBIT} positions (6-voxel circle, +-8 degrees), the per-frame seam of main.rs:426-453 issued every frame "
+                             "(settings, camera, chunk_roots, world data, dispatch) with the chunk_roots rewrite through vrt_write_chunk_roots_tagged — the mirror's "
+                             "table generation as the tag; the untagged rewrite at the client's own 30^3 chunks, with the blit, is the `operating_point` object",
                    "rays_per_frame_actual": rays_fixed if fixed else float(np.mean(orbit_rays)), "rays_per_frame_nominal": 2 * args.width * args.height,
                    "rays_per_frame_fixed_camera": rays_fixed,
                    "sharding": ("whole frame" if not sharded else "whole frame through the one-rank gather pipeline") if (world == 1 and not devices) else
@@ -638,6 +737,8 @@ def main():
         "hbm": hbm,
     }
     out.update(extras)
+    if operating_point:
+        out["operating_point"] = operating_point
     if args.mode != "shadow":
         out["metric"] = f"Mrays/s at {args.width}x{args.height}, mode {args.mode}" + (f" {args.bounces} bounces {args.spp} spp" if args.mode == "path" else "")
         out["config"]["workload"] = out["config"]["workload"].replace("C2:", "non-headline:").replace("1 primary + 1 shadow ray per solid hit", f"mode {args.mode}")

@@ -271,9 +271,11 @@ int vrt_read_output(vrt_ctx *ctx, float *rgb, uint32_t *ids, uint8_t *rgba8);
  * with the crosshair, written as unorm8 RGBA, screen_w*screen_h*4 bytes (synchronises).  Whole-frame contexts only. */
 int vrt_present(vrt_ctx *ctx, const vrt_crosshair *crosshair, uint32_t screen_w, uint32_t screen_h, uint8_t *rgba8);
 
-/* The same, left on the device: *rgba8_device points at screen_w*screen_h*4 bytes of the context's own screen buffer,
- * valid until the next vrt_present / vrt_present_device / vrt_destroy; the blit is enqueued on the context's stream
- * (vrt_set_stream) and nothing is copied to the host — for a host that hands the image to its window system through GPU
+/* The same, left on the device, and asynchronous: the blit is enqueued behind the frame it presents, on that frame's stream
+ * (the caller's after vrt_set_stream), so a host that draws and presents frame after frame (main.rs:452-454) keeps its
+ * frames in flight — nothing is copied to the host and nothing waits.  *rgba8_device points at screen_w*screen_h*4 bytes of
+ * the screen buffer of the frame's set: valid until the present of the frame vrt_set_frames_in_flight frames later (the
+ * next one with one frame in flight) or vrt_destroy.  For a host that hands the image to its window system through GPU
  * interop (a 1080p frame is 8 MB of PCIe traffic otherwise).  vrt_synchronize before reading it from another stream. */
 int vrt_present_device(vrt_ctx *ctx, const vrt_crosshair *crosshair, uint32_t screen_w, uint32_t screen_h, void **rgba8_device,
                        uint64_t *bytes);

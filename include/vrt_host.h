@@ -53,9 +53,12 @@ uint32_t vrth_world_max_nodes(const vrth_world *w);
 
 /* ChunkGrid::chunk_roots — world.rs:154-159. Writes min(cap, S^3) entries, returns S^3. */
 uint32_t vrth_world_chunk_roots(const vrth_world *w, uint32_t *out, uint32_t cap);
-/* The table itself (S^3 entries; valid until the grid next changes) and a number that changes whenever its contents may
- * have: the tag of vrt_write_chunk_roots_tagged, which lets the per-frame rewrite of an unchanged table (main.rs:446) cost
- * nothing.  (The mirror keeps the table; the reference builds a fresh Vec per frame.) */
+/* The table itself (S^3 entries) and a number that changes whenever its contents may have: the tag of
+ * vrt_write_chunk_roots_tagged, which lets the per-frame rewrite of an unchanged table (main.rs:446) cost nothing.  (The mirror
+ * keeps the table up to date inside the calls that change the grid; the reference builds a fresh Vec per frame.)
+ * Lifetime: the pointer stays valid until vrth_world_resize (which replaces the grid); the entries change under it with
+ * every create_chunk / chunk message / center_chunks, and the generation with them.  Threading: a world belongs to one
+ * thread at a time, as the reference's ClientWorld does (main.rs: everything on the event-loop thread) — nothing here locks. */
 const uint32_t *vrth_world_chunk_roots_ptr(const vrth_world *w);
 uint64_t vrth_world_chunk_roots_generation(const vrth_world *w);
 

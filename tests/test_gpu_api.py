@@ -216,6 +216,38 @@ def test_present_quantise_and_crosshair_blit(orc):
         gpu.present((0, 36))
 
 
+@pytest.mark.parametrize("in_flight", [1, 2, 3])
+def test_present_device_follows_its_frame_without_waiting(orc, in_flight):
+    """vrt_present_device enqueues the blit behind the frame it presents, on that frame's stream, into the screen buffer of
+    the frame's set: a draw + present loop (main.rs:452-454) keeps its frames in flight, and each of the last `in_flight`
+    images is still there after a synchronise."""
+    from voxelraytracing_amd import _ffi
+    sc = scenes.c2((160, 96))
+    gpu = gpu_for_scene(sc)
+    gpu.set_frames_in_flight(in_flight)
+    cams = [g.cam_data_create((20.0 + 9 * k, 35.0 + 50 * k, 0.0), (sc.eye[0] + 2 * k, sc.eye[1] + k, sc.eye[2] - k), 70.0, (160.0, 96.0)) for k in range(5)]
+    want = []
+    for cam in cams:                          # the synchronous present of every frame
+        gpu.write_cam_data(cam)
+        gpu.render(MODE_PRIMARY_SHADOW)
+        want.append(gpu.present((200, 120)))
+    assert any(not np.array_equal(want[0], w) for w in want[1:])
+    ptrs = []
+    for cam in cams:                          # the loop of the client: draw, present, next frame — no wait in between
+        gpu.write_cam_data(cam)
+        gpu.render(MODE_PRIMARY_SHADOW)
+        ptrs.append(gpu.present_device((200, 120)))
+    gpu.synchronize()
+    assert len({p for p, _ in ptrs[-in_flight:]}) == in_flight, "the frames in flight share a screen buffer"
+    hip_memcpy = _ffi.vrt().hipMemcpy
+    hip_memcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    for k in range(len(cams) - in_flight, len(cams)):
+        ptr, nbytes = ptrs[k]
+        host = np.empty(nbytes, dtype=np.uint8)
+        assert nbytes == 200 * 120 * 4 and hip_memcpy(host.ctypes.data, ptr, nbytes, 2) == 0
+        assert np.array_equal(host.reshape(120, 200, 4), want[k]), f"frame {k} of {len(cams)}, {in_flight} in flight"
+
+
 @pytest.mark.parametrize("in_flight", [1, 2, 3, 4])
 def test_frames_in_flight_keep_frames_apart(orc, in_flight):
     """Back-to-back vrt_render calls with different cameras and no synchronisation in between: every read-back is the
@@ -278,6 +310,71 @@ def test_a_frame_stays_announced_when_the_event_pool_is_folded(orc, in_flight, m
         if i >= 500:
             _, ids, _ = gpu.read_output()
             assert np.array_equal(ids, refs[k]), f"frame {i}: {int((ids != refs[k]).sum())} id words of another frame"
+
+
+def test_an_edit_behind_the_fold_frame_waits_for_the_frame_that_reads_the_shared_tables(orc, monkeypatch):
+    """With two frames in flight and no edit for a while both frame sets read table set 0.  A frame of the second set that
+    falls on the fold of the timing-event pool (every 512 timed frames: a drain between picking the frame's stream and
+    enqueueing it) must still count as a reader of set 0 afterwards: an edit right behind it makes the next frame rebuild
+    the edited chunk IN set 0, and without the reader's flag that rebuild ran beside the frame still marching over the
+    tables (round 3's advisor finding).  The fold frame here is a long one — a 16-sample path trace — and is read out of its
+    own buffer after the edit's frame: it must be the oracle's frame of the world BEFORE the edit."""
+    from voxelraytracing_amd import _ffi
+    monkeypatch.setenv("VRT_TIMING_EVERY", "1")
+    W, H = 640, 360
+    sc = scenes.c4((W, H))
+    gpu = gpu_for_scene(sc)
+    gpu.set_frames_in_flight(2)
+    o = orc.from_package_scene(sc)
+    r_rgb, r_ids, _, _ = o.render(orc.MODE_PATH, W, H, spp=16, seed=5)     # the world before the edit
+    gpu.render(MODE_PRIMARY)
+    gpu.stats()                                  # folds the pool here, so that the next fold falls on a frame of the second set
+    for i in range(512):
+        gpu.render(MODE_PRIMARY)                 # (no edits: the table sets stay merged)
+    gpu.render(MODE_PATH, spp=16, seed=5)        # timed frame 513 since the fold: the pool is folded inside this call
+    ptr, nbytes = gpu.device_output()
+    # a plate of limestone a few voxels in front of the camera (a chunk's range uploaded once), then the next frame
+    ex, ey, ez = (int(v) for v in sc.eye)
+    ranges = {}
+    for dx in range(-5, 2):
+        for dy in range(-4, 3):
+            start, n = sc.world.set_voxel((ex + dx, ey + dy, ez - 3), 4)
+            ranges[start] = n
+    for start, n in ranges.items():
+        gpu.write_nodes(sc.world.nodes_ptr(), start, start + n)
+    gpu.render(MODE_PRIMARY)
+    p2, _ = gpu.device_output()
+    assert p2 != ptr, "the edit's frame went to the fold frame's buffer: the frames did not alternate as this test assumes"
+    gpu.synchronize()
+    host = np.zeros(nbytes // 4, dtype=np.uint32)
+    hip_memcpy = _ffi.vrt().hipMemcpy
+    hip_memcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    assert hip_memcpy(host.ctypes.data, ptr, nbytes, 2) == 0    # hipMemcpyDeviceToHost
+    t = host.reshape(H, W, 4)
+    assert_frame_parity(t[..., :3].copy().view(np.float32), t[..., 3], r_rgb, r_ids, "the fold frame, read after the edit's frame")
+    # and the edit itself arrived
+    _, ids, _ = gpu.read_output()
+    o2 = orc.from_package_scene(sc)
+    _, e_ids, _, _ = o2.render(orc.MODE_PRIMARY, W, H)
+    assert np.array_equal(ids, e_ids) and int((e_ids != r_ids).sum()) > 2000
+
+
+def test_staged_node_writes_survive_a_lap_of_the_upload_ring(orc):
+    """vrt_write_nodes stages its bytes in the pinned ring until the next frame; uploads that are not staged (the material
+    table: 8 KB a call) share the ring.  More than a lap of them (8 MiB) between the edit and its frame must not write over
+    the staged range: the ring flushes what a segment still holds before it reuses the segment."""
+    sc = scenes.c2((160, 96))
+    gpu = gpu_for_scene(sc)
+    gpu.render(MODE_PRIMARY)
+    ex, ey, ez = (int(v) for v in sc.eye)
+    start, n = sc.world.set_voxel((ex - 2, ey - 1, ez - 3), 4)
+    gpu.write_nodes(sc.world.nodes_ptr(), start, start + n)
+    for _ in range(1100):                      # 1100 x 8 KB: the ring's eight segments and a bit
+        gpu.write_materials(sc.materials)
+    gpu.render(MODE_PRIMARY)
+    rgb, ids, _ = gpu.read_output()
+    r_rgb, r_ids, _, _ = orc.from_package_scene(sc).render(orc.MODE_PRIMARY, 160, 96)
+    assert_frame_parity(rgb, ids, r_rgb, r_ids, "the edit's frame after a lap of the ring")
 
 
 def test_render_on_own_streams_with_a_caller_stream_and_bound_outputs(orc):

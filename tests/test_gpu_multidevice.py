@@ -114,6 +114,39 @@ def test_group_follows_edits_uploads_and_resizes(orc):
     one.close()
 
 
+@pytest.mark.parametrize("threads", ["0", "1"])
+def test_group_is_consistent_after_a_frame_that_failed_on_a_shard(c2_small, threads, monkeypatch):
+    """A frame that one device refuses — here the step-count view, which 8-byte records cannot carry — has taken a message
+    slot and may have been enqueued on other devices: the group drains and starts over, and the frames after the error
+    are the single-device frames again (round 3's advisor finding: the slot's `consumed` event was never recorded)."""
+    monkeypatch.setenv("VRT_GROUP_THREADS", threads)
+    sc = c2_small
+    w, h = sc.size
+    cams = [g.cam_data_create((18.0 + 9 * k, 30.0 + 41 * k, 0.0), (sc.eye[0] + k, sc.eye[1], sc.eye[2] - k), 70.0, (float(w), float(h))) for k in range(4)]
+    want, _ = reference_frames(sc, cams, MODE_PRIMARY_SHADOW)
+    grp = gpu_for_scene(sc, devices=[0, 0, 0])
+    grp.write_cam_data(cams[0])
+    grp.render(MODE_PRIMARY_SHADOW)                # slot 0 in use
+    debug = g.make_settings(sun_pos=scenes.SUN_POS)
+    debug.show_step_count = 1
+    grp.write_settings(debug)
+    for _ in range(3):                             # an odd number of failures: the slot sequence would be out of step
+        with pytest.raises(g.VrtError):
+            grp.render(MODE_PRIMARY_SHADOW)
+    grp.write_settings(sc.settings)
+    for k, cam in enumerate(cams):                 # back to back, both slots
+        grp.write_cam_data(cam)
+        grp.render(MODE_PRIMARY_SHADOW)
+    rgb, ids, _ = grp.read_output()
+    assert np.array_equal(ids, want[3][1]) and np.array_equal(rgb, want[3][0])
+    for k in (1, 2):
+        grp.write_cam_data(cams[k])
+        grp.render(MODE_PRIMARY_SHADOW)
+        rgb, ids, _ = grp.read_output()
+        assert np.array_equal(ids, want[k][1]) and np.array_equal(rgb, want[k][0]), f"frame {k} after the failed frames"
+    grp.close()
+
+
 def test_group_with_texel_messages_runs_every_kind_of_frame(orc):
     sc = scenes.c4((256, 144), bounces=3)
     grp = gpu_for_scene(sc, devices=[0, 0, 0, 0], texel_messages=True)

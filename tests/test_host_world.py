@@ -136,6 +136,49 @@ def test_chunk_roots_indexing_and_missing_chunks():
     assert tuple(wd.min) == w.min_voxel() and wd.size == 96 and wd.size_in_chunks == 3
 
 
+def test_the_kept_chunk_roots_table_follows_every_change_of_the_grid():
+    """The mirror keeps the chunk_roots table (the reference builds a fresh Vec per frame, main.rs:446) and hands its
+    generation to vrt_write_chunk_roots_tagged as "the table I wrote last time": every call that can change an entry must
+    change the generation, and the kept table must equal a fresh walk of the grid after each of them — a new chunk, a chunk
+    re-created in place (same root: the table is unchanged, a new tag is harmless), one moved by the allocator,
+    center_chunks, resize."""
+    w = ClientWorld((1, 1, 1), 1 << 16, 3)
+
+    def fresh():   # what ChunkGrid::chunk_roots would build (world.rs:154-159), from the public queries
+        S = w.size_in_chunks()
+        mn = [v // 32 for v in w.min_voxel()]
+        out = np.zeros(S ** 3, dtype=np.uint32)
+        for z in range(S):
+            for y in range(S):
+                for x in range(S):
+                    st = w.chunk_state((mn[0] + x, mn[1] + y, mn[2] + z))
+                    out[x + y * S + z * S * S] = st.range_start if st else 0
+        return out
+
+    gens = [w.roots_generation()]
+
+    def step(what):
+        assert np.array_equal(w.chunk_roots(), fresh()), what
+        assert np.array_equal(w.chunk_roots_view(), w.chunk_roots()), what
+        gens.append(w.roots_generation())
+        assert gens[-1] not in gens[:-1], f"{what}: the generation did not change"
+
+    view = w.chunk_roots_view()
+    assert not view.any()
+    leaf = np.array([4], dtype=np.uint16)
+    w.create_chunk((0, 1, 1), leaf); step("a first chunk")
+    w.create_chunk((2, 1, 1), leaf); step("a second chunk")
+    assert np.array_equal(view, w.chunk_roots())            # the same memory: entries change under the pointer
+    r = w.create_chunk((0, 1, 1), np.full(3000, 7, dtype=np.uint16)); step("a chunk the allocator had to move")
+    assert w.chunk_roots()[0 + 1 * 3 + 1 * 9] == r
+    assert w.center_chunks((2, 1, 1)) == 1; step("center_chunks")
+    w.resize(5); step("resize")
+    w.resize(2); step("resize to a smaller grid")
+    g0 = w.roots_generation()
+    w.set_voxel((70, 40, 40), 9)                             # an edit inside a chunk moves no root
+    assert w.roots_generation() == g0 and np.array_equal(w.chunk_roots(), fresh())
+
+
 def test_get_set_voxel_errors_and_world_coordinates():
     w = ClientWorld((0, 0, 0), 1 << 16, 2)  # min chunk (-1,-1,-1): negative voxel coordinates
     w.create_chunk((-1, -1, -1), np.array([0], dtype=np.uint16))

@@ -29,10 +29,17 @@ for k in range(40):
     except Exception: continue
     t0=time.perf_counter()
     gpu.write_nodes(sc.world.nodes_ptr(), start, start+n)
+    t1=time.perf_counter()
     gpu.write_chunk_roots(sc.world.chunk_roots())
-    gpu.render(MODE_PRIMARY_SHADOW); gpu.synchronize()
-    ts.append(time.perf_counter()-t0)
+    t2=time.perf_counter()
+    gpu.render(MODE_PRIMARY_SHADOW)
+    t3=time.perf_counter()
+    gpu.synchronize()
+    t4=time.perf_counter()
+    ts.append(t4-t0); bs.append((t1-t0,t2-t1,t3-t2,t4-t3))
 ts.sort()
+print("lone edit, host us: write_nodes %.1f, chunk_roots + write_chunk_roots (untagged) %.1f, render %.1f, synchronise (the device's share) %.1f" %
+      tuple(sorted(b[i] for b in bs)[len(bs)//2]*1e6 for i in range(4)))
 edits=[]
 for k in range(200):
     p=(ex+(k%7)-3, ey-8-(k%5), ez+(k%9)-4)

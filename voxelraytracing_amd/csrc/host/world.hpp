@@ -230,6 +230,7 @@ class ChunkGrid {
 public:
     ChunkGrid(ChunkPos center, uint32_t size_in_chunks) : size_(size_in_chunks) {
         chunks_.assign((size_t)size_ * size_ * size_, std::nullopt);
+        roots_.assign(chunks_.size(), 0u);
         const int32_t h = (int32_t)size_ / 2;
         min_ = {center.x - h, center.y - h, center.z - h};
     }
@@ -267,6 +268,7 @@ public:
                     if (!lp) continue;
                     g.chunks_[local_pos_to_idx(*lp, size_in_chunks)] = std::move(src);
                 }
+        g.rebuild_roots();
         *this = std::move(g);
     }
 
@@ -285,20 +287,15 @@ public:
                     nc[local_pos_to_idx({(uint32_t)dx, (uint32_t)dy, (uint32_t)dz}, size_)] = std::move(src);
                 }
         chunks_ = std::move(nc);
-        touch_roots();
+        rebuild_roots();
     }
 
     // chunk_roots, :154-159: root of every cell, 0 (the permanent air leaf) for a missing chunk.  The reference builds a
-    // fresh Vec every frame (main.rs:446: 27 000 entries at its 30^3 chunks); here the table is kept and rebuilt only after
-    // the grid changed, and roots_generation() says whether it did — the tag of vrt_write_chunk_roots_tagged.
-    const std::vector<NodeAddr> &chunk_roots() const {
-        if (roots_stale_) {
-            roots_.resize(chunks_.size());
-            for (size_t i = 0; i < chunks_.size(); i++) roots_[i] = chunks_[i] ? chunks_[i]->range.start : 0u;
-            roots_stale_ = false;
-        }
-        return roots_;
-    }
+    // fresh Vec every frame (main.rs:446: 27 000 entries at its 30^3 chunks); here the table is kept up to date by the calls
+    // that change the grid (set_chunk: one entry; shift_chunks, resize: all of them), and roots_generation() changes with
+    // every one of them — the tag of vrt_write_chunk_roots_tagged.  A plain read: nothing is built behind a const call.
+    // The reference stays valid until resize() replaces the grid; its contents are the grid's as of the last mutating call.
+    const std::vector<NodeAddr> &chunk_roots() const { return roots_; }
     uint64_t roots_generation() const { return roots_gen_; }
     size_t populated_count() const { size_t r = 0; for (auto &c : chunks_) r += c.has_value(); return r; }
     std::vector<ChunkPos> empty_chunks() const {  // :169-183
@@ -312,7 +309,9 @@ public:
     bool set_chunk(ChunkPos p, Chunk c) {
         auto lp = local_pos_for(p);
         if (!lp) return false;
-        chunks_[local_pos_to_idx(*lp, size_)] = std::move(c);
+        const size_t i = local_pos_to_idx(*lp, size_);
+        roots_[i] = c.range.start;
+        chunks_[i] = std::move(c);
         touch_roots();
         return true;
     }
@@ -328,12 +327,16 @@ protected:
     friend class ClientWorld;
     // (values never repeat, whichever grid object hands them out: resize() replaces the grid by a new one)
     static uint64_t next_generation() { static std::atomic<uint64_t> g{1}; return g.fetch_add(1) + 1; }
-    void touch_roots() { roots_stale_ = true; roots_gen_ = next_generation(); }
+    void touch_roots() { roots_gen_ = next_generation(); }
+    void rebuild_roots() {
+        roots_.resize(chunks_.size());
+        for (size_t i = 0; i < chunks_.size(); i++) roots_[i] = chunks_[i] ? chunks_[i]->range.start : 0u;
+        touch_roots();
+    }
     ChunkPos min_;
     std::vector<std::optional<Chunk>> chunks_;
     uint32_t size_;
-    mutable std::vector<NodeAddr> roots_;
-    mutable bool roots_stale_ = true;
+    std::vector<NodeAddr> roots_;
     uint64_t roots_gen_ = next_generation();
 };
 

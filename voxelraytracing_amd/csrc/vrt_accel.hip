@@ -40,6 +40,8 @@
 // and produces the same frame bit for bit; variant 1 (the literal walk) and variant 2 (ancestor cache) still
 // read the octree itself and are compared against it in the tests.  Rebuilt lazily before the next frame
 // whenever nodes, chunk_roots or the world size changed; never inside the kernels' timed region.
+#include <atomic>
+
 #include "vrt_device.h"
 
 namespace vrt {
@@ -386,7 +388,8 @@ __global__ void __launch_bounds__(512) accel_chunks_kernel(const uint16_t *nodes
     uint32_t w[32];
     assemble_brick(lds_node, node, w);
     store_brick(bricks, brick, w);
-    __threadfence();
+    // (no fence between the brick and the entry that names it: nothing reads this table set while the kernel runs — its frames
+    // are later on this very stream, and frames of other sets that shared it were waited for, update_tables)
     grid[cell] = 0x80000000u | (brick * 64u);
     if (mcell) *mcell = split_march_cell(lq, brick, w);
 }
@@ -400,12 +403,31 @@ __global__ void __launch_bounds__(256) upload_words_kernel(uint32_t *dst, const 
 
 // A batch of staged ranges — everything vrt_write_nodes / vrt_write_chunk_roots staged since the last frame — in ONE launch:
 // a workgroup per piece of at most kUploadPieceWords words (the host cuts the ranges up; the pieces ride in the kernarg).
+// The source is host memory: a load takes a PCIe round trip (~1.5 us), so every thread has ALL its loads in flight before
+// it stores anything — four 16-byte loads cover a 16-KiB piece (one word at a time the piece was sixteen round trips in a
+// row: 20 us for a chunk's 79 KB, most of a lone edit's latency; ~3 us now).  The ring side of a piece is 64-byte aligned,
+// the destination only word aligned (NodeBuffer::write widens to even nodes, not to 16 bytes): word stores.
 __global__ void __launch_bounds__(256) upload_batch_kernel(uint32_t *dst0, uint32_t *dst1, const uint32_t *ring, UploadBatch batch) {
     const UploadPiece p = batch.piece[blockIdx.x];
     uint32_t *dst = ((p.n_words >> 31) ? dst1 : dst0) + p.dst_word;
     const uint32_t *src = ring + p.src_word;
-    const uint32_t n = p.n_words & 0x7FFFFFFFu;
-    for (uint32_t i = threadIdx.x; i < n; i += 256u) dst[i] = src[i];
+    const uint32_t n = p.n_words & 0x7FFFFFFFu, n4 = n / 4u;
+    static_assert(kUploadPieceWords == 4u * 4u * 256u, "four 16-byte loads per thread cover a piece");
+    const uint4 *src4 = reinterpret_cast<const uint4 *>(src);
+    uint4 v[4];
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; j++) {
+        const uint32_t i = threadIdx.x + 256u * j;
+        v[j] = i < n4 ? src4[i] : make_uint4(0u, 0u, 0u, 0u);
+    }
+    const uint32_t tail = n4 * 4u + threadIdx.x;
+    const uint32_t last = tail < n ? src[tail] : 0u;   // (a piece that is not whole 16-byte vectors: up to three words more)
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; j++) {
+        const uint32_t i = threadIdx.x + 256u * j;
+        if (i < n4) { dst[4u * i] = v[j].x; dst[4u * i + 1u] = v[j].y; dst[4u * i + 2u] = v[j].z; dst[4u * i + 3u] = v[j].w; }
+    }
+    if (tail < n) dst[tail] = last;
 }
 
 }  // namespace
@@ -461,7 +483,16 @@ void launch_accel_chunks(const uint16_t *nodes, uint32_t n_nodes, const uint32_t
                          const uint32_t *chunks, const uint32_t *extents, uint32_t n, hipStream_t st) {
     // 64 KiB + of dynamic LDS needs opting in (the CU has 160 KiB); per device, and any thread may be the first
     const size_t lds = (size_t)(kChunkNodesMax + 16u) * sizeof(uint16_t);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(accel_chunks_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    {   // (once per device: the call is a few microseconds of every edit's frame otherwise)
+        static std::atomic<uint64_t> opted_in{0};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const uint64_t bit = 1ull << (dev & 63);
+        if (!(opted_in.load(std::memory_order_relaxed) & bit)) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(accel_chunks_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            opted_in.fetch_or(bit, std::memory_order_relaxed);
+        }
+    }
     const MarchCells mc{dir, blocks, block_tail, block_cap, dir ? 0u : 1u};
     for (uint32_t i = 0; i < n; i += 64u) {
         ChunkList list;

@@ -143,8 +143,10 @@ struct vrt_ctx {
     uint32_t *d_steps = nullptr;
     unsigned long long *d_clock = nullptr;  // clock-probe frames: {s_memtime ticks, s_memrealtime ticks}, summed until vrt_get_stats
     uint8_t *d_rgba8 = nullptr;
-    uint8_t *d_screen = nullptr;   // vrt_present's target
-    size_t screen_cap = 0;
+    // vrt_present's targets: one per frame set, written on the stream of the frame that is presented (vrt_present.hip)
+    uint8_t *d_screen[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t screen_cap[4] = {0, 0, 0, 0};
+    hipStream_t screen_stream[4] = {nullptr, nullptr, nullptr, nullptr};   // the stream of the buffer's last blit
 
     // derived lookup tables of the grid march (vrt_accel.hip), brought up to date lazily when their inputs changed: the whole
     // world (accel_dirty) or only the chunks a write touched.  One set per frame set in use (tabs[0] always; tabs[k] once

@@ -654,7 +654,7 @@ void vrt_destroy(vrt_ctx *c) {
         for (auto ev : evs)
             if (ev) (void)hipEventDestroy(ev);
     if (c->ev_frames) (void)hipEventDestroy(c->ev_frames);
-    if (c->ev_upload) (void)hipEventDestroy(c->ev_upload); (void)hipFree(c->d_ndc); (void)hipFree(c->d_screen); (void)hipFree(c->d_heads);
+    if (c->ev_upload) (void)hipEventDestroy(c->ev_upload); (void)hipFree(c->d_ndc); for (uint8_t *p : c->d_screen) (void)hipFree(p); (void)hipFree(c->d_heads);
     for (auto &t : c->ev_pool)
         for (auto &ev : t)
             if (ev) (void)hipEventDestroy(ev);
@@ -776,6 +776,8 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     const uint32_t tab = c->tables_split ? f.slot : 0u;
     const vrt_ctx::Tables &T = c->tabs[tab];
     c->last_tab = tab;
+    // a frame of another frame set that reads the shared set: an edit's update of tabs[0] must wait for it (update_tables)
+    const bool shares = wants_tables && c->accel_ok && tab == 0u && f.slot != 0u;
     if (wants_tables && c->accel_ok) {
         rc = frame_waits_for_uploads(c, f.st, f.slot);
         if (rc) return rc;
@@ -843,6 +845,9 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
         if (f.st == c->own_stream) c->own_pending = true;
         else c->alt_pending = true;
     }
+    // (the same drain clears shared_readers_in_flight: without this an edit right behind the fold frame let the next slot-0
+    // frame rebuild chunks of tabs[0] in place while this frame still read them)
+    if (shares) c->shared_readers_in_flight = true;
     // longest tiles first: the one-launch primary + shadow kernel over the derived tables, plain frames, one frame at a time
     // on the context's own stream (a frame, the sort behind it and the next frame are then ordered by the stream alone)
     const bool lpt = c->tile_lpt && c->in_flight == 1u && f.st == c->stream && (o.mode == VRT_MODE_PRIMARY_SHADOW || o.mode == VRT_MODE_PRIMARY) && variant == 0u && !kstats &&

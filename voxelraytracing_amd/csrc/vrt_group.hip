@@ -141,7 +141,26 @@ int grp_resize_output(vrt_ctx *c, uint32_t w, uint32_t h) {
     return grp_alloc_messages(c);
 }
 
+static int grp_render_frame(vrt_ctx *c, const vrt_render_opts *opts, bool &issued);
+
+// A frame that fails half-way has been enqueued on some devices and not on others, its message slot is taken and nobody will
+// record that it was consumed: the group is drained and starts over at slot 0 with no slot owing a wait, so that the frames
+// after the error find a consistent group (the error itself goes to the caller as it is).
 int grp_render(vrt_ctx *c, const vrt_render_opts *opts) {
+    bool issued = false;
+    const int rc = grp_render_frame(c, opts, issued);
+    if (rc && issued) {
+        vrt_group *g = c->grp;
+        const std::string keep = c->err;
+        (void)grp_synchronize(c);
+        c->err = keep;
+        g->slot = 0;
+        for (bool &u : g->consumed_used) u = false;
+    }
+    return rc;
+}
+
+static int grp_render_frame(vrt_ctx *c, const vrt_render_opts *opts, bool &issued) {
     vrt_group *g = c->grp;
     vrt_ctx *root = g->dev[0];
     vrt_render_opts o;
@@ -160,6 +179,7 @@ int grp_render(vrt_ctx *c, const vrt_render_opts *opts) {
     g->last_was_stats = !plain;
     const uint32_t k = g->slot;
     g->slot = (g->slot + 1u) % (g->in_flight > 1u ? vrt_group::kSlots : 1u);
+    issued = true;
     o.flags |= VRT_RENDER_OWN_STREAMS;   // every device's frame runs on that context's in-flight streams, into the buffer bound here
     // what is issued to device r >= 1 for this frame — by its worker thread, or here
     auto issue = [g, k, o, root](uint32_t r) -> int {

@@ -2,25 +2,35 @@
 // tile-major messages into the row-major frame.
 #include "vrt_ctx.h"
 
-// ScreenShader::encode_pass into the context's screen buffer on the device; asynchronous on c->stream.
-static int present_on_device(vrt_ctx *c, const vrt_crosshair *crosshair, uint32_t screen_w, uint32_t screen_h, const char *who) {
+// ScreenShader::encode_pass into one of the context's screen buffers on the device, asynchronous: the blit is enqueued BEHIND
+// THE FRAME it presents, on that frame's stream, into the screen buffer of the frame's set — a host that draws and presents
+// frame after frame (main.rs:452-454) keeps its frames in flight; nothing here waits for the device.  *screen: the buffer.
+static_assert(vrt_ctx::kMaxInFlight == 4, "one screen buffer per frame set");
+static int present_on_device(vrt_ctx *c, const vrt_crosshair *crosshair, uint32_t screen_w, uint32_t screen_h, const char *who,
+                             uint8_t **screen, hipStream_t *stream) {
     if (!c->rendered) return fail(c, VRT_ERR_STATE, "%s: nothing rendered yet", who);
     if (c->tile_major || (c->shard_count > 1u && !c->whole_frame_owner))
         return fail(c, VRT_ERR_STATE, "%s: needs the whole row-major frame", who);
     if (screen_w == 0u || screen_h == 0u || (uint64_t)screen_w * screen_h > (1ull << 28))
         return fail(c, VRT_ERR_INVALID_ARG, "%s: screen %ux%u out of range", who, screen_w, screen_h);
     HIP_TRY(c, hipSetDevice(c->device));
-    QUIESCE(c);
+    hipStream_t st = c->last_stream ? c->last_stream : c->stream;
+    const uint32_t k = c->last_slot < vrt_ctx::kMaxInFlight ? c->last_slot : 0u;
     const size_t bytes = (size_t)screen_w * screen_h * 4u;
-    if (bytes > c->screen_cap) {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));   // an earlier present may still be writing the old buffer
-        (void)hipFree(c->d_screen);
-        c->d_screen = nullptr; c->screen_cap = 0;
-        HIP_TRY(c, hipMalloc(&c->d_screen, bytes));
-        c->screen_cap = bytes;
+    // the buffer's previous blit ran on the frame set's stream of that time: almost always this one
+    if (c->screen_stream[k] && c->screen_stream[k] != st) HIP_TRY(c, hipStreamSynchronize(c->screen_stream[k]));
+    if (bytes > c->screen_cap[k]) {
+        HIP_TRY(c, hipStreamSynchronize(st));   // an earlier present may still be writing the old buffer
+        (void)hipFree(c->d_screen[k]);
+        c->d_screen[k] = nullptr; c->screen_cap[k] = 0;
+        HIP_TRY(c, hipMalloc(&c->d_screen[k], bytes));
+        c->screen_cap[k] = bytes;
     }
-    vrt::launch_present(c->last_out, c->width, c->height, screen_w, screen_h, *crosshair, c->d_screen, c->stream);
+    vrt::launch_present(c->last_out, c->width, c->height, screen_w, screen_h, *crosshair, c->d_screen[k], st);
     HIP_TRY(c, hipGetLastError());
+    c->screen_stream[k] = st;
+    *screen = c->d_screen[k];
+    *stream = st;
     return VRT_OK;
 }
 
@@ -30,10 +40,12 @@ int vrt_present(vrt_ctx *c, const vrt_crosshair *crosshair, uint32_t screen_w, u
     if (c && c->grp) { const int rc_ = grp_synchronize(c); if (rc_) return rc_; }
     GRP_ROOT(c, vrt_present(d, crosshair, screen_w, screen_h, rgba8));
     if (!c || !crosshair || !rgba8) return fail(c, VRT_ERR_INVALID_ARG, "vrt_present: null argument");
-    const int rc = present_on_device(c, crosshair, screen_w, screen_h, "vrt_present");
+    uint8_t *screen = nullptr;
+    hipStream_t st = nullptr;
+    const int rc = present_on_device(c, crosshair, screen_w, screen_h, "vrt_present", &screen, &st);
     if (rc) return rc;
-    HIP_TRY(c, hipMemcpyAsync(rgba8, c->d_screen, (size_t)screen_w * screen_h * 4u, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpyAsync(rgba8, screen, (size_t)screen_w * screen_h * 4u, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
     return VRT_OK;
 }
 
@@ -41,9 +53,11 @@ int vrt_present_device(vrt_ctx *c, const vrt_crosshair *crosshair, uint32_t scre
     if (c && c->grp) { const int rc_ = grp_synchronize(c); if (rc_) return rc_; }
     GRP_ROOT(c, vrt_present_device(d, crosshair, screen_w, screen_h, rgba8_device, bytes));
     if (!c || !crosshair || !rgba8_device) return fail(c, VRT_ERR_INVALID_ARG, "vrt_present_device: null argument");
-    const int rc = present_on_device(c, crosshair, screen_w, screen_h, "vrt_present_device");
+    uint8_t *screen = nullptr;
+    hipStream_t st = nullptr;
+    const int rc = present_on_device(c, crosshair, screen_w, screen_h, "vrt_present_device", &screen, &st);
     if (rc) return rc;
-    *rgba8_device = c->d_screen;
+    *rgba8_device = screen;
     if (bytes) *bytes = (uint64_t)screen_w * screen_h * 4u;
     return VRT_OK;
 }

@@ -100,7 +100,14 @@ static int ring_place(vrt_ctx *c, size_t bytes, size_t *at) {
     }
     const size_t need = (bytes + 63u) & ~(size_t)63u;
     if (c->ring_off + need > vrt_ctx::kRingSegBytes) {
-        c->ring_seg = (c->ring_seg + 1u) % vrt_ctx::kRingSegs;
+        const uint32_t next = (c->ring_seg + 1u) % vrt_ctx::kRingSegs;
+        // staged ranges have no event until they are flushed: a segment that still holds some (only possible when uploads that
+        // are not staged — materials, ndc tables — have walked the ring round since) is flushed before it is written again
+        if (c->staged_seg[next]) {
+            const int rc = flush_staged(c);
+            if (rc) return rc;
+        }
+        c->ring_seg = next;
         c->ring_off = 0;
         // the segment's previous copies must have left it (seven segments ago: practically always long done)
         for (int k = 0; k < 2; k++)
@@ -178,6 +185,11 @@ static int stage_pool_upload(vrt_ctx *c, uint32_t buf, uint32_t dst_word, const 
     c->staged.push_back({buf, dst_word, (uint32_t)(bytes / 4u), at});
     c->staged_bytes += bytes;
     c->staged_seg[at / vrt_ctx::kRingSegBytes] = true;
+    // Batching pays while frames are in flight (the launches would queue up behind them anyway).  With the device idle — a
+    // lone edit with a synchronise behind its frame, main.rs:352-362 — the copy goes out now and runs while the host is
+    // still on its way to vrt_render, instead of at the head of that call (170 -> 200 us in round 3's edit_cost).
+    if (c->rendered && c->last_stream && hipStreamQuery(c->last_stream) == hipSuccess) return flush_staged(c);
+    (void)hipGetLastError();   // (hipErrorNotReady is not an error)
     return VRT_OK;
 }
 

@@ -154,7 +154,7 @@ class ClientWorld:
         return out
 
     def chunk_roots_view(self) -> np.ndarray:
-        """The mirror's own table, zero-copy and read-only; valid until the grid next changes."""
+        """The mirror's own table, zero-copy and read-only: valid until resize(); its entries follow the grid (include/vrt_host.h)."""
         n = self._lib.vrth_world_chunk_roots(self._h, None, 0)
         a = np.frombuffer((C.c_uint32 * n).from_address(self._lib.vrth_world_chunk_roots_ptr(self._h)), dtype=np.uint32)
         a.flags.writeable = False
