@@ -60,6 +60,19 @@ KERNEL(k_rcp_f32, "v_rcp_f32 %0, %0\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3\n v_rc
 KERNEL(k_mov_b32, "v_mov_b32 %0, %1\n v_mov_b32 %2, %3\n v_mov_b32 %3, %4\n v_mov_b32 %4, %5\n v_mov_b32 %5, %6\n v_mov_b32 %6, %7\n v_mov_b32 %7, %0\n v_mov_b32 %1, %2\n")
 KERNEL(k_mad_i24, "v_mad_i32_i24 %8, %8, %9, %10\n v_mad_i32_i24 %9, %9, %10, %11\n v_mad_i32_i24 %10, %10, %11, %8\n v_mad_i32_i24 %11, %11, %8, %9\n v_mad_i32_i24 %8, %8, %10, %11\n v_mad_i32_i24 %9, %9, %11, %8\n v_mad_i32_i24 %10, %10, %8, %9\n v_mad_i32_i24 %11, %11, %9, %10\n")
 KERNEL(k_mul_abs, "v_mul_f32_e64 %0, |%0|, %1\n v_mul_f32_e64 %2, |%2|, %1\n v_mul_f32_e64 %3, |%3|, %1\n v_mul_f32_e64 %4, |%4|, %1\n v_mul_f32_e64 %5, |%5|, %1\n v_mul_f32_e64 %6, |%6|, %1\n v_mul_f32_e64 %7, |%7|, %1\n v_mul_f32_e64 %0, |%0|, %2\n")
+// round 4: candidates for the march's half-rate instructions — the three-input boolean op (gfx950's v_bitop3_b32: is a
+// bit-field insert at full rate?), and float adds bracketed by two writes of the rounding mode (floor as an add of 2^23
+// rounded towards minus infinity instead of v_cvt_flr_i32_f32)
+KERNEL(k_bitop3, "v_bitop3_b32 %8, %8, %9, %10 bitop3:0xca\n v_bitop3_b32 %9, %9, %10, %11 bitop3:0xca\n v_bitop3_b32 %10, %10, %11, %8 bitop3:0xca\n v_bitop3_b32 %11, %11, %8, %9 bitop3:0xca\n v_bitop3_b32 %8, %8, %10, %11 bitop3:0xca\n v_bitop3_b32 %9, %9, %11, %8 bitop3:0xca\n v_bitop3_b32 %10, %10, %8, %9 bitop3:0xca\n v_bitop3_b32 %11, %11, %9, %10 bitop3:0xca\n")
+KERNEL(k_bitop3_2src, "v_bitop3_b32 %8, %8, %9, %8 bitop3:0x30\n v_bitop3_b32 %9, %9, %10, %9 bitop3:0x30\n v_bitop3_b32 %10, %10, %11, %10 bitop3:0x30\n v_bitop3_b32 %11, %11, %8, %11 bitop3:0x30\n v_bitop3_b32 %8, %8, %10, %8 bitop3:0x30\n v_bitop3_b32 %9, %9, %11, %9 bitop3:0x30\n v_bitop3_b32 %10, %10, %8, %10 bitop3:0x30\n v_bitop3_b32 %11, %11, %9, %11 bitop3:0x30\n")
+KERNEL(k_setreg_add, "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 2\n v_add_f32 %0, %0, %1\n v_add_f32 %2, %2, %1\n v_add_f32 %3, %3, %1\n s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0\n v_add_f32 %4, %4, %1\n v_add_f32 %5, %5, %1\n v_add_f32 %6, %6, %1\n")
+KERNEL(k_bfe_u32, "v_bfe_u32 %8, %8, 3, 7\n v_bfe_u32 %9, %9, 3, 7\n v_bfe_u32 %10, %10, 3, 7\n v_bfe_u32 %11, %11, 3, 7\n v_bfe_u32 %8, %8, 1, 9\n v_bfe_u32 %9, %9, 1, 9\n v_bfe_u32 %10, %10, 1, 9\n v_bfe_u32 %11, %11, 1, 9\n")
+KERNEL(k_lshl_add, "v_lshl_add_u32 %8, %8, 2, %9\n v_lshl_add_u32 %9, %9, 2, %10\n v_lshl_add_u32 %10, %10, 2, %11\n v_lshl_add_u32 %11, %11, 2, %8\n v_lshl_add_u32 %8, %8, 1, %10\n v_lshl_add_u32 %9, %9, 1, %11\n v_lshl_add_u32 %10, %10, 1, %8\n v_lshl_add_u32 %11, %11, 1, %9\n")
+KERNEL(k_fmac_f32, "v_fmac_f32 %0, %1, %2\n v_fmac_f32 %2, %1, %3\n v_fmac_f32 %3, %1, %4\n v_fmac_f32 %4, %1, %5\n v_fmac_f32 %5, %1, %6\n v_fmac_f32 %6, %1, %7\n v_fmac_f32 %7, %1, %0\n v_fmac_f32 %0, %2, %3\n")
+KERNEL(k_pk_mul_f32, "v_pk_mul_f32 v[20:21], v[20:21], v[22:23]\n v_pk_mul_f32 v[24:25], v[24:25], v[22:23]\n v_pk_mul_f32 v[26:27], v[26:27], v[22:23]\n v_pk_mul_f32 v[28:29], v[28:29], v[22:23]\n v_pk_mul_f32 v[20:21], v[20:21], v[24:25]\n v_pk_mul_f32 v[24:25], v[24:25], v[26:27]\n v_pk_mul_f32 v[26:27], v[26:27], v[28:29]\n v_pk_mul_f32 v[28:29], v[28:29], v[20:21]\n")
+KERNEL(k_sub_f32_lit, "v_add_f32 %0, 0xcb000000, %0\n v_add_f32 %2, 0xcb000000, %2\n v_add_f32 %3, 0xcb000000, %3\n v_add_f32 %4, 0xcb000000, %4\n v_add_f32 %5, 0xcb000000, %5\n v_add_f32 %6, 0xcb000000, %6\n v_add_f32 %7, 0xcb000000, %7\n v_add_f32 %1, 0xcb000000, %1\n")
+KERNEL(k_cndmask_lit, "v_cndmask_b32 %0, 0, %1, vcc\n v_cndmask_b32 %2, 0, %1, vcc\n v_cndmask_b32 %3, 0, %1, vcc\n v_cndmask_b32 %4, 0, %1, vcc\n v_cndmask_b32 %5, 0, %1, vcc\n v_cndmask_b32 %6, 0, %1, vcc\n v_cndmask_b32 %7, 0, %1, vcc\n v_cndmask_b32 %0, 0, %2, vcc\n")
+KERNEL(k_cmp_sgpr_f32, "v_cmp_eq_f32 s[10:11], %0, %1\n v_cmp_eq_f32 s[12:13], %2, %1\n v_cmp_eq_f32 s[14:15], %3, %1\n v_cmp_eq_f32 s[16:17], %4, %1\n v_cmp_eq_f32 s[10:11], %5, %1\n v_cmp_eq_f32 s[12:13], %6, %1\n v_cmp_eq_f32 s[14:15], %7, %1\n v_cmp_eq_f32 s[16:17], %0, %2\n")
 // scalar instructions: alone, and interleaved one to one with simple VALU (does the scalar stream ride along for free?)
 KERNEL(k_salu, "s_and_b64 s[10:11], s[10:11], s[12:13]\n s_or_b64 s[12:13], s[12:13], s[14:15]\n s_xor_b64 s[14:15], s[14:15], s[16:17]\n s_and_b64 s[16:17], s[16:17], s[10:11]\n s_or_b64 s[10:11], s[10:11], s[14:15]\n s_andn2_b64 s[12:13], s[12:13], s[16:17]\n s_xor_b64 s[14:15], s[14:15], s[10:11]\n s_and_b64 s[16:17], s[16:17], s[12:13]\n")
 KERNEL(k_salu_valu, "s_and_b64 s[10:11], s[10:11], s[12:13]\n v_add_f32 %0, %0, %1\n s_or_b64 s[12:13], s[12:13], s[14:15]\n v_add_f32 %2, %2, %1\n s_xor_b64 s[14:15], s[14:15], s[16:17]\n v_add_f32 %3, %3, %1\n s_and_b64 s[16:17], s[16:17], s[10:11]\n v_add_f32 %4, %4, %1\n")
@@ -140,6 +153,7 @@ int main() {
     RUN(k_lshl_or); RUN(k_add3_u32); RUN(k_cvt_flr); RUN(k_cvt_i32_f32); RUN(k_cvt_f32_i32); RUN(k_floor_f32); RUN(k_cmp_u32); RUN(k_cmp_f32);
     RUN(k_bfi_b32); RUN(k_mad_u24); RUN(k_mad_i24); RUN(k_max3_u32); RUN(k_div_fixup); RUN(k_pk_add_f32);
     RUN(k_sqrt_f32); RUN(k_rcp_f32);
+    RUN(k_bitop3); RUN(k_bitop3_2src); RUN(k_setreg_add); RUN(k_bfe_u32); RUN(k_lshl_add); RUN(k_fmac_f32); RUN(k_pk_mul_f32); RUN(k_sub_f32_lit); RUN(k_cndmask_lit); RUN(k_cmp_sgpr_f32);
     RUN(k_salu); RUN(k_salu_valu); RUN(k_nop);
     RUN(k_fma_lanes_0_15); RUN(k_fma_lanes_0_31); RUN(k_fma_every_4th); RUN(k_fma_one_in_16); RUN(k_min3_lanes_0_15); RUN(k_min3_lanes_0_31); RUN(k_min3_every_4th);
     return 0;

@@ -447,8 +447,11 @@ __device__ __forceinline__ uint32_t mad_i24(int a, uint32_t uniform_b, uint32_t 
 }
 
 __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {
-    uint32_t r;  // (mask & a) | (~mask & b)
-    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
+    // (mask & a) | (~mask & b) as gfx950's three-input boolean op, truth table 0xCA (index = mask << 2 | a << 1 | b):
+    // v_bitop3_b32 issues at full rate (2.35 cycles per wave-instruction per SIMD, profiles/r04_valu_issue_rates.txt) where
+    // v_bfi_b32 — like every other three-operand integer instruction — takes 4.25
+    uint32_t r;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xca" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
     return r;
 }
 
