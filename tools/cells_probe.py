@@ -48,10 +48,20 @@ for t in np.linspace(0, e.max(), 16):
     alive = (s <= t) & (e > t)
     print(f"  t={t:6.1f} us: {int(alive.sum()):5d} waves alive")
 
+# what a wave-step costs with the pool still handing out rays (57 lanes marching) and after it ran dry (15): least squares over
+# the waves of life = a wet + b dry + c (phases A and C, the hand-outs)
+A_ = np.stack([wet, dry, np.ones_like(wet)], axis=1)
+coef, *_ = np.linalg.lstsq(A_, life, rcond=None)
+res = life - A_ @ coef
+print(f"wave life ~ {coef[0]:.3f} us x wave-steps while the pool has rays + {coef[1]:.3f} us x wave-steps after it ran dry + {coef[2]:.1f} us "
+      f"(rms residual {np.sqrt((res ** 2).mean()):.1f} us of a mean life of {life.mean():.1f}); the dry steps are {100 * coef[1] * dry.sum() / life.sum():.0f} % of the waves' time")
+
 # what a lookup finds and whether the lane's previous lookup was in the same line — the misses a ray cannot avoid — under
 # today's layout (16-byte cells, a line = 8^3 voxels) and under denser ones
 t = tot.astype(float)
 L = t[0]
+if L == 0:   # (the light probe build: no lookup classes)
+    sys.exit(0)
 pc = lambda a, b=None: f"{100 * a / (L if b is None else b):5.1f} %"
 print(f"lookups {L:.0f}; into a line the lane's previous lookup was not in: 8x8x8 {pc(t[1])}, 16x8x8 (8-byte cells) {pc(t[2])}, 16x8x16 (4-byte) {pc(t[3])}")
 print(f"  air leaves of 8 voxels or more {pc(t[4])} of the lookups, new line {pc(t[5], t[4])} of them; a byte per 8^3 voxels in lines of 64x32x32: new line {pc(t[6], t[4])}")

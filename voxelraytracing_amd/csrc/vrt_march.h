@@ -520,6 +520,8 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
     // (q) the exit plane as a float without a conversion: plane + 0x4B000000 is the bit pattern of 2^23 + plane for
     // 0 <= plane < 2^23, and (2^23 + plane) - 2^23 is exact — two full-rate instructions for v_cvt_f32_i32's half-rate one
     // (the bias rides on the subtraction of the direction mask that is there anyway)
+    // (the biased masks could serve as the insert's mask too — it reads their low five bits only — but with three registers
+    // fewer the allocator closes the primary loop with eight moves per trip: measured on the ISA, round 4)
     constexpr uint32_t kTwo23 = 0x4B000000u;
     uint32_t mxb = mxm - kTwo23, myb = mym - kTwo23, mzb = mzm - kTwo23;
     asm("" : "+v"(mxb), "+v"(myb), "+v"(mzb));   // (held in registers)

@@ -953,11 +953,13 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
     const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
     const uint32_t dbg_n0 = n;
     uint32_t dbg_wet = 0, dbg_wet_lanes = 0, dbg_dry = 0, dbg_dry_lanes = 0, dbg_segments = 0, dbg_air4 = 0, dbg_air8 = 0, dbg_air16 = 0;
+#ifdef VRT_EXP_CELLDBG_FULL   // (the lookup classes: 30 registers more — a build of its own, 4 waves per SIMD)
     uint32_t dbg_tot[20], dbg_lines = 0, dbg_line_steps = 0;   // (per lane; summed at the wave's end)
     for (int q = 0; q < 20; q++) dbg_tot[q] = 0;
     // per lane: the previous lookup's lines under the layouts compared, its class, and the ray's origin voxel
     uint32_t dbg_l8 = ~0u, dbg_l16 = ~0u, dbg_lc = ~0u, dbg_l4 = ~0u, dbg_prev_big = 0u;
     int dbg_ox = 0, dbg_oy = 0, dbg_oz = 0;
+#endif
 #endif
     const uint32_t base = __builtin_amdgcn_readfirstlane(seg * K.in_seg_cap + wg_begin + wave * per);
     // The wave keeps its paths for ALL the segments that are left (`segments` of them): the survivors of one segment are
@@ -1015,6 +1017,8 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
         const uint32_t wsize = P.world.size;
         V3 pos{0.f, 0.f, 0.f}, dir{0.f, 0.f, 0.f};
         float ux = 0.f, uy = 0.f, uz = 0.f, step = -1.f, adx = 0.f, ady = 0.f, adz = 0.f;
+        // the direction masks with (q) of vrt_march.h riding on them: 0 or ~0, minus the bits of 2^23 — the bit-field insert
+        // looks at their low five bits only (lo <= 31), which are the plain mask's
         uint32_t mxm = 0u, mym = 0u, mzm = 0u, ref = 0u, iter = 0u, idx = 0u;
         int vx = 0, vy = 0, vz = 0;
         // the chunk the ray is in — its coordinates as one number — and where that chunk's block of march cells begins
@@ -1039,7 +1043,8 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
             dir = V3{__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z)};
             not_finite = !(finite3(origin) && finite3(dir));
             ux = pool[0u * E + idx]; uy = pool[1u * E + idx]; uz = pool[2u * E + idx];
-            mxm = dir.x >= 0.0f ? ~0u : 0u; mym = dir.y >= 0.0f ? ~0u : 0u; mzm = dir.z >= 0.0f ? ~0u : 0u;
+            constexpr uint32_t kTwo23 = 0x4B000000u;
+            mxm = (dir.x >= 0.0f ? ~0u : 0u) - kTwo23; mym = (dir.y >= 0.0f ? ~0u : 0u) - kTwo23; mzm = (dir.z >= 0.0f ? ~0u : 0u) - kTwo23;
             ref = 0u;
             ckey = kNoChunk;
             marching = true;
@@ -1055,7 +1060,7 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
                 park();
             }
             vx = trunc2i(pos.x); vy = trunc2i(pos.y); vz = trunc2i(pos.z);
-#ifdef VRT_EXP_CELLDBG
+#ifdef VRT_EXP_CELLDBG_FULL
             dbg_l8 = dbg_l16 = dbg_lc = dbg_l4 = ~0u; dbg_prev_big = 0u; dbg_ox = vx; dbg_oy = vy; dbg_oz = vz;
 #endif
 #ifdef VRT_EXP_NOMARCH   // counting experiment: every ray ends where it starts
@@ -1064,9 +1069,10 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
         };
         // the step to the leaf's exit face for a leaf of size lo + 1 (take_step of march_grid)
         auto take_step = [&](uint32_t lo) __attribute__((always_inline)) {
-            const float tx = (float)(int)(bfi(lo, mxm, (uint32_t)vx) - mxm) - pos.x;
-            const float ty = (float)(int)(bfi(lo, mym, (uint32_t)vy) - mym) - pos.y;
-            const float tz = (float)(int)(bfi(lo, mzm, (uint32_t)vz) - mzm) - pos.z;
+            // (h), (q) of vrt_march.h: the exit plane (v | lo) + 1 or v & ~lo, as a float without a conversion
+            const float tx = (__uint_as_float(bfi(lo, mxm, (uint32_t)vx) - mxm) - 8388608.0f) - pos.x;
+            const float ty = (__uint_as_float(bfi(lo, mym, (uint32_t)vy) - mym) - 8388608.0f) - pos.y;
+            const float tz = (__uint_as_float(bfi(lo, mzm, (uint32_t)vz) - mzm) - 8388608.0f) - pos.z;
             adx = abs_mul(tx, ux);
             ady = abs_mul(ty, uy);
             adz = abs_mul(tz, uz);
@@ -1183,6 +1189,8 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
                     dbg_air4 += (uint32_t)__popcll(__ballot(c.x >= 3u && c.x <= 31u));     // lookups answered by an air leaf of the cell grid
                     dbg_air8 += (uint32_t)__popcll(__ballot(c.x >= 7u && c.x <= 31u));     // ... of 8 voxels or more: a whole line of cells
                     dbg_air16 += (uint32_t)__popcll(__ballot(c.x >= 15u && c.x <= 31u));
+#endif
+#ifdef VRT_EXP_CELLDBG_FULL
                     {
                         auto cnt = [&](int q, bool b) __attribute__((always_inline)) { dbg_tot[q] += b ? 1u : 0u; };
                         const uint32_t X = (uint32_t)(vx + 64), Y = (uint32_t)(vy + 64), Z = (uint32_t)(vz + 64);   // (coordinates -1 .. size)
@@ -1341,12 +1349,14 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
             d[4] = dbg_wet_lanes | ((unsigned long long)dbg_dry_lanes << 32); d[5] = dbg_segments;
             d[6] = dbg_air4 | ((unsigned long long)dbg_air8 << 32); d[7] = dbg_air16;
         }
+#ifdef VRT_EXP_CELLDBG_FULL
 #pragma unroll
         for (int q = 0; q < 20; q++) {
             const unsigned long long sum = wave_sum((unsigned long long)dbg_tot[q]);
             if (lane == 0) atomicAdd(&g_cells_tot[q], sum);
         }
         if (lane == 0) { atomicAdd(&g_cells_tot[20], (unsigned long long)dbg_lines); atomicAdd(&g_cells_tot[21], (unsigned long long)dbg_line_steps); }
+#endif
     }
 #endif
     if (left == 1u || n_out == 0u) break;
