@@ -9,6 +9,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from voxelraytracing_amd import Gpu, MODE_PATH, _ffi, scenes
 
 sc = scenes.c4()
+if len(sys.argv) > 1:   # another world size (chunks): how the wave-step's time depends on the table's size against the 4 MB L2s
+    sc = scenes.c5((1920, 1080), chunks=int(sys.argv[1]))
 gpu = Gpu(sc.world.max_nodes(), sc.world.size_in_chunks(), sc.size)
 gpu.upload_world(sc.world, sc.materials)
 gpu.write_settings(sc.settings)

@@ -1180,6 +1180,23 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
                     // one 16-byte load answers the step: c.x the cell's entry, c.y the size-2 mask of a split cell, c.z / c.w
                     // the voxels a ray passes (zero stops it)
                     const uint4 c = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(mb, off, 0, VRT_CELLS_LOAD_AUX));
+#ifdef VRT_EXP_CELLS_LOAD   // tools/ab experiments only: one more 16-byte load per step — 1: the cell just read (an L1 hit), 2: a line
+                            // nobody shares (a miss of L1, a hit or miss of L2), 3: the line next to the cell's (L2-resident like it)
+                    {
+                        const uint32_t off_ = VRT_EXP_CELLS_LOAD == 1 ? off : VRT_EXP_CELLS_LOAD == 3 ? (off ^ 128u) :
+                                              ((iter * 0x9E3779B9u + idx * 0x85EBCA6Bu + lane * 0xC2B2AE35u) % (P.mblk_bytes / 16u)) * 16u;
+                        const uint4 x_ = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(mb, off_, 0, 0));
+                        asm volatile("" :: "v"(x_.x), "v"(x_.y), "v"(x_.z), "v"(x_.w));
+                    }
+#endif
+#ifdef VRT_EXP_CELLS_VALU   // ... extra full-rate vector instructions per step
+#pragma unroll
+                    for (int k_ = 0; k_ < VRT_EXP_CELLS_VALU; k_++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(idx) : "v"(0u));
+#endif
+#ifdef VRT_EXP_CELLS_SALU
+#pragma unroll
+                    for (int k_ = 0; k_ < VRT_EXP_CELLS_SALU; k_++) asm volatile("s_mov_b32 vcc_lo, 0" ::: "vcc");
+#endif
                     iter += 1u;
                     // u = (x&3) | (y&3) << 2 | (z&3) << 4, with z's upper bits left on top: the shifts below use the low bits only
                     const uint32_t u = ((((uint32_t)vz << 2) | ((uint32_t)vy & 3u)) << 2) | ((uint32_t)vx & 3u);
