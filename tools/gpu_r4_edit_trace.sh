@@ -19,7 +19,7 @@ for i in idx[5:]:
     prev_end = int(rows[lo - 1]["End_Timestamp"]) if lo else t0
     print(f"--- idle before: {(t0 - prev_end) / 1e3:.1f} us")
     for r in rows[lo:hi]:
-        n = r["Kernel_Name"].split("(")[0][-60:]
+        n = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-60:]
         print(f"  {n:60s} start {(int(r['Start_Timestamp']) - t0) / 1e3:8.1f} us  dur {(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:7.1f} us  stream {r.get('Stream_Id', r.get('Queue_Id', '?'))}")
     shown += 1
 PY

@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(512) accel_bricks_kernel(const uint16_t *nodes
 // slack); otherwise the chunk moves to a fresh 512-brick region — the most a chunk can ever need — taken from the tail of
 // the pool with one atomic.  The host keeps the tail from overflowing: it counts the chunks that may have moved since
 // the last whole-world build and asks for one of those instead when the tail could run out (vrt_uploads.hip).
-struct ChunkList { uint32_t chunk[64]; uint32_t extent[64]; };   // extent: nodes from the chunk's root up to the next chunk's (host's estimate)
+struct ChunkList { uint32_t chunk[64]; uint32_t extent[64]; uint32_t root[64]; };   // extent: nodes from the chunk's root up to the next chunk's (host's estimate); root: chunk_roots[chunk] as uploaded (the host's mirror: one memory round trip less on a lone workgroup's critical path)
 
 constexpr uint32_t kChunkNodesMax = 0x7FFFu + 8u;  // child_idx <= 0x7FFF, + 8 children
 
@@ -321,23 +321,39 @@ __global__ void __launch_bounds__(512) accel_chunks_kernel(const uint16_t *nodes
     __shared__ uint32_t s_base, s_blk;
     const uint32_t chunk = list.chunk[blockIdx.x];
     const uint32_t t = threadIdx.x, cx = t & 7u, cy = (t >> 3) & 7u, cz = t >> 6;
-    const uint32_t root = roots[chunk];
+    const uint32_t root = list.root[blockIdx.x];
+    (void)roots;
+    // the region's base and size are wanted after two barriers: asked for now, beside the staging loads
+    uint32_t base0 = 0u, cap0 = 0u;
+    if (t == 0) { base0 = chunk_bases[chunk]; cap0 = chunk_caps[chunk]; }
     // stage the chunk's own extent, eight nodes (16 bytes) per load; the pool is 16-byte aligned (hipMalloc)
     const uint32_t head = root & 7u, first = root - head;
     const uint32_t staged = min(list.extent[blockIdx.x], kChunkNodesMax);
     const uint32_t vecs = (head + staged + 7u) / 8u;
-    for (uint32_t v = t; v < vecs; v += 512u) {
-        const uint64_t g = (uint64_t)first + (uint64_t)v * 8u;
-        uint4 w = make_uint4(0u, 0u, 0u, 0u);
-        if (g + 8u <= n_nodes) {
-            w = *reinterpret_cast<const uint4 *>(nodes + g);
-        } else {   // the pool ends inside this vector: past the end reads as air leaves (what the march's buffer loads return)
-            uint32_t h[8];
+    // (a lone workgroup again: all of a thread's loads are issued before the first of them is stored — one load per loop trip
+    // was up to nine memory round trips in a row, 15 of the kernel's 17 us for a chunk of 40 000 nodes)
+    constexpr uint32_t kVecsPerThread = (kChunkNodesMax + 16u + 8u * 512u - 1u) / (8u * 512u);
+    uint4 sw[kVecsPerThread];
 #pragma unroll
-            for (uint32_t k = 0; k < 8u; k++) h[k] = g + k < n_nodes ? (uint32_t)nodes[g + k] : 0u;
-            w = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+    for (uint32_t j = 0; j < kVecsPerThread; j++) {
+        const uint32_t v = t + 512u * j;
+        const uint64_t g = (uint64_t)first + (uint64_t)v * 8u;
+        sw[j] = make_uint4(0u, 0u, 0u, 0u);
+        if (v < vecs) {
+            if (g + 8u <= n_nodes) {
+                sw[j] = *reinterpret_cast<const uint4 *>(nodes + g);
+            } else {   // the pool ends inside this vector: past the end reads as air leaves (what the march's buffer loads return)
+                uint32_t h[8];
+#pragma unroll
+                for (uint32_t k = 0; k < 8u; k++) h[k] = g + k < n_nodes ? (uint32_t)nodes[g + k] : 0u;
+                sw[j] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+            }
         }
-        reinterpret_cast<uint4 *>(s_raw)[v] = w;
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < kVecsPerThread; j++) {
+        const uint32_t v = t + 512u * j;
+        if (v < vecs) reinterpret_cast<uint4 *>(s_raw)[v] = sw[j];
     }
     __syncthreads();
     const ChunkNodes lds_node{s_raw + head, nodes, staged, root, n_nodes};
@@ -353,8 +369,8 @@ __global__ void __launch_bounds__(512) accel_chunks_kernel(const uint16_t *nodes
     uint32_t total;
     const uint32_t rank = rank_split_cells(split, s_wave, total);
     if (t == 0) {
-        uint32_t base = chunk_bases[chunk];
-        if (total > chunk_caps[chunk]) {
+        uint32_t base = base0;
+        if (total > cap0) {
             base = atomicAdd(tail, 512u);
             chunk_bases[chunk] = base;
             chunk_caps[chunk] = 512u;
@@ -480,7 +496,7 @@ void launch_accel_bricks(const uint16_t *nodes, uint32_t n_nodes, const uint32_t
 void launch_accel_chunks(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S, uint32_t *grid,
                          uint32_t *chunk_bricks, uint32_t *chunk_bases, uint32_t *chunk_caps, uint32_t *tail, uint16_t *bricks,
                          uint32_t brick_cap, uint32_t *dir, uint4 *blocks, uint32_t *block_tail, uint32_t block_cap, const uint32_t liquid[8],
-                         const uint32_t *chunks, const uint32_t *extents, uint32_t n, hipStream_t st) {
+                         const uint32_t *chunks, const uint32_t *extents, const uint32_t *chunk_roots_host, uint32_t n, hipStream_t st) {
     // 64 KiB + of dynamic LDS needs opting in (the CU has 160 KiB); per device, and any thread may be the first
     const size_t lds = (size_t)(kChunkNodesMax + 16u) * sizeof(uint16_t);
     {   // (once per device: the call is a few microseconds of every edit's frame otherwise)
@@ -497,7 +513,7 @@ void launch_accel_chunks(const uint16_t *nodes, uint32_t n_nodes, const uint32_t
     for (uint32_t i = 0; i < n; i += 64u) {
         ChunkList list;
         const uint32_t m = n - i < 64u ? n - i : 64u;
-        for (uint32_t k = 0; k < m; k++) { list.chunk[k] = chunks[i + k]; list.extent[k] = extents[i + k]; }
+        for (uint32_t k = 0; k < m; k++) { list.chunk[k] = chunks[i + k]; list.extent[k] = extents[i + k]; list.root[k] = chunk_roots_host[i + k]; }
         hipLaunchKernelGGL(accel_chunks_kernel, dim3(m), dim3(512), lds, st, nodes, n_nodes, roots, S, grid, chunk_bricks, chunk_bases,
                            chunk_caps, tail, bricks, brick_cap, mc, liquid_mask(liquid), list);
     }

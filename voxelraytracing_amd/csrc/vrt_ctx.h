@@ -66,7 +66,7 @@ void launch_upload_batch(void *dst0, void *dst1, const void *pinned_ring, const 
 void launch_accel_chunks(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S, uint32_t *grid,
                          uint32_t *chunk_bricks, uint32_t *chunk_bases, uint32_t *chunk_caps, uint32_t *tail, uint16_t *bricks,
                          uint32_t brick_cap, uint32_t *dir, uint4 *blocks, uint32_t *block_tail, uint32_t block_cap, const uint32_t liquid[8],
-                         const uint32_t *chunks, const uint32_t *extents, uint32_t n, hipStream_t st);
+                         const uint32_t *chunks, const uint32_t *extents, const uint32_t *chunk_roots_host, uint32_t n, hipStream_t st);
 }  // namespace vrt
 
 static_assert(sizeof(vrt_material) == 32, "Material layout (mod.rs:20-28)");
@@ -220,6 +220,7 @@ struct vrt_ctx {
     uint32_t view_gen = 0;              // counts the changes of anything a tile's trips depend on
     uint32_t frame_view_gen = ~0u;      // ... as of the last frame rendered
     uint32_t order_view_gen = ~0u;      // ... as of the frame the order was made from
+    bool tile_order_stale = false;      // a chunk was edited since the order was made: still used, made again by the next frame without an edit in front of it
     uint32_t frame_mode = ~0u;          // vrt_mode of the last frame rendered (a change of mode is a change of view)
     uint32_t last_slot = 0, last_tab = 0;   // the frame set and the table set of the last frame
     float accel_last_ms = 0.f;

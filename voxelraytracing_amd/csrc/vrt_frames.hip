@@ -775,6 +775,7 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     }
     const uint32_t tab = c->tables_split ? f.slot : 0u;
     const vrt_ctx::Tables &T = c->tabs[tab];
+    const bool edit_in_front = !T.dirty_chunks.empty();   // this frame brings an edited chunk's tables up to date first
     c->last_tab = tab;
     // a frame of another frame set that reads the shared set: an edit's update of tabs[0] must wait for it (update_tables)
     const bool shares = wants_tables && c->accel_ok && tab == 0u && f.slot != 0u;
@@ -868,6 +869,9 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
         if (c->order_view_gen != c->view_gen) c->tile_order_valid = false;   // the order of another view: worse than none
         if (c->tile_order_valid) P.tile_order = c->d_tile_order;
         tile_sort = !c->tile_order_valid && c->frame_view_gen == c->view_gen;   // the view has come to rest: this frame notes its trips
+        // an order made before a chunk was edited: kept for the edit's own frame, made again by the first frame behind it
+        // that has no fresh edit in front of it (its launch reads the old order, the sort behind it writes the new one)
+        if (c->tile_order_valid && c->tile_order_stale && !edit_in_front) tile_sort = true;
         if (tile_sort) P.tile_cost = c->d_tile_cost;
     }
     c->frame_view_gen = c->view_gen;
@@ -882,6 +886,7 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
         HIP_TRY(c, hipGetLastError());
         c->tile_order_valid = true;
         c->order_view_gen = c->view_gen;
+        c->tile_order_stale = false;
     }
     c->rendered = true;
     c->last_stats = o.stats == 1u;

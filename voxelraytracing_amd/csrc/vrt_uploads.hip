@@ -264,7 +264,10 @@ void mark_all_dirty(vrt_ctx *c) {
 
 // every table set in use hears of it (a set's list: what changed since *that set* was last brought up to date)
 static void mark_chunk_dirty(vrt_ctx *c, uint32_t chunk) {
-    c->view_gen++;
+    // A chunk's edit moves the cost of the few tiles that see it by a few steps: the tile order of the view stays the
+    // better order for the edit's own frame (screen order costs a lone frame 15 us), and the next frame without an edit
+    // notes its trips again (vrt_render).  Whole-world changes (mark_all_dirty) drop the order as a camera move does.
+    c->tile_order_stale = true;
     if (c->accel_dirty) return;
     c->tables_split = true;   // (from the next frame on; see vrt_render)
     c->quiet_frames = 0;
@@ -571,16 +574,17 @@ int update_tables(vrt_ctx *c, uint32_t k, hipStream_t st) {
     // how far each chunk's nodes can reach: up to the next chunk's root (ChunkAlloc's ranges are disjoint); the kernel
     // stages that much of the pool and reads anything beyond from the pool itself
     refresh_roots_index(c);
-    std::vector<uint32_t> extents(T.dirty_chunks.size());
+    std::vector<uint32_t> extents(T.dirty_chunks.size()), roots_now(T.dirty_chunks.size());
     for (size_t i = 0; i < extents.size(); i++) {
         const uint32_t r = T.dirty_chunks[i] < c->n_roots ? c->h_roots[T.dirty_chunks[i]] : 0u;
+        roots_now[i] = r;
         auto nx = std::upper_bound(c->roots_index.begin(), c->roots_index.end(), std::make_pair(r, 0xFFFFFFFFu));
         const uint32_t end = nx != c->roots_index.end() ? nx->first : c->max_nodes;
         extents[i] = r ? (end > r ? end - r : 0u) : 1u;   // (a missing chunk is node 0 alone: one air leaf)
     }
     vrt::launch_accel_chunks(c->d_nodes, c->max_nodes, c->d_roots, c->accel_S, T.d_grid, T.d_chunk_bricks, T.d_chunk_bases, T.d_chunk_caps,
                              T.d_brick_tail, T.d_bricks, T.brick_cap, c->march_direct ? nullptr : T.d_cdir, T.d_mblk, T.d_mblk_tail, T.mblk_cap, c->liquid_mask,
-                             T.dirty_chunks.data(), extents.data(), (uint32_t)T.dirty_chunks.size(), st);
+                             T.dirty_chunks.data(), extents.data(), roots_now.data(), (uint32_t)T.dirty_chunks.size(), st);
     HIP_TRY(c, hipGetLastError());
     // the next upload of nodes or roots waits for this reader
     if (!T.ev_updated) HIP_TRY(c, hipEventCreateWithFlags(&T.ev_updated, hipEventDisableTiming));
