@@ -69,6 +69,35 @@ void launch_accel_chunks(const uint16_t *nodes, uint32_t n_nodes, const uint32_t
                          const uint32_t *chunks, const uint32_t *extents, const uint32_t *chunk_roots_host, uint32_t n, hipStream_t st);
 }  // namespace vrt
 
+// Host-time profile of the frame path (experiments build, VRT_HOST_PROF=1: printed at process exit): where the calling
+// thread's microseconds per frame go, section by section (tools/gpu_bench_modes.sh; profiles/r04_group_host_profile.txt).
+#ifdef VRT_EXPERIMENTS
+#include <chrono>
+struct vrt_host_prof {
+    double us[24] = {};
+    unsigned long long n[24] = {};
+    const char *name[24] = {};
+    ~vrt_host_prof() {
+        if (!getenv("VRT_HOST_PROF")) return;
+        for (int i = 0; i < 24; i++)
+            if (n[i]) fprintf(stderr, "host-prof %-34s %9llu calls %8.2f us each\n", name[i] ? name[i] : "?", n[i], us[i] / (double)n[i]);
+    }
+};
+extern __attribute__((visibility("hidden"))) vrt_host_prof g_host_prof;
+struct vrt_prof_scope {
+    int i;
+    std::chrono::steady_clock::time_point t0;
+    vrt_prof_scope(int i_, const char *name) : i(i_), t0(std::chrono::steady_clock::now()) { g_host_prof.name[i] = name; }
+    ~vrt_prof_scope() {
+        g_host_prof.us[i] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        g_host_prof.n[i] += 1;
+    }
+};
+#define VRT_PROF(i, name) vrt_prof_scope prof_scope_##i(i, name)
+#else
+#define VRT_PROF(i, name) do { } while (0)
+#endif
+
 static_assert(sizeof(vrt_material) == 32, "Material layout (mod.rs:20-28)");
 static_assert(sizeof(vrt_cam_data) == 160, "CamData layout (mod.rs:82-91)");
 static_assert(sizeof(vrt_world_data) == 32, "WorldData layout (mod.rs:113-120)");

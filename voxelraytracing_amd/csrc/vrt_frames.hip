@@ -17,6 +17,10 @@ int fail(vrt_ctx *ctx, int code, const char *fmt, ...) {
 }
 
 // Wait for the frame that may still be running on the second stream.
+#ifdef VRT_EXPERIMENTS
+vrt_host_prof g_host_prof;
+#endif
+
 int quiesce(vrt_ctx *c) {
     if (c->alt_pending) {
         for (hipStream_t st : c->extra_stream)
@@ -706,6 +710,7 @@ int vrt_resize_output(vrt_ctx *c, uint32_t width, uint32_t height) {
 int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     if (c && c->grp) return grp_render(c, opts);
     if (!c) return VRT_ERR_INVALID_ARG;
+    VRT_PROF(3, "vrt_render (one context)");
     vrt_render_opts o;
     memset(&o, 0, sizeof o);
     if (opts) o = *opts;
@@ -717,9 +722,13 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     if (o.variant == 4u && (o.mode != VRT_MODE_PRIMARY_SHADOW || o.stats))
         return fail(c, VRT_ERR_INVALID_ARG, "vrt_render: variant 4 (persistent grid) renders plain primary + shadow frames only");
     if (!vrt::variant_supported(o.variant)) return fail(c, VRT_ERR_INVALID_ARG, "vrt_render: unknown kernel variant %u", o.variant);
-    int rc = validate_frame(c);
-    if (rc) return rc;
-    HIP_TRY(c, hipSetDevice(c->device));
+    int rc;
+    {
+        VRT_PROF(7, "  validate + hipSetDevice");
+        rc = validate_frame(c);
+        if (rc) return rc;
+        HIP_TRY(c, hipSetDevice(c->device));
+    }
 
     if (c->compact && (o.mode == VRT_MODE_PATH || (o.variant != 0u && o.variant != 2u) || c->settings.show_step_count == 1u))
         return fail(c, VRT_ERR_STATE, "vrt_render: a VRT_FLAG_COMPACT context renders primary(+shadow) frames with the default march "
@@ -734,8 +743,11 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
         const int rc2 = publish_upload(c);
         if (rc2) return rc2;
     }
-    rc = ensure_ndc(c);
-    if (rc) return rc;
+    {
+        VRT_PROF(8, "  ensure_ndc");
+        rc = ensure_ndc(c);
+        if (rc) return rc;
+    }
     uint32_t variant = o.variant;
     // The fast marches never ask whether *air* is liquid (ray_tracer.wgsl:226 asks for every voxel, voxel 0 included): a
     // material table that flags voxel 0 as liquid — nothing the reference's data packs do — is traced by the literal march.
@@ -746,6 +758,7 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
         variant = 1u;
     }
     if (variant == 0u || variant == 3u || variant == 4u || (o.mode == VRT_MODE_PATH && !air_liquid)) {
+        VRT_PROF(9, "  ensure_accel_world");
         rc = ensure_accel_world(c);
         if (rc) return rc;
         if (!c->accel_ok && (variant == 0u || variant == 3u || variant == 4u)) variant = 2u;  // world too large for the tables: walk the octree
@@ -755,8 +768,11 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     const bool kstats = o.stats == 1u || c->settings.show_step_count == 1u;
 
     FrameSet f;
-    rc = pick_frame_set(c, o, variant, kstats, f);
-    if (rc) return rc;
+    {
+        VRT_PROF(10, "  pick_frame_set (+ its upload waits)");
+        rc = pick_frame_set(c, o, variant, kstats, f);
+        if (rc) return rc;
+    }
     c->last_out = f.out;
     c->last_blk = f.blk;
     c->last_stream = f.st;
@@ -780,6 +796,7 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     // a frame of another frame set that reads the shared set: an edit's update of tabs[0] must wait for it (update_tables)
     const bool shares = wants_tables && c->accel_ok && tab == 0u && f.slot != 0u;
     if (wants_tables && c->accel_ok) {
+        VRT_PROF(11, "  frame_waits_for_uploads + update_tables");
         rc = frame_waits_for_uploads(c, f.st, f.slot);
         if (rc) return rc;
         rc = update_tables(c, tab, f.st);
@@ -834,6 +851,7 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
         ev = &no_events;   // an untimed frame: the launches carry no events (vrt_stats' kernel times average the timed ones)
         ev_kind = &no_kind;
     } else {
+        VRT_PROF(12, "  next_events");
         rc = next_events(c, &ev, &ev_kind);
         if (rc) return rc;
     }
@@ -878,9 +896,12 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     c->frame_mode = o.mode;
     // the counters feed stats frames and the path trace's segment cursors; a plain primary(+shadow) frame reads none
     if (kstats || o.mode == VRT_MODE_PATH) HIP_TRY(c, hipMemsetAsync(f.counters, 0, kCounterBytes, f.st));
-    if (o.mode == VRT_MODE_PATH) rc = launch_path_frame(c, P, f, o, kstats, air_liquid, *ev, *ev_kind);
-    else rc = launch_march_frame(c, P, f, o.mode == VRT_MODE_PRIMARY_SHADOW, variant, kstats, *ev, *ev_kind);
-    if (rc) return rc;
+    {
+        VRT_PROF(13, "  the launch(es)");
+        if (o.mode == VRT_MODE_PATH) rc = launch_path_frame(c, P, f, o, kstats, air_liquid, *ev, *ev_kind);
+        else rc = launch_march_frame(c, P, f, o.mode == VRT_MODE_PRIMARY_SHADOW, variant, kstats, *ev, *ev_kind);
+        if (rc) return rc;
+    }
     if (tile_sort) {   // (the frame above read the old order and is over when this runs; the next frame starts after it)
         vrt::launch_tile_order(c->d_tile_cost, c->tiles_local, 1u, c->d_tile_scratch, c->d_tile_order, f.st);   // classes of two trips
         HIP_TRY(c, hipGetLastError());

@@ -161,6 +161,7 @@ int grp_render(vrt_ctx *c, const vrt_render_opts *opts) {
 }
 
 static int grp_render_frame(vrt_ctx *c, const vrt_render_opts *opts, bool &issued) {
+    VRT_PROF(0, "grp_render (a frame of the group)");
     vrt_group *g = c->grp;
     vrt_ctx *root = g->dev[0];
     vrt_render_opts o;
@@ -183,6 +184,7 @@ static int grp_render_frame(vrt_ctx *c, const vrt_render_opts *opts, bool &issue
     o.flags |= VRT_RENDER_OWN_STREAMS;   // every device's frame runs on that context's in-flight streams, into the buffer bound here
     // what is issued to device r >= 1 for this frame — by its worker thread, or here
     auto issue = [g, k, o, root](uint32_t r) -> int {
+        VRT_PROF(1, " issue to a shard device");
         vrt_ctx *d = g->dev[r];
         if (hipSetDevice(d->device) != hipSuccess) return fail(d, VRT_ERR_DEVICE, "hipSetDevice(%d) failed", d->device);
         void *slot = (uint8_t *)g->recv[k] + (size_t)r * g->rank_stride;
@@ -196,6 +198,7 @@ static int grp_render_frame(vrt_ctx *c, const vrt_render_opts *opts, bool &issue
         if (d->tiles_local && g->staged[r] &&
             hipMemcpyPeerAsync(slot, root->device, g->stage[r][k], d->device, g->rank_stride, d->last_stream) != hipSuccess)
             return fail(d, VRT_ERR_DEVICE, "hipMemcpyPeerAsync from device %d to device %d failed", d->device, root->device);
+        VRT_PROF(2, "  record done");
         if (d->tiles_local && hipEventRecord(g->done[r][k], d->last_stream) != hipSuccess)
             return fail(d, VRT_ERR_DEVICE, "hipEventRecord failed on device %d", d->device);
         return VRT_OK;
@@ -220,6 +223,7 @@ static int grp_render_frame(vrt_ctx *c, const vrt_render_opts *opts, bool &issue
     }
     if (rc) { c->err = root->err; return rc; }
     if (wrc) return wrc;
+    VRT_PROF(4, " root: waits + assemble + record");
     hipStream_t X = root->last_stream ? root->last_stream : root->stream;
     for (uint32_t r = 1; r < n; r++)
         if (g->dev[r]->tiles_local) HIP_TRY(c, hipStreamWaitEvent(X, g->done[r][k], 0));
