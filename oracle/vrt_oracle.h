@@ -7,12 +7,17 @@
  * voxelraytracing_amd/ may include, link or call it.  Only tests/, __graft_entry__.smoke() and
  * bench.py's cpu_baseline leg use it.
  *
- * PARITY STATUS: "parity unpinned" by the reference — the reference has no tests, golden vectors or
- * fixtures for this path and cannot be built here (Rust + WGSL via wgpu; no
- * cargo/rustc/naga in the image).  The oracle is pinned instead by hand-derived known-answer tests
- * from the shader text (tests/test_oracle_kat.py), by golden vectors it generated itself
- * (tests/golden/, generator script committed), and by a second restatement of the live shader written
- * separately in numpy (tests/wgsl_numpy.py) that it agrees with bit for bit on ids and iteration counts.
+ * PARITY STATUS: the reference has no tests, golden vectors or fixtures for this path and cannot be
+ * built here (Rust + WGSL via wgpu; no cargo/rustc/naga in the image) — but its shader text can be executed:
+ * tests/wgsl_interp.py, a generic WGSL interpreter, runs clientdesktop/src/graphics/ray_tracer.wgsl as it stands
+ * (tests/golden/make_wgsl_fixtures.py, read from /root/reference at generation time) and this oracle reproduces what the
+ * shader computes on six scenes — voxel, hit, normal, water distance, hit position, iteration count bit for bit for every
+ * pixel, colour to 1e-6 — as well as rng_next / rng_next_dir of path_tracer.wgsl and fs_main of screen_shader.wgsl
+ * (tests/test_oracle_vs_reference_wgsl.py).  That pins it to the reference's SOURCE, not to a run of the reference's binary:
+ * what WGSL leaves to the implementation (min with a NaN, i32(NaN), summation orders, pow's last ulps, reads past the end
+ * of an array) is decided once, identically, here and in the interpreter.  Also: hand-derived known-answer tests
+ * (tests/test_oracle_kat.py), golden vectors it generated itself (tests/golden/c*.npz) and a second restatement of the live
+ * shader in numpy (tests/wgsl_numpy.py) that it agrees with bit for bit on ids and iteration counts.
  *
  * Every function cites the reference file:line it follows (paths relative to /root/reference).
  */

@@ -1,0 +1,126 @@
+"""The oracle against the REFERENCE'S OWN SHADER TEXT.
+
+tests/golden/wgsl_*.npz were made by executing `/root/reference/clientdesktop/src/graphics/ray_tracer.wgsl` as it stands,
+invocation by invocation, with tests/wgsl_interp.py — a generic WGSL interpreter that knows nothing about octrees or ray
+marching (tests/golden/make_wgsl_fixtures.py, which reads the shader from the reference at generation time; no shader text is
+stored here).  oracle/vrt_oracle.c must reproduce what the shader computed: which voxel every ray stops on, the `hit` flag,
+the normal's axes, whether the ray went through water — bit for bit — the per-pixel iteration count of `ray_world`, the hit
+position and water distance as binary32 values, and the colour handed to textureStore to 1e-6 (`pow` in the sky).  That pins
+the oracle to the reference's source up to the corners WGSL leaves to the implementation (the interpreter lists its choices).
+Where /root/reference exists (the build container) a few pixels are traced again, so the fixtures cannot drift from the
+generator."""
+import os
+import sys
+import zlib
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_wgsl_fixtures as mk   # noqa: E402  (the scenes' definitions live with the generator)
+
+GOLD = os.path.join(HERE, "golden")
+
+
+def _load(case):
+    return np.load(os.path.join(GOLD, f"wgsl_{case}.npz"))
+
+
+@pytest.mark.parametrize("case", mk.CASES)
+def test_scene_inputs_are_the_ones_the_shader_was_run_on(case):
+    f = _load(case)
+    sc, win = mk.case_scene(case)
+    ck = mk.scene_checksums(sc)
+    for k, v in ck.items():
+        assert np.array_equal(v, f[k]), f"{case}: {k} differs — the fixture was made from another scene"
+    assert tuple(f["window"]) == win and tuple(f["size"]) == tuple(sc.size)
+
+
+@pytest.mark.parametrize("case", mk.CASES)
+def test_oracle_computes_what_the_reference_shader_computes(case, orc):
+    f = _load(case)
+    sc, (x0, y0, x1, y1) = mk.case_scene(case)
+    w, h = sc.size
+    o = orc.from_package_scene(sc)
+    rgb, ids, steps, _ = o.render(orc.MODE_PRIMARY, w, h, want_steps=True)
+    rgb, ids, steps = rgb[y0:y1, x0:x1], ids[y0:y1, x0:x1], steps[y0:y1, x0:x1]
+    hit = f["hit"].astype(bool)
+    # the id word, composed as the kernels and the oracle compose it, from what the SHADER computed
+    want = np.where(hit, f["voxel"] & orc.ID_VOXEL_MASK, 0).astype(np.uint32)
+    want |= np.where(hit, orc.ID_HIT, 0).astype(np.uint32)
+    for axis, bit in enumerate((orc.ID_NX, orc.ID_NY, orc.ID_NZ)):
+        want |= np.where(f["norm"][..., axis] != 0.0, bit, 0).astype(np.uint32)
+    want |= np.where(f["water_dist"] != 0.0, orc.ID_WATER, 0).astype(np.uint32)
+    bad = np.argwhere(ids != want)
+    assert bad.size == 0, f"{case}: {len(bad)} id words differ from the shader's, first at (y, x) = {tuple(bad[0])}: " \
+                          f"oracle {ids[tuple(bad[0])]:#x}, shader {want[tuple(bad[0])]:#x}"
+    assert np.array_equal(steps, f["iters"]), f"{case}: per-pixel iteration counts of ray_world differ from the shader's"
+    assert hit.any() and (~hit).any() or case.startswith("c1_axis"), f"{case}: a fixture should hold hits and misses"
+    err = np.abs(rgb - f["rgb"])
+    assert np.isnan(rgb).sum() == np.isnan(f["rgb"]).sum()
+    assert float(np.nanmax(err)) <= 1e-6, f"{case}: colour differs from the shader's textureStore argument by {np.nanmax(err)}"
+    # every pixel through the oracle's single-ray entry point: the HitResult's position, normal and water distance are the
+    # shader's binary32 values, bit for bit (a miss leaves position and normal at their zero initial values in both)
+    def bits(a):
+        return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+    for y in range(y0, y1):
+        for x in range(x0, x1):
+            _, _, _, out = o.trace_pixel(orc.MODE_PRIMARY, x, y)
+            yy, xx = y - y0, x - x0
+            got = np.float32(out)
+            assert np.array_equal(bits(got[6:7]), bits(f["water_dist"][yy, xx:xx + 1])), (case, y, x, "water_dist", got[6], f["water_dist"][yy, xx])
+            assert int(got[7]) == int(f["iters"][yy, xx])
+            if hit[yy, xx]:
+                assert np.array_equal(bits(got[0:3]), bits(f["pos"][yy, xx])), (case, y, x, "pos", got[0:3], f["pos"][yy, xx])
+                # (the sign of a zero component is -sign(dir) * 0 in the shader: compare the values)
+                assert np.array_equal(got[3:6], f["norm"][yy, xx]), (case, y, x, "norm", got[3:6], f["norm"][yy, xx])
+
+
+@pytest.mark.skipif(not os.path.exists(mk.SHADER), reason="the reference tree is only in the build container")
+@pytest.mark.parametrize("case", ["c1_48", "c2_64x40"])
+def test_the_generator_still_makes_the_fixtures(case):
+    """A few rows traced again from the reference's shader: the committed fixtures are what the generator produces today."""
+    f = _load(case)
+    assert int(f["shader_crc"][0]) == zlib.crc32(open(mk.SHADER, "rb").read()), "the reference's shader changed"
+    mk._init(case)
+    _, (x0, y0, x1, y1) = mk.case_scene(case)
+    for y in (y0 + 3, (y0 + y1) // 2):
+        _, row = mk._trace_row((y, x0, min(x0 + 12, x1)))
+        for i, (c, hh, v, it, nn, wd, pp) in enumerate(row):
+            assert np.array_equal(np.float32(c), f["rgb"][y - y0, i]) and bool(hh) == bool(f["hit"][y - y0, i])
+            assert v == f["voxel"][y - y0, i] and it == f["iters"][y - y0, i]
+
+
+def test_rng_is_the_reference_shaders(orc):
+    """rng_next (path_tracer.wgsl:56-61): state sequence and uniforms bit for bit; rng_next_dir (:62-72) to 1e-6 (log, cos)."""
+    import ctypes as C
+    f = np.load(os.path.join(GOLD, "wgsl_rng.npz"))
+    L = orc.lib()
+    for k, seed in enumerate(f["seeds"]):
+        st = C.c_uint32(int(seed))
+        for j in range(16):
+            u = L.orc_rng_next(C.byref(st))
+            assert st.value == int(f["states"][k, j]), (seed, j)
+            assert np.float32(u).view(np.uint32) == f["uniforms"][k, j].view(np.uint32), (seed, j, u, f["uniforms"][k, j])
+        st = C.c_uint32(int(seed))
+        d = (C.c_float * 3)()
+        L.orc_test_rng_dir(C.byref(st), d)
+        assert st.value == int(f["dir_states"][k])
+        # (the oracle clamps the uniform under the logarithm to 1e-10, the shader would take log(0): none of these seeds draws a zero)
+        assert float(np.abs(np.float32(list(d)) - f["dirs"][k]).max()) <= 1e-6, (seed, list(d), f["dirs"][k])
+
+
+def test_present_is_the_reference_fragment_shader(orc):
+    """fs_main of screen_shader.wgsl:43-65 at 1:1: crosshair off / dot / cross — the oracle's blit, byte for byte after the
+    unorm8 conversion of the colour attachment."""
+    f = np.load(os.path.join(GOLD, "wgsl_present.npz"))
+    src = np.load(os.path.join(GOLD, "wgsl_c1_48.npz"))["rgb"]
+    h, w, _ = src.shape
+    for k, row in enumerate(f["styles"]):
+        style, size, color = int(row[0]), float(row[1]), tuple(float(c) for c in row[2:6])
+        got = orc.present(src, (w, h), color=color, style=style, size=size)
+        want = np.rint(np.clip(f[f"img{k}"], 0.0, 1.0) * np.float32(255.0)).astype(np.uint8)
+        assert np.array_equal(got, want), f"crosshair {row}: {int((got != want).any(axis=2).sum())} pixels differ from fs_main's"
+        if style:
+            assert (want != np.rint(np.clip(f["img0"], 0.0, 1.0) * 255.0).astype(np.uint8)).any()
