@@ -75,7 +75,7 @@ def test_oracle_computes_what_the_reference_shader_computes(case, orc):
             if hit[yy, xx]:
                 assert np.array_equal(bits(got[0:3]), bits(f["pos"][yy, xx])), (case, y, x, "pos", got[0:3], f["pos"][yy, xx])
                 # (the sign of a zero component is -sign(dir) * 0 in the shader: compare the values)
-                assert np.array_equal(got[3:6], f["norm"][yy, xx]), (case, y, x, "norm", got[3:6], f["norm"][yy, xx])
+                assert np.array_equal(got[3:6], f["norm"][yy, xx], equal_nan=True), (case, y, x, "norm", got[3:6], f["norm"][yy, xx])
 
 
 @pytest.mark.skipif(not os.path.exists(mk.SHADER), reason="the reference tree is only in the build container")
