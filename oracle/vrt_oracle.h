@@ -11,7 +11,7 @@
  * built here (Rust + WGSL via wgpu; no cargo/rustc/naga in the image) — but its shader text can be executed:
  * tests/wgsl_interp.py, a generic WGSL interpreter, runs clientdesktop/src/graphics/ray_tracer.wgsl as it stands
  * (tests/golden/make_wgsl_fixtures.py, read from /root/reference at generation time) and this oracle reproduces what the
- * shader computes on eleven scenes — voxel, hit, normal, water distance, hit position, iteration count bit for bit for every
+ * shader computes on thirteen scenes (config C1 at its full size among them) — voxel, hit, normal, water distance, hit position, iteration count bit for bit for every
  * pixel, colour to 1e-6 — as well as rng_next / rng_next_dir of path_tracer.wgsl and fs_main of screen_shader.wgsl
  * (tests/test_oracle_vs_reference_wgsl.py).  That pins it to the reference's SOURCE, not to a run of the reference's binary:
  * what WGSL leaves to the implementation (min with a NaN, i32(NaN), summation orders, pow's last ulps, reads past the end

@@ -31,8 +31,12 @@ F32, I32, U32 = np.float32, np.int32, np.uint32
 
 def case_scene(name):
     """(scene, (x0, y0, x1, y1) window of pixels to trace) — deterministic, rebuilt identically by the test."""
+    if name == "c1_256":         # BASELINE config C1 at its full size: 256 x 256 (65 536 invocations of the shader)
+        return scenes.c1_flat((256, 256)), (0, 0, 256, 256)
     if name == "c1_48":          # config C1's scene: Superflat built by set_node, looking down at the ground and out to the sky
         return scenes.c1_flat((48, 48)), (0, 0, 48, 48)
+    if name == "c2_480x272":     # config C2's scene at a quarter of its resolution (130 560 invocations)
+        return scenes.c2((480, 272)), (0, 0, 480, 272)
     if name == "c2_64x40":       # config C2's scene at 64 x 40: terrain, trees, water, sky
         return scenes.c2((64, 40)), (0, 0, 64, 40)
     if name == "c2_water_40x24":  # the same world from just above its lake (water to y = 70 over a bed at 40): rays through water to the
@@ -87,7 +91,7 @@ def case_scene(name):
     raise KeyError(name)
 
 
-CASES = ["c1_48", "c2_64x40", "c2_water_40x24", "c2_underwater_24x16", "c2_steps_32x24", "c2_sun_24x16", "minsign_40x24", "nan_eye_8x8", "nan_exhaust_8x8", "nan_x_eye_8x8", "c1_axis_16"]
+CASES = ["c1_256", "c2_480x272", "c1_48", "c2_64x40", "c2_water_40x24", "c2_underwater_24x16", "c2_steps_32x24", "c2_sun_24x16", "minsign_40x24", "nan_eye_8x8", "nan_exhaust_8x8", "nan_x_eye_8x8", "c1_axis_16"]
 # (result sizes are whole 8 x 8 tiles: the reference dispatches size / 8 workgroups per axis, main.rs:452)
 
 
@@ -158,12 +162,19 @@ def make(case):
     norm = np.zeros((h, w, 3), np.float32)
     water = np.zeros((h, w), np.float32)
     pos = np.zeros((h, w, 3), np.float32)
-    _init(case)   # (one process: ~ 25 ms per pixel, the five cases take a few minutes)
-    for y in range(y0, y1):
-        _, row = _trace_row((y, x0, x1))
+    def put(y, row):
         for i, (c, hh, v, it, nn, wdist, pp) in enumerate(row):
             rgb[y - y0, i], hit[y - y0, i], voxel[y - y0, i], iters[y - y0, i] = c, hh, v, it
             norm[y - y0, i], water[y - y0, i], pos[y - y0, i] = nn, wdist, pp
+    if w * h > 20000:   # (the full-size frame: rows over freshly started worker processes — a forked one would inherit the host library's threads)
+        import multiprocessing as mp
+        with mp.get_context("spawn").Pool(min(8, os.cpu_count() or 1), initializer=_init, initargs=(case,)) as pool:
+            for y, row in pool.imap_unordered(_trace_row, [(y, x0, x1) for y in range(y0, y1)]):
+                put(y, row)
+    else:               # one process: ~ 10-25 ms per pixel
+        _init(case)
+        for y in range(y0, y1):
+            put(*_trace_row((y, x0, x1)))
     np.savez_compressed(os.path.join(HERE, f"wgsl_{case}.npz"), window=np.array([x0, y0, x1, y1]), size=np.array(sc.size), rgb=rgb, hit=hit,
                         voxel=voxel, iters=iters, norm=norm, water_dist=water, pos=pos,
                         shader_crc=np.array([zlib.crc32(open(SHADER, "rb").read())], dtype=np.uint32), **scene_checksums(sc))

@@ -65,17 +65,12 @@ def test_oracle_computes_what_the_reference_shader_computes(case, orc):
     def bits(a):   # the binary32 patterns, every NaN as one pattern (a NaN's payload is not something WGSL defines)
         a = np.ascontiguousarray(a, dtype=np.float32)
         return np.where(np.isnan(a), np.uint32(0x7FC00000), a.view(np.uint32))
-    for y in range(y0, y1):
-        for x in range(x0, x1):
-            _, _, _, out = o.trace_pixel(orc.MODE_PRIMARY, x, y)
-            yy, xx = y - y0, x - x0
-            got = np.float32(out)
-            assert np.array_equal(bits(got[6:7]), bits(f["water_dist"][yy, xx:xx + 1])), (case, y, x, "water_dist", got[6], f["water_dist"][yy, xx])
-            assert int(got[7]) == int(f["iters"][yy, xx])
-            if hit[yy, xx]:
-                assert np.array_equal(bits(got[0:3]), bits(f["pos"][yy, xx])), (case, y, x, "pos", got[0:3], f["pos"][yy, xx])
-                # (the sign of a zero component is -sign(dir) * 0 in the shader: compare the values)
-                assert np.array_equal(got[3:6], f["norm"][yy, xx], equal_nan=True), (case, y, x, "norm", got[3:6], f["norm"][yy, xx])
+    got = np.array([[o.trace_pixel(orc.MODE_PRIMARY, x, y)[3] for x in range(x0, x1)] for y in range(y0, y1)], dtype=np.float32)
+    assert np.array_equal(bits(got[..., 6]), bits(f["water_dist"])), f"{case}: water distances differ from the shader's"
+    assert np.array_equal(got[..., 7].astype(np.uint32), f["iters"])
+    assert np.array_equal(bits(got[..., 0:3])[hit], bits(f["pos"])[hit]), f"{case}: hit positions differ from the shader's"
+    # (the sign of a zero component is -sign(dir) * 0 in the shader: the normals compare as values)
+    assert np.array_equal(got[..., 3:6][hit], f["norm"][hit], equal_nan=True), f"{case}: normals differ from the shader's"
 
 
 @pytest.mark.skipif(not os.path.exists(mk.SHADER), reason="the reference tree is only in the build container")
