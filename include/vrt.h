@@ -307,7 +307,8 @@ typedef struct {
     uint32_t chunk_builds; /* chunks rebuilt alone since vrt_create: a vrt_write_nodes range or a changed chunk_roots slot
                             * rebuilds only the chunks it touches, stream-ordered, with no host round trip (every copy of the
                             * tables rebuilds every dirtied chunk once: the count of the copy that has rebuilt most) */
-    uint32_t _reserved;
+    uint32_t ordered_frames; /* (not about the tables) frames since vrt_create whose tiles were launched longest first: one-frame-at-a-time
+                            * contexts, a view at rest or a view a camera step away from the frame before */
 } vrt_accel_info;
 int vrt_get_accel_info(vrt_ctx *ctx, vrt_accel_info *out);
 

@@ -903,6 +903,57 @@ def test_samples_per_launch_chain_do_not_change_the_frame(orc, monkeypatch, per_
     assert np.array_equal(ids1, o_ids) and np.array_equal(rgb1, o_rgb)
 
 
+def test_tiles_ordered_under_a_moving_camera_are_the_same_frames(orc, monkeypatch):
+    """Round 4 (VRT_TILE_ORDER_MOVING=1): a one-frame-at-a-time context keeps launching its tiles longest first while the camera MOVES — the order made
+    from the frame before, its trips dilated over the image motion of a camera step (vrt_kernels.hip:
+    launch_tile_order_moving).  A walk of small steps (the bench's orbit step: < 1 voxel, ~ 1 degree), a rest, a jump (screen
+    order again), more steps: every frame is the screen-order context's frame, the last one the oracle's; and the counter
+    says which frames were ordered."""
+    from voxelraytracing_amd import graphics as g
+    sc = scenes.c2()
+    monkeypatch.setenv("VRT_TILE_ORDER_MOVING", "1")   # (off by default: profiles/r04_tile_order_moving.txt)
+    mov = gpu_for_scene(sc)
+    mov.set_frames_in_flight(1)
+    monkeypatch.delenv("VRT_TILE_ORDER_MOVING")
+    monkeypatch.setenv("VRT_TILE_ORDER", "0")
+    ref = gpu_for_scene(sc)
+    ref.set_frames_in_flight(1)
+    monkeypatch.delenv("VRT_TILE_ORDER")
+
+    def cam_at(k, jump=0.0):
+        return g.cam_data_create((sc.rot[0] + 0.3 * k, sc.rot[1] + 0.9 * k + jump, 0.0), (sc.eye[0] + 0.5 * k + jump, sc.eye[1] + 0.1 * (k % 3), sc.eye[2] - 0.4 * k), 70.0, (1920.0, 1080.0))
+    #           steps 0..5 move, 6..8 rest at step 5's camera, 9 jumps 40 degrees / 40 voxels, 10..13 move on from there
+    plan = [(k, 0.0) for k in range(6)] + [(5, 0.0)] * 3 + [(9 + k, 40.0) for k in range(5)]
+    ordered = []
+    cam = None
+    for n, (k, jump) in enumerate(plan):
+        cam = cam_at(k, jump)
+        for gpu in (mov, ref):
+            gpu.write_cam_data(cam)
+            gpu.render(MODE_PRIMARY_SHADOW)
+        a_rgb, a_ids, _ = mov.read_output()
+        b_rgb, b_ids, _ = ref.read_output()
+        assert np.array_equal(a_ids, b_ids) and np.array_equal(a_rgb, b_rgb), n
+        ordered.append(mov.accel_info().ordered_frames)
+    used = [b - a for a, b in zip([0] + ordered[:-1], ordered)]
+    # the first frame has no order; every frame a step (or no step) from its predecessor has one; the frame after the jump has none
+    assert used == [0, 1, 1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1], used
+    assert ref.accel_info().ordered_frames == 0
+    o = orc.from_package_scene(sc)
+    o.set_cam(cam)
+    r_rgb, r_ids, _, _ = o.render(MODE_PRIMARY_SHADOW, 1920, 1080)
+    assert_frame_parity(a_rgb, a_ids, r_rgb, r_ids, "tiles ordered under a moving camera")
+    # the default is round 3's rule: screen order whenever the view has changed
+    old = gpu_for_scene(sc)
+    old.set_frames_in_flight(1)
+    for k in range(4):
+        old.write_cam_data(cam_at(k))
+        old.render(MODE_PRIMARY_SHADOW)
+    assert old.accel_info().ordered_frames == 0
+    for gpu in (mov, ref, old):
+        gpu.close()
+
+
 def test_longest_tiles_first_is_the_same_frame(orc, monkeypatch):
     """A context that renders one frame at a time launches the tiles of a view at rest longest first (the order from the
     trips the view's second frame noted; any change of the view goes back to screen order): any order of the tiles is the

@@ -72,7 +72,7 @@ class Crosshair(C.Structure):
 class AccelInfo(C.Structure):
     _fields_ = [("available", C.c_uint32), ("world_size_chunks", C.c_uint32), ("cells", C.c_uint64),
                 ("bricks", C.c_uint64), ("bytes", C.c_uint64), ("builds", C.c_uint32), ("last_build_ms", C.c_float),
-                ("chunk_builds", C.c_uint32), ("_reserved", C.c_uint32)]
+                ("chunk_builds", C.c_uint32), ("ordered_frames", C.c_uint32)]
 
 
 assert C.sizeof(Material) == 32 and C.sizeof(CamData) == 160

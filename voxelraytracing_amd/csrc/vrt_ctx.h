@@ -47,6 +47,7 @@ void launch_path_bounce(const FrameParams &P, bool stats, bool literal, hipStrea
 void launch_path_bounce_cells(const FrameParams &P, uint32_t refill_at, uint32_t segments, uint32_t lds_pad, hipStream_t st);
 void launch_path_finish(Texel *out, uint32_t n, uint32_t spp, hipStream_t st);
 void launch_tile_order(const uint32_t *cost, uint32_t n, uint32_t shift, uint32_t *scratch, uint32_t *order, hipStream_t st);
+void launch_tile_order_moving(uint32_t *cost, uint32_t tiles_x, uint32_t tiles_y, uint32_t shift, uint32_t radius, uint32_t *scratch, uint32_t *order, hipStream_t st);
 void launch_path_chain_finish(Texel *out, const Texel *acc, uint32_t n, uint32_t chain, bool first, bool last, uint32_t spp, hipStream_t st);
 void launch_quantize(const Texel *out, uint8_t *rgba8, uint32_t w, uint32_t h, hipStream_t st);
 void launch_assemble(const Texel *gathered, Texel *dst, uint32_t width, uint32_t tiles_x, uint32_t tiles_total,
@@ -249,6 +250,17 @@ struct vrt_ctx {
     uint32_t view_gen = 0;              // counts the changes of anything a tile's trips depend on
     uint32_t frame_view_gen = ~0u;      // ... as of the last frame rendered
     uint32_t order_view_gen = ~0u;      // ... as of the frame the order was made from
+    // ... and while the view MOVES (round 4): every such frame notes its trips, and the order for the next frame is made from
+    // them dilated over the image motion a camera step can cause (vrt_kernels.hip: launch_tile_order_moving) — used by a frame
+    // whose camera is close to the one the trips were noted under and whose view differs from it in the camera only
+    // OFF unless VRT_TILE_ORDER_MOVING=1: the frame's launch gets 6.4 us shorter (112.4 -> 106.0) and the six small launches that
+    // make the order take 17 of a stream that runs its frames back to back (profiles/r04_tile_order_moving.txt) — it pays only
+    // for a host that waits for every frame, whose wait hides them
+    bool tile_lpt_moving = false;
+    uint32_t ordered_frames = 0;        // frames launched in an order (vrt_accel_info.ordered_frames)
+    bool order_dilated = false;         // the order in d_tile_order is a dilated one
+    uint32_t cam_gen = 0, order_cam_gen = 0;   // counts the changes of the camera (each is a change of the view too)
+    vrt_cam_data order_cam{};           // the camera of the frame the order was made from
     bool tile_order_stale = false;      // a chunk was edited since the order was made: still used, made again by the next frame without an edit in front of it
     uint32_t frame_mode = ~0u;          // vrt_mode of the last frame rendered (a change of mode is a change of view)
     uint32_t last_slot = 0, last_tab = 0;   // the frame set and the table set of the last frame

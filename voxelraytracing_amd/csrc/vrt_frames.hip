@@ -570,6 +570,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         if (v >= 0 && v <= (long)kMarchDirectMaxS) c->march_direct_max_s = (uint32_t)v;
     }
     if (const char *e = getenv("VRT_TILE_ORDER")) c->tile_lpt = e[0] != '0';
+    if (const char *e = getenv("VRT_TILE_ORDER_MOVING")) c->tile_lpt_moving = e[0] != '0';
 #ifdef VRT_EXPERIMENTS
     if (const char *e = getenv("VRT_PATH_PERSISTENT")) c->path_persistent = e[0] == '1';
     if (const char *e = getenv("VRT_PATH_POOL")) c->path_pool = e[0] != '0';
@@ -670,10 +671,28 @@ void vrt_destroy(vrt_ctx *c) {
 
 const char *vrt_last_error(const vrt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
+// Whether a tile order made from camera a's frame, dilated over ~ 10 tiles each way, still serves camera b: the same projection,
+// the eye within a voxel and a half, every axis of the view within two degrees (a NaN camera is close to nothing).
+static bool cameras_close(const vrt_cam_data &a, const vrt_cam_data &b) {
+    if (memcmp(a.inv_proj_mat, b.inv_proj_mat, sizeof a.inv_proj_mat) != 0 || memcmp(a.proj_size, b.proj_size, sizeof a.proj_size) != 0) return false;
+    float d2 = 0.f;
+    for (int k = 0; k < 3; k++) d2 += (a.pos[k] - b.pos[k]) * (a.pos[k] - b.pos[k]);
+    if (!(d2 <= 2.25f)) return false;
+    for (int col = 0; col < 3; col++) {
+        float dot = 0.f, na = 0.f, nb = 0.f;
+        for (int k = 0; k < 3; k++) {
+            const float x = a.inv_view_mat[4 * col + k], y = b.inv_view_mat[4 * col + k];
+            dot += x * y; na += x * x; nb += y * y;
+        }
+        if (!(dot >= 0.99939f * sqrtf(na * nb))) return false;
+    }
+    return true;
+}
+
 int vrt_set_camera(vrt_ctx *c, const vrt_cam_data *cam) {
     GRP_EACH(c, vrt_set_camera(d, cam));
     if (!c || !cam) return fail(c, VRT_ERR_INVALID_ARG, "vrt_set_camera: null argument");
-    if (memcmp(&c->cam, cam, sizeof *cam) != 0) c->view_gen++;
+    if (memcmp(&c->cam, cam, sizeof *cam) != 0) { c->view_gen++; c->cam_gen++; }
     c->cam = *cam;
     return VRT_OK;
 }
@@ -871,7 +890,7 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     // on the context's own stream (a frame, the sort behind it and the next frame are then ordered by the stream alone)
     const bool lpt = c->tile_lpt && c->in_flight == 1u && f.st == c->stream && (o.mode == VRT_MODE_PRIMARY_SHADOW || o.mode == VRT_MODE_PRIMARY) && variant == 0u && !kstats &&
                      o.stats == 0u && P.grid && c->tiles_local >= 128u;
-    bool tile_sort = false;
+    bool tile_sort = false, dilate = false;
     // (a tile's trips depend on the mode too — a primary-only frame has no shadow march: an order made from the other
     // mode's frame is a stale order, and the frame before a sort must be of the same kind)
     if (c->frame_mode != o.mode) c->view_gen++;
@@ -884,12 +903,20 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
             c->tile_buf_tiles = c->tiles_local;
             c->tile_order_valid = false;
         }
-        if (c->order_view_gen != c->view_gen) c->tile_order_valid = false;   // the order of another view: worse than none
-        if (c->tile_order_valid) P.tile_order = c->d_tile_order;
-        tile_sort = !c->tile_order_valid && c->frame_view_gen == c->view_gen;   // the view has come to rest: this frame notes its trips
+        // an order is used by the very view it was made from, or — a dilated one — by a view a camera step away from it
+        const bool exact = c->tile_order_valid && !c->order_dilated && c->order_view_gen == c->view_gen;
+        const bool moving_ok = c->tile_lpt_moving && c->tiles_local == P.tiles_total && P.tiles_total % P.tiles_x == 0u;
+        const bool near = c->tile_order_valid && c->order_dilated && moving_ok &&
+                          c->view_gen - c->order_view_gen == c->cam_gen - c->order_cam_gen && cameras_close(c->order_cam, c->cam);
+        if (!exact && !near) c->tile_order_valid = false;   // the order of another view: worse than none
+        if (c->tile_order_valid) { P.tile_order = c->d_tile_order; c->ordered_frames++; }
+        if (!exact) {
+            if (c->frame_view_gen == c->view_gen) tile_sort = true;   // the view has come to rest: this frame notes its trips
+            else if (moving_ok) tile_sort = dilate = true;            // it moves: the next frame's order from this frame's trips, dilated
+        }
         // an order made before a chunk was edited: kept for the edit's own frame, made again by the first frame behind it
         // that has no fresh edit in front of it (its launch reads the old order, the sort behind it writes the new one)
-        if (c->tile_order_valid && c->tile_order_stale && !edit_in_front) tile_sort = true;
+        if (exact && c->tile_order_stale && !edit_in_front) tile_sort = true;
         if (tile_sort) P.tile_cost = c->d_tile_cost;
     }
     c->frame_view_gen = c->view_gen;
@@ -903,10 +930,14 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
         if (rc) return rc;
     }
     if (tile_sort) {   // (the frame above read the old order and is over when this runs; the next frame starts after it)
-        vrt::launch_tile_order(c->d_tile_cost, c->tiles_local, 1u, c->d_tile_scratch, c->d_tile_order, f.st);   // classes of two trips
+        if (dilate) vrt::launch_tile_order_moving(c->d_tile_cost, P.tiles_x, P.tiles_total / P.tiles_x, 1u, 2u, c->d_tile_scratch, c->d_tile_order, f.st);
+        else vrt::launch_tile_order(c->d_tile_cost, c->tiles_local, 1u, c->d_tile_scratch, c->d_tile_order, f.st);   // classes of two trips
         HIP_TRY(c, hipGetLastError());
         c->tile_order_valid = true;
         c->order_view_gen = c->view_gen;
+        c->order_dilated = dilate;
+        c->order_cam_gen = c->cam_gen;
+        c->order_cam = c->cam;
         c->tile_order_stale = false;
     }
     c->rendered = true;

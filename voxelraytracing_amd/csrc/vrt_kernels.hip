@@ -390,6 +390,41 @@ void launch_tile_order(const uint32_t *cost, uint32_t n, uint32_t shift, uint32_
     hipLaunchKernelGGL(tile_order_scatter_kernel, dim3((chunks + 3u) / 4u), dim3(256), 0, st, cost, n, chunks, shift, (const uint32_t *)scratch, order);
 }
 
+// The order for a view that MOVES: made from the frame before, whose trips are this frame's only near where they were
+// noted — a silhouette that has moved into a tile the order starts last (it was sky) runs its whole length behind everything
+// else (profiles/r02_tile_order_staleness.txt: an exact order one camera step old is 17 % worse than screen order).  So every
+// tile takes the largest cost within reach of the image's motion: the maximum over its block of 4 x 4 tiles and the `radius`
+// blocks around it (radius 2: 8-11 tiles each way, what the study's r = 8 covers), and the order is made from that.  Two
+// launches in front of the four of launch_tile_order; the block maxima live in its scratch until it counts.
+__global__ void __launch_bounds__(256) tile_block_max_kernel(const uint32_t *cost, uint32_t tiles_x, uint32_t tiles_y, uint32_t bw, uint32_t blocks, uint32_t *blk) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= blocks) return;
+    const uint32_t bx = b % bw, by = b / bw;
+    uint32_t m = 0u;
+    for (uint32_t y = by * 4u; y < min(by * 4u + 4u, tiles_y); y++)
+        for (uint32_t x = bx * 4u; x < min(bx * 4u + 4u, tiles_x); x++) m = max(m, cost[y * tiles_x + x]);
+    blk[b] = m;
+}
+__global__ void __launch_bounds__(256) tile_dilate_kernel(const uint32_t *blk, uint32_t tiles_x, uint32_t n, uint32_t bw, uint32_t bh, uint32_t radius, uint32_t *cost) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t bx = (t % tiles_x) / 4u, by = (t / tiles_x) / 4u;
+    uint32_t m = 0u;
+    for (uint32_t y = by - min(by, radius); y <= min(by + radius, bh - 1u); y++)
+        for (uint32_t x = bx - min(bx, radius); x <= min(bx + radius, bw - 1u); x++) m = max(m, blk[y * bw + x]);
+    cost[t] = m;
+}
+
+// cost: [tiles_x * tiles_y] trips in screen order (overwritten with the dilated ones); scratch as for launch_tile_order
+void launch_tile_order_moving(uint32_t *cost, uint32_t tiles_x, uint32_t tiles_y, uint32_t shift, uint32_t radius, uint32_t *scratch, uint32_t *order, hipStream_t st) {
+    const uint32_t n = tiles_x * tiles_y;
+    if (!n) return;
+    const uint32_t bw = (tiles_x + 3u) / 4u, bh = (tiles_y + 3u) / 4u;   // bw * bh <= n: fits the scratch
+    hipLaunchKernelGGL(tile_block_max_kernel, dim3((bw * bh + 255u) / 256u), dim3(256), 0, st, (const uint32_t *)cost, tiles_x, tiles_y, bw, bw * bh, scratch);
+    hipLaunchKernelGGL(tile_dilate_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, (const uint32_t *)scratch, tiles_x, n, bw, bh, radius, cost);
+    launch_tile_order(cost, n, shift, scratch, order, st);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Output helpers
 // ------------------------------------------------------------------------------------------------

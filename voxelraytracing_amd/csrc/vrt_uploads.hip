@@ -731,6 +731,7 @@ int vrt_get_accel_info(vrt_ctx *c, vrt_accel_info *out) {
     out->bytes = G * (G + 1u) * (G + 1u) * sizeof(uint32_t) + (uint64_t)used * 64u * sizeof(uint16_t);
     out->builds = c->accel_builds;
     out->last_build_ms = c->accel_last_ms;
+    out->ordered_frames = c->ordered_frames;
     for (const auto &T : c->tabs)
         if (T.live && T.chunk_builds > out->chunk_builds) out->chunk_builds = T.chunk_builds;   // every set rebuilds every dirty chunk once
     return VRT_OK;
