@@ -145,7 +145,7 @@ pub struct vrt_accel_info {
     pub builds: u32,
     pub last_build_ms: f32,
     pub chunk_builds: u32,
-    pub _reserved: u32,
+    pub ordered_frames: u32,
 }
 
 pub const VRT_ID_VOXEL_MASK: u32 = 0x7FFF;
