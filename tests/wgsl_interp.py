@@ -19,6 +19,7 @@ takes, and says here, the same choice the oracle documents
   mix(a, b, t)                     -> a*(1-t) + b*t;  smoothstep: t = clamp((x-lo)/(hi-lo), 0, 1), t*t*(3-2t);  clamp = min(max(x, lo), hi)
   pow(x, y)                        -> the binary32 rounding of the double-precision power
   v * M (vector times matrix)      -> component i = dot(v, column i of M)            (WGSL: transpose(M) * v)
+  M * v                            -> component i = dot(row i of M, v), left to right
   an array index past the end      -> an error (the fixtures' scenes never do it: what such a read yields is not defined)
 """
 from __future__ import annotations
@@ -181,6 +182,8 @@ def default_concrete(x):
         if x.t == "abs_f":
             return Vec("f32", [F32(e) for e in x.v])
         return x
+    if isinstance(x, list):   # an array value
+        return [default_concrete(e) for e in x]
     s = scalar_type(x) if not isinstance(x, (Struct, Mat4)) else None
     if s == "abs_i":
         return I32(x)
@@ -274,8 +277,13 @@ def binary(op, a, b):
         if op != "*":
             raise TypeError("vector (op) matrix")
         return Vec("f32", [dot(a, c) for c in b.cols])
+    if isinstance(a, Mat4) and isinstance(b, Vec):
+        if op != "*":
+            raise TypeError("matrix (op) vector")
+        # the linear combination of the columns, component i = dot(row i, v), summed left to right (no fused multiply-add)
+        return Vec("f32", [dot(Vec("f32", [c.v[i] for c in a.cols]), b) for i in range(4)])
     if isinstance(a, Mat4) or isinstance(b, Mat4):
-        raise TypeError("only vector * matrix is implemented")
+        raise TypeError("only vector * matrix and matrix * vector are implemented")
     if isinstance(a, Vec) or isinstance(b, Vec):
         n = len(a.v) if isinstance(a, Vec) else len(b.v)
         av = a.v if isinstance(a, Vec) else [a] * n
@@ -300,6 +308,11 @@ def unary(op, a):
         if t in ("i32", "u32"):
             return wrap_int(-int(a), t)
         return -a
+    if op == "~":   # bitwise complement of an integer
+        t = scalar_type(a)
+        if t in ("i32", "u32"):
+            return wrap_int(~int(a), t)
+        return ~a
     raise TypeError(op)
 
 
@@ -588,7 +601,7 @@ class Parser:
         return lhs
 
     def parse_unary(self):
-        if self.peek()[0] == "op" and self.peek()[1] in ("-", "!"):
+        if self.peek()[0] == "op" and self.peek()[1] in ("-", "!", "~"):
             op = self.next()[1]
             return ("un", op, self.parse_unary())
         if self.peek()[0] == "op" and self.peek()[1] == "&":     # address-of: a pointer to a function-scope variable
@@ -815,6 +828,13 @@ class Module:
             return Vec(t, [concretize(x, t) for x in flat])
         if name == "array":
             return [default_concrete(copy_value(a)) for a in args]
+        if name == "mat4x4":   # four columns, or sixteen scalars column by column
+            flat = []
+            for a in args:
+                flat.extend(a.v if isinstance(a, Vec) else [a])
+            if len(flat) != 16:
+                raise TypeError(f"mat4x4 from {len(flat)} components")
+            return Mat4([Vec("f32", [convert_scalar(x, "f32") for x in flat[4 * c:4 * c + 4]]) for c in range(4)])
         raise TypeError(f"constructor {name}")
 
     def call_expr(self, name, args):
@@ -950,6 +970,10 @@ class Module:
             i = int(self.eval(lhs[2], env))
             if isinstance(base, Vec):
                 base.v[i] = concretize(val, base.t)
+                return
+            if isinstance(base, list):   # an element of a function-scope array
+                old = base[i]
+                base[i] = concretize(val, scalar_type(old)) if not isinstance(old, (Vec, Struct, Mat4, list)) else copy_value(val)
                 return
         if lhs[0] == "deref":
             r = self.eval(lhs[1], env)
