@@ -312,6 +312,13 @@ struct ChunkNodes {
     }
 };
 
+#ifdef VRT_EXP_CHUNKDBG   // experiment (tools/chunk_probe.py): when the LAST thread of workgroup 0 passes each phase (shader clock; [8 + i]: 100 MHz clock)
+__device__ unsigned long long g_chunk_dbg[16];
+#define CHUNK_STAMP(i) do { if (blockIdx.x == 0 && (int)(threadIdx.x & 63u) == __ffsll((long long)__ballot(1)) - 1) { atomicMax(&g_chunk_dbg[i], (unsigned long long)__builtin_amdgcn_s_memtime()); \
+                                                   atomicMax(&g_chunk_dbg[8 + (i)], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } } while (0)
+#else
+#define CHUNK_STAMP(i) do { } while (0)
+#endif
 __global__ void __launch_bounds__(512) accel_chunks_kernel(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S,
                                                            uint32_t *grid, uint32_t *chunk_bricks, uint32_t *chunk_bases,
                                                            uint32_t *chunk_caps, uint32_t *tail, uint16_t *bricks, uint32_t brick_cap,
@@ -319,55 +326,74 @@ __global__ void __launch_bounds__(512) accel_chunks_kernel(const uint16_t *nodes
     extern __shared__ __attribute__((aligned(16))) uint16_t s_raw[];  // the chunk's node words from the 16-byte boundary at or below its root
     __shared__ uint32_t s_wave[8];
     __shared__ uint32_t s_base, s_blk;
+    __shared__ uint32_t s_split[512];
+    __shared__ uint32_t s_lq[8];
+    // (The kernel is written for SIZE: a lone workgroup runs it once, cold — the frame before it owned the instruction cache — and
+    // straight-line code is then fetched a cache line per memory round trip.  The 11.7 KB of the first wave-per-cell version ran in
+    // 14 us whatever its loops did; see tools/chunk_probe.py.  Hence buffer loads instead of a tail path per staged vector, the
+    // liquid mask in LDS instead of a select chain per use, one place that reads a node, and loops that are not unrolled.)
+    CHUNK_STAMP(0);
+    // (512 threads, not more: sixteen waves halve the lone kernel — 9.3 us, a lone edit 162.7 — but a workgroup that needs a
+    // whole CU at once waits for one while frames are in flight: an edit before every frame 97 -> 107 us per frame, measured)
     const uint32_t chunk = list.chunk[blockIdx.x];
     const uint32_t t = threadIdx.x, cx = t & 7u, cy = (t >> 3) & 7u, cz = t >> 6;
     const uint32_t root = list.root[blockIdx.x];
     (void)roots;
     // the region's base and size are wanted after two barriers: asked for now, beside the staging loads
-    uint32_t base0 = 0u, cap0 = 0u;
-    if (t == 0) { base0 = chunk_bases[chunk]; cap0 = chunk_caps[chunk]; }
-    // stage the chunk's own extent, eight nodes (16 bytes) per load; the pool is 16-byte aligned (hipMalloc)
+    uint32_t base0 = 0u, cap0 = 0u, blk0 = 0u;
+    if (t == 0) {
+        base0 = chunk_bases[chunk]; cap0 = chunk_caps[chunk];
+        if (mc.blocks && !mc.direct) blk0 = mc.dir[chunk_dir_index(S, chunk)];
+    }
+    if (t < 8u) s_lq[t] = lq.w[t];
+    // stage the chunk's own extent, eight nodes (16 bytes) per load; the pool is 16-byte aligned (hipMalloc).  Range-checked
+    // loads: what lies past the end of the pool reads as air leaves, as the march's own loads have it (whole words of two
+    // nodes are checked: the last node of a pool of odd size is put in place below)
     const uint32_t head = root & 7u, first = root - head;
     const uint32_t staged = min(list.extent[blockIdx.x], kChunkNodesMax);
     const uint32_t vecs = (head + staged + 7u) / 8u;
-    // (a lone workgroup again: all of a thread's loads are issued before the first of them is stored — one load per loop trip
+    const __amdgpu_buffer_rsrc_t nb = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(nodes), 0, (n_nodes & ~1u) * 2u, 0x00020000);   // (n_nodes <= 2^31 - 2: vrt_create)
+    // (a lone workgroup: all of a thread's loads are issued before the first of them is stored — one load per loop trip
     // was up to nine memory round trips in a row, 15 of the kernel's 17 us for a chunk of 40 000 nodes)
     constexpr uint32_t kVecsPerThread = (kChunkNodesMax + 16u + 8u * 512u - 1u) / (8u * 512u);
     uint4 sw[kVecsPerThread];
 #pragma unroll
     for (uint32_t j = 0; j < kVecsPerThread; j++) {
         const uint32_t v = t + 512u * j;
-        const uint64_t g = (uint64_t)first + (uint64_t)v * 8u;
         sw[j] = make_uint4(0u, 0u, 0u, 0u);
-        if (v < vecs) {
-            if (g + 8u <= n_nodes) {
-                sw[j] = *reinterpret_cast<const uint4 *>(nodes + g);
-            } else {   // the pool ends inside this vector: past the end reads as air leaves (what the march's buffer loads return)
-                uint32_t h[8];
-#pragma unroll
-                for (uint32_t k = 0; k < 8u; k++) h[k] = g + k < n_nodes ? (uint32_t)nodes[g + k] : 0u;
-                sw[j] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
-            }
-        }
+        if (v < vecs) sw[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(nb, (first + v * 8u) * 2u, 0, 0));
     }
 #pragma unroll
     for (uint32_t j = 0; j < kVecsPerThread; j++) {
         const uint32_t v = t + 512u * j;
         if (v < vecs) reinterpret_cast<uint4 *>(s_raw)[v] = sw[j];
     }
+    CHUNK_STAMP(1);
     __syncthreads();
-    const ChunkNodes lds_node{s_raw + head, nodes, staged, root, n_nodes};
+    if (t == 0 && (n_nodes & 1u) && n_nodes - 1u >= first && n_nodes - 1u - first < vecs * 8u) s_raw[n_nodes - 1u - first] = nodes[n_nodes - 1u];
+    if (n_nodes & 1u) __syncthreads();   // (uniform)
+    CHUNK_STAMP(2);
+    // node `idx` of the chunk, relative to its root: the one place that reads one (ChunkNodes above, spelled out once)
+    const uint16_t *lds = s_raw + head;
+    auto node_at = [&](uint32_t idx) __attribute__((always_inline)) -> uint32_t {
+        if (idx < staged) return (uint32_t)lds[idx];
+        if (idx >= kChunkNodesMax) return 0u;
+        const uint64_t g = (uint64_t)root + idx;
+        return g < n_nodes ? (uint32_t)nodes[g] : 0u;
+    };
     // the three levels above this thread's cell
-    uint32_t node = lds_node(0u), depth = 0u;
+    const uint32_t root_node = node_at(0u);
+    uint32_t node = root_node, depth = 0u;
     while ((node & 0x8000u) && depth < 3u) {
         const uint32_t sh = 2u - depth;
         const uint32_t sel = ((cx >> sh) & 1u) | (((cy >> sh) & 1u) << 1) | (((cz >> sh) & 1u) << 2);
-        node = lds_node((node & 0x7FFFu) + sel);
+        node = node_at((node & 0x7FFFu) + sel);
         depth += 1u;
     }
     const bool split = (node & 0x8000u) != 0u;
     uint32_t total;
     const uint32_t rank = rank_split_cells(split, s_wave, total);
+    if (split) s_split[rank] = t | (node << 16);   // the split cells in rank order: which cell, and its depth-3 node
     if (t == 0) {
         uint32_t base = base0;
         if (total > cap0) {
@@ -381,34 +407,119 @@ __global__ void __launch_bounds__(512) accel_chunks_kernel(const uint16_t *nodes
         // from the tail when a chunk that was one air leaf is that no longer
         uint32_t blk = 0u;
         if (mc.blocks && !mc.direct) {
-            const size_t d = chunk_dir_index(S, chunk);
-            blk = mc.dir[d];
-            if (blk < 2u && chunk_needs_block(lds_node(0u))) {
+            blk = blk0;
+            if (blk < 2u && chunk_needs_block(root_node)) {
                 blk = atomicAdd(mc.tail, 1u);
-                mc.dir[d] = blk < mc.cap ? blk : 1u;   // (cannot overflow: the host accounts for every possible new block)
+                mc.dir[chunk_dir_index(S, chunk)] = blk < mc.cap ? blk : 1u;   // (cannot overflow: the host accounts for every possible new block)
             }
         }
         s_blk = blk;
     }
+    CHUNK_STAMP(3);
     __syncthreads();
-    uint4 *mcell = s_blk >= 2u && s_blk < mc.cap ? mc.blocks + (size_t)s_blk * 512u + cell_in_block(cx, cy, cz) : nullptr;
-    if (mc.blocks && mc.direct) mcell = mc.blocks + direct_cell_index(S, chunk, cx, cy, cz);
-    const size_t cell = cell_index(S, chunk, cx, cy, cz);
-    if (!split) {
-        grid[cell] = leaf_entry(node, (32u >> depth) - 1u);
-        if (mcell) *mcell = leaf_march_cell(lq, node, (32u >> depth) - 1u);
-        return;
+    CHUNK_STAMP(4);
+    const bool own_block = s_blk >= 2u && s_blk < mc.cap;
+    // what a cell writes — its entry of the cell grid and its march cell — in one place: a leaf cell's thread, or lane 0 of the
+    // wave that did a split cell's brick
+    auto stops = [&](uint32_t voxel) __attribute__((always_inline)) {   // stops_a_ray on the mask in LDS
+        const uint32_t v = min(voxel, 255u);
+        return voxel != 0u && !((s_lq[v >> 5] >> (v & 31u)) & 1u);
+    };
+    auto write_cell = [&](uint32_t ct, uint4 mcell_value) __attribute__((always_inline)) {
+        const uint32_t x = ct & 7u, y = (ct >> 3) & 7u, z = ct >> 6;
+        grid[cell_index(S, chunk, x, y, z)] = mcell_value.x;
+        uint4 *mcell = nullptr;
+        if (mc.blocks && mc.direct) mcell = mc.blocks + direct_cell_index(S, chunk, x, y, z);
+        else if (own_block) mcell = mc.blocks + (size_t)s_blk * 512u + cell_in_block(x, y, z);
+        if (mcell) *mcell = mcell_value;
+    };
+    if (!split) {   // a leaf cell: its thread writes it (a march cell's first word is the cell's entry of the grid)
+        const uint32_t m = stops(node & 0x7FFFu) ? 0u : 0xFFFFFFFFu;
+        write_cell(t, make_uint4(leaf_entry(node, (32u >> depth) - 1u), 0u, m, m));
     }
-    const uint32_t brick = s_base + rank;
-    if (brick >= brick_cap) return;  // cannot happen: the host accounts for every possible move
-    uint32_t w[32];
-    assemble_brick(lds_node, node, w);
-    store_brick(bricks, brick, w);
-    // (no fence between the brick and the entry that names it: nothing reads this table set while the kernel runs — its frames
-    // are later on this very stream, and frames of other sets that shared it were waited for, update_tables)
-    grid[cell] = 0x80000000u | (brick * 64u);
-    if (mcell) *mcell = split_march_cell(lq, brick, w);
+    CHUNK_STAMP(7);
+    // The split cells: A WAVE PER CELL, A LANE PER VOXEL of its brick.  (One thread per cell — round 3 — had the threads of the
+    // split cells walk 72 nodes and classify 64 voxels each, alone in their waves, while the threads of the leaf cells were
+    // done.)  Lane e = x | y << 2 | z << 4 reads its depth-4 node — eight different ones per wave — and, below a split one, its
+    // depth-5 node; the brick is one 128-byte store per wave; which voxels a ray passes is a ballot; the size-2 bit of an entry
+    // pair is that of its even lane (both are under the same depth-4 node).  Same words in the same places as assemble_brick /
+    // split_march_cell produce (the whole-world build still uses those: tests/test_gpu_accel.py compares the two).
+    const uint32_t lane = t & 63u, wave = t >> 6;
+    const uint32_t c4 = ((lane >> 1) & 1u) | (((lane >> 3) & 1u) << 1) | (((lane >> 5) & 1u) << 2);   // the depth-4 child the voxel is in
+    const uint32_t g5 = (lane & 1u) | (((lane >> 2) & 1u) << 1) | (((lane >> 4) & 1u) << 2);          // the voxel inside it
+    // Four cells at a time, every step for all four before the next: a cell is a chain of six LDS round trips (its list entry,
+    // the depth-4 node, the depth-5 node, the liquid mask, the shuffle, ~ 150 cycles each with two waves on a SIMD:
+    // tools/chunk_probe.py) and the lone workgroup has nothing else to put between them.  The reads are branch-free — an index
+    // beyond what was staged (no world the host mirror builds) is patched afterwards, under a branch the whole wave skips.
+    constexpr uint32_t kAtOnce = 4u;
+    const uint32_t last = staged ? staged - 1u : 0u;
+#pragma clang loop unroll(disable)
+    for (uint32_t r0 = wave; r0 < total; r0 += 8u * kAtOnce) {
+        uint32_t ent[kAtOnce], i4[kAtOnce], n4[kAtOnce], i5[kAtOnce], w[kAtOnce], lq_word[kAtOnce], lo_even[kAtOnce];
+#pragma unroll
+        for (uint32_t k = 0; k < kAtOnce; k++) ent[k] = s_split[min(r0 + 8u * k, 511u)];   // (past the list: whatever is there, unused)
+        bool beyond = false;
+#pragma unroll
+        for (uint32_t k = 0; k < kAtOnce; k++) {
+            i4[k] = ((ent[k] >> 16) & 0x7FFFu) + c4;
+            n4[k] = (uint32_t)lds[min(i4[k], last)];
+            beyond = beyond || i4[k] >= staged;
+        }
+        if (__ballot(beyond) != 0ull) {
+#pragma unroll
+            for (uint32_t k = 0; k < kAtOnce; k++) n4[k] = node_at(i4[k]);
+        }
+        beyond = false;
+#pragma unroll
+        for (uint32_t k = 0; k < kAtOnce; k++) {
+            i5[k] = (n4[k] & 0x7FFFu) + g5;
+            w[k] = (uint32_t)lds[min(i5[k], last)];   // (read whether the depth-4 node is split or not)
+            beyond = beyond || ((n4[k] & 0x8000u) != 0u && i5[k] >= staged);
+        }
+        if (__ballot(beyond) != 0ull) {
+#pragma unroll
+            for (uint32_t k = 0; k < kAtOnce; k++) w[k] = node_at(i5[k]);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kAtOnce; k++) {
+            w[k] = (n4[k] & 0x8000u) ? (w[k] & 0x7FFFu) << 1         // depth 5: the walk stops here, size 1
+                                     : ((n4[k] & 0x7FFFu) << 1) | 1u;   // depth-4 leaf, size 2
+            lq_word[k] = s_lq[min(w[k] >> 1, 255u) >> 5];
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kAtOnce; k++) lo_even[k] = (uint32_t)__shfl((int)(w[k] & 1u), (int)((2u * lane) & 63u), 64);
+        // the four cells' entries are written by lanes 0..3, one cell each
+        uint32_t my_ct = 0u, my_brick = 0u, my_size2 = 0u, my_pass_lo = 0u, my_pass_hi = 0u;
+        bool mine = false;
+#pragma unroll
+        for (uint32_t k = 0; k < kAtOnce; k++) {
+            const uint32_t r = r0 + 8u * k, brick = s_base + r;
+            if (r >= total || brick >= brick_cap) break;  // (the second cannot happen: the host accounts for every possible move)
+            bricks[(size_t)brick * 64u + lane] = (uint16_t)w[k];
+            const uint32_t voxel = w[k] >> 1, v = min(voxel, 255u);
+            const unsigned long long pass = __ballot(!(voxel != 0u && !((lq_word[k] >> (v & 31u)) & 1u)));   // stops_a_ray
+            const uint32_t size2 = (uint32_t)__ballot(lane < 32u && lo_even[k] != 0u);
+            if (lane == k) { mine = true; my_ct = ent[k] & 0x1FFu; my_brick = brick; my_size2 = size2; my_pass_lo = (uint32_t)pass; my_pass_hi = (uint32_t)(pass >> 32); }
+        }
+        // (no fence between the brick and the entry that names it: nothing reads this table set while the kernel runs — its
+        // frames are later on this very stream, and frames of other sets that shared it were waited for, update_tables)
+        if (mine) write_cell(my_ct, make_uint4(0x80000000u | (my_brick * 64u), my_size2, my_pass_lo, my_pass_hi));
+    }
+    CHUNK_STAMP(6);
 }
+#ifdef VRT_EXP_CHUNKDBG
+}  // namespace
+}  // namespace vrt
+extern "C" void vrt_exp_chunk_dbg(unsigned long long *out) {   // read and reset
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(vrt::g_chunk_dbg), sizeof(unsigned long long) * 16);
+    void *p = nullptr;
+    (void)hipGetSymbolAddress(&p, HIP_SYMBOL(vrt::g_chunk_dbg));
+    (void)hipMemset(p, 0, sizeof(unsigned long long) * 16);
+}
+namespace vrt {
+namespace {
+#endif
 
 // Upload of a staged range: the pinned ring is mapped into the device's address space, so a kernel reads it over PCIe and
 // writes the resident buffer — a launch like any other on the stream, where hipMemcpyAsync makes the host wait for the
