@@ -41,6 +41,7 @@
 // read the octree itself and are compared against it in the tests.  Rebuilt lazily before the next frame
 // whenever nodes, chunk_roots or the world size changed; never inside the kernels' timed region.
 #include <atomic>
+#include <hip/hip_ext.h>
 
 #include "vrt_device.h"
 
@@ -607,7 +608,7 @@ void launch_accel_bricks(const uint16_t *nodes, uint32_t n_nodes, const uint32_t
 void launch_accel_chunks(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S, uint32_t *grid,
                          uint32_t *chunk_bricks, uint32_t *chunk_bases, uint32_t *chunk_caps, uint32_t *tail, uint16_t *bricks,
                          uint32_t brick_cap, uint32_t *dir, uint4 *blocks, uint32_t *block_tail, uint32_t block_cap, const uint32_t liquid[8],
-                         const uint32_t *chunks, const uint32_t *extents, const uint32_t *chunk_roots_host, uint32_t n, hipStream_t st) {
+                         const uint32_t *chunks, const uint32_t *extents, const uint32_t *chunk_roots_host, uint32_t n, hipStream_t st, hipEvent_t done) {
     // 64 KiB + of dynamic LDS needs opting in (the CU has 160 KiB); per device, and any thread may be the first
     const size_t lds = (size_t)(kChunkNodesMax + 16u) * sizeof(uint16_t);
     {   // (once per device: the call is a few microseconds of every edit's frame otherwise)
@@ -625,8 +626,13 @@ void launch_accel_chunks(const uint16_t *nodes, uint32_t n_nodes, const uint32_t
         ChunkList list;
         const uint32_t m = n - i < 64u ? n - i : 64u;
         for (uint32_t k = 0; k < m; k++) { list.chunk[k] = chunks[i + k]; list.extent[k] = extents[i + k]; list.root[k] = chunk_roots_host[i + k]; }
-        hipLaunchKernelGGL(accel_chunks_kernel, dim3(m), dim3(512), lds, st, nodes, n_nodes, roots, S, grid, chunk_bricks, chunk_bases,
-                           chunk_caps, tail, bricks, brick_cap, mc, liquid_mask(liquid), list);
+        // `done` (may be null): an event the LAST launch completes — the launch's own completion signal, no marker packet behind it
+        if (done && i + 64u >= n)
+            hipExtLaunchKernelGGL(accel_chunks_kernel, dim3(m), dim3(512), (uint32_t)lds, st, nullptr, done, 0, nodes, n_nodes, roots, S, grid, chunk_bricks,
+                                  chunk_bases, chunk_caps, tail, bricks, brick_cap, mc, liquid_mask(liquid), list);
+        else
+            hipLaunchKernelGGL(accel_chunks_kernel, dim3(m), dim3(512), lds, st, nodes, n_nodes, roots, S, grid, chunk_bricks, chunk_bases,
+                               chunk_caps, tail, bricks, brick_cap, mc, liquid_mask(liquid), list);
     }
 }
 

@@ -67,7 +67,7 @@ void launch_upload_batch(void *dst0, void *dst1, const void *pinned_ring, const 
 void launch_accel_chunks(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S, uint32_t *grid,
                          uint32_t *chunk_bricks, uint32_t *chunk_bases, uint32_t *chunk_caps, uint32_t *tail, uint16_t *bricks,
                          uint32_t brick_cap, uint32_t *dir, uint4 *blocks, uint32_t *block_tail, uint32_t block_cap, const uint32_t liquid[8],
-                         const uint32_t *chunks, const uint32_t *extents, const uint32_t *chunk_roots_host, uint32_t n, hipStream_t st);
+                         const uint32_t *chunks, const uint32_t *extents, const uint32_t *chunk_roots_host, uint32_t n, hipStream_t st, hipEvent_t done);
 }  // namespace vrt
 
 // Host-time profile of the frame path (experiments build, VRT_HOST_PROF=1: printed at process exit): where the calling

@@ -582,13 +582,13 @@ int update_tables(vrt_ctx *c, uint32_t k, hipStream_t st) {
         const uint32_t end = nx != c->roots_index.end() ? nx->first : c->max_nodes;
         extents[i] = r ? (end > r ? end - r : 0u) : 1u;   // (a missing chunk is node 0 alone: one air leaf)
     }
+    if (!T.ev_updated) HIP_TRY(c, hipEventCreateWithFlags(&T.ev_updated, hipEventDisableTiming));
+    // (the next upload of nodes or roots waits for this reader: ev_updated is the completion signal of the launch itself — a
+    // record behind it is one more packet between the rebuild and the frame that waits for it)
     vrt::launch_accel_chunks(c->d_nodes, c->max_nodes, c->d_roots, c->accel_S, T.d_grid, T.d_chunk_bricks, T.d_chunk_bases, T.d_chunk_caps,
                              T.d_brick_tail, T.d_bricks, T.brick_cap, c->march_direct ? nullptr : T.d_cdir, T.d_mblk, T.d_mblk_tail, T.mblk_cap, c->liquid_mask,
-                             T.dirty_chunks.data(), extents.data(), roots_now.data(), (uint32_t)T.dirty_chunks.size(), st);
+                             T.dirty_chunks.data(), extents.data(), roots_now.data(), (uint32_t)T.dirty_chunks.size(), st, T.ev_updated);
     HIP_TRY(c, hipGetLastError());
-    // the next upload of nodes or roots waits for this reader
-    if (!T.ev_updated) HIP_TRY(c, hipEventCreateWithFlags(&T.ev_updated, hipEventDisableTiming));
-    HIP_TRY(c, hipEventRecord(T.ev_updated, st));
     T.update_pending = true;
     for (uint32_t ch : T.dirty_chunks) {
         if (!T.chunk_may_have_moved[ch]) { T.chunk_may_have_moved[ch] = 1; T.chunks_moved += 1; }
