@@ -472,18 +472,36 @@ __global__ void present_kernel(const Texel *out, uint32_t w, uint32_t h, uint32_
     const float a = ut - fu, b = vt - fv;
     const int x0 = min(max((int)fu, 0), (int)w - 1), x1 = min(max((int)fu + 1, 0), (int)w - 1);
     const int y0 = min(max((int)fv, 0), (int)h - 1), y1 = min(max((int)fv + 1, 0), (int)h - 1);
-    const Texel t00 = out[(size_t)y0 * w + x0], t10 = out[(size_t)y0 * w + x1], t01 = out[(size_t)y1 * w + x0], t11 = out[(size_t)y1 * w + x1];
-    const uint32_t c00[3] = {t00.x, t00.y, t00.z}, c10[3] = {t10.x, t10.y, t10.z}, c01[3] = {t01.x, t01.y, t01.z}, c11[3] = {t11.x, t11.y, t11.z};
+    const Texel t00 = out[(size_t)y0 * w + x0];
+    const uint32_t c00[3] = {t00.x, t00.y, t00.z};
+    // alpha: 1 where the compute pass stored a texel, 0 beyond its workgroups (all of it when w and h are multiples of 8)
+    const float a00 = ((uint32_t)x0 < cov_w && (uint32_t)y0 < cov_h) ? 1.0f : 0.0f;
     float texel[4];
+    if (a == 0.0f && b == 0.0f) {
+        // The sample is at a texel's centre — every pixel of a window of the texture's size (main.rs:454 after a resize).  The other
+        // three taps have weight zero, and x * 1 + y * 0 is x for the finite x and y a decoded unorm8 is: one load, one texel
+        // decoded, instead of four (the blit was 20 us alone for a 1080p window, most of it twelve IEEE divides per pixel).
+        if (mask == 0.0f) {   // ... and outside the crosshair the pixel IS the stored texel: unorm8(q / 255 * 1 + c * 0) = q for q = 0 .. 255 (checked: all 256)
+            uint32_t q = a00 != 0.0f ? 0xFF000000u : 0u;
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const float v00 = (float)unorm8(__uint_as_float(c00[k])) / 255.0f, v10 = (float)unorm8(__uint_as_float(c10[k])) / 255.0f;
-        const float v01 = (float)unorm8(__uint_as_float(c01[k])) / 255.0f, v11 = (float)unorm8(__uint_as_float(c11[k])) / 255.0f;
-        const float top = v00 * (1.0f - a) + v10 * a, bot = v01 * (1.0f - a) + v11 * a;
-        texel[k] = top * (1.0f - b) + bot * b;
-    }
-    {   // alpha: 1 where the compute pass stored a texel, 0 beyond its workgroups (all of it when w and h are multiples of 8)
-        const float a00 = ((uint32_t)x0 < cov_w && (uint32_t)y0 < cov_h) ? 1.0f : 0.0f, a10 = ((uint32_t)x1 < cov_w && (uint32_t)y0 < cov_h) ? 1.0f : 0.0f;
+            for (int k = 0; k < 3; k++) q |= unorm8(__uint_as_float(c00[k])) << (8 * k);
+            reinterpret_cast<uint32_t *>(rgba8)[(size_t)sy * screen_w + sx] = q;
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) texel[k] = (float)unorm8(__uint_as_float(c00[k])) / 255.0f;
+        texel[3] = a00;
+    } else {
+        const Texel t10 = out[(size_t)y0 * w + x1], t01 = out[(size_t)y1 * w + x0], t11 = out[(size_t)y1 * w + x1];
+        const uint32_t c10[3] = {t10.x, t10.y, t10.z}, c01[3] = {t01.x, t01.y, t01.z}, c11[3] = {t11.x, t11.y, t11.z};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float v00 = (float)unorm8(__uint_as_float(c00[k])) / 255.0f, v10 = (float)unorm8(__uint_as_float(c10[k])) / 255.0f;
+            const float v01 = (float)unorm8(__uint_as_float(c01[k])) / 255.0f, v11 = (float)unorm8(__uint_as_float(c11[k])) / 255.0f;
+            const float top = v00 * (1.0f - a) + v10 * a, bot = v01 * (1.0f - a) + v11 * a;
+            texel[k] = top * (1.0f - b) + bot * b;
+        }
+        const float a10 = ((uint32_t)x1 < cov_w && (uint32_t)y0 < cov_h) ? 1.0f : 0.0f;
         const float a01 = ((uint32_t)x0 < cov_w && (uint32_t)y1 < cov_h) ? 1.0f : 0.0f, a11 = ((uint32_t)x1 < cov_w && (uint32_t)y1 < cov_h) ? 1.0f : 0.0f;
         const float top = a00 * (1.0f - a) + a10 * a, bot = a01 * (1.0f - a) + a11 * a;
         texel[3] = top * (1.0f - b) + bot * b;
