@@ -101,6 +101,28 @@ def test_resize_output_and_rgba8_readback(orc):
     assert float(np.abs(b_rgb - r_rgb).max()) <= 1e-4
 
 
+@pytest.mark.parametrize("size", [(360, 200), (364, 100), (1920, 1080)])
+def test_a_window_of_the_textures_size_is_blitted_by_the_short_kernel_to_the_same_bytes(orc, size):
+    """Round 4: a window of the texture's size goes through present_plain_kernel — a texel quantised per pixel, the general
+    routine only inside the crosshair's box — when the host has found every sample within 1e-4 of its own texel's centre.
+    These sizes have columns and rows whose sample is NOT exactly the centre in binary32 (360: 40 of them, 364: 42 and a
+    texture whose last four columns no workgroup stores to, 1920 x 1080: 51 and 42): the bytes are the oracle's general
+    bilinear blit, for every crosshair — none, the default cross, a dot, a cross as large as the window, sizes that are not numbers."""
+    w, h = size
+    sc = scenes.c2((w, h))
+    gpu = gpu_for_scene(sc)
+    gpu.render(MODE_PRIMARY_SHADOW)
+    rgb, _, q = gpu.read_output(rgba8=True)
+    kinds = [dict(style=0), dict(), dict(style=1, size=9.5, color=(1.0, 0.2, 0.1, 0.75)), dict(style=2, size=17.0, color=(0.0, 0.0, 0.0, 1.0))]
+    if w <= 400:
+        kinds += [dict(style=2, size=1.0e4, color=(0.3, 0.6, 0.9, 0.5)), dict(style=1, size=float("nan")), dict(style=2, size=-3.0), dict(style=1, size=0.4)]
+    for kw in kinds:
+        got = gpu.present((w, h), **kw)
+        assert np.array_equal(got, orc.present(rgb, (w, h), **kw)), kw
+    assert np.array_equal(gpu.present((w, h), style=0), q)
+    gpu.close()
+
+
 @pytest.mark.parametrize("size", [(203, 77), (128, 75), (131, 72), (7, 40), (40, 5)])
 def test_result_textures_of_any_size(orc, size):
     """The reference's result texture is 1080 rows at the window's aspect — any width (main.rs:257-262) — and its compute

@@ -53,7 +53,7 @@ void launch_quantize(const Texel *out, uint8_t *rgba8, uint32_t w, uint32_t h, h
 void launch_assemble(const Texel *gathered, Texel *dst, uint32_t width, uint32_t tiles_x, uint32_t tiles_total,
                      uint32_t root_weight, uint32_t period, bool skip_root, uint64_t rank_stride, hipStream_t st);
 void launch_present(const Texel *out, uint32_t w, uint32_t h, uint32_t screen_w, uint32_t screen_h, const vrt_crosshair &ch,
-                    uint8_t *rgba8, hipStream_t st);
+                    uint8_t *rgba8, bool one_to_one, const uint32_t box[4], hipStream_t st);
 void launch_assemble_shade(const FrameParams &P, const void *gathered, Texel *dst, uint32_t root_weight, uint32_t period,
                            uint64_t rank_stride, hipStream_t st);
 void launch_accel_cells(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S, uint32_t *grid,
@@ -257,6 +257,9 @@ struct vrt_ctx {
     // make the order take 17 of a stream that runs its frames back to back (profiles/r04_tile_order_moving.txt) — it pays only
     // for a host that waits for every frame, whose wait hides them
     bool tile_lpt_moving = false;
+    // vrt_present*: whether a window of (one_w x one_h) over a texture of the same size samples every texel at its centre
+    uint32_t one_w = 0, one_h = 0;
+    bool one_to_one = false;
     uint32_t ordered_frames = 0;        // frames launched in an order (vrt_accel_info.ordered_frames)
     bool order_dilated = false;         // the order in d_tile_order is a dilated one
     uint32_t cam_gen = 0, order_cam_gen = 0;   // counts the changes of the camera (each is a change of the view too)

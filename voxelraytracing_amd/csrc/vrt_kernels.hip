@@ -447,10 +447,8 @@ __global__ void quantize_rgba8_kernel(const Texel *out, uint8_t *rgba8, uint32_t
 // per screen pixel: the sampler's (bilinear) sample of the texture at the pixel centre, crosshair mask, blend, unorm8 store.
 __device__ __forceinline__ uint32_t unorm8(float x) { return (uint32_t)rintf(vclamp(x, 0.0f, 1.0f) * 255.0f) & 0xFFu; }
 
-__global__ void present_kernel(const Texel *out, uint32_t w, uint32_t h, uint32_t cov_w, uint32_t cov_h, uint32_t screen_w, uint32_t screen_h,
-                               vrt_crosshair ch, uint8_t *rgba8) {
-    const uint32_t sx = blockIdx.x * blockDim.x + threadIdx.x, sy = blockIdx.y;
-    if (sx >= screen_w) return;
+__device__ __forceinline__ uint32_t present_pixel(const Texel *out, uint32_t w, uint32_t h, uint32_t cov_w, uint32_t cov_h, uint32_t screen_w, uint32_t screen_h,
+                                                   const vrt_crosshair &ch, uint32_t sx, uint32_t sy) {
     const float ssx = (float)screen_w, ssy = (float)screen_h;
     const float cx = ssx * 0.5f, cy = ssy * 0.5f;
     const float u = ((float)sx + 0.5f) / ssx, v = ((float)sy + 0.5f) / ssy;
@@ -485,8 +483,7 @@ __global__ void present_kernel(const Texel *out, uint32_t w, uint32_t h, uint32_
             uint32_t q = a00 != 0.0f ? 0xFF000000u : 0u;
 #pragma unroll
             for (int k = 0; k < 3; k++) q |= unorm8(__uint_as_float(c00[k])) << (8 * k);
-            reinterpret_cast<uint32_t *>(rgba8)[(size_t)sy * screen_w + sx] = q;
-            return;
+            return q;
         }
 #pragma unroll
         for (int k = 0; k < 3; k++) texel[k] = (float)unorm8(__uint_as_float(c00[k])) / 255.0f;
@@ -510,7 +507,41 @@ __global__ void present_kernel(const Texel *out, uint32_t w, uint32_t h, uint32_
     uint32_t q = 0u;
 #pragma unroll
     for (int k = 0; k < 4; k++) q |= unorm8(texel[k] * (1.0f - mask) + cc[k] * mask) << (8 * k);
-    reinterpret_cast<uint32_t *>(rgba8)[(size_t)sy * screen_w + sx] = q;
+    return q;
+}
+
+
+__global__ void present_kernel(const Texel *out, uint32_t w, uint32_t h, uint32_t cov_w, uint32_t cov_h, uint32_t screen_w, uint32_t screen_h,
+                               vrt_crosshair ch, uint8_t *rgba8) {
+    const uint32_t sx = blockIdx.x * blockDim.x + threadIdx.x, sy = blockIdx.y;
+    if (sx >= screen_w) return;
+    reinterpret_cast<uint32_t *>(rgba8)[(size_t)sy * screen_w + sx] = present_pixel(out, w, h, cov_w, cov_h, screen_w, screen_h, ch, sx, sy);
+}
+
+// The blit of a window of the texture's size (what the reference's window is after every resize, main.rs:454) when the HOST has
+// found — in this kernel's own arithmetic, vrt_present.hip: present_is_one_to_one, where the proof is — that every pixel samples
+// its own texel's centre to within 1e-4 of a texel: then a pixel outside the crosshair is its texel quantised, and the two IEEE divides,
+// the floors and the clamps that only find that out again per pixel (~ 110 instructions, two thirds of the blit's issue slots
+// beside a frame that is bound by exactly those) are not executed.  Four pixels per thread: 64 bytes of texels in, 16 bytes out.
+// Inside the box around the crosshair (the host's, a pixel wider than the mask can reach) every pixel takes present_pixel.
+__global__ void __launch_bounds__(256) present_plain_kernel(const Texel *out, uint32_t w, uint32_t h, uint32_t cov_w, uint32_t cov_h, vrt_crosshair ch,
+                                                            uint32_t box_x0, uint32_t box_x1, uint32_t box_y0, uint32_t box_y1, uint8_t *rgba8) {
+    const uint32_t x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4u, sy = blockIdx.y;   // (w % 4 == 0: the launcher's condition)
+    if (x4 >= w) return;
+    uint32_t q[4];
+    if (ch.style != 0u && sy >= box_y0 && sy < box_y1 && x4 + 4u > box_x0 && x4 < box_x1) {
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; k++) q[k] = present_pixel(out, w, h, cov_w, cov_h, w, h, ch, x4 + k, sy);
+    } else {
+        Texel t[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; k++) t[k] = out[(size_t)sy * w + x4 + k];
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; k++)
+            q[k] = (x4 + k < cov_w && sy < cov_h ? 0xFF000000u : 0u) | unorm8(__uint_as_float(t[k].x)) | (unorm8(__uint_as_float(t[k].y)) << 8) |
+                   (unorm8(__uint_as_float(t[k].z)) << 16);
+    }
+    reinterpret_cast<uint4 *>(rgba8)[((size_t)sy * w + x4) / 4u] = make_uint4(q[0], q[1], q[2], q[3]);
 }
 
 // Gather root: tile-major [rank][slots_per_rank] texels -> row-major frame of texels.  Tiles are dealt out in periods
@@ -686,8 +717,14 @@ void launch_assemble_shade(const FrameParams &P, const void *gathered, Texel *ds
                        (const uint2 *)gathered, dst, root_weight, period, rank_stride);
 }
 
+// one_to_one: the host's finding for this pair of sizes (screen == texture, every sample at its own texel's centre); box: the
+// pixels the crosshair's mask can reach, [x0, x1) x [y0, y1)
 void launch_present(const Texel *out, uint32_t w, uint32_t h, uint32_t screen_w, uint32_t screen_h, const vrt_crosshair &ch,
-                    uint8_t *rgba8, hipStream_t st) {
+                    uint8_t *rgba8, bool one_to_one, const uint32_t box[4], hipStream_t st) {
+    if (one_to_one && screen_w == w && screen_h == h && w % 4u == 0u) {
+        hipLaunchKernelGGL(present_plain_kernel, dim3((w / 4u + 255u) / 256u, h), dim3(256), 0, st, out, w, h, w & ~7u, h & ~7u, ch, box[0], box[1], box[2], box[3], rgba8);
+        return;
+    }
     hipLaunchKernelGGL(present_kernel, dim3((screen_w + 255u) / 256u, screen_h), dim3(256), 0, st, out, w, h, w & ~7u, h & ~7u, screen_w,
                        screen_h, ch, rgba8);
 }

@@ -6,6 +6,32 @@
 // THE FRAME it presents, on that frame's stream, into the screen buffer of the frame's set — a host that draws and presents
 // frame after frame (main.rs:452-454) keeps its frames in flight; nothing here waits for the device.  *screen: the buffer.
 static_assert(vrt_ctx::kMaxInFlight == 4, "one screen buffer per frame set");
+// present_kernel's sample position for every column and row of a window of the texture's size, in the kernel's own binary32
+// arithmetic (both sides divide correctly rounded; -ffp-contract=off): true if every pixel's sample is — to within 1e-4 of a texel
+// — the centre of ITS OWN texel.  (Exactly the centre it is not for every size: at 1920 columns, 51 land 2e-6 to 8e-6 beside it —
+// (s + 0.5) / 1920 * 1920 is not always s + 0.5 — and take 0.999998 of texel s and 0.000002 of its neighbour.)  Then
+// present_plain_kernel's shortcut is present_kernel's byte: the bilinear sample of decoded unorm8 values v_i = q_i / 255 with at
+// least (1 - 1e-4)^2 of the weight on v_s is within 2.1e-4 of v_s, 255 times that within 0.06 of the integer q_s, and the
+// quantisation rounds it to q_s; likewise the alpha (0 or 1 per tap).  Inside the crosshair's box every pixel takes present_pixel.
+static bool present_is_one_to_one(uint32_t w, uint32_t h) {
+    for (int axis = 0; axis < 2; axis++) {
+        const uint32_t n = axis ? h : w;
+        const volatile float ss = (float)n;
+        for (uint32_t s = 0; s < n; s++) {
+            const volatile float u = ((float)s + 0.5f) / ss;
+            const volatile float ut = u * ss - 0.5f;
+            const float fu = floorf(ut);
+            const volatile float a = ut - fu;
+            int x0 = (int)fu, x1 = (int)fu + 1;
+            x0 = x0 < 0 ? 0 : (x0 > (int)n - 1 ? (int)n - 1 : x0);
+            x1 = x1 < 0 ? 0 : (x1 > (int)n - 1 ? (int)n - 1 : x1);
+            const bool on_x0 = a <= 1.0e-4f && (uint32_t)x0 == s, on_x1 = a >= 1.0f - 1.0e-4f && (uint32_t)x1 == s;
+            if (!(on_x0 || on_x1)) return false;
+        }
+    }
+    return true;
+}
+
 static int present_on_device(vrt_ctx *c, const vrt_crosshair *crosshair, uint32_t screen_w, uint32_t screen_h, const char *who,
                              uint8_t **screen, hipStream_t *stream) {
     if (!c->rendered) return fail(c, VRT_ERR_STATE, "%s: nothing rendered yet", who);
@@ -26,7 +52,26 @@ static int present_on_device(vrt_ctx *c, const vrt_crosshair *crosshair, uint32_
         HIP_TRY(c, hipMalloc(&c->d_screen[k], bytes));
         c->screen_cap[k] = bytes;
     }
-    vrt::launch_present(c->last_out, c->width, c->height, screen_w, screen_h, *crosshair, c->d_screen[k], st);
+    // a window of the texture's size: is every pixel's sample its own texel's centre?  (found once per size, below)
+    if (screen_w == c->width && screen_h == c->height && (c->one_w != screen_w || c->one_h != screen_h)) {
+        c->one_to_one = present_is_one_to_one(screen_w, screen_h);
+        c->one_w = screen_w; c->one_h = screen_h;
+    }
+    const bool one = screen_w == c->width && screen_h == c->height && c->one_to_one;
+    // the pixels the crosshair's mask can reach: those within `size` of the centre, and two more for the rounding of px, py
+    uint32_t box[4] = {0u, 0u, 0u, 0u};
+    if (one && crosshair->style != 0u) {
+        const float reach = crosshair->size + 2.0f;
+        const float cx = (float)screen_w * 0.5f, cy = (float)screen_h * 0.5f;
+        if (reach == reach && reach > 0.0f && reach < 1.0e6f) {
+            const float x0 = floorf(cx - reach - 0.5f), x1 = ceilf(cx + reach + 0.5f), y0 = floorf(cy - reach - 0.5f), y1 = ceilf(cy + reach + 0.5f);
+            box[0] = x0 > 0.0f ? (uint32_t)x0 : 0u; box[1] = x1 < (float)screen_w ? (uint32_t)(x1 > 0.0f ? x1 : 0.0f) : screen_w;
+            box[2] = y0 > 0.0f ? (uint32_t)y0 : 0u; box[3] = y1 < (float)screen_h ? (uint32_t)(y1 > 0.0f ? y1 : 0.0f) : screen_h;
+        } else {   // a size that is not a number, negative or huge: every pixel decides for itself
+            box[1] = screen_w; box[3] = screen_h;
+        }
+    }
+    vrt::launch_present(c->last_out, c->width, c->height, screen_w, screen_h, *crosshair, c->d_screen[k], one, box, st);
     HIP_TRY(c, hipGetLastError());
     c->screen_stream[k] = st;
     *screen = c->d_screen[k];
