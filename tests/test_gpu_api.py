@@ -101,12 +101,13 @@ def test_resize_output_and_rgba8_readback(orc):
     assert float(np.abs(b_rgb - r_rgb).max()) <= 1e-4
 
 
-@pytest.mark.parametrize("size", [(360, 200), (364, 100), (1920, 1080)])
+@pytest.mark.parametrize("size", [(360, 200), (364, 100), (1920, 1080), (16380, 8)])
 def test_a_window_of_the_textures_size_is_blitted_by_the_short_kernel_to_the_same_bytes(orc, size):
     """Round 4: a window of the texture's size goes through present_plain_kernel — a texel quantised per pixel, the general
     routine only inside the crosshair's box — when the host has found every sample within 1e-4 of its own texel's centre.
     These sizes have columns and rows whose sample is NOT exactly the centre in binary32 (360: 40 of them, 364: 42 and a
-    texture whose last four columns no workgroup stores to, 1920 x 1080: 51 and 42): the bytes are the oracle's general
+    texture whose last four columns no workgroup stores to, 1920 x 1080: 51 and 42; 16 380 columns: one is 5e-4 off its texel,
+    beyond what the short kernel's proof covers, so that window takes the general one): the bytes are the oracle's general
     bilinear blit, for every crosshair — none, the default cross, a dot, a cross as large as the window, sizes that are not numbers."""
     w, h = size
     sc = scenes.c2((w, h))
