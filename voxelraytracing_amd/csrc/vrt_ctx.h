@@ -254,8 +254,8 @@ struct vrt_ctx {
     // them dilated over the image motion a camera step can cause (vrt_kernels.hip: launch_tile_order_moving) — used by a frame
     // whose camera is close to the one the trips were noted under and whose view differs from it in the camera only
     // OFF unless VRT_TILE_ORDER_MOVING=1: the frame's launch gets 6.4 us shorter (112.4 -> 106.0) and the six small launches that
-    // make the order take 17 of a stream that runs its frames back to back (profiles/r04_tile_order_moving.txt) — it pays only
-    // for a host that waits for every frame, whose wait hides them
+    // make the order take 17 of a stream that runs its frames back to back, and of the wait of a host that synchronises every frame
+    // (profiles/r04_tile_order_moving.txt): an experiment, not a mode anybody should switch on as it stands
     bool tile_lpt_moving = false;
     // vrt_present*: whether a window of (one_w x one_h) over a texture of the same size samples every texel at its centre
     uint32_t one_w = 0, one_h = 0;
