@@ -289,6 +289,7 @@ struct vrt_ctx {
     struct Staged { uint32_t buf, dst_word, n_words; size_t ring_at; };
     std::vector<Staged> staged;
     size_t staged_bytes = 0;
+    bool flushed_at_call = false;     // a staged range went out at its vrt_write_* call since the last frame (the device was idle): the next ones wait for the batch
     bool staged_seg[kRingSegs] = {};  // ring segments the staged ranges lie in (their events are recorded at the flush)
     hipEvent_t ev_frames = nullptr;   // scratch: "everything enqueued on that frame stream so far"
     hipEvent_t ev_upload = nullptr;   // the last upload / table rebuild on c->stream

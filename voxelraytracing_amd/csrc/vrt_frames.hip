@@ -941,6 +941,7 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
         c->tile_order_stale = false;
     }
     c->rendered = true;
+    c->flushed_at_call = false;   // (the next frame's first staged range may go out at its call again: vrt_uploads.hip)
     c->last_stats = o.stats == 1u;
     c->last_mode = o.mode;
     c->timing_pending = true;

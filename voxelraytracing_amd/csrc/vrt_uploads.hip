@@ -188,7 +188,14 @@ static int stage_pool_upload(vrt_ctx *c, uint32_t buf, uint32_t dst_word, const 
     // Batching pays while frames are in flight (the launches would queue up behind them anyway).  With the device idle — a
     // lone edit with a synchronise behind its frame, main.rs:352-362 — the copy goes out now and runs while the host is
     // still on its way to vrt_render, instead of at the head of that call (170 -> 200 us in round 3's edit_cost).
-    if (c->rendered && c->last_stream && hipStreamQuery(c->last_stream) == hipSuccess) return flush_staged(c);
+    // ONE range per frame goes out like that.  A burst — chunks arriving at a join, main.rs:289-295: hundreds of ranges before one
+    // frame — outlasts the frames in flight, and from then on every call found the device idle and launched its own copy:
+    // 1.5 us per call became 6 (256 uploads per frame: 2.0 ms per frame, tools/stream_burst.py); the rest of a burst is batched.
+    if (c->flushed_at_call || !c->rendered || !c->last_stream) return VRT_OK;
+    if (hipStreamQuery(c->last_stream) == hipSuccess) {
+        c->flushed_at_call = true;   // (until the next vrt_render)
+        return flush_staged(c);
+    }
     (void)hipGetLastError();   // (hipErrorNotReady is not an error)
     return VRT_OK;
 }
