@@ -167,13 +167,29 @@ int flush_staged(vrt_ctx *c) {
 
 // Stage `bytes` for words [dst_word, ...) of the node pool (buf 0) or chunk_roots (buf 1): copied now, launched at the flush.
 static int stage_pool_upload(vrt_ctx *c, uint32_t buf, uint32_t dst_word, const void *src, size_t bytes) {
-    // a range that overlaps one staged earlier must land after it: the batch's pieces run side by side
-    for (const auto &s : c->staged)
-        if (s.buf == buf && dst_word < s.dst_word + s.n_words && s.dst_word < dst_word + (uint32_t)(bytes / 4u)) {
+    // The batch's pieces run side by side, so the staged ranges of a buffer are kept disjoint.  A range INSIDE one staged earlier
+    // overwrites that one's bytes in the ring (several edits of one chunk before a frame: main.rs:352-362 uploads the chunk's
+    // range after every edit — a launch per edit was 10 us per edit, tools/edit_burst.py); one that COVERS staged ranges takes their
+    // place; any other overlap must land after what is staged: that goes out first.
+    {
+        const uint32_t n_words = (uint32_t)(bytes / 4u), end_word = dst_word + n_words;
+        bool partial = false;
+        for (auto &s : c->staged) {
+            if (s.buf != buf || !s.n_words || !(dst_word < s.dst_word + s.n_words && s.dst_word < end_word)) continue;
+            if (dst_word >= s.dst_word && end_word <= s.dst_word + s.n_words) {   // inside: the staged copy becomes this one's data
+                memcpy(c->h_ring + s.ring_at + (size_t)(dst_word - s.dst_word) * 4u, src, bytes);
+                return VRT_OK;
+            }
+            if (!(s.dst_word >= dst_word && s.dst_word + s.n_words <= end_word)) partial = true;
+        }
+        if (partial) {
             const int rc = flush_staged(c);
             if (rc) return rc;
-            break;
+        } else {
+            for (auto &s : c->staged)   // covered ones: dropped (their ring bytes are simply not copied)
+                if (s.buf == buf && s.n_words && s.dst_word >= dst_word && s.dst_word + s.n_words <= end_word) { c->staged_bytes -= (size_t)s.n_words * 4u; s.n_words = 0u; }
         }
+    }
     if (c->staged_bytes + bytes > 4u * vrt_ctx::kRingSegBytes) {   // (half the ring: staged data is never overwritten by what follows)
         const int rc = flush_staged(c);
         if (rc) return rc;
