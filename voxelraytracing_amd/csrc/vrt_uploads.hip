@@ -190,7 +190,9 @@ static int stage_pool_upload(vrt_ctx *c, uint32_t buf, uint32_t dst_word, const 
                 if (s.buf == buf && s.n_words && s.dst_word >= dst_word && s.dst_word + s.n_words <= end_word) { c->staged_bytes -= (size_t)s.n_words * 4u; s.n_words = 0u; }
         }
     }
-    if (c->staged_bytes + bytes > 4u * vrt_ctx::kRingSegBytes) {   // (half the ring: staged data is never overwritten by what follows)
+    // (half the ring: staged data is never overwritten by what follows; and no more ranges than the scan above looks through in a
+    // microsecond — a host that writes node by node would otherwise pay for every range staged before it, quadratically)
+    if (c->staged_bytes + bytes > 4u * vrt_ctx::kRingSegBytes || c->staged.size() >= 512u) {
         const int rc = flush_staged(c);
         if (rc) return rc;
     }
