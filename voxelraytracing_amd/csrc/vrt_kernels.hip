@@ -476,7 +476,7 @@ __device__ __forceinline__ uint32_t present_pixel(const Texel *out, uint32_t w, 
     const float a00 = ((uint32_t)x0 < cov_w && (uint32_t)y0 < cov_h) ? 1.0f : 0.0f;
     float texel[4];
     if (a == 0.0f && b == 0.0f) {
-        // The sample is at a texel's centre — every pixel of a window of the texture's size (main.rs:454 after a resize).  The other
+        // The sample is at a texel's centre — every pixel of a window of the texture's size (the reference's texture is 1080 rows at the window's aspect, main.rs:255-262: a window 1080 rows tall).  The other
         // three taps have weight zero, and x * 1 + y * 0 is x for the finite x and y a decoded unorm8 is: one load, one texel
         // decoded, instead of four (the blit was 20 us alone for a 1080p window, most of it twelve IEEE divides per pixel).
         if (mask == 0.0f) {   // ... and outside the crosshair the pixel IS the stored texel: unorm8(q / 255 * 1 + c * 0) = q for q = 0 .. 255 (checked: all 256)
@@ -518,7 +518,8 @@ __global__ void present_kernel(const Texel *out, uint32_t w, uint32_t h, uint32_
     reinterpret_cast<uint32_t *>(rgba8)[(size_t)sy * screen_w + sx] = present_pixel(out, w, h, cov_w, cov_h, screen_w, screen_h, ch, sx, sy);
 }
 
-// The blit of a window of the texture's size (what the reference's window is after every resize, main.rs:454) when the HOST has
+// The blit of a window of the texture's size (the reference keeps its texture at 1080 rows and the window's aspect, main.rs:255-262:
+// that is a window 1080 rows tall — full HD, full screen) when the HOST has
 // found — in this kernel's own arithmetic, vrt_present.hip: present_is_one_to_one, where the proof is — that every pixel samples
 // its own texel's centre to within 1e-4 of a texel: then a pixel outside the crosshair is its texel quantised, and the two IEEE divides,
 // the floors and the clamps that only find that out again per pixel (~ 110 instructions, two thirds of the blit's issue slots
