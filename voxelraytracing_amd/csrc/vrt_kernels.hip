@@ -447,8 +447,10 @@ __global__ void quantize_rgba8_kernel(const Texel *out, uint8_t *rgba8, uint32_t
 // per screen pixel: the sampler's (bilinear) sample of the texture at the pixel centre, crosshair mask, blend, unorm8 store.
 __device__ __forceinline__ uint32_t unorm8(float x) { return (uint32_t)rintf(vclamp(x, 0.0f, 1.0f) * 255.0f) & 0xFFu; }
 
+// decoded[q] = q / 255 as the sampler decodes an rgba8unorm texel, a table of the workgroup (256 threads, a correctly rounded divide each):
+// a sample took twelve such divides — ~ 130 of the general blit's ~ 250 instructions per pixel, 68 us for a 4K window
 __device__ __forceinline__ uint32_t present_pixel(const Texel *out, uint32_t w, uint32_t h, uint32_t cov_w, uint32_t cov_h, uint32_t screen_w, uint32_t screen_h,
-                                                   const vrt_crosshair &ch, uint32_t sx, uint32_t sy) {
+                                                   const vrt_crosshair &ch, uint32_t sx, uint32_t sy, const float *decoded) {
     const float ssx = (float)screen_w, ssy = (float)screen_h;
     const float cx = ssx * 0.5f, cy = ssy * 0.5f;
     const float u = ((float)sx + 0.5f) / ssx, v = ((float)sy + 0.5f) / ssy;
@@ -486,15 +488,15 @@ __device__ __forceinline__ uint32_t present_pixel(const Texel *out, uint32_t w, 
             return q;
         }
 #pragma unroll
-        for (int k = 0; k < 3; k++) texel[k] = (float)unorm8(__uint_as_float(c00[k])) / 255.0f;
+        for (int k = 0; k < 3; k++) texel[k] = decoded[unorm8(__uint_as_float(c00[k]))];
         texel[3] = a00;
     } else {
         const Texel t10 = out[(size_t)y0 * w + x1], t01 = out[(size_t)y1 * w + x0], t11 = out[(size_t)y1 * w + x1];
         const uint32_t c10[3] = {t10.x, t10.y, t10.z}, c01[3] = {t01.x, t01.y, t01.z}, c11[3] = {t11.x, t11.y, t11.z};
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            const float v00 = (float)unorm8(__uint_as_float(c00[k])) / 255.0f, v10 = (float)unorm8(__uint_as_float(c10[k])) / 255.0f;
-            const float v01 = (float)unorm8(__uint_as_float(c01[k])) / 255.0f, v11 = (float)unorm8(__uint_as_float(c11[k])) / 255.0f;
+            const float v00 = decoded[unorm8(__uint_as_float(c00[k]))], v10 = decoded[unorm8(__uint_as_float(c10[k]))];
+            const float v01 = decoded[unorm8(__uint_as_float(c01[k]))], v11 = decoded[unorm8(__uint_as_float(c11[k]))];
             const float top = v00 * (1.0f - a) + v10 * a, bot = v01 * (1.0f - a) + v11 * a;
             texel[k] = top * (1.0f - b) + bot * b;
         }
@@ -513,9 +515,12 @@ __device__ __forceinline__ uint32_t present_pixel(const Texel *out, uint32_t w, 
 
 __global__ void present_kernel(const Texel *out, uint32_t w, uint32_t h, uint32_t cov_w, uint32_t cov_h, uint32_t screen_w, uint32_t screen_h,
                                vrt_crosshair ch, uint8_t *rgba8) {
+    __shared__ float s_decoded[256];
+    s_decoded[threadIdx.x] = (float)threadIdx.x / 255.0f;   // (256 threads: the launcher's)
+    __syncthreads();
     const uint32_t sx = blockIdx.x * blockDim.x + threadIdx.x, sy = blockIdx.y;
     if (sx >= screen_w) return;
-    reinterpret_cast<uint32_t *>(rgba8)[(size_t)sy * screen_w + sx] = present_pixel(out, w, h, cov_w, cov_h, screen_w, screen_h, ch, sx, sy);
+    reinterpret_cast<uint32_t *>(rgba8)[(size_t)sy * screen_w + sx] = present_pixel(out, w, h, cov_w, cov_h, screen_w, screen_h, ch, sx, sy, s_decoded);
 }
 
 // The blit of a window of the texture's size (the reference keeps its texture at 1080 rows and the window's aspect, main.rs:255-262:
@@ -527,12 +532,18 @@ __global__ void present_kernel(const Texel *out, uint32_t w, uint32_t h, uint32_
 // Inside the box around the crosshair (the host's, a pixel wider than the mask can reach) every pixel takes present_pixel.
 __global__ void __launch_bounds__(256) present_plain_kernel(const Texel *out, uint32_t w, uint32_t h, uint32_t cov_w, uint32_t cov_h, vrt_crosshair ch,
                                                             uint32_t box_x0, uint32_t box_x1, uint32_t box_y0, uint32_t box_y1, uint8_t *rgba8) {
+    __shared__ float s_decoded[256];
+    const bool box_row = ch.style != 0u && blockIdx.y >= box_y0 && blockIdx.y < box_y1;   // (uniform)
+    if (box_row) {
+        s_decoded[threadIdx.x] = (float)threadIdx.x / 255.0f;
+        __syncthreads();
+    }
     const uint32_t x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4u, sy = blockIdx.y;   // (w % 4 == 0: the launcher's condition)
     if (x4 >= w) return;
     uint32_t q[4];
-    if (ch.style != 0u && sy >= box_y0 && sy < box_y1 && x4 + 4u > box_x0 && x4 < box_x1) {
+    if (box_row && x4 + 4u > box_x0 && x4 < box_x1) {
 #pragma unroll
-        for (uint32_t k = 0; k < 4u; k++) q[k] = present_pixel(out, w, h, cov_w, cov_h, w, h, ch, x4 + k, sy);
+        for (uint32_t k = 0; k < 4u; k++) q[k] = present_pixel(out, w, h, cov_w, cov_h, w, h, ch, x4 + k, sy, s_decoded);
     } else {
         Texel t[4];
 #pragma unroll
