@@ -181,6 +181,53 @@ def test_chunks_that_outgrow_their_brick_region_move_and_many_dirty_chunks_rebui
     assert_frame_parity(rgb, ids, r_rgb, r_ids, "after the edit bursts")
 
 
+@pytest.mark.parametrize("in_flight", [1, 2])
+def test_random_overlapping_writes_leave_the_pool_the_calls_describe(in_flight):
+    """A model of queue.write_buffer (writes land in call order) against the staged uploads (csrc/vrt_uploads.hip: ranges of a
+    batch are kept disjoint — a write inside a staged range overwrites it in the ring, one that covers staged ranges replaces
+    them, other overlaps send the batch out first; at most 512 ranges and half the ring staged): 300 random writes a round from
+    three variants of the pool (the same trees, other voxels in a twentieth of the leaves), crowded into a window so that
+    they overlap in every way, between frames in flight.  The derived tables must be what a walk of the modelled pool finds
+    for every voxel."""
+    import ctypes as C
+    sc = scenes.c2((160, 96))
+    world = sc.world
+    S = world.size_in_chunks()
+    right = np.frombuffer((C.c_uint16 * world.max_nodes()).from_address(world.nodes_ptr()), dtype=np.uint16)
+    used = (int(np.nonzero(right)[0].max()) + 2) & ~1
+    rng = np.random.default_rng(23 + in_flight)
+    variants = [right]
+    for _ in range(2):
+        v = right.copy()
+        leaves = np.nonzero((v[:used] & 0x8000) == 0)[0]
+        pick = rng.choice(leaves[leaves > 0], len(leaves) // 20, replace=False)
+        v[pick] = rng.integers(0, 7, len(pick)).astype(np.uint16)       # other voxels (air among them), the trees as they are
+        variants.append(v)
+    expected = right.copy()
+    gpu = gpu_for_scene(sc)
+    gpu.set_frames_in_flight(in_flight)
+    roots = world.chunk_roots()
+    for round_ in range(3):
+        for _ in range(3):
+            gpu.render(MODE_PRIMARY_SHADOW)            # frames in flight: the writes below are staged
+        lo = int(rng.integers(2, used - 30000)) & ~1
+        for k in range(300):
+            src = variants[int(rng.integers(0, 3))]
+            a = lo + (int(rng.integers(0, 24000)) & ~1)
+            b = min(a + 2 * int(rng.integers(1, [8, 200, 2500][k % 3])), used)
+            gpu.write_nodes(src.ctypes.data, a, b)
+            expected[a:b] = src[a:b]
+            if k % 97 == 96:
+                gpu.render(MODE_PRIMARY_SHADOW)        # a frame in the middle of the burst
+        gpu.render(MODE_PRIMARY_SHADOW)
+        grid, bricks = gpu.read_accel()
+        v_ref, d_ref = walk_octree(expected, roots, S)
+        v, size = lookup_tables(grid, bricks, S)
+        assert np.array_equal(v, v_ref), (in_flight, round_, int((v != v_ref).sum()))
+        assert np.array_equal(size, 32 >> d_ref)
+    gpu.close()
+
+
 def test_procedural_world_tables_and_shrinking_world(orc):
     sc = scenes.procedural(4, (160, 96), MODE_PRIMARY_SHADOW)   # 4^3 chunks = 2 M voxels
     gpu = gpu_for_scene(sc)

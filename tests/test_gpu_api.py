@@ -413,49 +413,6 @@ def test_a_pool_uploaded_in_ragged_pieces_is_the_pool(orc):
     assert a.available and a.builds >= 1
 
 
-def test_overlapping_writes_before_a_frame_land_in_call_order(orc):
-    """wgpu's queue.write_buffer semantics: writes land in call order, the last one wins.  Staged ranges of one batch are
-    copied side by side, so the backend keeps them disjoint (round 4): a write INSIDE a staged range overwrites its bytes in
-    the ring, one that COVERS staged ranges replaces them, any other overlap sends the batch out first.  Random sequences of
-    such writes from a wrong pool and the right one, ending with the right bytes everywhere, between frames in flight (so that
-    the ranges are staged, not sent at the call): the frame is the right pool's frame."""
-    sc = scenes.c2((160, 96))
-    n_nodes = sc.world.max_nodes()
-    right = np.frombuffer((C.c_uint16 * n_nodes).from_address(sc.world.nodes_ptr()), dtype=np.uint16)
-    used = int(np.nonzero(right)[0].max()) + 2
-    wrong = right.copy()
-    rng = np.random.default_rng(11)
-    wrong[1:used] = rng.integers(0, 1 << 16, used - 1, dtype=np.uint16)      # garbage trees (node 0 stays the air leaf)
-    r_rgb, r_ids, _, _ = orc.from_package_scene(sc).render(orc.MODE_PRIMARY_SHADOW, 160, 96)
-    for in_flight in (1, 2):
-        gpu = gpu_for_scene(sc)
-        gpu.set_frames_in_flight(in_flight)
-        for round_ in range(6):
-            for _ in range(3):
-                gpu.render(MODE_PRIMARY_SHADOW)            # frames in flight: what follows is staged
-            lo = int(rng.integers(2, used - 6000))
-            a, b = lo + 1000, lo + 3000
-            seq = [(wrong, a, b), (right, a + 100, b - 100),              # inside
-                   (wrong, a + 200, a + 300), (wrong, a + 250, a + 260),   # inside, twice over the same words
-                   (wrong, a - 500, b + 500),                             # covers everything staged so far
-                   (right, a - 400, b + 400), (wrong, b + 400, b + 900),   # inside; a disjoint neighbour
-                   (right, b + 300, b + 1000),                            # overlaps both without covering the first: sent out first
-                   (right, a - 500, a - 300), (wrong, 2, 40), (right, 2, 41)]
-            for src, x, y in seq:
-                gpu.write_nodes(src.ctypes.data, x & ~1, (y + 1) & ~1)
-            gpu.write_nodes(right.ctypes.data, (a - 500) & ~1, (b + 1000 + 1) & ~1) if round_ % 2 else None
-            if round_ % 2 == 0:   # without the final cover: what the sequence itself leaves must already be the right pool...
-                gpu.write_nodes(right.ctypes.data, (b + 500) & ~1, (b + 500 + 2) & ~1)
-                # ... except [b + 400, b + 300 + ...): covered by the (right, b + 300, b + 1000) write; and [a - 500, a - 400), (b + 400, b + 500] of
-                # the wrong cover, rewritten here
-                gpu.write_nodes(right.ctypes.data, (a - 500) & ~1, (a - 400 + 1) & ~1)
-                gpu.write_nodes(right.ctypes.data, (b + 400) & ~1, (b + 500 + 1) & ~1)
-            gpu.render(MODE_PRIMARY_SHADOW)
-            rgb, ids, _ = gpu.read_output()
-            assert_frame_parity(rgb, ids, r_rgb, r_ids, f"overlapping writes, {in_flight} in flight, round {round_}")
-        gpu.close()
-
-
 def test_staged_node_writes_survive_a_lap_of_the_upload_ring(orc):
     """vrt_write_nodes stages its bytes in the pinned ring until the next frame; uploads that are not staged (the material
     table: 8 KB a call) share the ring.  More than a lap of them (8 MiB) between the edit and its frame must not write over
