@@ -1,4 +1,4 @@
-"""tools/soak_edits.py [seconds] [seed] [devices, e.g. 0,0,0] [texel|staged|poison ...] — a long random session against the oracle: edits (0-3 before a frame), camera moves,
+"""tools/soak_edits.py [seconds] [seed] [devices, e.g. 0,0,0] [texel|staged|poison ...] — a long random session against the oracle: edits (0-3 before a frame, now and then a cluster of 8-40 in one place), camera moves,
 chunk_roots rewrites, the grid recentred by a chunk (center_chunks: the table shifts, world.min changes, the chunks that came
 into the grid arrive over the next frames), quiet stretches, changes of the number of frames in flight, whole-world rebuilds, the primary and the
 primary + shadow mode, variants 0 and 2 — and every few dozen frames the last frame is compared with the oracle's frame of
@@ -43,8 +43,14 @@ while time.time() < t_end:
     for _ in range(burst):
         r = rng.random()
         if r < 0.5:
-            for _ in range(int(rng.integers(1, 4))):
+            # (one time in twelve a cluster of 8-40 edits within a few voxels: several uploads of one chunk's range before a frame — the
+            # staged ranges are merged in the pinned ring, csrc/vrt_uploads.hip)
+            cluster = rng.random() < 1.0 / 12.0
+            c0 = (int(ex) + int(rng.integers(-20, 21)), int(ey) + int(rng.integers(-24, 2)), int(ez) + int(rng.integers(-20, 21)))
+            for _ in range(int(rng.integers(8, 41)) if cluster else int(rng.integers(1, 4))):
                 p = (int(ex) + int(rng.integers(-24, 25)), int(ey) + int(rng.integers(-28, 6)), int(ez) + int(rng.integers(-24, 25)))
+                if cluster:
+                    p = (c0[0] + int(rng.integers(-3, 4)), c0[1] + int(rng.integers(-3, 4)), c0[2] + int(rng.integers(-3, 4)))
                 try:
                     start, n = sc.world.set_voxel(p, int(rng.choice([0, 0, 0, 3, 4, 40, 47, 62])))
                 except Exception as e:
