@@ -332,7 +332,8 @@ __global__ void __launch_bounds__(512) accel_chunks_kernel(const uint16_t *nodes
     // (The kernel is written for SIZE: a lone workgroup runs it once, cold — the frame before it owned the instruction cache — and
     // straight-line code is then fetched a cache line per memory round trip.  The 11.7 KB of the first wave-per-cell version ran in
     // 14 us whatever its loops did; see tools/chunk_probe.py.  Hence buffer loads instead of a tail path per staged vector, the
-    // liquid mask in LDS instead of a select chain per use, one place that reads a node, and loops that are not unrolled.)
+    // liquid mask in LDS instead of a select chain per use, one place that reads a node, and no unrolling but the four cells the
+    // last loop keeps in flight for its latency chain: 7.6 KB.)
     CHUNK_STAMP(0);
     // (512 threads, not more: sixteen waves halve the lone kernel — 9.3 us, a lone edit 162.7 — but a workgroup that needs a
     // whole CU at once waits for one while frames are in flight: an edit before every frame 97 -> 107 us per frame, measured)
