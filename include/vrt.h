@@ -251,8 +251,8 @@ int vrt_render(vrt_ctx *ctx, const vrt_render_opts *opts);
  * settings, world and materials unchanged since the previous frame) the launch's tail is then shortened from within:
  * primary + shadow frames launch their 8x8 tiles longest first, in the order of the march-loop trips the view's second frame
  * noted.  Any change of the view returns to screen order: an order made for another view, however close, is worse than
- * none.  The frame is the same whatever the order; VRT_TILE_ORDER=0 keeps screen order always.  (VRT_TILE_ORDER_MOVING=1: an
- * experiment that keeps ordering while the camera moves in small steps — measured slower) */
+ * none.  The frame is the same whatever the order; VRT_TILE_ORDER=0 keeps screen order always.  (Keeping an order while the camera moves in
+ * small steps was built and measured slower: the experiments build's VRT_TILE_ORDER_MOVING=1) */
 int vrt_set_frames_in_flight(vrt_ctx *ctx, uint32_t n);
 
 /* Block until everything enqueued on the context's stream has finished. */

@@ -909,9 +909,10 @@ def test_tiles_ordered_under_a_moving_camera_are_the_same_frames(orc, monkeypatc
     launch_tile_order_moving).  A walk of small steps (the bench's orbit step: < 1 voxel, ~ 1 degree), a rest, a jump (screen
     order again), more steps: every frame is the screen-order context's frame, the last one the oracle's; and the counter
     says which frames were ordered."""
+    needs_experiments()                                # (built, measured, not chosen: profiles/r04_tile_order_moving.txt)
     from voxelraytracing_amd import graphics as g
     sc = scenes.c2()
-    monkeypatch.setenv("VRT_TILE_ORDER_MOVING", "1")   # (off by default: profiles/r04_tile_order_moving.txt)
+    monkeypatch.setenv("VRT_TILE_ORDER_MOVING", "1")
     mov = gpu_for_scene(sc)
     mov.set_frames_in_flight(1)
     monkeypatch.delenv("VRT_TILE_ORDER_MOVING")

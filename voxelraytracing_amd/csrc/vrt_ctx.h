@@ -47,7 +47,9 @@ void launch_path_bounce(const FrameParams &P, bool stats, bool literal, hipStrea
 void launch_path_bounce_cells(const FrameParams &P, uint32_t refill_at, uint32_t segments, uint32_t lds_pad, hipStream_t st);
 void launch_path_finish(Texel *out, uint32_t n, uint32_t spp, hipStream_t st);
 void launch_tile_order(const uint32_t *cost, uint32_t n, uint32_t shift, uint32_t *scratch, uint32_t *order, hipStream_t st);
+#ifdef VRT_EXPERIMENTS
 void launch_tile_order_moving(uint32_t *cost, uint32_t tiles_x, uint32_t tiles_y, uint32_t shift, uint32_t radius, uint32_t *scratch, uint32_t *order, hipStream_t st);
+#endif
 void launch_path_chain_finish(Texel *out, const Texel *acc, uint32_t n, uint32_t chain, bool first, bool last, uint32_t spp, hipStream_t st);
 void launch_quantize(const Texel *out, uint8_t *rgba8, uint32_t w, uint32_t h, hipStream_t st);
 void launch_assemble(const Texel *gathered, Texel *dst, uint32_t width, uint32_t tiles_x, uint32_t tiles_total,
@@ -253,7 +255,7 @@ struct vrt_ctx {
     // ... and while the view MOVES (round 4): every such frame notes its trips, and the order for the next frame is made from
     // them dilated over the image motion a camera step can cause (vrt_kernels.hip: launch_tile_order_moving) — used by a frame
     // whose camera is close to the one the trips were noted under and whose view differs from it in the camera only
-    // OFF unless VRT_TILE_ORDER_MOVING=1: the frame's launch gets 6.4 us shorter (112.4 -> 106.0) and the six small launches that
+    // The experiments build only (make experiments), and there OFF unless VRT_TILE_ORDER_MOVING=1: the frame's launch gets 6.4 us shorter (112.4 -> 106.0) and the six small launches that
     // make the order take 17 of a stream that runs its frames back to back, and of the wait of a host that synchronises every frame
     // (profiles/r04_tile_order_moving.txt): an experiment, not a mode anybody should switch on as it stands
     bool tile_lpt_moving = false;

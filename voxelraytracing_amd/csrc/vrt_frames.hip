@@ -570,7 +570,9 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         if (v >= 0 && v <= (long)kMarchDirectMaxS) c->march_direct_max_s = (uint32_t)v;
     }
     if (const char *e = getenv("VRT_TILE_ORDER")) c->tile_lpt = e[0] != '0';
+#ifdef VRT_EXPERIMENTS
     if (const char *e = getenv("VRT_TILE_ORDER_MOVING")) c->tile_lpt_moving = e[0] != '0';
+#endif
 #ifdef VRT_EXPERIMENTS
     if (const char *e = getenv("VRT_PATH_PERSISTENT")) c->path_persistent = e[0] == '1';
     if (const char *e = getenv("VRT_PATH_POOL")) c->path_pool = e[0] != '0';
@@ -930,8 +932,11 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
         if (rc) return rc;
     }
     if (tile_sort) {   // (the frame above read the old order and is over when this runs; the next frame starts after it)
+#ifdef VRT_EXPERIMENTS
         if (dilate) vrt::launch_tile_order_moving(c->d_tile_cost, P.tiles_x, P.tiles_total / P.tiles_x, 1u, 2u, c->d_tile_scratch, c->d_tile_order, f.st);
-        else vrt::launch_tile_order(c->d_tile_cost, c->tiles_local, 1u, c->d_tile_scratch, c->d_tile_order, f.st);   // classes of two trips
+        else
+#endif
+        vrt::launch_tile_order(c->d_tile_cost, c->tiles_local, 1u, c->d_tile_scratch, c->d_tile_order, f.st);   // classes of two trips
         HIP_TRY(c, hipGetLastError());
         c->tile_order_valid = true;
         c->order_view_gen = c->view_gen;

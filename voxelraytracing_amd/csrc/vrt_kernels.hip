@@ -390,6 +390,7 @@ void launch_tile_order(const uint32_t *cost, uint32_t n, uint32_t shift, uint32_
     hipLaunchKernelGGL(tile_order_scatter_kernel, dim3((chunks + 3u) / 4u), dim3(256), 0, st, cost, n, chunks, shift, (const uint32_t *)scratch, order);
 }
 
+#ifdef VRT_EXPERIMENTS   // (built, measured, not chosen: profiles/r04_tile_order_moving.txt)
 // The order for a view that MOVES: made from the frame before, whose trips are this frame's only near where they were
 // noted — a silhouette that has moved into a tile the order starts last (it was sky) runs its whole length behind everything
 // else (profiles/r02_tile_order_staleness.txt: an exact order one camera step old is 17 % worse than screen order).  So every
@@ -424,6 +425,7 @@ void launch_tile_order_moving(uint32_t *cost, uint32_t tiles_x, uint32_t tiles_y
     hipLaunchKernelGGL(tile_dilate_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, (const uint32_t *)scratch, tiles_x, n, bw, bh, radius, cost);
     launch_tile_order(cost, n, shift, scratch, order, st);
 }
+#endif  // VRT_EXPERIMENTS
 
 // ------------------------------------------------------------------------------------------------
 // Output helpers
