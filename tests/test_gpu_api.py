@@ -116,10 +116,16 @@ def test_a_window_of_the_textures_size_is_blitted_by_the_short_kernel_to_the_sam
     rgb, _, q = gpu.read_output(rgba8=True)
     kinds = [dict(style=0), dict(), dict(style=1, size=9.5, color=(1.0, 0.2, 0.1, 0.75)), dict(style=2, size=17.0, color=(0.0, 0.0, 0.0, 1.0))]
     if w <= 400:
-        kinds += [dict(style=2, size=1.0e4, color=(0.3, 0.6, 0.9, 0.5)), dict(style=1, size=float("nan")), dict(style=2, size=-3.0), dict(style=1, size=0.4)]
+        kinds += [dict(style=2, size=1.0e4, color=(0.3, 0.6, 0.9, 0.5)), dict(style=1, size=float("nan")), dict(style=2, size=-3.0), dict(style=1, size=0.4),
+                  # colours that are not numbers reach every pixel (0 * NaN, 0 * inf): no shortcut may be taken for them
+                  dict(style=2, size=7.0, color=(float("nan"), 0.5, 0.5, 0.5)), dict(style=1, size=7.0, color=(0.5, float("inf"), 0.5, 0.5)),
+                  dict(style=2, size=7.0, color=(0.5, 0.5, 0.5, float("nan"))), dict(style=1, size=7.0, color=(0.5, 0.5, -float("inf"), float("inf")))]
     for kw in kinds:
         got = gpu.present((w, h), **kw)
         assert np.array_equal(got, orc.present(rgb, (w, h), **kw)), kw
+        if w <= 400:   # ... and a window of another size (the general kernel skips the crosshair's arithmetic outside its box)
+            other = (w + w // 3, h - h // 5)
+            assert np.array_equal(gpu.present(other, **kw), orc.present(rgb, other, **kw)), (kw, other)
     assert np.array_equal(gpu.present((w, h), style=0), q)
     gpu.close()
 

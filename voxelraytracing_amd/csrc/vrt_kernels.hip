@@ -451,18 +451,34 @@ __device__ __forceinline__ uint32_t unorm8(float x) { return (uint32_t)rintf(vcl
 
 // decoded[q] = q / 255 as the sampler decodes an rgba8unorm texel, a table of the workgroup (256 threads, a correctly rounded divide each):
 // a sample took twelve such divides — ~ 130 of the general blit's ~ 250 instructions per pixel, 68 us for a 4K window
-__device__ __forceinline__ uint32_t present_pixel(const Texel *out, uint32_t w, uint32_t h, uint32_t cov_w, uint32_t cov_h, uint32_t screen_w, uint32_t screen_h,
-                                                   const vrt_crosshair &ch, uint32_t sx, uint32_t sy, const float *decoded) {
+// one tap of the sampler: the texel as the rgba8unorm texture holds it, decoded (alpha: 1 where the compute pass stored a texel,
+// 0 beyond its workgroups — all of it when w and h are multiples of 8).  (Sampling a texture quantised once by its own launch
+// instead — 4 bytes a tap, no quantisation per tap — was measured for windows larger than the texture: no faster, the blit is
+// bound by its ~ 170 vector instructions per pixel, not by its loads: profiles/r04_present_cost.txt.)
+__device__ __forceinline__ void present_tap(const Texel *tex, size_t i, bool covered, const float *decoded, float v[4]) {
+    const Texel t = tex[i];
+    v[0] = decoded[unorm8(__uint_as_float(t.x))]; v[1] = decoded[unorm8(__uint_as_float(t.y))]; v[2] = decoded[unorm8(__uint_as_float(t.z))];
+    v[3] = covered ? 1.0f : 0.0f;
+}
+
+__device__ __forceinline__ uint32_t present_pixel(const Texel *tex, uint32_t w, uint32_t h, uint32_t cov_w, uint32_t cov_h, uint32_t screen_w, uint32_t screen_h,
+                                                   const vrt_crosshair &ch, uint32_t sx, uint32_t sy, const float *decoded, bool in_box) {
+    // in_box: the pixel is within the host's box around the crosshair (a pixel wider than the mask can reach, vrt_present.hip) —
+    // outside it the mask is zero without being computed
     const float ssx = (float)screen_w, ssy = (float)screen_h;
     const float cx = ssx * 0.5f, cy = ssy * 0.5f;
     const float u = ((float)sx + 0.5f) / ssx, v = ((float)sy + 0.5f) / ssy;
     const float px = u * ssx, py = v * ssy;
+    // (uniform) outside the crosshair the blend is x * 1 + c * 0 = x — for a FINITE colour c (x >= 0: adding -0 changes nothing
+    // either); a crosshair whose colour is not a number takes the blend everywhere, as the shader would
+    const bool colour_finite = ((__float_as_uint(ch.color[0]) & 0x7F800000u) != 0x7F800000u) && ((__float_as_uint(ch.color[1]) & 0x7F800000u) != 0x7F800000u) &&
+                               ((__float_as_uint(ch.color[2]) & 0x7F800000u) != 0x7F800000u);
     float mask = 0.0f;
-    if (ch.style == 1u) {
+    if (in_box && ch.style == 1u) {
         const float dx = cx - px, dy = cy - py;
         mask = (sqrtf(dx * dx + dy * dy) < ch.size ? 1.0f : 0.0f) * ch.color[3];
     }
-    if (ch.style == 2u) {
+    if (in_box && ch.style == 2u) {
         const float dx = fabsf(cx - px), dy = fabsf(cy - py);
         const float wd = ch.size * 0.25f;
         mask = (((dx < ch.size && dy < wd) || (dy < ch.size && dx < wd)) ? 1.0f : 0.0f) * ch.color[3];
@@ -474,55 +490,49 @@ __device__ __forceinline__ uint32_t present_pixel(const Texel *out, uint32_t w, 
     const float a = ut - fu, b = vt - fv;
     const int x0 = min(max((int)fu, 0), (int)w - 1), x1 = min(max((int)fu + 1, 0), (int)w - 1);
     const int y0 = min(max((int)fv, 0), (int)h - 1), y1 = min(max((int)fv + 1, 0), (int)h - 1);
-    const Texel t00 = out[(size_t)y0 * w + x0];
-    const uint32_t c00[3] = {t00.x, t00.y, t00.z};
     // alpha: 1 where the compute pass stored a texel, 0 beyond its workgroups (all of it when w and h are multiples of 8)
-    const float a00 = ((uint32_t)x0 < cov_w && (uint32_t)y0 < cov_h) ? 1.0f : 0.0f;
+    float v00[4];
+    present_tap(tex, (size_t)y0 * w + x0, (uint32_t)x0 < cov_w && (uint32_t)y0 < cov_h, decoded, v00);
     float texel[4];
     if (a == 0.0f && b == 0.0f) {
-        // The sample is at a texel's centre — every pixel of a window of the texture's size (the reference's texture is 1080 rows at the window's aspect, main.rs:255-262: a window 1080 rows tall).  The other
-        // three taps have weight zero, and x * 1 + y * 0 is x for the finite x and y a decoded unorm8 is: one load, one texel
-        // decoded, instead of four (the blit was 20 us alone for a 1080p window, most of it twelve IEEE divides per pixel).
-        if (mask == 0.0f) {   // ... and outside the crosshair the pixel IS the stored texel: unorm8(q / 255 * 1 + c * 0) = q for q = 0 .. 255 (checked: all 256)
-            uint32_t q = a00 != 0.0f ? 0xFF000000u : 0u;
+        // The sample is at a texel's centre: the other three taps have weight zero, and x * 1 + y * 0 is x for the finite x and y a
+        // decoded unorm8 is — one tap instead of four (every pixel of a window of the texture's size that present_plain_kernel
+        // does not take)
 #pragma unroll
-            for (int k = 0; k < 3; k++) q |= unorm8(__uint_as_float(c00[k])) << (8 * k);
-            return q;
-        }
-#pragma unroll
-        for (int k = 0; k < 3; k++) texel[k] = decoded[unorm8(__uint_as_float(c00[k]))];
-        texel[3] = a00;
+        for (int k = 0; k < 4; k++) texel[k] = v00[k];
     } else {
-        const Texel t10 = out[(size_t)y0 * w + x1], t01 = out[(size_t)y1 * w + x0], t11 = out[(size_t)y1 * w + x1];
-        const uint32_t c10[3] = {t10.x, t10.y, t10.z}, c01[3] = {t01.x, t01.y, t01.z}, c11[3] = {t11.x, t11.y, t11.z};
+        float v10[4], v01[4], v11[4];
+        present_tap(tex, (size_t)y0 * w + x1, (uint32_t)x1 < cov_w && (uint32_t)y0 < cov_h, decoded, v10);
+        present_tap(tex, (size_t)y1 * w + x0, (uint32_t)x0 < cov_w && (uint32_t)y1 < cov_h, decoded, v01);
+        present_tap(tex, (size_t)y1 * w + x1, (uint32_t)x1 < cov_w && (uint32_t)y1 < cov_h, decoded, v11);
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const float v00 = decoded[unorm8(__uint_as_float(c00[k]))], v10 = decoded[unorm8(__uint_as_float(c10[k]))];
-            const float v01 = decoded[unorm8(__uint_as_float(c01[k]))], v11 = decoded[unorm8(__uint_as_float(c11[k]))];
-            const float top = v00 * (1.0f - a) + v10 * a, bot = v01 * (1.0f - a) + v11 * a;
+        for (int k = 0; k < 4; k++) {
+            const float top = v00[k] * (1.0f - a) + v10[k] * a, bot = v01[k] * (1.0f - a) + v11[k] * a;
             texel[k] = top * (1.0f - b) + bot * b;
         }
-        const float a10 = ((uint32_t)x1 < cov_w && (uint32_t)y0 < cov_h) ? 1.0f : 0.0f;
-        const float a01 = ((uint32_t)x0 < cov_w && (uint32_t)y1 < cov_h) ? 1.0f : 0.0f, a11 = ((uint32_t)x1 < cov_w && (uint32_t)y1 < cov_h) ? 1.0f : 0.0f;
-        const float top = a00 * (1.0f - a) + a10 * a, bot = a01 * (1.0f - a) + a11 * a;
-        texel[3] = top * (1.0f - b) + bot * b;
+    }
+    uint32_t q = 0u;
+    if (mask == 0.0f && colour_finite) {   // unorm8(x * 1 + c * 0) = unorm8(x)
+#pragma unroll
+        for (int k = 0; k < 4; k++) q |= unorm8(texel[k]) << (8 * k);
+        return q;
     }
     const float cc[4] = {ch.color[0], ch.color[1], ch.color[2], 1.0f};
-    uint32_t q = 0u;
 #pragma unroll
     for (int k = 0; k < 4; k++) q |= unorm8(texel[k] * (1.0f - mask) + cc[k] * mask) << (8 * k);
     return q;
 }
 
 
-__global__ void present_kernel(const Texel *out, uint32_t w, uint32_t h, uint32_t cov_w, uint32_t cov_h, uint32_t screen_w, uint32_t screen_h,
-                               vrt_crosshair ch, uint8_t *rgba8) {
+__global__ void present_kernel(const Texel *tex, uint32_t w, uint32_t h, uint32_t cov_w, uint32_t cov_h, uint32_t screen_w, uint32_t screen_h,
+                               vrt_crosshair ch, uint32_t box_x0, uint32_t box_x1, uint32_t box_y0, uint32_t box_y1, uint8_t *rgba8) {
     __shared__ float s_decoded[256];
     s_decoded[threadIdx.x] = (float)threadIdx.x / 255.0f;   // (256 threads: the launcher's)
     __syncthreads();
     const uint32_t sx = blockIdx.x * blockDim.x + threadIdx.x, sy = blockIdx.y;
     if (sx >= screen_w) return;
-    reinterpret_cast<uint32_t *>(rgba8)[(size_t)sy * screen_w + sx] = present_pixel(out, w, h, cov_w, cov_h, screen_w, screen_h, ch, sx, sy, s_decoded);
+    const bool in_box = sx >= box_x0 && sx < box_x1 && sy >= box_y0 && sy < box_y1;
+    reinterpret_cast<uint32_t *>(rgba8)[(size_t)sy * screen_w + sx] = present_pixel(tex, w, h, cov_w, cov_h, screen_w, screen_h, ch, sx, sy, s_decoded, in_box);
 }
 
 // The blit of a window of the texture's size (the reference keeps its texture at 1080 rows and the window's aspect, main.rs:255-262:
@@ -545,7 +555,7 @@ __global__ void __launch_bounds__(256) present_plain_kernel(const Texel *out, ui
     uint32_t q[4];
     if (box_row && x4 + 4u > box_x0 && x4 < box_x1) {
 #pragma unroll
-        for (uint32_t k = 0; k < 4u; k++) q[k] = present_pixel(out, w, h, cov_w, cov_h, w, h, ch, x4 + k, sy, s_decoded);
+        for (uint32_t k = 0; k < 4u; k++) q[k] = present_pixel(out, w, h, cov_w, cov_h, w, h, ch, x4 + k, sy, s_decoded, true);
     } else {
         Texel t[4];
 #pragma unroll
@@ -740,7 +750,7 @@ void launch_present(const Texel *out, uint32_t w, uint32_t h, uint32_t screen_w,
         return;
     }
     hipLaunchKernelGGL(present_kernel, dim3((screen_w + 255u) / 256u, screen_h), dim3(256), 0, st, out, w, h, w & ~7u, h & ~7u, screen_w,
-                       screen_h, ch, rgba8);
+                       screen_h, ch, box[0], box[1], box[2], box[3], rgba8);
 }
 
 void launch_assemble(const Texel *gathered, Texel *dst, uint32_t width, uint32_t tiles_x, uint32_t tiles_total,

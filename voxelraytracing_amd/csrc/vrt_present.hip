@@ -60,14 +60,17 @@ static int present_on_device(vrt_ctx *c, const vrt_crosshair *crosshair, uint32_
     const bool one = screen_w == c->width && screen_h == c->height && c->one_to_one;
     // the pixels the crosshair's mask can reach: those within `size` of the centre, and two more for the rounding of px, py
     uint32_t box[4] = {0u, 0u, 0u, 0u};
-    if (one && crosshair->style != 0u) {
+    if (crosshair->style != 0u) {   // (for every window: the general kernel asks its pixels the same question)
         const float reach = crosshair->size + 2.0f;
         const float cx = (float)screen_w * 0.5f, cy = (float)screen_h * 0.5f;
-        if (reach == reach && reach > 0.0f && reach < 1.0e6f) {
+        // (a colour or an alpha that is not a number reaches every pixel: 0 * NaN is not 0)
+        bool finite = true;
+        for (int k = 0; k < 4; k++) finite = finite && crosshair->color[k] - crosshair->color[k] == 0.0f;
+        if (finite && reach == reach && reach > 0.0f && reach < 1.0e6f) {
             const float x0 = floorf(cx - reach - 0.5f), x1 = ceilf(cx + reach + 0.5f), y0 = floorf(cy - reach - 0.5f), y1 = ceilf(cy + reach + 0.5f);
             box[0] = x0 > 0.0f ? (uint32_t)x0 : 0u; box[1] = x1 < (float)screen_w ? (uint32_t)(x1 > 0.0f ? x1 : 0.0f) : screen_w;
             box[2] = y0 > 0.0f ? (uint32_t)y0 : 0u; box[3] = y1 < (float)screen_h ? (uint32_t)(y1 > 0.0f ? y1 : 0.0f) : screen_h;
-        } else {   // a size that is not a number, negative or huge: every pixel decides for itself
+        } else {   // a size that is not a number, negative or huge; a colour that is not finite: every pixel decides for itself
             box[1] = screen_w; box[3] = screen_h;
         }
     }
