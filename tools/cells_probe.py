@@ -31,8 +31,9 @@ gpu.synchronize()
 lib.vrt_exp_cells_dbg(buf.ctypes.data)
 lib.vrt_exp_cells_tot(tot.ctypes.data)
 raw = buf[buf[:, 0] > 0]
+life_sum = ((raw[:, 2].astype(float) - raw[:, 1].astype(float)) / 100).sum()
 lo = np.uint64(0xFFFFFFFF)
-n = raw[:, 0].astype(float)
+n = (raw[:, 0] & np.uint64(0xFFFFFFFF)).astype(float)
 t0, t1 = raw[:, 1].astype(float), raw[:, 2].astype(float)
 wet, dry = (raw[:, 3] & lo).astype(float), (raw[:, 3] >> np.uint64(32)).astype(float)
 wl, dl = (raw[:, 4] & lo).astype(float), (raw[:, 4] >> np.uint64(32)).astype(float)
@@ -44,7 +45,12 @@ print(f"launch span {e.max():.1f} us; wave start p50 {np.percentile(s, 50):.1f} 
       f"wave end p10 {np.percentile(e, 10):.1f} p50 {np.percentile(e, 50):.1f} p90 {np.percentile(e, 90):.1f} p99 {np.percentile(e, 99):.1f} max {e.max():.1f}")
 life = e - s
 print(f"us per wave-step (wave life / its wave-steps): mean {(life / (wet + dry)).mean():.3f}, of the 1 % slowest waves {(life / (wet + dry))[e >= np.percentile(e, 99)].mean():.3f}")
-air4, air8, air16 = (raw[:, 6] & lo).astype(float).sum(), (raw[:, 6] >> np.uint64(32)).astype(float).sum(), raw[:, 7].astype(float).sum()
+air4, air8, air16 = (raw[:, 6] & lo).astype(float).sum(), (raw[:, 6] >> np.uint64(32)).astype(float).sum(), (raw[:, 7] & lo).astype(float).sum()
+refills, refill_us = (raw[:, 5] >> np.uint64(32)).astype(float), (raw[:, 7] >> np.uint64(32)).astype(float) * 16.0 / 2400.0   # (shader clock ~ 2.4 GHz)
+park_us = (raw[:, 0] >> np.uint64(32)).astype(float) * 16.0 / 2400.0
+load_us = ((raw[:, 5] >> np.uint64(8)) & np.uint64(0xFFFFFF)).astype(float) * 16.0 / 2400.0
+print(f"  of a round: parking {park_us.sum() / max(refills.sum(), 1):.2f} us, until the records are there {load_us.sum() / max(refills.sum(), 1):.2f} us, the set-up behind them {(refill_us.sum() - park_us.sum() - load_us.sum()) / max(refills.sum(), 1):.2f} us")
+print(f"hand-out rounds that took rays: {refills.mean():.1f} per wave, {refill_us.sum() / max(refills.sum(), 1):.2f} us each (park + the records' loads + the set-up, waited for): {100 * refill_us.sum() / life_sum:.1f} % of the waves' time")
 print(f"lookups {wl.sum() + dl.sum():.0f}: in an air leaf of the cell grid (4 voxels or more) {100 * air4 / (wl.sum() + dl.sum()):.1f} %, of 8 or more {100 * air8 / (wl.sum() + dl.sum()):.1f} %, of 16 or more {100 * air16 / (wl.sum() + dl.sum()):.1f} %")
 for t in np.linspace(0, e.max(), 16):
     alive = (s <= t) & (e > t)

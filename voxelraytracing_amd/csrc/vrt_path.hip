@@ -953,6 +953,8 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
     const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
     const uint32_t dbg_n0 = n;
     uint32_t dbg_wet = 0, dbg_wet_lanes = 0, dbg_dry = 0, dbg_dry_lanes = 0, dbg_segments = 0, dbg_air4 = 0, dbg_air8 = 0, dbg_air16 = 0;
+    uint32_t dbg_refill_ticks = 0, dbg_refills = 0, dbg_park_ticks = 0, dbg_load_ticks = 0;
+    uint32_t dbg_t_loaded = 0;   // hand-out rounds that took rays: their time in 16-cycle ticks of the shader clock, their number
 #ifdef VRT_EXP_CELLDBG_FULL   // (the lookup classes: 30 registers more — a build of its own, 4 waves per SIMD)
     uint32_t dbg_tot[20], dbg_lines = 0, dbg_line_steps = 0;   // (per lane; summed at the wave's end)
     for (int q = 0; q < 20; q++) dbg_tot[q] = 0;
@@ -1039,6 +1041,10 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
             idx = at;
             const uint32_t rec = base + idx;
             const uint4 a = recs[in_at + rec], b = recs[in_at + P.in_cap + rec];
+#ifdef VRT_EXP_CELLDBG
+            asm volatile("s_waitcnt vmcnt(0)" :: "v"(a.x), "v"(b.x) : "memory");
+            dbg_t_loaded = (uint32_t)(__builtin_amdgcn_s_memtime() >> 4);
+#endif
             const V3 origin{__uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w)};
             dir = V3{__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z)};
             not_finite = !(finite3(origin) && finite3(dir));
@@ -1130,13 +1136,29 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
         };
         for (;;) {
             // ---- refill: park what has stopped, hand out the pool's next rays ----
+#ifdef VRT_EXP_CELLDBG
+            const unsigned long long dbg_r0 = __builtin_amdgcn_s_memtime();
+            const uint32_t dbg_next0 = next;
+#endif
             if (!marching && !parked) park();
+#ifdef VRT_EXP_CELLDBG
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long dbg_r1 = __builtin_amdgcn_s_memtime();
+            dbg_t_loaded = 0;
+#endif
             {
                 const unsigned long long idle = __ballot(!marching);
                 const uint32_t at = next + lanes_below(idle);
                 if (!marching && at < n) take(at);
                 next = min(n, next + (uint32_t)__popcll(idle));
             }
+#ifdef VRT_EXP_CELLDBG
+            { const unsigned long long took_ = __ballot(dbg_t_loaded != 0u); if (took_) { dbg_park_ticks += (uint32_t)((dbg_r1 - dbg_r0) >> 4); dbg_load_ticks += (uint32_t)__builtin_amdgcn_readlane((int)dbg_t_loaded, (int)__builtin_ctzll(took_)) - (uint32_t)(dbg_r1 >> 4); } }
+#endif
+#ifdef VRT_EXP_CELLDBG
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (next != dbg_next0) { dbg_refill_ticks += (uint32_t)((__builtin_amdgcn_s_memtime() - dbg_r0) >> 4); dbg_refills++; }
+#endif
             if (__ballot(marching) == 0ull) {
                 if (next >= n) break;   // the pool is empty and nobody marches (every ray is parked: take() parks the ones that start outside)
                 continue;
@@ -1362,9 +1384,9 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
         const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
         if (lane == 0 && blockIdx.x * 4u + wave < 16384u) {
             unsigned long long *d = &g_cells_dbg[(blockIdx.x * 4u + wave) * 8u];
-            d[0] = dbg_n0; d[1] = dbg_t0; d[2] = t1; d[3] = dbg_wet | ((unsigned long long)dbg_dry << 32);
-            d[4] = dbg_wet_lanes | ((unsigned long long)dbg_dry_lanes << 32); d[5] = dbg_segments;
-            d[6] = dbg_air4 | ((unsigned long long)dbg_air8 << 32); d[7] = dbg_air16;
+            d[0] = dbg_n0 | ((unsigned long long)dbg_park_ticks << 32); d[1] = dbg_t0; d[2] = t1; d[3] = dbg_wet | ((unsigned long long)dbg_dry << 32);
+            d[4] = dbg_wet_lanes | ((unsigned long long)dbg_dry_lanes << 32); d[5] = (dbg_segments & 0xFFu) | ((unsigned long long)(dbg_load_ticks & 0xFFFFFFu) << 8) | ((unsigned long long)dbg_refills << 32);
+            d[6] = dbg_air4 | ((unsigned long long)dbg_air8 << 32); d[7] = dbg_air16 | ((unsigned long long)dbg_refill_ticks << 32);
         }
 #ifdef VRT_EXP_CELLDBG_FULL
 #pragma unroll
