@@ -840,10 +840,13 @@ def test_persistent_path_kernel_gives_the_same_frames(orc, monkeypatch):
 
 
 @pytest.mark.parametrize("env", [{"VRT_PATH_POOL": "0"}, {"VRT_PATH_CELLS": "0"}, {"VRT_PATH_CELLS": "0", "VRT_PATH_POOL_CHAIN": "1"},
-                                 {"VRT_PATH_CELLS": "0", "VRT_PATH_POOL_CHAIN": "1", "VRT_PATH_POOL_EJECT": "40"}])
+                                 {"VRT_PATH_CELLS": "0", "VRT_PATH_POOL_CHAIN": "1", "VRT_PATH_POOL_EJECT": "40"}] +
+                                [{"VRT_PATH_WINDOW": "1", "VRT_PATH_WINDOW_SHAPE": str(k)} for k in range(5)])
 def test_every_form_of_the_bounce_launch_gives_the_same_frames(orc, monkeypatch, env):
     """The default bounce launch is the pool kernel over the march cells (a wave refills its lanes from its own LDS pool of
     rays; one 16-byte load per step).  VRT_PATH_POOL=0: lane = path for the whole kernel, the round-1 structure.
+    VRT_PATH_WINDOW=1 (round 5; built and measured, not the default: profiles/r05_window_ab.txt): the rays grouped by screen block,
+    the march cells around a group staged in LDS (shapes 0-3), or (shape 4) the pool kernel with its rays' state in global memory.
     VRT_PATH_CELLS=0: the round-2 pool kernel over cell grid + bricks; with VRT_PATH_POOL_CHAIN=1 (built and measured, not the
     default) its rays still marching when a wave's pool runs dry go to a chain of launches on a side stream.  All bit for
     bit the same frame, with several samples (the chains join per sample), sharded, and with two frames in flight."""

@@ -45,6 +45,11 @@ void launch_path_persistent(const FrameParams &P, uint32_t *heads, uint32_t n_cu
 void launch_path_primary(const FrameParams &P, bool stats, bool literal, hipStream_t st);
 void launch_path_bounce(const FrameParams &P, bool stats, bool literal, hipStream_t st);
 void launch_path_bounce_cells(const FrameParams &P, uint32_t refill_at, uint32_t segments, uint32_t lds_pad, hipStream_t st);
+#ifdef VRT_EXPERIMENTS
+void launch_path_primary_grouped(const FrameParams &P, hipStream_t st);
+uint32_t window_group_regions(uint32_t shape);
+void launch_path_bounce_window(const FrameParams &P, uint32_t segments, uint32_t n_regions, uint32_t samples, uint32_t shape, int32_t lift, hipStream_t st);
+#endif
 void launch_path_finish(Texel *out, uint32_t n, uint32_t spp, hipStream_t st);
 void launch_tile_order(const uint32_t *cost, uint32_t n, uint32_t shift, uint32_t *scratch, uint32_t *order, hipStream_t st);
 #ifdef VRT_EXPERIMENTS
@@ -232,6 +237,14 @@ struct vrt_ctx {
     bool path_pool = true;         // VRT_PATH_POOL=0: bounce launches with lane = path (the round-1 structure) instead of the pool kernel
     bool path_chain = false;       // VRT_PATH_POOL_CHAIN=1: the pool kernel's stragglers go to a chain of launches on a side stream
     bool path_cells = true;        // VRT_PATH_CELLS=0: the pool kernel over cell grid + bricks instead of the one over the march cells
+    // VRT_PATH_WINDOW=1 (experiments build; built and measured in round 5, not chosen: profiles/r05_window_*): the bounce launch over
+    // LDS-staged windows of march cells (experiments/vrt_path_window.hip).  Per frame set: the regions' counts (two 16-byte planes
+    // of per-ray state lie behind the path buffer's six)
+    bool path_window = false;
+    uint32_t path_window_shape = 2;   // VRT_PATH_WINDOW_SHAPE: 0 = 32^3 voxels, 1 = 48^3, 2 = 64 x 32 x 64, 3 = 64^3, 4 = no window (the rays' state in global memory)
+    int32_t path_window_lift = 8;     // VRT_PATH_WINDOW_LIFT: the window's centre above the mean origin, voxels
+    uint32_t *path_grp_counts[kMaxInFlight] = {nullptr, nullptr, nullptr, nullptr};
+    size_t path_grp_regions[kMaxInFlight] = {0, 0, 0, 0};
     uint32_t path_samples = 8;     // VRT_PATH_SAMPLES_PER_CHAIN: samples a launch chain traces at once when spp > 1 (1: one, as round 1 did)
     vrt::Texel *path_acc[kMaxInFlight] = {nullptr, nullptr, nullptr, nullptr};   // ... their accumulation planes, per frame set
     size_t path_acc_texels[kMaxInFlight] = {0, 0, 0, 0}, path_buf_records[kMaxInFlight] = {0, 0, 0, 0}, path_cont_records[kMaxInFlight] = {0, 0, 0, 0};

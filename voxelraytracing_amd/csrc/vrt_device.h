@@ -67,6 +67,11 @@ struct FrameParams {
     Texel *acc;              // null: one sample per chain, radiance accumulates in `out` itself
     uint32_t chain, acc_slots;
     uint32_t last_bounce;    // 1: paths that hit on this segment end (max_ray_bounces reached)
+    // the window bounce launch (vrt_path_window.hip): the primary launch's workgroup b compacts its survivors into records
+    // [b * grp_cap, b * grp_cap + grp_counts[b]) of path_out instead of appending to a segment
+    uint32_t *grp_counts;
+    uint32_t grp_cap;
+    uint32_t blk_w, blk_h;   // ... and takes the tiles in blocks of blk_w x blk_h (a bounce workgroup's regions: one block)
     uint32_t n_nodes, n_roots;
     uint32_t width, height;
     uint32_t tiles_x, tiles_total;

@@ -68,6 +68,8 @@ static int alloc_output(vrt_ctx *c) {
     for (auto &p : c->extra_path) { (void)hipFree(p); p = nullptr; }
     for (auto &p : c->path_cont) { (void)hipFree(p); p = nullptr; }
     for (auto &p : c->path_acc) { (void)hipFree(p); p = nullptr; }
+    for (auto &p : c->path_grp_counts) { (void)hipFree(p); p = nullptr; }
+    for (auto &n : c->path_grp_regions) n = 0;
     (void)hipFree(c->d_tile_cost); c->d_tile_cost = nullptr;
     (void)hipFree(c->d_tile_order); c->d_tile_order = nullptr;
     (void)hipFree(c->d_tile_scratch); c->d_tile_scratch = nullptr;
@@ -338,7 +340,11 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
     if (c->path_buf_records[f.slot] < cap) {   // (grows only; hipFree waits for whatever still uses the old one)
         (void)hipFree(*f.path_buf);
         *f.path_buf = nullptr; c->path_buf_records[f.slot] = 0;
+#ifdef VRT_EXPERIMENTS
+        HIP_TRY(c, hipMalloc(f.path_buf, (2 * 3 + 2) * cap * sizeof(uint4)));   // two sets of three record planes + two of per-ray state (experiments/vrt_path_window.hip)
+#else
         HIP_TRY(c, hipMalloc(f.path_buf, 2 * 3 * cap * sizeof(uint4)));
+#endif
         c->path_buf_records[f.slot] = cap;
     }
     if (planes && c->path_acc_texels[f.slot] < (size_t)samples * c->slots) {
@@ -372,6 +378,33 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
     // the record sets' cursors (atomics).  The chains join at the end of every sample.
     const bool pool = !kstats && !literal && P.grid && bounces > 1 && c->path_pool;
     const bool cells = pool && P.mblk && c->path_cells;
+    // ... and among those the window launch (vrt_path_window.hip): the primary launch compacts each workgroup's survivors into
+    // the workgroup's own region (256 records per sample of the chain), the bounce launch stages the march cells around a
+    // group of four regions in LDS
+#ifdef VRT_EXPERIMENTS
+    const bool window = cells && c->path_window;
+#else
+    const bool window = false;   // (the window launch: the experiments build)
+#endif
+    const uint32_t n_regions = (c->tiles_local + 3u) / 4u;
+    if (window) {
+        if (c->path_grp_regions[f.slot] < n_regions) {
+            (void)hipFree(c->path_grp_counts[f.slot]);
+            c->path_grp_counts[f.slot] = nullptr; c->path_grp_regions[f.slot] = 0;
+            HIP_TRY(c, hipMalloc(&c->path_grp_counts[f.slot], (size_t)n_regions * sizeof(uint32_t)));
+            c->path_grp_regions[f.slot] = n_regions;
+        }
+    }
+    P.grp_counts = window ? c->path_grp_counts[f.slot] : nullptr;
+    P.grp_cap = 256u * samples;   // (n_regions * grp_cap <= cap: a segment holds what its workgroups can produce)
+    P.blk_w = P.blk_h = 4u;
+#ifdef VRT_EXPERIMENTS
+    {   // a bounce workgroup's regions are one block of tiles: 4 x 4 (4 regions), 8 x 4 (8), 8 x 8 (16)
+        const uint32_t nw = vrt::window_group_regions(c->path_window_shape);
+        P.blk_w = nw == 4u ? 4u : 8u;
+        P.blk_h = nw == 16u ? 8u : 4u;
+    }
+#endif
 #ifdef VRT_EXPERIMENTS
     const bool chain = pool && !cells && bounces - 1u <= kContSets && c->path_chain;
 #else
@@ -417,6 +450,10 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
             P.cont_counts = nullptr;
             // one sample per pixel: the lane that ends a path has the pixel's final value (x / 1 = x) — no finishing pass
             if (b == 0) {
+#ifdef VRT_EXPERIMENTS
+                if (window) vrt::launch_path_primary_grouped(P, f.st);
+                else
+#endif
                 vrt::launch_path_primary(P, kstats, literal, f.st);
             } else if (!pool) {
                 vrt::launch_path_bounce(P, kstats, literal, f.st);
@@ -425,6 +462,11 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
                 // (one cursor set, one swap of the path buffers per LAUNCH: g counts launches)
                 const uint32_t segments = bounces - b;
                 P.last_bounce = 1u;
+#ifdef VRT_EXPERIMENTS
+                if (window)
+                    vrt::launch_path_bounce_window(P, segments, n_regions, samples, c->path_window_shape, c->path_window_lift, f.st);
+                else
+#endif
                 vrt::launch_path_bounce_cells(P, c->path_refill, segments, c->path_lds_pad, f.st);
                 b += segments - 1u;
             } else {
@@ -578,6 +620,9 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     if (const char *e = getenv("VRT_PATH_POOL")) c->path_pool = e[0] != '0';
     if (const char *e = getenv("VRT_PATH_POOL_CHAIN")) c->path_chain = e[0] == '1';
     if (const char *e = getenv("VRT_PATH_CELLS")) c->path_cells = e[0] != '0';
+    if (const char *e = getenv("VRT_PATH_WINDOW")) c->path_window = e[0] == '1';
+    if (const char *e = getenv("VRT_PATH_WINDOW_SHAPE")) { const int v = atoi(e); if (v >= 0 && v <= 4) c->path_window_shape = (uint32_t)v; }
+    if (const char *e = getenv("VRT_PATH_WINDOW_LIFT")) { const int v = atoi(e); if (v >= -64 && v <= 64) c->path_window_lift = v; }
     if (const char *e = getenv("VRT_PATH_POOL_REFILL")) c->path_refill = (uint32_t)atoi(e);
     if (const char *e = getenv("VRT_PATH_POOL_EJECT")) c->path_eject = (uint32_t)atoi(e);
     if (const char *e = getenv("VRT_PATH_LDS_PAD")) { const long v = strtol(e, nullptr, 10); if (v >= 0 && v <= 45000) c->path_lds_pad = (uint32_t)v; }
@@ -639,6 +684,7 @@ void vrt_destroy(vrt_ctx *c) {
     for (auto p : c->extra_counters) (void)hipFree(p);
     for (auto p : c->path_cont) (void)hipFree(p);
     for (auto p : c->path_acc) (void)hipFree(p);
+    for (auto p : c->path_grp_counts) (void)hipFree(p);
     (void)hipFree(c->d_tile_cost); (void)hipFree(c->d_tile_order); (void)hipFree(c->d_tile_scratch);
     for (auto st : c->side_stream)
         if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }

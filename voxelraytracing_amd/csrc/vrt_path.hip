@@ -13,98 +13,9 @@
 // radiance accumulates into the pixel's texel with plain read-modify-writes.
 #include <cstdlib>
 
-#include "vrt_march.h"
+#include "vrt_path_common.h"
 
 namespace vrt {
-
-// rng_next, path_tracer.wgsl:56-61
-__device__ __forceinline__ float rng_next(uint32_t &state) {
-    state = state * 747796405u + 2891336453u;
-    uint32_t r = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
-    r = (r >> 22u) ^ r;
-    return (float)r / 4294967295.0f;
-}
-
-// ln(x), x normal > 0: x = m * 2^e with m in (sqrt(1/2), sqrt(2)], ln m = 2 atanh((m-1)/(m+1))
-__device__ __forceinline__ float vlog(float x) {
-    const uint32_t b = __float_as_uint(x);
-    int e = (int)(b >> 23) - 127;
-    float m = __uint_as_float((b & 0x007FFFFFu) | 0x3F800000u);
-    if (m > 1.41421354f) { m = m * 0.5f; e += 1; }
-    const float s = (m - 1.0f) / (m + 1.0f);
-    const float z = s * s;
-    const float p = z * (0.333333343f + z * (0.2f + z * (0.142857149f + z * (0.111111112f + z * 0.0909090936f))));
-    return (float)e * 0.693147182f + (s + s * p) * 2.0f;
-}
-
-// cos(2*pi*u), u in [0,1]
-__device__ __forceinline__ float vcos2pi(float u) {
-    const float t = u * 4.0f;
-    const float q = floorf(t);
-    const float a = (t - q) * 1.57079637f;
-    const float a2 = a * a;
-    const float sn = a * (1.0f + a2 * (-0.166666672f + a2 * (0.00833333377f + a2 * (-0.000198412701f + a2 * (2.75573188e-06f + a2 * -2.50521079e-08f)))));
-    const float cs = 1.0f + a2 * (-0.5f + a2 * (0.0416666679f + a2 * (-0.00138888892f + a2 * (2.48015876e-05f + a2 * (-2.75573199e-07f + a2 * 2.08767559e-09f)))));
-    const int qi = (int)q & 3;
-    return qi == 0 ? cs : (qi == 1 ? -sn : (qi == 2 ? -cs : sn));
-}
-
-// rng_next_norm / rng_next_dir, path_tracer.wgsl:62-72
-__device__ __forceinline__ float rng_next_norm(uint32_t &state) {
-    const float u1 = rng_next(state);
-    float u2 = rng_next(state);
-    if (u2 < 1.0e-10f) u2 = 1.0e-10f;
-    const float rho = sqrtf(-2.0f * vlog(u2));
-    return rho * vcos2pi(u1);
-}
-__device__ __forceinline__ V3 rng_next_dir(uint32_t &state) {
-    const float x = rng_next_norm(state);
-    const float y = rng_next_norm(state);
-    const float z = rng_next_norm(state);
-    return normalize_wave(V3{x, y, z});
-}
-
-// The material colour of a hit after face shading (ray_tracer.wgsl:296-314) — shade()'s first half.
-__device__ __forceinline__ V3 hit_color(const FrameParams &P, const MarchResult &R) {
-    const vrt_material *m = &P.mats[min(R.voxel, 255u)];
-    V3 mc{m->color[0], m->color[1], m->color[2]};
-    if (R.norm.x != 0.0f) { mc.x *= 0.5f; mc.y *= 0.5f; mc.z *= 0.5f; }
-    if (R.norm.z != 0.0f) { mc.x *= 0.7f; mc.y *= 0.7f; mc.z *= 0.7f; }
-    if (R.norm.y == -1.0f) { mc.x *= 0.2f; mc.y *= 0.2f; mc.z *= 0.2f; }
-    if (P.settings.show_step_count == 1u) {
-        const float f = vclamp((float)R.iters / 500.0f, 0.0f, 1.0f);
-        mc = V3{f, f, f};
-    }
-    return mc;
-}
-
-struct PathState {
-    uint32_t slot;
-    V3 origin, dir, thr;
-    uint32_t rng;
-};
-
-// What follows a segment's march (the rest of the body of ray_color's loop, path_tracer.wgsl:155-192).  Returns true if the
-// path goes on (st updated to the next segment); a miss puts the sky's light, weighted, into `light`.
-__device__ __forceinline__ bool path_after_march(const FrameParams &P, PathState &st, const MarchResult &R, V3 &light, bool &missed) {
-    missed = !R.hit;
-    if (!R.hit) {
-        const V3 sky = ray_sky(P, st.origin, st.dir);
-        light = V3{sky.x * st.thr.x, sky.y * st.thr.y, sky.z * st.thr.z};
-        return false;
-    }
-    const V3 mc = hit_color(P, R);
-    const float d = vdot(R.norm, st.dir);
-    const V3 spec{st.dir.x - 2.0f * R.norm.x * d, st.dir.y - 2.0f * R.norm.y * d, st.dir.z - 2.0f * R.norm.z * d};
-    const V3 rd = rng_next_dir(st.rng);
-    const V3 sc = normalize_wave(V3{R.norm.x + rd.x, R.norm.y + rd.y, R.norm.z + rd.z});
-    const float scatter = P.mats[min(R.voxel, 255u)].scatter;
-    const V3 nd = normalize_wave(V3{vmix(spec.x, sc.x, scatter), vmix(spec.y, sc.y, scatter), vmix(spec.z, sc.z, scatter)});
-    st.thr = V3{st.thr.x * mc.x, st.thr.y * mc.y, st.thr.z * mc.z};
-    st.origin = V3{R.pos.x + R.norm.x * kShadowBias, R.pos.y + R.norm.y * kShadowBias, R.pos.z + R.norm.z * kShadowBias};
-    st.dir = nd;
-    return true;
-}
 
 // One segment of a path: its march, then path_after_march.
 template <int MARCH, bool LDS_ROOTS, bool STATS>
@@ -132,23 +43,68 @@ __device__ __forceinline__ void append_paths(const FrameParams &P, bool alive, c
     }
 }
 
+// The same into the workgroup's own region (path_primary_kernel<GROUPED>): the cursor is a word of the workgroup's LDS.
+__device__ __forceinline__ void append_paths_grouped(const FrameParams &P, bool alive, const PathState &st, uint32_t lane, uint32_t *s_count) {
+    const unsigned long long ballot = __ballot(alive);
+    const uint32_t n = (uint32_t)__popcll(ballot);
+    if (!n) return;
+    const int leader = __ffsll((long long)ballot) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(s_count, n);
+    base = __shfl(base, leader, 64) + blockIdx.x * P.grp_cap;
+    if (alive) {
+        const uint32_t i = base + lanes_below(ballot);
+        P.path_out[i] = make_uint4(st.slot, __float_as_uint(st.origin.x), __float_as_uint(st.origin.y), __float_as_uint(st.origin.z));
+        P.path_out[P.path_cap + i] = make_uint4(__float_as_uint(st.dir.x), __float_as_uint(st.dir.y), __float_as_uint(st.dir.z), st.rng);
+        P.path_out[2u * P.path_cap + i] = make_uint4(__float_as_uint(st.thr.x), __float_as_uint(st.thr.y), __float_as_uint(st.thr.z), 0u);
+    }
+}
+
+// The launch's q-th tile when the tiles are taken in blocks of blk_w x blk_h (bands of blk_h tile rows, the blocks of a band
+// from left to right, a block's tiles row by row: a workgroup's four waves are four tiles of a row, the workgroups of a block
+// consecutive).  A ragged last band (or last block of a band) is shorter (narrower); the order stays a permutation of the
+// frame's tiles.  Sharded frames keep their order (their tiles are interleaved with the other shards' anyway).
+__device__ __forceinline__ uint32_t block_order_tile(uint32_t q, const FrameParams &P) {
+    if (P.shard_period != 1u || P.tiles_local != P.tiles_total) return q;
+    const uint32_t tx = P.tiles_x, ty = P.tiles_total / P.tiles_x, bw = P.blk_w, bh = P.blk_h;
+    const uint32_t band = q / (bh * tx), r = q - band * bh * tx;
+    const uint32_t h = min(bh, ty - bh * band), full = tx / bw;
+    uint32_t x, y;
+    if (r < full * bw * h) {
+        const uint32_t cb = r / (bw * h), j = r - cb * bw * h;
+        x = bw * cb + j % bw;
+        y = j / bw;
+    } else {
+        const uint32_t w = tx - bw * full, rr = r - full * bw * h;
+        x = bw * full + rr % w;
+        y = rr / w;
+    }
+    return (bh * band + y) * tx + x;
+}
+
 static_assert(kHitSegments == 256, "a launch's first workgroup (256 threads) clears the next launch's 256 segment cursors");
 
 // Bounce 0: primary rays of sample P.sample. Sample 0 initialises the texel {light, id}; later samples add.
 // MULTI: the samples of a launch chain (P.acc, P.chain) share the primary march; otherwise one sample, straight into `out`
-template <int MARCH, bool LDS_ROOTS, bool STATS, bool MULTI = false>
+// GROUPED (the window bounce launch, vrt_path_window.hip): a workgroup's survivors are compacted — by the workgroup, through a
+// counter in LDS — into the workgroup's own region of the path buffer (P.grp_cap records; the count into P.grp_counts), and
+// the workgroups take the tiles in blocks of 4 x 4, so that four consecutive regions hold the paths of 32 x 32 pixels: a
+// bounce workgroup's rays then start within a few voxels of each other.  No cursors, no global atomics.
+template <int MARCH, bool LDS_ROOTS, bool STATS, bool MULTI = false, bool GROUPED = false>
 __global__ void __launch_bounds__(256) path_primary_kernel(FrameParams P) {
     extern __shared__ uint32_t smem[];
     uint32_t *s_liquid = smem, *s_roots = smem + 24;
     unsigned long long *s_acc = reinterpret_cast<unsigned long long *>(smem + 8);
     if (STATS && threadIdx.x < 8) s_acc[threadIdx.x] = 0ull;
+    if (GROUPED && threadIdx.x == 0) smem[8] = 0u;   // (no stats in a grouped launch: the word is free)
     stage_lds(P, s_roots, s_liquid, LDS_ROOTS);
 
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t t_local = blockIdx.x * 4u + (threadIdx.x >> 6);
-    const bool live = t_local < P.tiles_local;
-    if (blockIdx.x == 0 && P.seg_clear) P.seg_clear[threadIdx.x * kSegStride] = 0u;   // kHitSegments == blockDim.x cursors
-    if (!STATS && !live) return;
+    const uint32_t t_launch = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const bool live = t_launch < P.tiles_local;
+    const uint32_t t_local = (GROUPED && live) ? block_order_tile(t_launch, P) : t_launch;
+    if (!GROUPED && blockIdx.x == 0 && P.seg_clear) P.seg_clear[threadIdx.x * kSegStride] = 0u;   // kHitSegments == blockDim.x cursors
+    if (!STATS && !GROUPED && !live) return;
     MarchResult R;
     R.iters = 0; R.visits = 0; R.hit = false;
     if (live) {
@@ -193,9 +149,14 @@ __global__ void __launch_bounds__(256) path_primary_kernel(FrameParams P) {
                 t.z = __float_as_uint(__uint_as_float(t.z) + light.z);
                 P.out[st.slot] = t;
             }
-            append_paths(P, alive, st, lane);
+            if (GROUPED) append_paths_grouped(P, alive, st, lane, &smem[8]);
+            else append_paths(P, alive, st, lane);
         }
         if (STATS && P.steps && P.sample == 0u) P.steps[pixel_slot] = R.iters;
+    }
+    if (GROUPED) {
+        __syncthreads();
+        if (threadIdx.x == 0) P.grp_counts[blockIdx.x] = smem[8];
     }
     if (STATS) {
         block_add(s_acc, 0, R.iters);
@@ -277,16 +238,6 @@ constexpr uint32_t kPoolBatches = VRT_POOL_K;            // K
 constexpr uint32_t kPoolEntries = kPoolBatches * 64u;
 constexpr uint32_t kPoolWords = 4u * kPoolEntries;
 constexpr uint32_t kPoolRefillAt = 16u;                  // idle lanes (of 64) that send the wave back to the pool
-
-// the nudge off a voxel face at the start of a march (ray_tracer.wgsl:204-207)
-__device__ __forceinline__ V3 nudged(V3 pos, V3 dir) {
-    if (pos.x - floorf(pos.x) < 0.001f || pos.y - floorf(pos.y) < 0.001f || pos.z - floorf(pos.z) < 0.001f) {
-        pos.x += 0.001f * dir.x;
-        pos.y += 0.001f * dir.y;
-        pos.z += 0.001f * dir.z;
-    }
-    return pos;
-}
 
 #ifdef VRT_EXPERIMENTS
 // ------------------------------------------------------------------------------------------------
@@ -918,11 +869,6 @@ struct CellsLaunch {
     uint32_t refill_at;   // a wave takes rays from its pool when this many of its lanes are idle
     uint32_t segments;    // bounce segments in this launch: all that the frame's paths have left
 };
-
-// how many lanes of the mask are below this one (two instructions over the mask's halves; no per-lane mask to keep)
-__device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) {
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-}
 
 #ifndef VRT_CELLS_LOAD_AUX
 #define VRT_CELLS_LOAD_AUX 0   // cache policy of the march-cell load (A/B builds: 1 sc0, 2 nt, 16 sc1)
@@ -1647,6 +1593,14 @@ void launch_path_primary(const FrameParams &P, bool stats, bool literal, hipStre
 }
 
 #ifdef VRT_EXPERIMENTS
+// the primary launch of a frame whose bounce launch is the window kernel (plain frames over the derived tables)
+void launch_path_primary_grouped(const FrameParams &P, hipStream_t st) {
+    if (P.tiles_local == 0) return;
+    const dim3 grid((P.tiles_local + 3u) / 4u), block(256);
+    if (P.acc) hipLaunchKernelGGL((path_primary_kernel<0, false, false, true, true>), grid, block, lds_bytes_path(P, false), st, P);
+    else hipLaunchKernelGGL((path_primary_kernel<0, false, false, false, true>), grid, block, lds_bytes_path(P, false), st, P);
+}
+
 // `continuations`: a launch of the straggler chain (P.path_in = four-plane records: rays a bounce launch handed on and the
 // next segments of the chain's own survivors), which marches every ray to its end.
 void launch_path_bounce_pool(const FrameParams &P, bool continuations, uint32_t refill_at, uint32_t eject_at, hipStream_t st) {

@@ -1,0 +1,115 @@
+// vrt_path_common.h — what the path-trace translation units share (vrt_path.hip: the primary launch and the lane = path
+// bounce kernels; vrt_path_window.hip: the fused bounce launch over LDS-staged windows of march cells): the RNG of
+// path_tracer.wgsl:56-72, log and cos spelled out in + - * / (host and device agree to the bit), and what follows a
+// segment's march (path_tracer.wgsl:155-192).  DESIGN.md, path trace.
+#pragma once
+
+#include "vrt_march.h"
+
+namespace vrt {
+
+// rng_next, path_tracer.wgsl:56-61
+__device__ __forceinline__ float rng_next(uint32_t &state) {
+    state = state * 747796405u + 2891336453u;
+    uint32_t r = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    r = (r >> 22u) ^ r;
+    return (float)r / 4294967295.0f;
+}
+
+// ln(x), x normal > 0: x = m * 2^e with m in (sqrt(1/2), sqrt(2)], ln m = 2 atanh((m-1)/(m+1))
+__device__ __forceinline__ float vlog(float x) {
+    const uint32_t b = __float_as_uint(x);
+    int e = (int)(b >> 23) - 127;
+    float m = __uint_as_float((b & 0x007FFFFFu) | 0x3F800000u);
+    if (m > 1.41421354f) { m = m * 0.5f; e += 1; }
+    const float s = (m - 1.0f) / (m + 1.0f);
+    const float z = s * s;
+    const float p = z * (0.333333343f + z * (0.2f + z * (0.142857149f + z * (0.111111112f + z * 0.0909090936f))));
+    return (float)e * 0.693147182f + (s + s * p) * 2.0f;
+}
+
+// cos(2*pi*u), u in [0,1]
+__device__ __forceinline__ float vcos2pi(float u) {
+    const float t = u * 4.0f;
+    const float q = floorf(t);
+    const float a = (t - q) * 1.57079637f;
+    const float a2 = a * a;
+    const float sn = a * (1.0f + a2 * (-0.166666672f + a2 * (0.00833333377f + a2 * (-0.000198412701f + a2 * (2.75573188e-06f + a2 * -2.50521079e-08f)))));
+    const float cs = 1.0f + a2 * (-0.5f + a2 * (0.0416666679f + a2 * (-0.00138888892f + a2 * (2.48015876e-05f + a2 * (-2.75573199e-07f + a2 * 2.08767559e-09f)))));
+    const int qi = (int)q & 3;
+    return qi == 0 ? cs : (qi == 1 ? -sn : (qi == 2 ? -cs : sn));
+}
+
+// rng_next_norm / rng_next_dir, path_tracer.wgsl:62-72
+__device__ __forceinline__ float rng_next_norm(uint32_t &state) {
+    const float u1 = rng_next(state);
+    float u2 = rng_next(state);
+    if (u2 < 1.0e-10f) u2 = 1.0e-10f;
+    const float rho = sqrtf(-2.0f * vlog(u2));
+    return rho * vcos2pi(u1);
+}
+__device__ __forceinline__ V3 rng_next_dir(uint32_t &state) {
+    const float x = rng_next_norm(state);
+    const float y = rng_next_norm(state);
+    const float z = rng_next_norm(state);
+    return normalize_wave(V3{x, y, z});
+}
+
+// The material colour of a hit after face shading (ray_tracer.wgsl:296-314) — shade()'s first half.
+__device__ __forceinline__ V3 hit_color(const FrameParams &P, const MarchResult &R) {
+    const vrt_material *m = &P.mats[min(R.voxel, 255u)];
+    V3 mc{m->color[0], m->color[1], m->color[2]};
+    if (R.norm.x != 0.0f) { mc.x *= 0.5f; mc.y *= 0.5f; mc.z *= 0.5f; }
+    if (R.norm.z != 0.0f) { mc.x *= 0.7f; mc.y *= 0.7f; mc.z *= 0.7f; }
+    if (R.norm.y == -1.0f) { mc.x *= 0.2f; mc.y *= 0.2f; mc.z *= 0.2f; }
+    if (P.settings.show_step_count == 1u) {
+        const float f = vclamp((float)R.iters / 500.0f, 0.0f, 1.0f);
+        mc = V3{f, f, f};
+    }
+    return mc;
+}
+
+struct PathState {
+    uint32_t slot;
+    V3 origin, dir, thr;
+    uint32_t rng;
+};
+
+// What follows a segment's march (the rest of the body of ray_color's loop, path_tracer.wgsl:155-192).  Returns true if the
+// path goes on (st updated to the next segment); a miss puts the sky's light, weighted, into `light`.
+__device__ __forceinline__ bool path_after_march(const FrameParams &P, PathState &st, const MarchResult &R, V3 &light, bool &missed) {
+    missed = !R.hit;
+    if (!R.hit) {
+        const V3 sky = ray_sky(P, st.origin, st.dir);
+        light = V3{sky.x * st.thr.x, sky.y * st.thr.y, sky.z * st.thr.z};
+        return false;
+    }
+    const V3 mc = hit_color(P, R);
+    const float d = vdot(R.norm, st.dir);
+    const V3 spec{st.dir.x - 2.0f * R.norm.x * d, st.dir.y - 2.0f * R.norm.y * d, st.dir.z - 2.0f * R.norm.z * d};
+    const V3 rd = rng_next_dir(st.rng);
+    const V3 sc = normalize_wave(V3{R.norm.x + rd.x, R.norm.y + rd.y, R.norm.z + rd.z});
+    const float scatter = P.mats[min(R.voxel, 255u)].scatter;
+    const V3 nd = normalize_wave(V3{vmix(spec.x, sc.x, scatter), vmix(spec.y, sc.y, scatter), vmix(spec.z, sc.z, scatter)});
+    st.thr = V3{st.thr.x * mc.x, st.thr.y * mc.y, st.thr.z * mc.z};
+    st.origin = V3{R.pos.x + R.norm.x * kShadowBias, R.pos.y + R.norm.y * kShadowBias, R.pos.z + R.norm.z * kShadowBias};
+    st.dir = nd;
+    return true;
+}
+
+// the nudge off a voxel face at the start of a march (ray_tracer.wgsl:204-207)
+__device__ __forceinline__ V3 nudged(V3 pos, V3 dir) {
+    if (pos.x - floorf(pos.x) < 0.001f || pos.y - floorf(pos.y) < 0.001f || pos.z - floorf(pos.z) < 0.001f) {
+        pos.x += 0.001f * dir.x;
+        pos.y += 0.001f * dir.y;
+        pos.z += 0.001f * dir.z;
+    }
+    return pos;
+}
+
+// how many lanes of the mask are below this one (two instructions over the mask's halves; no per-lane mask to keep)
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+}  // namespace vrt
