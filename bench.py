@@ -34,6 +34,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 N_SIMD = 1024               # 256 CUs x 4 SIMD-32
 NOMINAL_GHZ = 2.4
+MIN_TIMED_SECONDS = 0.05    # a timed window shorter than this is followed by a second, longer one (see `steps_timed`)
 
 
 def parse_args():
@@ -54,6 +55,7 @@ def parse_args():
                     help="frames the backend keeps in flight (vrt_set_frames_in_flight; 1 = one launch at a time)")
     ap.add_argument("--fixed-camera", action="store_true", help="headline loop with a standing camera and no per-frame seam calls")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra legs (fixed camera, 1 in flight, clock probe)")
+    ap.add_argument("--exact-steps", action="store_true", help="time the requested steps only, however short (no second, >= 50 ms window)")
     ap.add_argument("--settle-seconds", type=float, default=2.0, help="upper bound of the clock-settling frames before the warm-up (0 = none)")
     ap.add_argument("--root-weight", type=int, default=0,
                     help="N > 1: tiles per period dealt to the gather root (vrt_config.shard_root_weight); 0 = measure "
@@ -260,7 +262,8 @@ def main():
         row-major frame (VRT_FLAG_ROW_MAJOR) and takes root_weight tiles of every root_weight + N - 1."""
         in_place = world > 1
         compact = in_place and MODE != MODE_PATH and args.variant == 0   # 8 B/pixel over the links, shaded at the root
-        kw = dict(devices=devices, root_weight=root_weight) if devices else \
+        # (one context over N devices: 8-byte records for primary(+shadow) frames of the default march, 16-byte texels otherwise)
+        kw = dict(devices=devices, root_weight=root_weight, texel_messages=MODE == MODE_PATH or args.variant != 0) if devices else \
             dict(shard_rank=rank, shard_count=world, tile_major=sharded and not (in_place and rank == 0), root_weight=root_weight,
                  row_major=in_place and rank == 0, compact=compact and rank != 0)
         gp = Gpu(sc.world.max_nodes(), sc.world.size_in_chunks(), sc.size, device=local_rank, **kw)
@@ -366,7 +369,28 @@ def main():
     elif sharded and args.gather_batch > 0:
         batch = args.gather_batch   # --force-gather: the one-rank pipeline with batched gathers
     elif devices:
-        root_weight = args.root_weight if args.root_weight > 0 else {2: 4, 4: 3, 8: 2}.get(args.gpus, 2)
+        # one context over N devices: the share of the root from the balance of DESIGN.md section 7 (shard.root_weight_model) on
+        # the unsharded frame's own time, measured here off the clock — a 34 ms path-trace frame is bound by its render and
+        # wants even shares, a 0.1 ms primary + shadow frame by its messages' links and wants the root to keep more
+        if args.root_weight > 0:
+            root_weight = args.root_weight
+        else:
+            from voxelraytracing_amd.shard import root_weight_model
+            probe = Gpu(sc.world.max_nodes(), sc.world.size_in_chunks(), sc.size, device=0)
+            probe.upload_world(sc.world, sc.materials)
+            probe.write_cam_data(sc.cam)
+            probe.write_settings(sc.settings)
+            probe.render(MODE, **rkw)
+            probe.synchronize()
+            n_p, t0 = 0, time.perf_counter()
+            while n_p < 50 and (n_p < 2 or time.perf_counter() - t0 < 0.1):
+                probe.render(MODE, **rkw)
+                n_p += 1
+            probe.synchronize()
+            t1_ms = (time.perf_counter() - t0) / n_p * 1e3
+            probe.close()
+            per_px = 16 if (MODE == MODE_PATH or args.variant != 0) else 8
+            root_weight = root_weight_model(args.gpus, t1_ms, args.width * args.height * per_px)
     gpu, fg = make_pipeline(root_weight, batch)
 
     # ---- exact ray / step / node-visit counts (deterministic; a stats frame is never timed): the scene's own camera,
@@ -413,31 +437,45 @@ def main():
     dt = timed(gpu, fg, args.steps, fixed)   # every timed frame is gathered and assembled on rank 0 before the clock stops
     host_submit_ms = submit[0] / args.steps * 1e3
     rays_total = rays_fixed * args.steps if fixed else int(sum(int(orbit_rays[i % ORBIT]) for i in range(args.steps)))
-    kst = gpu.stats()   # per-kernel durations over exactly the timed frames: HIP events on the streams the kernels ran on
+    # A short request (the driver's 20 steps are 1.9 ms of frames: two of them pipeline fill and drain, and one scheduling hiccup
+    # of the host is a tenth of it) is followed by a second timed window of the same loop, long enough for >= 50 ms of frames,
+    # bracketed like the first (barrier + synchronise on both sides, maximum over ranks).  `value` / `ms_per_step` are then the
+    # LONG window's, `steps_timed` its length; the requested K steps alone stay in `value_requested_steps` /
+    # `ms_per_step_requested_steps`.  A request that is itself >= 50 ms of frames is timed once, as before.
+    requested = {"steps": args.steps, "value": rays_total / dt / 1e6, "ms_per_step": dt / args.steps * 1e3, "host_submit_ms_per_step": host_submit_ms}
+    steps_timed = args.steps
+    if dt < MIN_TIMED_SECONDS and not args.exact_steps:
+        steps_timed = max(args.steps, int(np.ceil(MIN_TIMED_SECONDS / (dt / args.steps))))
+        first = frame_no[0]
+        dt = timed(gpu, fg, steps_timed, fixed)
+        host_submit_ms = submit[0] / steps_timed * 1e3
+        rays_total = rays_fixed * steps_timed if fixed else int(sum(int(orbit_rays[(first + i) % ORBIT]) for i in range(steps_timed)))
+    kst = gpu.stats()   # per-kernel durations over the timed frames (both windows): HIP events on the streams the kernels ran on
 
     # ---- extra legs, off the headline clock (N = 1): standing camera, one launch at a time, the clock the march runs at ----
     extras = {}
+    xs = steps_timed   # (the extra legs' windows are as long as the headline's)
     if world == 1 and not sharded and not devices and not args.no_extras:
         if not fixed:
             gpu.write_cam_data(sc.cam)
             run_frames(gpu, fg, 50, True)
-            d2 = timed(gpu, fg, args.steps, True)
+            d2 = timed(gpu, fg, xs, True)
             gpu.stats()
-            extras["value_fixed_camera"] = rays_fixed * args.steps / d2 / 1e6
-            extras["ms_per_step_fixed_camera"] = d2 / args.steps * 1e3
+            extras["value_fixed_camera"] = rays_fixed * xs / d2 / 1e6
+            extras["ms_per_step_fixed_camera"] = d2 / xs * 1e3
         if args.frames_in_flight != 1:
             gpu.set_frames_in_flight(1)
             gpu.write_cam_data(sc.cam)
             run_frames(gpu, fg, 50, True)
-            d1 = timed(gpu, fg, args.steps, True)
+            d1 = timed(gpu, fg, xs, True)
             gpu.stats()
             # the lone launch's own duration: every frame timed (VRT_RENDER_TIMED) — between untimed neighbours a timed
             # launch's begin stamp falls into its predecessor's tail
             for _ in range(300):
                 gpu.render(MODE, timed=True, **rkw)
             k1 = gpu.stats()
-            extras["value_1_in_flight"] = rays_fixed * args.steps / d1 / 1e6
-            extras["ms_per_step_1_in_flight"] = d1 / args.steps * 1e3
+            extras["value_1_in_flight"] = rays_fixed * xs / d1 / 1e6
+            extras["ms_per_step_1_in_flight"] = d1 / xs * 1e3
             extras["avg_launch_ms_1_in_flight"] = k1.sum_ms_primary / max(k1.frames, 1)
             if MODE == MODE_PATH:   # per frame: the primary launch(es) and the bounce launch(es), each alone on the GPU
                 extras["avg_bounce_launches_ms_1_in_flight"] = k1.sum_ms_secondary / max(k1.frames, 1)
@@ -447,10 +485,10 @@ def main():
                 frame_no[0] = 0
                 run_frames(gpu, fg, 50, False)
                 frame_no[0] = 0
-                d1o = timed(gpu, fg, args.steps, False)
+                d1o = timed(gpu, fg, xs, False)
                 gpu.stats()
-                extras["value_1_in_flight_orbit"] = rays_total / d1o / 1e6
-                extras["ms_per_step_1_in_flight_orbit"] = d1o / args.steps * 1e3
+                extras["value_1_in_flight_orbit"] = int(sum(int(orbit_rays[i % ORBIT]) for i in range(xs))) / d1o / 1e6
+                extras["ms_per_step_1_in_flight_orbit"] = d1o / xs * 1e3
             gpu.set_frames_in_flight(args.frames_in_flight)
         if MODE == MODE_PRIMARY_SHADOW and args.variant == 0:
             # the clock: right behind the timed load, frames of the probe build (the same kernel + two stamps per wave)
@@ -515,6 +553,19 @@ def main():
                                                   "value": sum(rays_op[i % ORBIT] for i in range(400)) / t_all / 1e6, "unit": "Mrays/s"}
         gp.close()
 
+    one_gpu_ms = [None]   # N > 1: the unsharded frame on this rank's GPU, timed off the clock (config.expected_scaling's input)
+
+    def time_unsharded(ref):
+        # (other ranks may still be busy on a rehearsal's one GPU: the figure is then an upper bound, and says so)
+        ref.render(MODE, **rkw)
+        ref.synchronize()
+        n_done, t0 = 0, time.perf_counter()
+        while n_done < 200 and (n_done < 3 or time.perf_counter() - t0 < 0.15):
+            ref.render(MODE, **rkw)
+            n_done += 1
+        ref.synchronize()
+        one_gpu_ms[0] = (time.perf_counter() - t0) / n_done * 1e3
+
     if sharded and rank == 0 and os.environ.get("VRT_BENCH_VERIFY", "1") == "1":
         # off the clock: the assembled frame must equal an unsharded render of the same frame on this GPU
         last = cams[(frame_no[0] - 1) % ORBIT] if not fixed else None
@@ -529,6 +580,7 @@ def main():
         a_rgb, a_ids = texels_to_frame(fg.frame.cpu().numpy().view(np.uint32))
         if not (np.array_equal(a_ids, r_ids) and np.array_equal(a_rgb, r_rgb)):
             raise SystemExit("gathered frame differs from the unsharded render")
+        time_unsharded(ref)
         ref.close()
     if devices and os.environ.get("VRT_BENCH_VERIFY", "1") == "1":
         ref = Gpu(sc.world.max_nodes(), sc.world.size_in_chunks(), sc.size, device=0)
@@ -541,6 +593,7 @@ def main():
         a_rgb, a_ids, _ = gpu.read_output()
         if not (np.array_equal(a_ids, r_ids) and np.array_equal(a_rgb, r_rgb)):
             raise SystemExit("the multi-device frame differs from the single-device render")
+        time_unsharded(ref)
         ref.close()
     if rank != 0:
         dist.destroy_process_group()
@@ -559,7 +612,7 @@ def main():
         dom_name, dom_bytes, dom_ms = ("path_primary_march", b_primary, ms_p) if ms_p >= ms_s else ("path_bounce_marches", b_shadow, ms_s)
     else:
         dom_name, dom_bytes, dom_ms = ("primary_march", b_primary, ms_p) if ms_p >= ms_s else ("shadow_march", b_shadow, ms_s)
-    period_s = dt / args.steps
+    period_s = dt / steps_timed
     in_flight = args.frames_in_flight if (world == 1 and not sharded and not devices and (fused or args.mode in ("primary", "path"))) else 1
 
     # ---- what bounds the dominant kernel: instruction issue.  Counters come from profiles/traffic_latest.json, which the
@@ -705,6 +758,14 @@ def main():
         "value": rays_total / dt / 1e6,
         "unit": "Mrays/s",
         "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+        # frames inside the timed window `value` comes from (> steps when the request was under 50 ms of frames: see
+        # `value_requested_steps` for the K steps alone)
+        "steps_timed": steps_timed,
+        "value_requested_steps": requested["value"], "ms_per_step_requested_steps": requested["ms_per_step"],
+        "value_is": ("the rate over exactly the requested steps" if steps_timed == args.steps else
+                     f"the rate over a second timed window of {steps_timed} frames of the same loop (the requested {args.steps} steps are "
+                     f"{requested['ms_per_step'] * args.steps:.2f} ms of frames, under the {MIN_TIMED_SECONDS * 1e3:.0f} ms a window needs to be more than pipeline fill and drain); "
+                     "the requested steps alone: value_requested_steps"),
         "ranks_seen": ranks_seen,   # an all-reduce of ones over the process group (1: no group)
         "links": links,
         "ms_per_step": period_s * 1e3,
@@ -732,10 +793,32 @@ def main():
                    "root_weight": root_weight, "root_weight_tuning_ms_per_frame": tuning,
                    "frames_per_gather": batch, "frames_per_gather_tuning_ms_per_frame": batch_tuning,
                    "frames_in_flight": args.frames_in_flight, "clock_settle": settle,
-                   "kernel_variant": args.variant, "derived_tables": derived},
+                   "kernel_variant": args.variant, "derived_tables": derived,
+                   # N > 1: what this split should give, term by term, from the unsharded frame timed on this GPU in this run —
+                   # stated so that the measured line can be read against it (shard.expected_scaling)
+                   "expected_scaling": None},
         "roofline": roof,
         "hbm": hbm,
     }
+    if (world > 1 or devices) and one_gpu_ms[0]:
+        from voxelraytracing_amd.shard import expected_scaling
+        texel_msgs = MODE == MODE_PATH or args.variant != 0
+        n_ = args.gpus
+        # the host's share per frame, as measured on one GPU (it cannot be taken from this run: a host that is ahead of its GPUs
+        # blocks on full queues and its submit time reads as the GPU's): one process per GPU — a collective call per `batch`
+        # frames (~ 35 us) + a render call (~ 8 us); one context over N devices — the root's render, N - 1 stream waits, the
+        # assembly's launch, an event record (~ 30 us) beside the shard devices' own threads (~ 10 us each, in parallel)
+        host_us = (35.0 / max(batch, 1) + 8.0) if world > 1 else 30.0 + 10.2
+        es = expected_scaling(n_, one_gpu_ms[0], args.width * args.height, 16 if texel_msgs else 8, root_weight,
+                              host_us_per_frame=host_us, fixed_ms_per_launch=min(0.016, one_gpu_ms[0]))
+        es["host_submit_us_per_frame_this_run"] = host_submit_ms * 1e3
+        es["frame_ms_1gpu_measured_in_this_run"] = one_gpu_ms[0]
+        es["measured_ms"] = period_s * 1e3
+        es["measured_speedup"] = one_gpu_ms[0] / (period_s * 1e3)
+        es["measured_over_predicted"] = (period_s * 1e3) / es["predicted_ms"] if es.get("predicted_ms") else None
+        if args.rehearse_on_one_gpu:
+            es["rehearsal"] = "every rank / device on ONE GPU: the measured line is not a scaling point; the prediction is for N distinct devices"
+        out["config"]["expected_scaling"] = es
     out.update(extras)
     if operating_point:
         out["operating_point"] = operating_point

@@ -93,7 +93,7 @@ typedef struct {
  * whose tiles all arrive over one xGMI link each. */
 #define VRT_MAX_DEVICES 16
 typedef struct {
-    uint32_t max_nodes;          /* NodeBuffer capacity in nodes (shader.rs:9-16; forced even) */
+    uint32_t max_nodes;          /* NodeBuffer capacity in nodes (shader.rs:9-16; forced even); 2 .. 2^31 - 2^17 */
     uint32_t world_size_chunks;  /* S: chunk_roots holds S^3 entries (shader.rs:59,67) */
     uint32_t width, height;      /* result texture size, any non-zero size (main.rs:257-262: 1080 rows at the window's
                                   * aspect).  As in the reference, width/8 x height/8 tiles of 8x8 pixels are traced

@@ -262,3 +262,18 @@ def test_root_weight_model():
     slow_links = [shard.root_weight_model(n, 0.14, 33e6, link_gbs=20.0) for n in (2, 4, 8)]
     assert fast_links == [1, 1, 1] and all(s > 1 for s in slow_links)
     assert slow_links[0] >= slow_links[1] >= slow_links[2]
+
+
+def test_expected_scaling_states_the_bound_before_the_run():
+    """shard.expected_scaling (what bench.py prints as config.expected_scaling on every N > 1 line): C3's primary + shadow frame
+    at 1080p is bound by one message over one link and predicted under 2 x at N = 8; C5's 34 ms path-trace frame by a shard's
+    render, near N x."""
+    from voxelraytracing_amd import shard
+    c3 = shard.expected_scaling(8, 0.133, 1920 * 1080, 8, 2)
+    assert c3["bound"] in ("link_ms_per_message", "root_render_plus_assemble_ms") and c3["speedup"] < 4.0
+    assert abs(c3["message_bytes_per_rank"] - 1920 * 1080 * 8 / 9) < 1
+    c5 = shard.expected_scaling(8, 34.0, 3840 * 2160, 16, 2)
+    assert c5["bound"] == "root_render_plus_assemble_ms" and 3.5 < c5["speedup"] < 8.0
+    even = shard.expected_scaling(8, 34.0, 3840 * 2160, 16, 1)
+    assert even["speedup"] > c5["speedup"] and even["speedup"] <= 8.0
+    assert shard.expected_scaling(1, 1.0, 100, 16, 1)["speedup"] == 1.0

@@ -354,7 +354,9 @@ __global__ void __launch_bounds__(512) accel_chunks_kernel(const uint16_t *nodes
     const uint32_t head = root & 7u, first = root - head;
     const uint32_t staged = min(list.extent[blockIdx.x], kChunkNodesMax);
     const uint32_t vecs = (head + staged + 7u) / 8u;
-    const __amdgpu_buffer_rsrc_t nb = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(nodes), 0, (n_nodes & ~1u) * 2u, 0x00020000);   // (n_nodes <= 2^31 - 2: vrt_create)
+    // (n_nodes <= 2^31 - 2^17: vrt_create — so that the byte offset of the extent's last vector, (first + 8 vecs) * 2 with at most
+    // kChunkNodesMax + 16 nodes behind `first`, cannot wrap around 2^32 and read the start of the pool instead of zeros)
+    const __amdgpu_buffer_rsrc_t nb = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(nodes), 0, (n_nodes & ~1u) * 2u, 0x00020000);
     // (a lone workgroup: all of a thread's loads are issued before the first of them is stored — one load per loop trip
     // was up to nine memory round trips in a row, 15 of the kernel's 17 us for a chunk of 40 000 nodes)
     constexpr uint32_t kVecsPerThread = (kChunkNodesMax + 16u + 8u * 512u - 1u) / (8u * 512u);
@@ -613,14 +615,15 @@ void launch_accel_chunks(const uint16_t *nodes, uint32_t n_nodes, const uint32_t
     // 64 KiB + of dynamic LDS needs opting in (the CU has 160 KiB); per device, and any thread may be the first
     const size_t lds = (size_t)(kChunkNodesMax + 16u) * sizeof(uint16_t);
     {   // (once per device: the call is a few microseconds of every edit's frame otherwise)
+        // (a device is marked only once its opt-in succeeded — a failed call is tried again by the next rebuild, whose launch then
+        // reports it; device ordinals beyond the mask's 64 bits opt in every time)
         static std::atomic<uint64_t> opted_in{0};
         int dev = 0;
         (void)hipGetDevice(&dev);
-        const uint64_t bit = 1ull << (dev & 63);
-        if (!(opted_in.load(std::memory_order_relaxed) & bit)) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(accel_chunks_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const uint64_t bit = (unsigned)dev < 64u ? 1ull << dev : 0ull;
+        if (!(opted_in.load(std::memory_order_relaxed) & bit) &&
+            hipFuncSetAttribute(reinterpret_cast<const void *>(accel_chunks_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
             opted_in.fetch_or(bit, std::memory_order_relaxed);
-        }
     }
     const MarchCells mc{dir, blocks, block_tail, block_cap, dir ? 0u : 1u};
     for (uint32_t i = 0; i < n; i += 64u) {

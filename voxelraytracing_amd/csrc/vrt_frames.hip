@@ -566,8 +566,10 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     if (!cfg || !out) return fail(nullptr, VRT_ERR_INVALID_ARG, "vrt_create: null argument");
     *out = nullptr;
     if (cfg->n_devices > 1u) return grp_create(cfg, out);
-    if (cfg->max_nodes < 2 || cfg->max_nodes > 0x7FFFFFFEu)
-        return fail(nullptr, VRT_ERR_INVALID_ARG, "max_nodes must be in [2, 2^31 - 2] (the pool is addressed through a 32-bit byte offset)");
+    // (2^17 nodes of headroom: a chunk rebuild stages up to a chunk's 32 767 + 24 nodes behind a root in one run of 16-byte loads,
+    // whose byte offsets must not wrap — vrt_accel.hip)
+    if (cfg->max_nodes < 2 || cfg->max_nodes > 0x7FFE0000u)
+        return fail(nullptr, VRT_ERR_INVALID_ARG, "max_nodes must be in [2, 2^31 - 2^17] (the pool is addressed through a 32-bit byte offset)");
     if (cfg->width == 0 || cfg->height == 0)
         return fail(nullptr, VRT_ERR_INVALID_ARG, "output %ux%u: dimensions must be non-zero", cfg->width, cfg->height);
     if ((uint64_t)cfg->width * cfg->height > (1ull << 28))

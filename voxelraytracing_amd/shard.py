@@ -80,6 +80,39 @@ def root_weight_model(count: int, frame_ms: float, message_bytes_total: float, l
     return best
 
 
+def expected_scaling(count: int, frame_ms_1gpu: float, pixels: int, bytes_per_pixel: int, root_weight: int, link_gbs: float = 60.0,
+                     assemble_ms_whole_frame: float = 0.02, host_us_per_frame: float = 0.0, fixed_ms_per_launch: float = 0.016) -> dict:
+    """What a frame sharded over `count` GPUs should take, term by term — the arithmetic of DESIGN.md section 7, stated before
+    the run so that a measured scaling curve can be read against it (bench.py prints it as config.expected_scaling on every
+    N > 1 line).  Tiles are dealt in periods of P = w0 + N - 1: w0 to the root (never cross a link), one to each other rank.
+
+    frame_ms_1gpu: the unsharded frame on one GPU (measured in the same run); fixed_ms_per_launch: what a launch costs however
+    few tiles it has (an all-sky frame: profiles/r02_fixed_cost.txt) — a share's render time does not fall below it;
+    link_gbs: one xGMI link, one direction (60-75 GB/s measured point to point; the guide's 153 GB/s is the link's peak);
+    the messages of the N - 1 ranks arrive over N - 1 different links at once.  Returns the terms, the bound that wins and
+    the predicted speed-up over one GPU."""
+    if count <= 1:
+        return {"n": 1, "predicted_ms": frame_ms_1gpu, "speedup": 1.0, "bound": "one GPU"}
+    period = root_weight + count - 1
+    march = max(frame_ms_1gpu - fixed_ms_per_launch, 0.0)
+    root_render = fixed_ms_per_launch + march * root_weight / period
+    rank_render = fixed_ms_per_launch + march / period
+    message_bytes = pixels * bytes_per_pixel / period                  # one rank's message: its own link
+    link_ms = message_bytes / (link_gbs * 1e9) * 1e3
+    assemble = assemble_ms_whole_frame * (count - 1) / period          # the root scatters / shades the other ranks' pixels
+    root_total = root_render + assemble
+    host_ms = host_us_per_frame * 1e-3
+    terms = {"root_render_plus_assemble_ms": root_total, "rank_render_ms": rank_render, "link_ms_per_message": link_ms, "host_ms_per_frame": host_ms}
+    # pipelined (frames in flight, ping-pong messages): the steady state is the slowest stage, not the sum
+    bound = max(terms, key=lambda k: terms[k])
+    predicted = terms[bound]
+    return {"n": count, "root_weight": root_weight, "period": period, "message_bytes_per_rank": message_bytes, "link_gbs_assumed": link_gbs,
+            **terms, "bound": bound, "predicted_ms": predicted, "speedup": frame_ms_1gpu / predicted if predicted > 0 else None,
+            "efficiency": (frame_ms_1gpu / predicted / count) if predicted > 0 else None,
+            "note": "steady-state frame period = the slowest of: the root's render + assembly, a shard's render, one message over one link, "
+                    "the host's per-frame issue cost; DESIGN.md section 7"}
+
+
 class FrameGather:
     """One process per GPU: owns the message tensors, binds the backend's output to them and gathers.
 
