@@ -1,86 +1,15 @@
-// vrt_path.hip — wavefront path trace (VRT_MODE_PATH) for gfx950.
-//
-// Structure after the reference's stale, never-dispatched path tracer
-// (clientdesktop/src/graphics/path_tracer.wgsl: rng_next* :56-76, ray_color :149-194, seed :328) on top of the
-// live march of ray_tracer.wgsl; the deliberate differences (bounce origin outside the hit voxel, clamped
-// log argument, no emission, water neither stops nor tints a segment) are DESIGN.md §Path trace and are the
-// same in oracle/vrt_oracle.c:trace_path.  log and cos are spelled out in + - * / so that host and device
-// agree to the bit: a one-ulp different bounce direction eventually hits a different voxel.
-//
-// One launch per bounce: bounce 0 traces the primary rays; every later bounce reads the compacted buffer of
-// paths that are still alive (same per-segment ballot compaction as the shadow hit buffer), marches them and
-// appends the survivors to the other buffer.  A pixel's path has exactly one owner lane per bounce, so
-// radiance accumulates into the pixel's texel with plain read-modify-writes.
+// experiments/vrt_path_cells_probe.hip — the shipping bounce launch (path_bounce_cells_probe_kernel, vrt_path.hip) WITH its probes: per-wave clock
+// stamps and step counts (VRT_EXP_CELLDBG, tools/cells_probe.py), the lookup classes (VRT_EXP_CELLDBG_FULL), marginal-cost knobs
+// (VRT_EXP_CELLS_LOAD / _VALU / _SALU, VRT_EXP_NOMARCH, VRT_CELLS_LOAD_AUX, VRT_CELLS_NO_WAVES_ATTR).  A variant build
+// (tools/ab/build_variant.sh NAME "-DVRT_EXP_CELLDBG ...") compiles this text with the flags and its launcher replaces the product's
+// through vrt_exp.h's hook; without any of the flags it is the product's kernel again and registers nothing.  The product's own text
+// carries none of this.
 #include <cstdlib>
 
-#include "vrt_path_primary.h"
+#include "../vrt_path_common.h"
+#include "../vrt_exp.h"
 
 namespace vrt {
-
-// One segment of a path: its march, then path_after_march.
-template <int MARCH, bool LDS_ROOTS, bool STATS>
-__device__ __forceinline__ bool path_segment(const FrameParams &P, const uint32_t *s_roots, const uint32_t *s_liquid,
-                                             PathState &st, MarchResult &R, V3 &light, bool &missed) {
-    R = march<MARCH, LDS_ROOTS, STATS>(P, s_roots, s_liquid, st.origin, st.dir);
-    return path_after_march(P, st, R, light, missed);
-}
-
-// Bounce b >= 1: lane = one live path of the in buffer.
-template <int MARCH, bool LDS_ROOTS, bool STATS>
-__global__ void __launch_bounds__(256) path_bounce_kernel(FrameParams P) {
-    extern __shared__ uint32_t smem[];
-    uint32_t *s_liquid = smem, *s_roots = smem + 24;
-    unsigned long long *s_acc = reinterpret_cast<unsigned long long *>(smem + 8);
-    if (STATS && threadIdx.x < 8) s_acc[threadIdx.x] = 0ull;
-    stage_lds(P, s_roots, s_liquid, LDS_ROOTS);
-
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t seg = blockIdx.x % kHitSegments, part = blockIdx.x / kHitSegments;
-    if (blockIdx.x == 0 && P.seg_clear) P.seg_clear[threadIdx.x * kSegStride] = 0u;
-    const uint32_t count = P.seg_in[seg * kSegStride];
-    const uint32_t j = part * blockDim.x + threadIdx.x;
-    const bool active = j < count;
-    if (!STATS && part * blockDim.x >= count) return;
-    MarchResult R;
-    R.iters = 0; R.visits = 0; R.hit = false;
-    bool alive = false;
-    PathState st;
-    st.slot = 0; st.rng = 0;
-    st.origin = st.dir = st.thr = V3{0.f, 0.f, 0.f};
-    if (active) {
-        const uint32_t i = seg * P.hit_seg_cap + j;
-        const uint4 a = P.path_in[i], b = P.path_in[P.path_cap + i], c = P.path_in[2u * P.path_cap + i];
-        st.slot = a.x;
-        st.origin = V3{__uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w)};
-        st.dir = V3{__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z)};
-        st.rng = b.w;
-        st.thr = V3{__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z)};
-        V3 light{0.f, 0.f, 0.f};
-        bool missed;
-        alive = path_segment<MARCH, LDS_ROOTS, STATS>(P, s_roots, s_liquid, st, R, light, missed) && !P.last_bounce;
-        if (missed) {
-            uint4 t = P.out[st.slot];
-            t.x = __float_as_uint(__uint_as_float(t.x) + light.x);
-            t.y = __float_as_uint(__uint_as_float(t.y) + light.y);
-            t.z = __float_as_uint(__uint_as_float(t.z) + light.z);
-            P.out[st.slot] = t;
-        }
-        if (STATS && P.steps && P.sample == 0u) P.steps[st.slot] += R.iters << 16;
-    }
-    append_paths(P, alive, st, lane);
-    if (STATS) {
-        block_add(s_acc, 0, active ? R.iters : 0u);
-        block_add(s_acc, 1, active ? R.visits : 0u);
-        block_add(s_acc, 2, active ? 1ull : 0ull);
-        __syncthreads();
-        if (threadIdx.x == 0 && s_acc[2]) {
-            atomicAdd(&P.counters[kCtrSteps], s_acc[0]);
-            atomicAdd(&P.counters[kCtrVisits], s_acc[1]);
-            atomicAdd(&P.counters[kCtrSecondary], s_acc[2]);
-        }
-    }
-}
-
 
 // ------------------------------------------------------------------------------------------------
 // Bounce b >= 1 over the MARCH CELLS (vrt_accel.hip; the default for plain frames of worlds that have them): the pool
@@ -98,11 +27,38 @@ __global__ void __launch_bounds__(256) path_bounce_kernel(FrameParams P) {
 // Every ray executes the arithmetic the other kernels execute for it: bit-identical frames (tests).
 // ------------------------------------------------------------------------------------------------
 
+#ifdef VRT_EXP_CELLDBG
+// experiment (tools/ab build, tools/cells_probe.py): per wave of the launch {rays, start, end (100 MHz), wave-steps with rays left
+// in the pool | after it ran dry << 32, lanes marching in them likewise, segments done, -, -}
+__device__ unsigned long long g_cells_dbg[16384 * 8];
+// launch totals of the lookups by what they find and whether the lane's previous lookup was in the same 128-byte line (the
+// misses a ray cannot avoid), for this layout and for denser ones that are not built: see tools/cells_probe.py
+__device__ unsigned long long g_cells_tot[32];
+extern "C" void vrt_exp_cells_tot(unsigned long long *out) {   // read and reset
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cells_tot), sizeof(unsigned long long) * 32);
+    void *p = nullptr;
+    (void)hipGetSymbolAddress(&p, HIP_SYMBOL(g_cells_tot));
+    (void)hipMemset(p, 0, sizeof(unsigned long long) * 32);
+}
+extern "C" void vrt_exp_cells_dbg(unsigned long long *out) {   // read and reset
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cells_dbg), sizeof(unsigned long long) * 16384 * 8);
+    void *p = nullptr;
+    (void)hipGetSymbolAddress(&p, HIP_SYMBOL(g_cells_dbg));
+    (void)hipMemset(p, 0, sizeof(unsigned long long) * 16384 * 8);
+}
+#endif
 
 
+#ifndef VRT_CELLS_LOAD_AUX
+#define VRT_CELLS_LOAD_AUX 0   // cache policy of the march-cell load (A/B builds: 1 sc0, 2 nt, 16 sc1)
+#endif
 template <bool DIRECT>
+#ifndef VRT_CELLS_NO_WAVES_ATTR
 __attribute__((amdgpu_waves_per_eu(8, 8)))
-__global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
+#endif
+__global__ void __launch_bounds__(256) path_bounce_cells_probe_kernel(CellsLaunch L) {
     const FrameParams &K = L.P;
     extern __shared__ uint32_t smem[];
     uint32_t *s_liquid = smem;
@@ -120,6 +76,20 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
     const uint32_t n_wg = min(4u * E, count - wg_begin), per = (n_wg + 3u) / 4u;
     if (wave * per >= n_wg) return;
     uint32_t n = __builtin_amdgcn_readfirstlane(min(per, n_wg - wave * per));   // <= E
+#ifdef VRT_EXP_CELLDBG
+    const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
+    const uint32_t dbg_n0 = n;
+    uint32_t dbg_wet = 0, dbg_wet_lanes = 0, dbg_dry = 0, dbg_dry_lanes = 0, dbg_segments = 0, dbg_air4 = 0, dbg_air8 = 0, dbg_air16 = 0;
+    uint32_t dbg_refill_ticks = 0, dbg_refills = 0, dbg_park_ticks = 0, dbg_load_ticks = 0;
+    uint32_t dbg_t_loaded = 0;   // hand-out rounds that took rays: their time in 16-cycle ticks of the shader clock, their number
+#ifdef VRT_EXP_CELLDBG_FULL   // (the lookup classes: 30 registers more — a build of its own, 4 waves per SIMD)
+    uint32_t dbg_tot[20], dbg_lines = 0, dbg_line_steps = 0;   // (per lane; summed at the wave's end)
+    for (int q = 0; q < 20; q++) dbg_tot[q] = 0;
+    // per lane: the previous lookup's lines under the layouts compared, its class, and the ray's origin voxel
+    uint32_t dbg_l8 = ~0u, dbg_l16 = ~0u, dbg_lc = ~0u, dbg_l4 = ~0u, dbg_prev_big = 0u;
+    int dbg_ox = 0, dbg_oy = 0, dbg_oz = 0;
+#endif
+#endif
     const uint32_t base = __builtin_amdgcn_readfirstlane(seg * K.in_seg_cap + wg_begin + wave * per);
     // The wave keeps its paths for ALL the segments that are left (`segments` of them): the survivors of one segment are
     // compacted — by the wave alone, no cursor, no atomic — into the same index range of the other path buffer and are the
@@ -198,6 +168,10 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
             idx = at;
             const uint32_t rec = base + idx;
             const uint4 a = recs[in_at + rec], b = recs[in_at + P.in_cap + rec];
+#ifdef VRT_EXP_CELLDBG
+            asm volatile("s_waitcnt vmcnt(0)" :: "v"(a.x), "v"(b.x) : "memory");
+            dbg_t_loaded = (uint32_t)(__builtin_amdgcn_s_memtime() >> 4);
+#endif
             const V3 origin{__uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w)};
             dir = V3{__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z)};
             not_finite = !(finite3(origin) && finite3(dir));
@@ -219,6 +193,12 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
                 park();
             }
             vx = trunc2i(pos.x); vy = trunc2i(pos.y); vz = trunc2i(pos.z);
+#ifdef VRT_EXP_CELLDBG_FULL
+            dbg_l8 = dbg_l16 = dbg_lc = dbg_l4 = ~0u; dbg_prev_big = 0u; dbg_ox = vx; dbg_oy = vy; dbg_oz = vz;
+#endif
+#ifdef VRT_EXP_NOMARCH   // counting experiment: every ray ends where it starts
+            if (marching) { marching = false; park(); }
+#endif
         };
         // the step to the leaf's exit face for a leaf of size lo + 1 (take_step of march_grid)
         auto take_step = [&](uint32_t lo) __attribute__((always_inline)) {
@@ -283,13 +263,29 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
         };
         for (;;) {
             // ---- refill: park what has stopped, hand out the pool's next rays ----
+#ifdef VRT_EXP_CELLDBG
+            const unsigned long long dbg_r0 = __builtin_amdgcn_s_memtime();
+            const uint32_t dbg_next0 = next;
+#endif
             if (!marching && !parked) park();
+#ifdef VRT_EXP_CELLDBG
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long dbg_r1 = __builtin_amdgcn_s_memtime();
+            dbg_t_loaded = 0;
+#endif
             {
                 const unsigned long long idle = __ballot(!marching);
                 const uint32_t at = next + lanes_below(idle);
                 if (!marching && at < n) take(at);
                 next = min(n, next + (uint32_t)__popcll(idle));
             }
+#ifdef VRT_EXP_CELLDBG
+            { const unsigned long long took_ = __ballot(dbg_t_loaded != 0u); if (took_) { dbg_park_ticks += (uint32_t)((dbg_r1 - dbg_r0) >> 4); dbg_load_ticks += (uint32_t)__builtin_amdgcn_readlane((int)dbg_t_loaded, (int)__builtin_ctzll(took_)) - (uint32_t)(dbg_r1 >> 4); } }
+#endif
+#ifdef VRT_EXP_CELLDBG
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (next != dbg_next0) { dbg_refill_ticks += (uint32_t)((__builtin_amdgcn_s_memtime() - dbg_r0) >> 4); dbg_refills++; }
+#endif
             if (__ballot(marching) == 0ull) {
                 if (next >= n) break;   // the pool is empty and nobody marches (every ray is parked: take() parks the ones that start outside)
                 continue;
@@ -305,6 +301,12 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
                 continue;
             }
             for (;;) {
+#ifdef VRT_EXP_CELLDBG
+                {
+                    const uint32_t m_ = (uint32_t)__popcll(__ballot(marching));
+                    if (next < n) { dbg_wet++; dbg_wet_lanes += m_; } else { dbg_dry++; dbg_dry_lanes += m_; }
+                }
+#endif
                 if (marching) {
                     // the chunk's block of march cells: looked up in the chunk directory when the ray has entered another chunk
                     // (coordinates -1 .. S: one voxel beyond the world at most; they make one number, base 128).  Outside the
@@ -326,12 +328,68 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
                     }
                     // one 16-byte load answers the step: c.x the cell's entry, c.y the size-2 mask of a split cell, c.z / c.w
                     // the voxels a ray passes (zero stops it)
-                    const uint4 c = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(mb, off, 0, 0));
+                    const uint4 c = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(mb, off, 0, VRT_CELLS_LOAD_AUX));
+#ifdef VRT_EXP_CELLS_LOAD   // tools/ab experiments only: one more 16-byte load per step — 1: the cell just read (an L1 hit), 2: a line
+                            // nobody shares (a miss of L1, a hit or miss of L2), 3: the line next to the cell's (L2-resident like it)
+                    {
+                        const uint32_t off_ = VRT_EXP_CELLS_LOAD == 1 ? off : VRT_EXP_CELLS_LOAD == 3 ? (off ^ 128u) :
+                                              ((iter * 0x9E3779B9u + idx * 0x85EBCA6Bu + lane * 0xC2B2AE35u) % (P.mblk_bytes / 16u)) * 16u;
+                        const uint4 x_ = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(mb, off_, 0, 0));
+                        asm volatile("" :: "v"(x_.x), "v"(x_.y), "v"(x_.z), "v"(x_.w));
+                    }
+#endif
+#ifdef VRT_EXP_CELLS_VALU   // ... extra full-rate vector instructions per step
+#pragma unroll
+                    for (int k_ = 0; k_ < VRT_EXP_CELLS_VALU; k_++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(idx) : "v"(0u));
+#endif
+#ifdef VRT_EXP_CELLS_SALU
+#pragma unroll
+                    for (int k_ = 0; k_ < VRT_EXP_CELLS_SALU; k_++) asm volatile("s_mov_b32 vcc_lo, 0" ::: "vcc");
+#endif
                     iter += 1u;
                     // u = (x&3) | (y&3) << 2 | (z&3) << 4, with z's upper bits left on top: the shifts below use the low bits only
                     const uint32_t u = ((((uint32_t)vz << 2) | ((uint32_t)vy & 3u)) << 2) | ((uint32_t)vx & 3u);
                     const uint32_t passes = (uint32_t)((((unsigned long long)c.w << 32) | c.z) >> (u & 63u)) & 1u;
                     const uint32_t lo = (c.x & 31u) | __builtin_amdgcn_ubfe(c.y, (u >> 1) & 31u, 1u);
+#ifdef VRT_EXP_CELLDBG
+                    dbg_air4 += (uint32_t)__popcll(__ballot(c.x >= 3u && c.x <= 31u));     // lookups answered by an air leaf of the cell grid
+                    dbg_air8 += (uint32_t)__popcll(__ballot(c.x >= 7u && c.x <= 31u));     // ... of 8 voxels or more: a whole line of cells
+                    dbg_air16 += (uint32_t)__popcll(__ballot(c.x >= 15u && c.x <= 31u));
+#endif
+#ifdef VRT_EXP_CELLDBG_FULL
+                    {
+                        auto cnt = [&](int q, bool b) __attribute__((always_inline)) { dbg_tot[q] += b ? 1u : 0u; };
+                        const uint32_t X = (uint32_t)(vx + 64), Y = (uint32_t)(vy + 64), Z = (uint32_t)(vz + 64);   // (coordinates -1 .. size)
+                        const uint32_t l8 = ((Z >> 3) << 20) | ((Y >> 3) << 10) | (X >> 3);        // today's line: 8 x 8 x 8 voxels
+                        const uint32_t l16 = ((Z >> 3) << 20) | ((Y >> 3) << 10) | (X >> 4);       // 8-byte cells: 16 x 8 x 8
+                        const uint32_t l4 = ((Z >> 4) << 20) | ((Y >> 3) << 10) | (X >> 4);        // (4-byte cells: 16 x 8 x 16)
+                        const uint32_t lc = ((Z >> 5) << 20) | ((Y >> 5) << 10) | (X >> 6);        // a byte per 8^3 voxels: 64 x 32 x 32
+                        const bool big = c.x >= 7u && c.x <= 31u, air4 = c.x == 3u, split = (int)c.x < 0;
+                        const bool n8 = l8 != dbg_l8, n16 = l16 != dbg_l16, n4 = l4 != dbg_l4, nc = lc != dbg_lc;
+                        const bool near = max(max(abs(vx - dbg_ox), abs(vy - dbg_oy)), abs(vz - dbg_oz)) < 32;
+                        cnt(0, true); cnt(1, n8); cnt(2, n16); cnt(3, n4);
+                        cnt(4, big); cnt(5, big && n8); cnt(6, big && nc);
+                        cnt(7, air4); cnt(8, air4 && n8); cnt(9, air4 && n16);
+                        cnt(10, split); cnt(11, split && n8); cnt(12, split && n16);
+                        cnt(13, !big && dbg_prev_big != 0u);            // a lane that was cruising in leaves of 8 or more finds something finer
+                        cnt(14, near); cnt(15, near && n8);
+                        cnt(16, !big && !air4 && !split); cnt(17, !big && !air4 && !split && n8);   // solid leaves of the grid, the border
+                        cnt(18, big && dbg_prev_big != 0u);             // cruising goes on
+                        cnt(19, big && dbg_prev_big != 0u && nc);       // ... into another line of the coarse table
+                        // distinct lines among the wave's marching lanes in this wave-step (a leader loop over the first lanes' lines)
+                        {
+                            unsigned long long todo = __ballot(true);
+                            uint32_t lines = 0;
+                            while (todo) {
+                                const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)l8, (int)__builtin_ctzll(todo));
+                                todo &= ~__ballot(l8 == first);
+                                lines++;
+                            }
+                            dbg_lines += lines; dbg_line_steps += 1u;
+                        }
+                        dbg_l8 = l8; dbg_l16 = l16; dbg_l4 = l4; dbg_lc = lc; dbg_prev_big = big ? 1u : 0u;
+                    }
+#endif
                     bool stop = passes == 0u;
                     ref = c.x;
                     if (!stop) {
@@ -447,6 +505,26 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
             n_out += (uint32_t)__popcll(m);
         }
     }
+#ifdef VRT_EXP_CELLDBG
+    dbg_segments++;
+    if (left == 1u || n_out == 0u) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0 && blockIdx.x * 4u + wave < 16384u) {
+            unsigned long long *d = &g_cells_dbg[(blockIdx.x * 4u + wave) * 8u];
+            d[0] = dbg_n0 | ((unsigned long long)dbg_park_ticks << 32); d[1] = dbg_t0; d[2] = t1; d[3] = dbg_wet | ((unsigned long long)dbg_dry << 32);
+            d[4] = dbg_wet_lanes | ((unsigned long long)dbg_dry_lanes << 32); d[5] = (dbg_segments & 0xFFu) | ((unsigned long long)(dbg_load_ticks & 0xFFFFFFu) << 8) | ((unsigned long long)dbg_refills << 32);
+            d[6] = dbg_air4 | ((unsigned long long)dbg_air8 << 32); d[7] = dbg_air16 | ((unsigned long long)dbg_refill_ticks << 32);
+        }
+#ifdef VRT_EXP_CELLDBG_FULL
+#pragma unroll
+        for (int q = 0; q < 20; q++) {
+            const unsigned long long sum = wave_sum((unsigned long long)dbg_tot[q]);
+            if (lane == 0) atomicAdd(&g_cells_tot[q], sum);
+        }
+        if (lane == 0) { atomicAdd(&g_cells_tot[20], (unsigned long long)dbg_lines); atomicAdd(&g_cells_tot[21], (unsigned long long)dbg_line_steps); }
+#endif
+    }
+#endif
     if (left == 1u || n_out == 0u) break;
     // the next segment: the records just written are read back by other lanes of this wave (same CU, same L1)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -460,106 +538,22 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
     }
 }
 
-
-// The end of a launch chain of several samples: the frame's running sum plus the chain's planes, in sample order — the
-// order the one-sample-per-chain launches add them in and the oracle's — and the division once the last chain is in.
-__global__ void path_chain_finish_kernel(Texel *out, const Texel *acc, uint32_t n, uint32_t chain, uint32_t first, uint32_t last, float spp) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint4 t = acc[i];   // the chain's first sample: the frame's first (light and id word as they are), or one more term
-    if (!first) {
-        const uint4 o = out[i];
-        t.x = __float_as_uint(__uint_as_float(o.x) + __uint_as_float(t.x));
-        t.y = __float_as_uint(__uint_as_float(o.y) + __uint_as_float(t.y));
-        t.z = __float_as_uint(__uint_as_float(o.z) + __uint_as_float(t.z));
-        t.w = o.w;
-    }
-    for (uint32_t s = 1; s < chain; s++) {
-        const uint4 a = acc[(size_t)s * n + i];
-        t.x = __float_as_uint(__uint_as_float(t.x) + __uint_as_float(a.x));
-        t.y = __float_as_uint(__uint_as_float(t.y) + __uint_as_float(a.y));
-        t.z = __float_as_uint(__uint_as_float(t.z) + __uint_as_float(a.z));
-    }
-    if (last) {
-        t.x = __float_as_uint(__uint_as_float(t.x) / spp);
-        t.y = __float_as_uint(__uint_as_float(t.y) / spp);
-        t.z = __float_as_uint(__uint_as_float(t.z) / spp);
-    }
-    out[i] = t;
-}
-
-// rgb /= spp after the last sample
-__global__ void path_finish_kernel(Texel *out, uint32_t n, float spp) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint4 t = out[i];
-    t.x = __float_as_uint(__uint_as_float(t.x) / spp);
-    t.y = __float_as_uint(__uint_as_float(t.y) / spp);
-    t.z = __float_as_uint(__uint_as_float(t.z) / spp);
-    out[i] = t;
-}
-
-
-// The path trace marches with the grid march when the derived tables exist (P.grid), else with the ancestor-cache walk;
-// `literal` (air flagged liquid, vrt_frames.hip) with the shader's text.
-#define VRT_PATH_LAUNCH(kernel)                                                                                           \
-    do {                                                                                                                  \
-        const bool lds = (!P.grid || literal) && P.n_roots <= kLdsRootsMax;                                               \
-        const size_t sh = lds_bytes_path(P, lds);                                                                         \
-        if (literal) {                                                                                                    \
-            if (lds) { if (stats) hipLaunchKernelGGL((kernel<1, true, true>), grid, block, sh, st, P); else hipLaunchKernelGGL((kernel<1, true, false>), grid, block, sh, st, P); } \
-            else { if (stats) hipLaunchKernelGGL((kernel<1, false, true>), grid, block, sh, st, P); else hipLaunchKernelGGL((kernel<1, false, false>), grid, block, sh, st, P); } \
-        } else if (P.grid) {                                                                                              \
-            if (stats) hipLaunchKernelGGL((kernel<0, false, true>), grid, block, sh, st, P);                              \
-            else hipLaunchKernelGGL((kernel<0, false, false>), grid, block, sh, st, P);                                   \
-        } else if (lds) {                                                                                                 \
-            if (stats) hipLaunchKernelGGL((kernel<2, true, true>), grid, block, sh, st, P);                               \
-            else hipLaunchKernelGGL((kernel<2, true, false>), grid, block, sh, st, P);                                    \
-        } else {                                                                                                          \
-            if (stats) hipLaunchKernelGGL((kernel<2, false, true>), grid, block, sh, st, P);                              \
-            else hipLaunchKernelGGL((kernel<2, false, false>), grid, block, sh, st, P);                                   \
-        }                                                                                                                 \
-    } while (0)
-
-void launch_path_primary(const FrameParams &P, bool stats, bool literal, hipStream_t st) {
-    if (P.tiles_local == 0) return;
-    const dim3 grid((P.tiles_local + 3u) / 4u), block(256);
-    if (P.acc) {   // several samples per launch chain: plain frames over the derived tables only (vrt_frames.hip)
-        hipLaunchKernelGGL((path_primary_kernel<0, false, false, true>), grid, block, lds_bytes_path(P, false), st, P);
-        return;
-    }
-    VRT_PATH_LAUNCH(path_primary_kernel);
-}
-
 // the pool kernel over the march cells (P.mblk): `segments` bounce segments in this one launch (every wave carries its own
 // survivors from one to the next; P.path_in / P.path_out are the two buffers it goes back and forth between)
-void launch_path_bounce_cells(const FrameParams &P, uint32_t refill_at, uint32_t segments, uint32_t lds_pad, hipStream_t st) {
+void launch_path_bounce_cells_probe(const FrameParams &P, uint32_t refill_at, uint32_t segments, uint32_t lds_pad, hipStream_t st) {
     if (P.tiles_local == 0 || segments == 0) return;
     const uint32_t refill = refill_at >= 1u && refill_at <= 64u ? refill_at : kPoolRefillAt;
     const uint32_t parts = (P.in_seg_cap + 4u * kPoolEntries - 1u) / (4u * kPoolEntries);
     const dim3 grid(kHitSegments * parts), block(256);
     const size_t sh = 8u * 4u + 4u * kCellsPoolBytesPerWave + lds_pad;   // (lds_pad: the occupancy sweep of profiles/r04_path_occupancy_sweep.txt)
     const CellsLaunch L{P, refill, segments};
-    if (P.march_direct) hipLaunchKernelGGL(path_bounce_cells_kernel<true>, grid, block, sh, st, L);
-    else hipLaunchKernelGGL(path_bounce_cells_kernel<false>, grid, block, sh, st, L);
+    if (P.march_direct) hipLaunchKernelGGL(path_bounce_cells_probe_kernel<true>, grid, block, sh, st, L);
+    else hipLaunchKernelGGL(path_bounce_cells_probe_kernel<false>, grid, block, sh, st, L);
 }
 
-void launch_path_bounce(const FrameParams &P, bool stats, bool literal, hipStream_t st) {
-    if (P.tiles_local == 0) return;
-    const dim3 grid(kHitSegments * (P.hit_seg_cap / 256u)), block(256);
-    VRT_PATH_LAUNCH(path_bounce_kernel);
-}
-#undef VRT_PATH_LAUNCH
-
-void launch_path_chain_finish(Texel *out, const Texel *acc, uint32_t n, uint32_t chain, bool first, bool last, uint32_t spp, hipStream_t st) {
-    if (!n) return;
-    hipLaunchKernelGGL(path_chain_finish_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, out, acc, n, chain, first ? 1u : 0u, last ? 1u : 0u,
-                       (float)spp);
-}
-
-void launch_path_finish(Texel *out, uint32_t n, uint32_t spp, hipStream_t st) {
-    if (!n) return;
-    hipLaunchKernelGGL(path_finish_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, out, n, (float)spp);
-}
+#if defined(VRT_EXP_CELLDBG) || defined(VRT_EXP_CELLS_LOAD) || defined(VRT_EXP_CELLS_VALU) || defined(VRT_EXP_CELLS_SALU) || defined(VRT_EXP_NOMARCH) || \
+    defined(VRT_CELLS_NO_WAVES_ATTR) || VRT_CELLS_LOAD_AUX != 0
+namespace { struct RegisterProbe { RegisterProbe() { g_exp.path_bounce_cells = launch_path_bounce_cells_probe; } } g_register_probe; }
+#endif
 
 }  // namespace vrt

@@ -28,7 +28,8 @@
 // Spec: clientdesktop/src/graphics/path_tracer.wgsl:149-194 over the march of ray_tracer.wgsl:220-291.
 #include <type_traits>
 
-#include "../vrt_path_common.h"
+#include "../vrt_path_primary.h"
+#include "../vrt_exp.h"
 
 namespace vrt {
 
@@ -549,6 +550,14 @@ __global__ void __launch_bounds__(NW * 64) path_bounce_window_kernel(WindowLaunc
         out_at = t;
     }
     }
+}
+
+// the primary launch of a frame whose bounce launch is the window kernel (plain frames over the derived tables)
+void launch_path_primary_grouped(const FrameParams &P, hipStream_t st) {
+    if (P.tiles_local == 0) return;
+    const dim3 grid((P.tiles_local + 3u) / 4u), block(256);
+    if (P.acc) hipLaunchKernelGGL((path_primary_kernel<0, false, false, true, true>), grid, block, lds_bytes_path(P, false), st, P);
+    else hipLaunchKernelGGL((path_primary_kernel<0, false, false, false, true>), grid, block, lds_bytes_path(P, false), st, P);
 }
 
 // LDS of a launch: the window, 16 words of liquid mask and sums, a u16 list per wave

@@ -31,30 +31,18 @@
 #include <vector>
 
 #include "vrt_device.h"
+#include "vrt_exp.h"
 
 namespace vrt {
 bool variant_supported(uint32_t variant);
 void launch_primary(const FrameParams &P, uint32_t variant, bool stats, bool shadow, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
 void launch_shadow(const FrameParams &P, uint32_t variant, bool stats, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
 void launch_primary_shadow_fused(const FrameParams &P, uint32_t march, bool stats, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
-#ifdef VRT_EXPERIMENTS   // measured and rejected structures, kept for tools/ab (make experiments): DESIGN.md section 5
-void launch_primary_shadow_persistent(const FrameParams &P, uint32_t *heads, uint32_t n_cus, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
-void launch_path_bounce_pool(const FrameParams &P, bool continuations, uint32_t refill_at, uint32_t eject_at, hipStream_t st);
-void launch_path_persistent(const FrameParams &P, uint32_t *heads, uint32_t n_cus, hipStream_t st);
-#endif
 void launch_path_primary(const FrameParams &P, bool stats, bool literal, hipStream_t st);
 void launch_path_bounce(const FrameParams &P, bool stats, bool literal, hipStream_t st);
 void launch_path_bounce_cells(const FrameParams &P, uint32_t refill_at, uint32_t segments, uint32_t lds_pad, hipStream_t st);
-#ifdef VRT_EXPERIMENTS
-void launch_path_primary_grouped(const FrameParams &P, hipStream_t st);
-uint32_t window_group_regions(uint32_t shape);
-void launch_path_bounce_window(const FrameParams &P, uint32_t segments, uint32_t n_regions, uint32_t samples, uint32_t shape, int32_t lift, hipStream_t st);
-#endif
 void launch_path_finish(Texel *out, uint32_t n, uint32_t spp, hipStream_t st);
 void launch_tile_order(const uint32_t *cost, uint32_t n, uint32_t shift, uint32_t *scratch, uint32_t *order, hipStream_t st);
-#ifdef VRT_EXPERIMENTS
-void launch_tile_order_moving(uint32_t *cost, uint32_t tiles_x, uint32_t tiles_y, uint32_t shift, uint32_t radius, uint32_t *scratch, uint32_t *order, hipStream_t st);
-#endif
 void launch_path_chain_finish(Texel *out, const Texel *acc, uint32_t n, uint32_t chain, bool first, bool last, uint32_t spp, hipStream_t st);
 void launch_quantize(const Texel *out, uint8_t *rgba8, uint32_t w, uint32_t h, hipStream_t st);
 void launch_assemble(const Texel *gathered, Texel *dst, uint32_t width, uint32_t tiles_x, uint32_t tiles_total,
@@ -77,16 +65,16 @@ void launch_accel_chunks(const uint16_t *nodes, uint32_t n_nodes, const uint32_t
                          const uint32_t *chunks, const uint32_t *extents, const uint32_t *chunk_roots_host, uint32_t n, hipStream_t st, hipEvent_t done);
 }  // namespace vrt
 
-// Host-time profile of the frame path (experiments build, VRT_HOST_PROF=1: printed at process exit): where the calling
-// thread's microseconds per frame go, section by section (tools/gpu_bench_modes.sh; profiles/r04_group_host_profile.txt).
-#ifdef VRT_EXPERIMENTS
+// Host-time profile of the frame path (VRT_HOST_PROF=1: printed at process exit): where the calling thread's microseconds per
+// frame go, section by section (profiles/r04_group_host_profile.txt).  Off, a section costs one test of a flag.
 #include <chrono>
 struct vrt_host_prof {
+    bool on = getenv("VRT_HOST_PROF") != nullptr;
     double us[24] = {};
     unsigned long long n[24] = {};
     const char *name[24] = {};
     ~vrt_host_prof() {
-        if (!getenv("VRT_HOST_PROF")) return;
+        if (!on) return;
         for (int i = 0; i < 24; i++)
             if (n[i]) fprintf(stderr, "host-prof %-34s %9llu calls %8.2f us each\n", name[i] ? name[i] : "?", n[i], us[i] / (double)n[i]);
     }
@@ -95,16 +83,16 @@ extern __attribute__((visibility("hidden"))) vrt_host_prof g_host_prof;
 struct vrt_prof_scope {
     int i;
     std::chrono::steady_clock::time_point t0;
-    vrt_prof_scope(int i_, const char *name) : i(i_), t0(std::chrono::steady_clock::now()) { g_host_prof.name[i] = name; }
+    vrt_prof_scope(int i_, const char *name) : i(i_) {
+        if (g_host_prof.on) { g_host_prof.name[i] = name; t0 = std::chrono::steady_clock::now(); }
+    }
     ~vrt_prof_scope() {
+        if (!g_host_prof.on) return;
         g_host_prof.us[i] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
         g_host_prof.n[i] += 1;
     }
 };
 #define VRT_PROF(i, name) vrt_prof_scope prof_scope_##i(i, name)
-#else
-#define VRT_PROF(i, name) do { } while (0)
-#endif
 
 static_assert(sizeof(vrt_material) == 32, "Material layout (mod.rs:20-28)");
 static_assert(sizeof(vrt_cam_data) == 160, "CamData layout (mod.rs:82-91)");

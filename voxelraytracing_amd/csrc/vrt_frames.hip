@@ -17,9 +17,8 @@ int fail(vrt_ctx *ctx, int code, const char *fmt, ...) {
 }
 
 // Wait for the frame that may still be running on the second stream.
-#ifdef VRT_EXPERIMENTS
 vrt_host_prof g_host_prof;
-#endif
+namespace vrt { ExpHooks g_exp; }   // all null here: experiments/vrt_exp_register.hip fills them in tools/ab/libvrt_exp.so
 
 int quiesce(vrt_ctx *c) {
     if (c->alt_pending) {
@@ -304,8 +303,7 @@ static int next_events(vrt_ctx *c, std::array<hipEvent_t, 4> **ev, uint8_t **kin
 static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f, const vrt_render_opts &o, bool kstats, bool literal,
                              std::array<hipEvent_t, 4> &ev, uint8_t &ev_kind) {
     const uint32_t spp = o.spp ? o.spp : 1u, bounces = c->settings.max_ray_bounces;
-#ifdef VRT_EXPERIMENTS
-    if (bounces > 0 && !kstats && !literal && P.grid && c->path_persistent) {
+    if (bounces > 0 && !kstats && !literal && P.grid && c->path_persistent && vrt::g_exp.path_persistent) {
         // VRT_PATH_PERSISTENT=1 (built and measured, not the default: 10.8 against 13.0 Grays/s on C4):
         // persistent waves whose lanes own pixels and are refilled in batches (vrt_path.hip); one launch per frame
         // whatever spp and the bounce count are, no path buffers.  The tile queues' eight heads live at the start of this
@@ -318,7 +316,7 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
         P.spp = spp;
         P.seed = o.seed;
         if (ev[0]) HIP_TRY(c, hipEventRecord(ev[0], f.st));
-        vrt::launch_path_persistent(P, P.seg_counts, c->n_cus, f.st);
+        vrt::g_exp.path_persistent(P, P.seg_counts, c->n_cus, f.st);
         HIP_TRY(c, hipGetLastError());
         if (ev[0]) {
             HIP_TRY(c, hipEventRecord(ev[1], f.st));
@@ -328,7 +326,6 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
         c->last_spp = spp;
         return VRT_OK;
     }
-#endif
     // Several samples per launch chain (plain frames, spp > 1): every launch of the chain carries `samples` times the rays —
     // 2.7 rays per lane are not enough to cover a bounce launch's tail — and a frame of 16 spp is 4 x 4
     // launches instead of 16 x 4.  Each sample accumulates into its own plane; the chain's finishing pass adds the planes
@@ -340,11 +337,8 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
     if (c->path_buf_records[f.slot] < cap) {   // (grows only; hipFree waits for whatever still uses the old one)
         (void)hipFree(*f.path_buf);
         *f.path_buf = nullptr; c->path_buf_records[f.slot] = 0;
-#ifdef VRT_EXPERIMENTS
-        HIP_TRY(c, hipMalloc(f.path_buf, (2 * 3 + 2) * cap * sizeof(uint4)));   // two sets of three record planes + two of per-ray state (experiments/vrt_path_window.hip)
-#else
-        HIP_TRY(c, hipMalloc(f.path_buf, 2 * 3 * cap * sizeof(uint4)));
-#endif
+        // two sets of three record planes (+ two of per-ray state for experiments/vrt_path_window.hip's launch)
+        HIP_TRY(c, hipMalloc(f.path_buf, (2 * 3 + (vrt::g_exp.path_bounce_window ? 2 : 0)) * cap * sizeof(uint4)));
         c->path_buf_records[f.slot] = cap;
     }
     if (planes && c->path_acc_texels[f.slot] < (size_t)samples * c->slots) {
@@ -381,11 +375,7 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
     // ... and among those the window launch (vrt_path_window.hip): the primary launch compacts each workgroup's survivors into
     // the workgroup's own region (256 records per sample of the chain), the bounce launch stages the march cells around a
     // group of four regions in LDS
-#ifdef VRT_EXPERIMENTS
-    const bool window = cells && c->path_window;
-#else
-    const bool window = false;   // (the window launch: the experiments build)
-#endif
+    const bool window = cells && c->path_window && vrt::g_exp.path_bounce_window;   // (the window launch: the experiments build)
     const uint32_t n_regions = (c->tiles_local + 3u) / 4u;
     if (window) {
         if (c->path_grp_regions[f.slot] < n_regions) {
@@ -398,18 +388,14 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
     P.grp_counts = window ? c->path_grp_counts[f.slot] : nullptr;
     P.grp_cap = 256u * samples;   // (n_regions * grp_cap <= cap: a segment holds what its workgroups can produce)
     P.blk_w = P.blk_h = 4u;
-#ifdef VRT_EXPERIMENTS
-    {   // a bounce workgroup's regions are one block of tiles: 4 x 4 (4 regions), 8 x 4 (8), 8 x 8 (16)
-        const uint32_t nw = vrt::window_group_regions(c->path_window_shape);
+    if (window) {   // a bounce workgroup's regions are one block of tiles: 4 x 4 (4 regions), 8 x 4 (8), 8 x 8 (16)
+        const uint32_t nw = vrt::g_exp.window_group_regions(c->path_window_shape);
         P.blk_w = nw == 4u ? 4u : 8u;
         P.blk_h = nw == 16u ? 8u : 4u;
     }
-#endif
-#ifdef VRT_EXPERIMENTS
-    const bool chain = pool && !cells && bounces - 1u <= kContSets && c->path_chain;
-#else
-    const bool chain = false;   // (the straggler chain on a side stream: the experiments build)
-#endif
+    // (the round-2 pool kernel and its straggler chain on a side stream: the experiments build)
+    const bool old_pool = pool && !cells && vrt::g_exp.path_bounce_pool;
+    const bool chain = old_pool && bounces - 1u <= kContSets && c->path_chain;
     uint32_t *cont_seg[kContSets];
     for (uint32_t i = 0; i < kContSets; i++) cont_seg[i] = P.seg_counts + (3 + i) * kSegWords;
     hipStream_t side = nullptr;
@@ -450,11 +436,8 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
             P.cont_counts = nullptr;
             // one sample per pixel: the lane that ends a path has the pixel's final value (x / 1 = x) — no finishing pass
             if (b == 0) {
-#ifdef VRT_EXPERIMENTS
-                if (window) vrt::launch_path_primary_grouped(P, f.st);
-                else
-#endif
-                vrt::launch_path_primary(P, kstats, literal, f.st);
+                if (window) vrt::g_exp.path_primary_grouped(P, f.st);
+                else vrt::launch_path_primary(P, kstats, literal, f.st);
             } else if (!pool) {
                 vrt::launch_path_bounce(P, kstats, literal, f.st);
             } else if (cells) {
@@ -462,22 +445,18 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
                 // (one cursor set, one swap of the path buffers per LAUNCH: g counts launches)
                 const uint32_t segments = bounces - b;
                 P.last_bounce = 1u;
-#ifdef VRT_EXPERIMENTS
-                if (window)
-                    vrt::launch_path_bounce_window(P, segments, n_regions, samples, c->path_window_shape, c->path_window_lift, f.st);
-                else
-#endif
-                vrt::launch_path_bounce_cells(P, c->path_refill, segments, c->path_lds_pad, f.st);
+                if (window) vrt::g_exp.path_bounce_window(P, segments, n_regions, samples, c->path_window_shape, c->path_window_lift, f.st);
+                else if (vrt::g_exp.path_bounce_cells) vrt::g_exp.path_bounce_cells(P, c->path_refill, segments, c->path_lds_pad, f.st);   // (a probe build)
+                else vrt::launch_path_bounce_cells(P, c->path_refill, segments, c->path_lds_pad, f.st);
                 b += segments - 1u;
             } else {
-#ifndef VRT_EXPERIMENTS
-                vrt::launch_path_bounce(P, kstats, literal, f.st);   // (a world without march cells: lane = path)
-#else
+                if (!old_pool) vrt::launch_path_bounce(P, kstats, literal, f.st);   // (a world without march cells: lane = path)
+                else {
                 if (chain) {
                     P.cont_out = cont + (size_t)(b - 1u) * 4 * cap;
                     P.cont_counts = cont_seg[b - 1u];
                 }
-                vrt::launch_path_bounce_pool(P, false, c->path_refill, c->path_eject, f.st);
+                vrt::g_exp.path_bounce_pool(P, false, c->path_refill, c->path_eject, f.st);
                 if (chain) {
                     HIP_TRY(c, hipGetLastError());
                     // S(b): after bounce launch b (its hand-overs) and S(b - 1) (stream order: its survivors)
@@ -491,9 +470,9 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
                     Q.seg_counts = nullptr;
                     Q.cont_out = P.last_bounce ? nullptr : cont + (size_t)b * 4 * cap;
                     Q.cont_counts = P.last_bounce ? nullptr : cont_seg[b];
-                    vrt::launch_path_bounce_pool(Q, true, c->path_refill, 0u, side);
+                    vrt::g_exp.path_bounce_pool(Q, true, c->path_refill, 0u, side);
                 }
-#endif
+                }
             }
             HIP_TRY(c, hipGetLastError());
             if (first) { if (timed) HIP_TRY(c, hipEventRecord(ev[1], f.st)); first = false; }
@@ -526,8 +505,8 @@ static int launch_march_frame(vrt_ctx *c, const vrt::FrameParams &P, const Frame
                               std::array<hipEvent_t, 4> &ev, uint8_t &ev_kind) {
     if (!c->tiles_local) return VRT_OK;  // an empty shard
     const uint32_t march = variant == 3u ? 0u : variant;  // variant 3 = the grid march in two launches
-#ifdef VRT_EXPERIMENTS
-    if (variant == 4u) {
+    if (variant == 4u) {   // (the persistent grid of the experiments build: variant_supported() refuses it elsewhere)
+        if (!vrt::g_exp.primary_shadow_persistent) return fail(c, VRT_ERR_INVALID_ARG, "vrt_render: variant 4 (the persistent grid) is in the experiments build only");
         if (!c->d_heads) {
             HIP_TRY(c, hipMalloc(&c->d_heads, 8 * 64));
             hipDeviceProp_t prop;
@@ -536,12 +515,11 @@ static int launch_march_frame(vrt_ctx *c, const vrt::FrameParams &P, const Frame
         }
         HIP_TRY(c, hipMemsetAsync(c->d_heads, 0, 8 * 64, f.st));
         c->n_counts = c->tiles_local;
-        vrt::launch_primary_shadow_persistent(P, c->d_heads, c->n_cus, f.st, ev[0], ev[1]);
+        vrt::g_exp.primary_shadow_persistent(P, c->d_heads, c->n_cus, f.st, ev[0], ev[1]);
         HIP_TRY(c, hipGetLastError());
         if (ev[0]) ev_kind = kEvOneKernel;
         return VRT_OK;
     }
-#endif
     // primary + shadow in one launch: the default march, and — on a context whose pixel slots are 8-byte records — the
     // octree walk it falls back to when the world is too large for the derived tables (the two-launch kernels store and
     // re-read 16-byte texels, which such a buffer has no room for)
@@ -614,10 +592,8 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         if (v >= 0 && v <= (long)kMarchDirectMaxS) c->march_direct_max_s = (uint32_t)v;
     }
     if (const char *e = getenv("VRT_TILE_ORDER")) c->tile_lpt = e[0] != '0';
-#ifdef VRT_EXPERIMENTS
-    if (const char *e = getenv("VRT_TILE_ORDER_MOVING")) c->tile_lpt_moving = e[0] != '0';
-#endif
-#ifdef VRT_EXPERIMENTS
+    // switches of the experiments build (tools/ab/libvrt_exp.so): without its hooks (vrt_exp.h) the first seven select nothing
+    if (const char *e = getenv("VRT_TILE_ORDER_MOVING")) c->tile_lpt_moving = e[0] != '0' && vrt::g_exp.tile_order_moving;
     if (const char *e = getenv("VRT_PATH_PERSISTENT")) c->path_persistent = e[0] == '1';
     if (const char *e = getenv("VRT_PATH_POOL")) c->path_pool = e[0] != '0';
     if (const char *e = getenv("VRT_PATH_POOL_CHAIN")) c->path_chain = e[0] == '1';
@@ -628,7 +604,6 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     if (const char *e = getenv("VRT_PATH_POOL_REFILL")) c->path_refill = (uint32_t)atoi(e);
     if (const char *e = getenv("VRT_PATH_POOL_EJECT")) c->path_eject = (uint32_t)atoi(e);
     if (const char *e = getenv("VRT_PATH_LDS_PAD")) { const long v = strtol(e, nullptr, 10); if (v >= 0 && v <= 45000) c->path_lds_pad = (uint32_t)v; }
-#endif
     if (const char *e = getenv("VRT_PATH_SAMPLES_PER_CHAIN")) { const int v = atoi(e); if (v >= 1 && v <= 16) c->path_samples = (uint32_t)v; }
     if (const char *e = getenv("VRT_TIMING_EVERY")) { const long v = strtol(e, nullptr, 10); if (v >= 1 && v <= 1000000) c->timing_every = (uint32_t)v; }
     memset(c->h_mats, 0, sizeof c->h_mats);
@@ -980,10 +955,8 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
         if (rc) return rc;
     }
     if (tile_sort) {   // (the frame above read the old order and is over when this runs; the next frame starts after it)
-#ifdef VRT_EXPERIMENTS
-        if (dilate) vrt::launch_tile_order_moving(c->d_tile_cost, P.tiles_x, P.tiles_total / P.tiles_x, 1u, 2u, c->d_tile_scratch, c->d_tile_order, f.st);
+        if (dilate) vrt::g_exp.tile_order_moving(c->d_tile_cost, P.tiles_x, P.tiles_total / P.tiles_x, 1u, 2u, c->d_tile_scratch, c->d_tile_order, f.st);
         else
-#endif
         vrt::launch_tile_order(c->d_tile_cost, c->tiles_local, 1u, c->d_tile_scratch, c->d_tile_order, f.st);   // classes of two trips
         HIP_TRY(c, hipGetLastError());
         c->tile_order_valid = true;
@@ -1183,9 +1156,5 @@ int vrt_shard_info(vrt_ctx *c, uint32_t *tiles_local, uint32_t *tiles_padded, ui
     if (tiles_total) *tiles_total = c->tiles_total;
     return VRT_OK;
 }
-
-#ifdef VRT_EXPERIMENTS
-int vrt_experiments_build(void) { return 1; }   // (not in include/vrt.h: only `make experiments` exports it)
-#endif
 
 }  // extern "C"

@@ -15,20 +15,11 @@
 //   * the 256-bit liquid mask (and, for variants 1-2, the chunk-root table) is staged in LDS.
 #include <hip/hip_ext.h>
 
-#include "vrt_march.h"
+#include "vrt_tile.h"
+#include "vrt_exp.h"
 
 namespace vrt {
 
-// One finished pixel: the 16-byte texel, or (VRT_FLAG_COMPACT, a shard whose tiles go over a link) the 8 bytes the
-// gather root needs to shade it itself: the id word (+ the sign of norm.y) and water_dist.  Everything else the colour
-// depends on — material, face factors, shadow factor, the sky of a miss — is a function of those and of the frame's
-// uniforms, which the root holds too (assemble_shade_kernel).
-__device__ __forceinline__ void store_pixel(const FrameParams &P, uint32_t slot, V3 color, uint32_t id, const MarchResult &R) {
-    if (P.compact)
-        reinterpret_cast<uint2 *>(P.out)[slot] = make_uint2(id | (R.norm.y < 0.0f ? kIdNormYNeg : 0u), __float_as_uint(R.water_dist));
-    else
-        P.out[slot] = make_uint4(__float_as_uint(color.x), __float_as_uint(color.y), __float_as_uint(color.z), id);
-}
 
 // ------------------------------------------------------------------------------------------------
 // Primary rays: one wave per 8x8 tile, 4 tiles per 256-thread workgroup.
@@ -173,41 +164,6 @@ __global__ void __launch_bounds__(256) shadow_kernel(FrameParams P) {
 // the terrain tiles that make up most of a frame).  (A workgroup-phase form — compact the four tiles' hits into an LDS
 // hit buffer, lane = record, flags back through LDS — ran in exactly the same time and was dropped: DESIGN.md §5.)
 // ------------------------------------------------------------------------------------------------
-// One tile = one wave: primary march, shading, the shadow march of the lanes that hit, one store per lane.
-template <int MARCH, bool LDS_ROOTS, bool STATS>
-__device__ __forceinline__ void trace_tile(const FrameParams &P, const uint32_t *s_roots, const uint32_t *s_liquid, uint32_t t_local,
-                                           uint32_t lane, MarchResult &R, MarchResult &S) {
-    const uint32_t tile = shard_tile(t_local, P.shard_first, P.shard_run, P.shard_period);
-    const uint32_t px = (tile % P.tiles_x) * 8u + (lane & 7u);
-    const uint32_t py = (tile / P.tiles_x) * 8u + (lane >> 3);
-    const uint32_t slot = P.tile_major ? t_local * 64u + lane : py * P.width + px;
-
-    V3 origin, dir;
-    create_ray(P, (int)px, (int)py, origin, dir);
-    R = march<MARCH, LDS_ROOTS, STATS>(P, s_roots, s_liquid, origin, dir);
-    V3 color;
-    uint32_t id = shade<MARCH == 1>(P, R, origin, dir, color);
-
-    const bool launch = R.hit && R.voxel != 0u && !is_liquid(s_liquid, R.voxel);
-    if (launch) {
-        id |= VRT_ID_SHADOW_RAY;
-        const V3 so{R.pos.x + R.norm.x * kShadowBias, R.pos.y + R.norm.y * kShadowBias, R.pos.z + R.norm.z * kShadowBias};
-        const V3 sd = normalize_wave(V3{P.settings.sun_pos[0] - (float)P.world.min[0] - so.x,
-                                    P.settings.sun_pos[1] - (float)P.world.min[1] - so.y,
-                                    P.settings.sun_pos[2] - (float)P.world.min[2] - so.z});
-        S = march<MARCH, LDS_ROOTS, STATS>(P, s_roots, s_liquid, so, sd);
-        if (S.hit) {
-            color.x *= kShadowFactor;
-            color.y *= kShadowFactor;
-            color.z *= kShadowFactor;
-            id |= VRT_ID_SHADOWED;
-        }
-    }
-    store_pixel(P, slot, color, id, R);
-    if (STATS && P.steps) P.steps[slot] = R.iters | (S.iters << 16);
-    const unsigned long long ballot = __ballot(launch);
-    if (lane == 0) P.blk_counts[t_local] = (uint32_t)__popcll(ballot);  // per tile: the launched-ray count of vrt_get_stats
-}
 
 // PROBE (vrt_render_opts.stats = 2, a diagnostic build of the timed kernel — in the real one no stamp executes): one wave
 // in sixteen stamps the shader clock (s_memtime) and the 100 MHz reference (s_memrealtime) around its work and adds the
@@ -266,45 +222,6 @@ __global__ void __launch_bounds__(64 * WAVES) primary_shadow_wave_kernel(FramePa
 }
 
 // ------------------------------------------------------------------------------------------------
-#ifdef VRT_EXPERIMENTS
-// The same work as a persistent grid (variant 4; north_star's "persistent-threads kernel", kept for the measurement):
-// exactly as many workgroups as the chip holds (8 per CU), every wave pulls tiles from the queue of the XCD it runs on
-// until that is empty.  Eight queue heads, one per XCD on its own 64-byte line: a single head saturates at ~88 returning
-// atomics per microsecond (MI355X_MICROARCH.md "dequeue"), which 32 400 tiles per 0.1 ms frame would exceed.  Tile i of
-// XCD x is this context's tile x + 8 i, so neighbouring tiles still spread over the XCDs as the plain launch spreads them.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u; }  // HW_REG_XCC_ID[3:0]
-
-// Next tile of this XCD's queue (wave-uniform): lane 0 takes a ticket, everybody reads it.
-__device__ __forceinline__ uint32_t pop_tile(uint32_t *heads, uint32_t xcc, uint32_t lane) {
-    uint32_t i = 0;
-    if (lane == 0) i = __hip_atomic_fetch_add(&heads[xcc * 16u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return xcc + 8u * (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
-}
-
-template <int MARCH, bool LDS_ROOTS>
-__global__ void __launch_bounds__(256) primary_shadow_persistent_kernel(FrameParams P, uint32_t *heads, uint32_t max_tiles_per_wave) {
-    extern __shared__ uint32_t smem[];
-    uint32_t *s_liquid = smem, *s_roots = smem + 24;
-    stage_lds(P, s_roots, s_liquid, LDS_ROOTS);
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t xcc = xcc_id();
-    // Own queue first; once it is empty the wave goes round the other seven, so the frame is complete whatever set of
-    // XCDs the grid landed on (a partitioned device or a CU-masked stream shows fewer than eight XCC ids).  Every trip
-    // count is bounded by the host (no queue holds more than max_tiles_per_wave - 1 tiles): whatever the queues do, every
-    // wave leaves the loops and the grid drains.
-    for (uint32_t q = 0; q < 8u; q++) {
-        const uint32_t queue = (xcc + q) & 7u;
-        uint32_t t_local = pop_tile(heads, queue, lane);
-        for (uint32_t k = 0; k < max_tiles_per_wave && t_local < P.tiles_local; k++) {
-            MarchResult R, S;
-            S.iters = 0; S.visits = 0; S.hit = false;
-            trace_tile<MARCH, LDS_ROOTS, false>(P, s_roots, s_liquid, t_local, lane, R, S);
-            t_local = pop_tile(heads, queue, lane);  // (taking the next ticket before tracing this tile was slower still: 183 us)
-        }
-    }
-}
-#endif  // VRT_EXPERIMENTS
 
 // ------------------------------------------------------------------------------------------------
 // Longest tiles first.  The dispatcher hands out workgroups in index order, and a launch ends when its slowest late
@@ -390,42 +307,6 @@ void launch_tile_order(const uint32_t *cost, uint32_t n, uint32_t shift, uint32_
     hipLaunchKernelGGL(tile_order_scatter_kernel, dim3((chunks + 3u) / 4u), dim3(256), 0, st, cost, n, chunks, shift, (const uint32_t *)scratch, order);
 }
 
-#ifdef VRT_EXPERIMENTS   // (built, measured, not chosen: profiles/r04_tile_order_moving.txt)
-// The order for a view that MOVES: made from the frame before, whose trips are this frame's only near where they were
-// noted — a silhouette that has moved into a tile the order starts last (it was sky) runs its whole length behind everything
-// else (profiles/r02_tile_order_staleness.txt: an exact order one camera step old is 17 % worse than screen order).  So every
-// tile takes the largest cost within reach of the image's motion: the maximum over its block of 4 x 4 tiles and the `radius`
-// blocks around it (radius 2: 8-11 tiles each way, what the study's r = 8 covers), and the order is made from that.  Two
-// launches in front of the four of launch_tile_order; the block maxima live in its scratch until it counts.
-__global__ void __launch_bounds__(256) tile_block_max_kernel(const uint32_t *cost, uint32_t tiles_x, uint32_t tiles_y, uint32_t bw, uint32_t blocks, uint32_t *blk) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= blocks) return;
-    const uint32_t bx = b % bw, by = b / bw;
-    uint32_t m = 0u;
-    for (uint32_t y = by * 4u; y < min(by * 4u + 4u, tiles_y); y++)
-        for (uint32_t x = bx * 4u; x < min(bx * 4u + 4u, tiles_x); x++) m = max(m, cost[y * tiles_x + x]);
-    blk[b] = m;
-}
-__global__ void __launch_bounds__(256) tile_dilate_kernel(const uint32_t *blk, uint32_t tiles_x, uint32_t n, uint32_t bw, uint32_t bh, uint32_t radius, uint32_t *cost) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    const uint32_t bx = (t % tiles_x) / 4u, by = (t / tiles_x) / 4u;
-    uint32_t m = 0u;
-    for (uint32_t y = by - min(by, radius); y <= min(by + radius, bh - 1u); y++)
-        for (uint32_t x = bx - min(bx, radius); x <= min(bx + radius, bw - 1u); x++) m = max(m, blk[y * bw + x]);
-    cost[t] = m;
-}
-
-// cost: [tiles_x * tiles_y] trips in screen order (overwritten with the dilated ones); scratch as for launch_tile_order
-void launch_tile_order_moving(uint32_t *cost, uint32_t tiles_x, uint32_t tiles_y, uint32_t shift, uint32_t radius, uint32_t *scratch, uint32_t *order, hipStream_t st) {
-    const uint32_t n = tiles_x * tiles_y;
-    if (!n) return;
-    const uint32_t bw = (tiles_x + 3u) / 4u, bh = (tiles_y + 3u) / 4u;   // bw * bh <= n: fits the scratch
-    hipLaunchKernelGGL(tile_block_max_kernel, dim3((bw * bh + 255u) / 256u), dim3(256), 0, st, (const uint32_t *)cost, tiles_x, tiles_y, bw, bw * bh, scratch);
-    hipLaunchKernelGGL(tile_dilate_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, (const uint32_t *)scratch, tiles_x, n, bw, bh, radius, cost);
-    launch_tile_order(cost, n, shift, scratch, order, st);
-}
-#endif  // VRT_EXPERIMENTS
 
 // ------------------------------------------------------------------------------------------------
 // Output helpers
@@ -664,19 +545,8 @@ static void launch_shadow_t(const FrameParams &P, bool stats, hipStream_t st, hi
 // 1: literal octree walk; 2: ancestor-cache octree walk; 3: grid march, shadow rays as a second launch from a hit buffer
 // in HBM (the wavefront form the path trace is built from); 4: variant 0's work as a persistent grid pulling tiles from
 // per-XCD queues (primary + shadow frames only)
-#ifdef VRT_EXPERIMENTS
-bool variant_supported(uint32_t variant) { return variant <= 4u; }
-#else
-bool variant_supported(uint32_t variant) { return variant <= 3u; }   // (4, the persistent grid: the experiments build)
-#endif
+bool variant_supported(uint32_t variant) { return variant <= 3u || (variant == 4u && g_exp.primary_shadow_persistent != nullptr); }   // (4, the persistent grid: the experiments build)
 
-// Variant 4: `heads` = 8 queue heads 64 bytes apart, zeroed by the caller on the same stream.
-#ifdef VRT_EXPERIMENTS
-void launch_primary_shadow_persistent(const FrameParams &P, uint32_t *heads, uint32_t n_cus, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
-    hipExtLaunchKernelGGL((primary_shadow_persistent_kernel<0, false>), dim3(n_cus * 8u), dim3(256), 24u * 4u, st, e0, e1, 0, P, heads,
-                          (P.tiles_local + 7u) / 8u + 1u);
-}
-#endif
 
 // One launch for primary + shadow; blk_counts gets one launched-ray count per tile.  march 0 = the grid march (variant 0);
 // march 2 = the ancestor-cache octree walk, for contexts whose pixels are 8-byte records (VRT_FLAG_COMPACT: the

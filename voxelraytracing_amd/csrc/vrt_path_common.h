@@ -112,4 +112,41 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+// Append the wave's surviving paths to this workgroup's segment of the out buffer (one atomic per wave).
+__device__ __forceinline__ void append_paths(const FrameParams &P, bool alive, const PathState &st, uint32_t lane) {
+    const unsigned long long ballot = __ballot(alive);
+    const uint32_t n = (uint32_t)__popcll(ballot);
+    if (!n) return;
+    const uint32_t seg = blockIdx.x % kHitSegments;
+    const int leader = __ffsll((long long)ballot) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(&P.seg_counts[seg * kSegStride], n);
+    base = __shfl(base, leader, 64) + seg * P.hit_seg_cap;
+    if (alive) {
+        const uint32_t i = base + (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
+        P.path_out[i] = make_uint4(st.slot, __float_as_uint(st.origin.x), __float_as_uint(st.origin.y), __float_as_uint(st.origin.z));
+        P.path_out[P.path_cap + i] = make_uint4(__float_as_uint(st.dir.x), __float_as_uint(st.dir.y), __float_as_uint(st.dir.z), st.rng);
+        P.path_out[2u * P.path_cap + i] = make_uint4(__float_as_uint(st.thr.x), __float_as_uint(st.thr.y), __float_as_uint(st.thr.z), 0u);
+    }
+}
+
+// A wave's pool of rays (the bounce launches below): K batches of 64 paths, 4 words each in the wave's own LDS — unit[3]
+// (phase A -> the hand-out), then pos[3] + the packed end state (the march -> phase C): 4 KiB per wave
+#ifndef VRT_POOL_K
+#define VRT_POOL_K 4
+#endif
+constexpr uint32_t kPoolBatches = VRT_POOL_K;            // K
+constexpr uint32_t kPoolEntries = kPoolBatches * 64u;
+constexpr uint32_t kPoolWords = 4u * kPoolEntries;
+constexpr uint32_t kPoolRefillAt = 16u;                  // idle lanes (of 64) that send the wave back to the pool
+
+constexpr uint32_t kCellsPoolBytesPerWave = kPoolWords * 4u + kPoolEntries * 2u;   // the pool + a u16 order per entry
+
+// what a launch of path_bounce_cells_kernel is given (one argument: the kernel reads it again for every segment)
+struct CellsLaunch {
+    FrameParams P;
+    uint32_t refill_at;   // a wave takes rays from its pool when this many of its lanes are idle
+    uint32_t segments;    // bounce segments in this launch: all that the frame's paths have left
+};
+
 }  // namespace vrt
