@@ -128,7 +128,10 @@ static found_node find_node(const orc_scene *s, v3 pos, uint32_t max_depth) {
     int32_t cz = orc_f2i(floorf(pos.z / 32.0f));
     v3 min = V3((float)(cx * 32), (float)(cy * 32), (float)(cz * 32));
     uint32_t chunk_idx = (uint32_t)cx + (uint32_t)cy * w + (uint32_t)cz * w * w;
-    /* wgpu clamps out-of-range storage reads; only reachable with NaN positions. */
+    /* A read past the table: WGSL leaves it to the implementation (any in-bounds element, or zero); the index is CLAMPED
+     * here, as naga's Restrict policy does.  Positions inside (0, size) cannot get here when size = 32 * size_in_chunks
+     * (i32(NaN) is 0); a WorldData that breaks that can — tests/golden/wgsl_oob.npz holds the shader's text under both
+     * policies for such a scene (and the C ABI refuses it). */
     if (chunk_idx >= s->n_chunk_roots) chunk_idx = s->n_chunk_roots - 1;
     uint32_t root = s->chunk_roots[chunk_idx];
     return find_chunk_node(s, pos, max_depth, min, root);
@@ -141,8 +144,10 @@ void orc_find_node(const orc_scene *scene, const float pos[3], uint32_t max_dept
     memcpy(out10 + 3, fl, sizeof fl);
 }
 
-/* voxel_mats[voxel]: the buffer holds 256 materials (shader.rs:48); ids >= 256 clamp to 255
- * (wgpu bounds-check policy for storage arrays). */
+/* voxel_mats[voxel]: the buffer holds 256 materials (shader.rs:48) and a voxel id has 15 bits: ids >= 256 read past it, which
+ * WGSL leaves to the implementation.  CLAMPED to 255 here and in the kernels (naga's Restrict policy);
+ * tests/golden/wgsl_oob.npz holds the reference's shader text under the clamp and under the zero-value policy, and
+ * tests/test_oracle_vs_reference_wgsl.py::test_reads_past_an_arrays_end_follow_the_clamp_policy pins the choice. */
 static inline const orc_material *mat_at(const orc_scene *s, uint32_t voxel) {
     return &s->materials[voxel > 255u ? 255u : voxel];
 }

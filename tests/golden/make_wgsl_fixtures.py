@@ -182,6 +182,82 @@ def make(case):
           f"{int((water != 0).sum())} pixels through water, voxels {sorted(set(voxel[hit == 1].tolist()))[:12]}", flush=True)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# The two reads of ray_tracer.wgsl that can go past the end of their arrays, under the two things WGSL lets an implementation
+# do about it (the index clamped to the last element / a zero value): what oracle and kernels implement is "clamp"
+# (oracle/vrt_oracle.c: find_node, mat_at; the kernels' min(voxel, 255)), and a maintainer with a real wgpu can settle which
+# one the reference's own runs get with one render of these two small scenes.
+#   material:  voxel ids >= 256 (a Voxel is 15 bits, common/src/world/mod.rs:137-148; voxel_mats holds 256, shader.rs:48)
+#              index voxel_mats at :226 (is_liquid) and for the colour.  Material 255 is given a colour of its own.
+#   chunk:     a WorldData whose `size` (96 voxels) is larger than 32 * size_in_chunks (2): positions with x in [64, 96) index
+#              chunk_roots_ past its 8 entries at :121-124 when they are in the upper chunk row and slab.  (The C ABI refuses such
+#              a WorldData — vrt_render: VRT_ERR_STATE — so this one is between the shader and the oracle only.)
+# ---------------------------------------------------------------------------------------------------------------------
+OOB_POLICIES = ("clamp", "zero")
+
+
+def oob_material_scene():
+    sc = scenes.c1_flat((24, 16))
+    for i, vid in enumerate((255, 256, 300, 1000, 32767)):      # a row of blocks on the grass, in view: ids at and beyond the table's end
+        for dx in range(2):
+            for dz in range(3):
+                sc.world.set_voxel((26 + 3 * i + dx, 13, 44 + dz), vid)
+    m = sc.materials[255]
+    m.color[0], m.color[1], m.color[2] = 1.0, 0.25, 0.5
+    m.is_empty, m.is_liquid = 0, 0
+    return sc
+
+
+def oob_chunk_scene():
+    sc = scenes.c1_flat((16, 8))
+    sc.world.create_chunk((1, 1, 1), np.zeros(1, dtype=np.uint16))   # (Superflat leaves the upper chunks missing: one air leaf, then the block)
+    for x in range(40, 48):                                      # a block in the last chunk (1, 1, 1): what a clamped index shows again at x + 32
+        for y in range(36, 44):
+            for z in range(40, 56):
+                sc.world.set_voxel((x, y, z), 4)
+    eye, rot = (88.5, 44.5, 48.5), (15.0, 90.0, 0.0)             # inside x in [64, 96): beyond the 2 x 2 x 2 chunks, looking back along -x
+    sc.cam = g.cam_data_create(rot, eye, 70.0, (16.0, 8.0))
+    sc.eye, sc.rot = eye, rot
+    wd = sc.world.world_data()
+    wd.size = 96                                                 # (size_in_chunks stays 2: 96 != 64)
+    return sc, wd
+
+
+def _trace_all(m, w, h):
+    rgb = np.zeros((h, w, 3), np.float32); hit = np.zeros((h, w), np.uint8); voxel = np.zeros((h, w), np.uint32); iters = np.zeros((h, w), np.uint32)
+    _state["m"] = m
+    for y in range(h):
+        _, row = _trace_row((y, 0, w))
+        for x, (c, hh, v, it, _n, _w, _p) in enumerate(row):
+            rgb[y, x], hit[y, x], voxel[y, x], iters[y, x] = c, hh, v, it
+    return rgb, hit, voxel, iters
+
+
+def make_oob():
+    out = {}
+    sc = oob_material_scene()
+    sc2, wd2 = oob_chunk_scene()
+    for pol in OOB_POLICIES:
+        m = W.Module(open(SHADER).read(), oob=pol)
+        bind_scene(m, sc)
+        for k, v in zip(("rgb", "hit", "voxel", "iters"), _trace_all(m, *sc.size)):
+            out[f"material_{pol}_{k}"] = v
+        m = W.Module(open(SHADER).read(), oob=pol)
+        bind_scene(m, sc2)
+        vec = lambda t, xs: W.Vec(t, [{"i32": I32}[t](x) for x in xs])   # noqa: E731
+        m.bind("world_", W.Struct("World", {"min": vec("i32", wd2.min), "size": U32(wd2.size), "size_in_chunks": U32(wd2.size_in_chunks)}))
+        for k, v in zip(("rgb", "hit", "voxel", "iters"), _trace_all(m, *sc2.size)):
+            out[f"chunk_{pol}_{k}"] = v
+    for name, s_ in (("material", sc), ("chunk", sc2)):
+        for k, v in scene_checksums(s_).items():
+            out[f"{name}_{k}"] = v
+    np.savez_compressed(os.path.join(HERE, "wgsl_oob.npz"), shader_crc=np.array([zlib.crc32(open(SHADER, "rb").read())], dtype=np.uint32), **out)
+    for name in ("material", "chunk"):
+        a, b = out[f"{name}_clamp_rgb"], out[f"{name}_zero_rgb"]
+        print(f"oob {name}: {int((np.abs(a - b).max(axis=-1) > 0).sum())} of {a.shape[0] * a.shape[1]} pixels differ between the policies; "
+              f"voxels seen (clamp) {sorted(set(out[f'{name}_clamp_voxel'].reshape(-1).tolist()))}", flush=True)
+
+
 PATH_SHADER = "/root/reference/clientdesktop/src/graphics/path_tracer.wgsl"
 SCREEN_SHADER = "/root/reference/clientdesktop/src/graphics/screen_shader.wgsl"
 RNG_SEEDS = [0, 1, 7, 12345, 1920 * 540 + 960, 0x9E3779B9, 0xFFFFFFFF]
@@ -247,9 +323,11 @@ def make_present():
 
 
 if __name__ == "__main__":
-    for c in (sys.argv[1:] or CASES + ["rng", "present"]):
+    for c in (sys.argv[1:] or CASES + ["rng", "present", "oob"]):
         if c == "rng":
             make_rng()
+        elif c == "oob":
+            make_oob()
         elif c == "present":
             make_present()
         else:

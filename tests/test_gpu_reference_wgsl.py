@@ -42,3 +42,39 @@ def test_kernels_compute_what_the_reference_shader_computes(case, variant):
     assert np.array_equal(steps, f["iters"]), f"{case} variant {variant}: iteration counts differ from the shader's"
     assert float(np.nanmax(np.abs(rgb - f["rgb"]))) <= RADIANCE_TOL
     gpu.close()
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+def test_material_ids_past_the_table_follow_the_clamp_policy(variant):
+    """Voxel ids >= 256 index voxel_mats past its 256 entries (ray_tracer.wgsl:226): tests/golden/wgsl_oob.npz holds the
+    reference's shader text under a clamped index and under a zero value.  Every march of the backend gives the CLAMPED
+    frame (material 255), as the oracle does — and not the zero-valued one."""
+    f = np.load(os.path.join(HERE, "golden", "wgsl_oob.npz"))
+    sc = mk.oob_material_scene()
+    for k, v in mk.scene_checksums(sc).items():
+        assert np.array_equal(v, f[f"material_{k}"])
+    gpu = gpu_for_scene(sc)
+    gpu.render(MODE_PRIMARY, variant=variant, stats=True)
+    rgb, ids, _ = gpu.read_output()
+    steps = gpu.read_steps() & 0xFFFF
+    hit = f["material_clamp_hit"].astype(bool)
+    assert np.array_equal((ids & ID_HIT) != 0, hit)
+    assert np.array_equal(np.where(hit, ids & ID_VOXEL_MASK, 0), np.where(hit, f["material_clamp_voxel"] & ID_VOXEL_MASK, 0))
+    assert np.array_equal(steps, f["material_clamp_iters"])
+    assert float(np.abs(rgb - f["material_clamp_rgb"]).max()) <= RADIANCE_TOL
+    differ = np.abs(f["material_clamp_rgb"] - f["material_zero_rgb"]).max(axis=-1) > 0
+    assert differ.any() and (np.abs(rgb - f["material_zero_rgb"]).max(axis=-1) > RADIANCE_TOL)[differ].all()
+    gpu.close()
+
+
+def test_a_world_data_that_indexes_past_chunk_roots_is_refused():
+    """The other read that can leave its array — chunk_roots_[idx] under a WorldData whose size is not 32 * size_in_chunks
+    (tests/golden/wgsl_oob.npz, `chunk`) — cannot happen behind the C ABI: vrt_render refuses such a frame (VRT_ERR_STATE)."""
+    from voxelraytracing_amd.graphics import VrtError
+    sc, wd = mk.oob_chunk_scene()
+    gpu = gpu_for_scene(sc)
+    with pytest.raises(VrtError) as e:
+        gpu.write_world_data(wd)
+        gpu.render(MODE_PRIMARY)
+    assert "size" in str(e.value)
+    gpu.close()

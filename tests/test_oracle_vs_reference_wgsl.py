@@ -120,3 +120,30 @@ def test_present_is_the_reference_fragment_shader(orc):
         assert np.array_equal(got, want), f"crosshair {row}: {int((got != want).any(axis=2).sum())} pixels differ from fs_main's"
         if style:
             assert (want != np.rint(np.clip(f["img0"], 0.0, 1.0) * 255.0).astype(np.uint8)).any()
+
+
+def test_reads_past_an_arrays_end_follow_the_clamp_policy(orc):
+    """The two reads of ray_tracer.wgsl that can go past their arrays (voxel_mats[voxel] for ids >= 256, :226; chunk_roots_[idx]
+    past the table, :121-124) under the two things WGSL lets an implementation do: tests/golden/wgsl_oob.npz holds what the
+    reference's shader text computes with the index CLAMPED and with a ZERO value.  The oracle implements the clamp (its
+    header says so; the kernels do too: tests/test_gpu_reference_wgsl.py) — this test pins that choice and shows that the
+    fixture can tell the two apart, so that one run of the same two scenes through a real wgpu settles which the reference gets."""
+    f = np.load(os.path.join(GOLD, "wgsl_oob.npz"))
+    sc = mk.oob_material_scene()
+    sc2, wd2 = mk.oob_chunk_scene()
+    for name, s_ in (("material", sc), ("chunk", sc2)):
+        for k, v in mk.scene_checksums(s_).items():
+            assert np.array_equal(v, f[f"{name}_{k}"]), f"{name}: {k} differs — the fixture was made from another scene"
+    scenes_ = {"material": (orc.from_package_scene(sc), sc.size),
+               "chunk": (orc.OracleScene(sc2.world.nodes(), sc2.world.chunk_roots(), sc2.materials, sc2.cam, sc2.settings, wd2), sc2.size)}
+    for name, (o, (w, h)) in scenes_.items():
+        rgb, ids, steps, _ = o.render(orc.MODE_PRIMARY, w, h, want_steps=True)
+        hit = f[f"{name}_clamp_hit"].astype(bool)
+        assert np.array_equal((ids & orc.ID_HIT) != 0, hit), f"{name}: hit flags differ from the shader's under the clamp policy"
+        assert np.array_equal(np.where(hit, ids & orc.ID_VOXEL_MASK, 0), np.where(hit, f[f"{name}_clamp_voxel"] & orc.ID_VOXEL_MASK, 0))
+        assert np.array_equal(steps, f[f"{name}_clamp_iters"]), f"{name}: iteration counts differ from the shader's under the clamp policy"
+        assert float(np.abs(rgb - f[f"{name}_clamp_rgb"]).max()) <= 1e-6
+        differ = np.abs(f[f"{name}_clamp_rgb"] - f[f"{name}_zero_rgb"]).max(axis=-1) > 0
+        assert differ.any(), f"{name}: the fixture cannot tell the two policies apart"
+        assert (np.abs(rgb - f[f"{name}_zero_rgb"]).max(axis=-1) > 1e-6)[differ].all(), f"{name}: the oracle follows the zero policy somewhere"
+    assert {255, 256, 300, 1000, 32767} <= set(f["material_clamp_voxel"].reshape(-1).tolist())

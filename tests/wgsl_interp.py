@@ -20,7 +20,9 @@ takes, and says here, the same choice the oracle documents
   pow(x, y)                        -> the binary32 rounding of the double-precision power
   v * M (vector times matrix)      -> component i = dot(v, column i of M)            (WGSL: transpose(M) * v)
   M * v                            -> component i = dot(row i of M, v), left to right
-  an array index past the end      -> an error (the fixtures' scenes never do it: what such a read yields is not defined)
+  an array index past the end      -> an error by default (the thirteen scene fixtures never do it); Module(src, oob="clamp" | "zero")
+                                      runs the two policies an implementation may take — the index clamped to the last element, or a
+                                      zero value — for tests/golden/wgsl_oob.npz, which records the shader under both
 """
 from __future__ import annotations
 
@@ -690,13 +692,33 @@ class _Return(Exception):
 _SWZ = {"x": 0, "y": 1, "z": 2, "w": 3, "r": 0, "g": 1, "b": 2, "a": 3}
 
 
+def zero_like(x):
+    """A zero value of x's type (a scalar, Vec, Mat4 or Struct)."""
+    if isinstance(x, Struct):
+        return Struct(x.name, {k: zero_like(v) for k, v in x.f.items()})
+    if isinstance(x, Vec):
+        return Vec(x.t, [zero_like(e) for e in x.v])
+    if isinstance(x, Mat4):
+        return Mat4([zero_like(c) for c in x.cols])
+    if isinstance(x, bool):
+        return False
+    return type(x)(0)
+
+
 class Module:
     """A parsed WGSL module with its resource bindings.  `bind(name, value)` sets a module-scope variable (a Struct for a
     uniform, a Python sequence for a storage array — arrays are only ever indexed); `call(name, *args)` runs a function;
     `hooks[name] = fn(locals, result)` is called whenever function `name` returns; `texture_stores` collects textureStore calls."""
 
-    def __init__(self, src: str):
+    def __init__(self, src: str, oob: str = "refuse"):
         self.structs, self.globals, self.funcs = Parser(src).parse_module()
+        # what an array read past its end yields is left to the implementation (WGSL 'out-of-bounds access': any in-bounds
+        # element or zero).  "refuse": such a read is an error here (the default: a fixture then cannot depend on it);
+        # "clamp": the index is clamped to the last element (naga's BoundsCheckPolicy::Restrict); "zero": the read yields a
+        # zero value of the element's type (ReadZeroSkipWrite).  tests/golden/wgsl_oob.npz holds both for the two reads of
+        # ray_tracer.wgsl that can go past their arrays (:121-124 chunk_roots_, :226 voxel_mats).
+        assert oob in ("refuse", "clamp", "zero")
+        self.oob = oob
         self.bound = {}
         self.hooks = {}
         self.externals = {}
@@ -778,6 +800,10 @@ class Module:
             if isinstance(base, Mat4):
                 return base.cols[idx]
             if idx < 0 or idx >= len(base):
+                if self.oob == "clamp":
+                    return base[min(max(idx, 0), len(base) - 1)]
+                if self.oob == "zero":
+                    return zero_like(base[0])
                 raise IndexError(f"array index {idx} outside [0, {len(base)}): what such a read yields is implementation-defined")
             return base[idx]
         if k == "construct":
