@@ -380,7 +380,8 @@ def main():
             probe.upload_world(sc.world, sc.materials)
             probe.write_cam_data(sc.cam)
             probe.write_settings(sc.settings)
-            probe.render(MODE, **rkw)
+            for _ in range(30 if MODE != MODE_PATH else 2):   # (first frames create streams, event pools and the derived tables)
+                probe.render(MODE, **rkw)
             probe.synchronize()
             n_p, t0 = 0, time.perf_counter()
             while n_p < 50 and (n_p < 2 or time.perf_counter() - t0 < 0.1):
@@ -557,7 +558,8 @@ def main():
 
     def time_unsharded(ref):
         # (other ranks may still be busy on a rehearsal's one GPU: the figure is then an upper bound, and says so)
-        ref.render(MODE, **rkw)
+        for _ in range(30 if MODE != MODE_PATH else 2):
+            ref.render(MODE, **rkw)
         ref.synchronize()
         n_done, t0 = 0, time.perf_counter()
         while n_done < 200 and (n_done < 3 or time.perf_counter() - t0 < 0.15):

@@ -16,14 +16,14 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
            "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   i=$((i+1))
   if [ -n "$PMC_GROUPS" ] && ! echo " $PMC_GROUPS " | grep -q " $i "; then continue; fi   # PMC_GROUPS="1 2": only those passes
-  timeout -k 10 150 rocprofv3 --pmc $grp --output-format csv -d $OUT/g$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --fixed-camera --no-extras --settle-seconds 0 "$@" > $OUT/g$i.log 2>&1 || echo "group $i failed: $grp"
+  timeout -k 10 150 rocprofv3 --pmc $grp --output-format csv -d $OUT/g$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --fixed-camera --no-extras --settle-seconds 0 --exact-steps "$@" > $OUT/g$i.log 2>&1 || echo "group $i failed: $grp"
 done
 # PMC_EXTRA="A B;C D": further counter groups, one run each
 if [ -n "$PMC_EXTRA" ]; then
   IFS=';' read -ra EXTRA <<< "$PMC_EXTRA"
   for grp in "${EXTRA[@]}"; do
     i=$((i+1))
-    timeout -k 10 150 rocprofv3 --pmc $grp --output-format csv -d $OUT/g$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --fixed-camera --no-extras --settle-seconds 0 "$@" > $OUT/g$i.log 2>&1 || echo "group $i failed: $grp"
+    timeout -k 10 150 rocprofv3 --pmc $grp --output-format csv -d $OUT/g$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --fixed-camera --no-extras --settle-seconds 0 --exact-steps "$@" > $OUT/g$i.log 2>&1 || echo "group $i failed: $grp"
   done
 fi
 python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT > $OUT/summary.txt
