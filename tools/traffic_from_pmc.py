@@ -54,7 +54,7 @@ n_v = sum(fp.get(k, 0) for k in ("valu_simple", "valu_half", "valu_pk", "valu_tr
 pick = {"primary_shadow_march": (["primary_shadow_wave_kernel<0, false, false, 4, false>"], True),
         "primary_march": (["primary_tile_kernel<0, false, false, true>", "primary_tile_kernel<0, false, false, false>"], True),
         "shadow_march": (["shadow_kernel<0, false, false>"], True),
-        "path_primary_march": (["path_primary_kernel<0, false, false, false>", "path_primary_kernel<0, false, false, true>"], False),
+        "path_primary_march": (["path_primary_kernel<0, false, false, false, false>", "path_primary_kernel<0, false, false, true, false>"], False),
         "path_bounce_marches": (["path_bounce_cells_kernel<true>(vrt::CellsLaunch)", "path_bounce_cells_kernel<false>(vrt::CellsLaunch)"], False)}
 frames = 8.0   # tools/pmc.sh: bench.py --steps 6 --warmup 2, standing camera, no extra legs
 kernels = {}
