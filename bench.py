@@ -814,6 +814,14 @@ def main():
         es = expected_scaling(n_, one_gpu_ms[0], args.width * args.height, 16 if texel_msgs else 8, root_weight,
                               host_us_per_frame=host_us, fixed_ms_per_launch=min(0.016, one_gpu_ms[0]))
         es["host_submit_us_per_frame_this_run"] = host_submit_ms * 1e3
+        # ... and at the root weight the same model would choose (this run's was measured, or — a rehearsal on one GPU — tuned
+        # for a machine on which sharing buys nothing)
+        from voxelraytracing_amd.shard import root_weight_model
+        w_model = root_weight_model(n_, one_gpu_ms[0], args.width * args.height * (16 if texel_msgs else 8))
+        if w_model != root_weight:
+            best = expected_scaling(n_, one_gpu_ms[0], args.width * args.height, 16 if texel_msgs else 8, w_model,
+                                    host_us_per_frame=host_us, fixed_ms_per_launch=min(0.016, one_gpu_ms[0]))
+            es["at_model_root_weight"] = {k: best[k] for k in ("root_weight", "predicted_ms", "speedup", "bound")}
         es["frame_ms_1gpu_measured_in_this_run"] = one_gpu_ms[0]
         es["measured_ms"] = period_s * 1e3
         es["measured_speedup"] = one_gpu_ms[0] / (period_s * 1e3)
