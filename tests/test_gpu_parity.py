@@ -906,16 +906,18 @@ def test_samples_per_launch_chain_do_not_change_the_frame(orc, monkeypatch, per_
     assert np.array_equal(ids1, o_ids) and np.array_equal(rgb1, o_rgb)
 
 
-def test_tiles_ordered_under_a_moving_camera_are_the_same_frames(orc, monkeypatch):
-    """Round 4 (VRT_TILE_ORDER_MOVING=1): a one-frame-at-a-time context keeps launching its tiles longest first while the camera MOVES — the order made
+@pytest.mark.parametrize("form", ["1", "2", "6"])
+def test_tiles_ordered_under_a_moving_camera_are_the_same_frames(orc, monkeypatch, form):
+    """VRT_TILE_ORDER_MOVING=1 (round 5: ONE launch that sorts blocks of 4 x 4 tiles, launch_tile_order_blocks) / 6 (round 4: six
+    small launches, experiments build): a one-frame-at-a-time context keeps launching its tiles longest first while the camera MOVES — the order made
     from the frame before, its trips dilated over the image motion of a camera step (vrt_kernels.hip:
     launch_tile_order_moving).  A walk of small steps (the bench's orbit step: < 1 voxel, ~ 1 degree), a rest, a jump (screen
     order again), more steps: every frame is the screen-order context's frame, the last one the oracle's; and the counter
     says which frames were ordered."""
-    needs_experiments()                                # (built, measured, not chosen: profiles/r04_tile_order_moving.txt)
+    needs_experiments()                                # (built, measured, not chosen: profiles/r04_tile_order_moving.txt, r05_tile_order_moving.txt)
     from voxelraytracing_amd import graphics as g
     sc = scenes.c2()
-    monkeypatch.setenv("VRT_TILE_ORDER_MOVING", "1")
+    monkeypatch.setenv("VRT_TILE_ORDER_MOVING", form)
     mov = gpu_for_scene(sc)
     mov.set_frames_in_flight(1)
     monkeypatch.delenv("VRT_TILE_ORDER_MOVING")
@@ -941,7 +943,11 @@ def test_tiles_ordered_under_a_moving_camera_are_the_same_frames(orc, monkeypatc
         ordered.append(mov.accel_info().ordered_frames)
     used = [b - a for a, b in zip([0] + ordered[:-1], ordered)]
     # the first frame has no order; every frame a step (or no step) from its predecessor has one; the frame after the jump has none
-    assert used == [0, 1, 1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1], used
+    # (form 2: an order is made beside the NEXT frame and used by the one after it — the first two frames and the two after the jump
+    # have none, nor has the second frame of the rest: the order made behind the last moving frame is the third's, the exact one of
+    # the view at rest comes after its second frame)
+    want = [0, 1, 1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1] if form != "2" else [0, 0, 1, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1, 1]
+    assert used == want, used
     assert ref.accel_info().ordered_frames == 0
     o = orc.from_package_scene(sc)
     o.set_cam(cam)
@@ -956,6 +962,35 @@ def test_tiles_ordered_under_a_moving_camera_are_the_same_frames(orc, monkeypatc
     assert old.accel_info().ordered_frames == 0
     for gpu in (mov, ref, old):
         gpu.close()
+
+
+@pytest.mark.parametrize("size", [(3840, 2160), (200, 104), (64, 8)])
+def test_block_order_on_other_frame_shapes(monkeypatch, size):
+    """The one-launch order of a moving view (launch_tile_order_blocks) on a 4K frame (8 160 blocks: 96 KiB of LDS, opted in), on one
+    whose tile rows and columns are not multiples of four, and on a single row of tiles: the frames of a walking camera equal the
+    screen-order context's, and the order is really used."""
+    needs_experiments()
+    from voxelraytracing_amd import graphics as g
+    sc = scenes.c2(size)
+    monkeypatch.setenv("VRT_TILE_ORDER_MOVING", "1")
+    mov = gpu_for_scene(sc)
+    mov.set_frames_in_flight(1)
+    monkeypatch.setenv("VRT_TILE_ORDER_MOVING", "0")
+    monkeypatch.setenv("VRT_TILE_ORDER", "0")
+    ref = gpu_for_scene(sc)
+    ref.set_frames_in_flight(1)
+    for k in range(5):
+        cam = g.cam_data_create((sc.rot[0] + 0.3 * k, sc.rot[1] + 0.9 * k, 0.0), (sc.eye[0] + 0.5 * k, sc.eye[1], sc.eye[2] - 0.4 * k), 70.0, (float(size[0]), float(size[1])))
+        for gpu in (mov, ref):
+            gpu.write_cam_data(cam)
+            gpu.render(MODE_PRIMARY_SHADOW)
+        a_rgb, a_ids, _ = mov.read_output()
+        b_rgb, b_ids, _ = ref.read_output()
+        assert np.array_equal(a_ids, b_ids) and np.array_equal(a_rgb, b_rgb), k
+    tiles = (size[0] // 8) * (size[1] // 8)
+    assert mov.accel_info().ordered_frames == (4 if tiles >= 128 else 0)   # (a frame of fewer than 128 tiles is not ordered at all)
+    assert ref.accel_info().ordered_frames == 0
+    mov.close(); ref.close()
 
 
 def test_longest_tiles_first_is_the_same_frame(orc, monkeypatch):

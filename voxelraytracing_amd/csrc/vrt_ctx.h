@@ -253,13 +253,23 @@ struct vrt_ctx {
     uint32_t view_gen = 0;              // counts the changes of anything a tile's trips depend on
     uint32_t frame_view_gen = ~0u;      // ... as of the last frame rendered
     uint32_t order_view_gen = ~0u;      // ... as of the frame the order was made from
-    // ... and while the view MOVES (round 4): every such frame notes its trips, and the order for the next frame is made from
-    // them dilated over the image motion a camera step can cause (vrt_kernels.hip: launch_tile_order_moving) — used by a frame
-    // whose camera is close to the one the trips were noted under and whose view differs from it in the camera only
-    // The experiments build only (make experiments), and there OFF unless VRT_TILE_ORDER_MOVING=1: the frame's launch gets 6.4 us shorter (112.4 -> 106.0) and the six small launches that
-    // make the order take 17 of a stream that runs its frames back to back, and of the wait of a host that synchronises every frame
-    // (profiles/r04_tile_order_moving.txt): an experiment, not a mode anybody should switch on as it stands
-    bool tile_lpt_moving = false;
+    // ... and while the view MOVES: every such frame notes its trips, and the order for the next frame is made from them dilated
+    // over the image motion a camera step can cause — used by a frame whose camera is close to the one the trips were noted
+    // under and whose view differs from it in the camera only.  1 (VRT_TILE_ORDER_MOVING=1): round 5's ONE launch over blocks of
+    // 4 x 4 tiles (vrt_kernels.hip: launch_tile_order_blocks); 6: round 4's six small launches (experiments build: the frame's
+    // launch 112.4 -> 106.0 us, the six launches 17 us of the stream, profiles/r04_tile_order_moving.txt); 0: screen order while
+    // the view moves
+    uint32_t tile_lpt_moving = 0;
+    // 2 (VRT_TILE_ORDER_MOVING=2): the order of a moving view made BESIDE the frame in between — frame k's trips are sorted on a
+    // side stream while frame k + 1 runs, and frame k + 2 launches in that order (dilated over two camera steps): the order
+    // costs the frames' stream nothing.  Two sets of trips / order buffers alternate; `mov_pend` is the order being made.
+    struct MovingOrder { bool valid = false; uint32_t view_gen = 0, cam_gen = 0, buf = 0; vrt_cam_data cam{}; };
+    MovingOrder mov_new, mov_pend, mov_cur;   // made behind the last frame -> being made beside this one -> this frame's
+    uint32_t *d_mov_cost[2] = {nullptr, nullptr}, *d_mov_order[2] = {nullptr, nullptr};
+    hipStream_t mov_stream = nullptr;
+    hipEvent_t mov_frame_done[2] = {nullptr, nullptr}, mov_order_done[2] = {nullptr, nullptr};
+    bool mov_order_recorded[2] = {false, false}, mov_pending = false, mov_side = true;   // (mov_side false: on the frames' own stream, for A/B)
+    uint32_t mov_count = 0, mov_radius = 3, mov_threads = 256;   // (a small workgroup finds room beside the frame's: VRT_TILE_ORDER_THREADS)
     // vrt_present*: whether a window of (one_w x one_h) over a texture of the same size samples every texel at its centre
     uint32_t one_w = 0, one_h = 0;
     bool one_to_one = false;

@@ -69,6 +69,9 @@ static int alloc_output(vrt_ctx *c) {
     for (auto &p : c->path_acc) { (void)hipFree(p); p = nullptr; }
     for (auto &p : c->path_grp_counts) { (void)hipFree(p); p = nullptr; }
     for (auto &n : c->path_grp_regions) n = 0;
+    if (c->mov_stream) (void)hipStreamSynchronize(c->mov_stream);
+    for (int k = 0; k < 2; k++) { (void)hipFree(c->d_mov_cost[k]); (void)hipFree(c->d_mov_order[k]); c->d_mov_cost[k] = c->d_mov_order[k] = nullptr; c->mov_order_recorded[k] = false; }
+    c->mov_new.valid = c->mov_pend.valid = c->mov_cur.valid = false;
     (void)hipFree(c->d_tile_cost); c->d_tile_cost = nullptr;
     (void)hipFree(c->d_tile_order); c->d_tile_order = nullptr;
     (void)hipFree(c->d_tile_scratch); c->d_tile_scratch = nullptr;
@@ -593,7 +596,12 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     }
     if (const char *e = getenv("VRT_TILE_ORDER")) c->tile_lpt = e[0] != '0';
     // switches of the experiments build (tools/ab/libvrt_exp.so): without its hooks (vrt_exp.h) the first seven select nothing
-    if (const char *e = getenv("VRT_TILE_ORDER_MOVING")) c->tile_lpt_moving = e[0] != '0' && vrt::g_exp.tile_order_moving;
+    // (the orders of a moving view: built, measured, not chosen — profiles/r05_tile_order_moving.txt; the experiments build's hooks)
+    if (const char *e = getenv("VRT_TILE_ORDER_MOVING"))
+        c->tile_lpt_moving = e[0] == '6' ? (vrt::g_exp.tile_order_moving ? 6u : 0u) : !vrt::g_exp.tile_order_blocks ? 0u : e[0] == '2' ? 2u : e[0] != '0' ? 1u : 0u;
+    if (const char *e = getenv("VRT_TILE_ORDER_SIDE")) c->mov_side = e[0] != '0';
+    if (const char *e = getenv("VRT_TILE_ORDER_THREADS")) { const int v = atoi(e); if (v >= 64 && v <= 1024) c->mov_threads = (uint32_t)v; }
+    if (const char *e = getenv("VRT_TILE_ORDER_RADIUS")) { const int v = atoi(e); if (v >= 1 && v <= 4) c->mov_radius = (uint32_t)v; }
     if (const char *e = getenv("VRT_PATH_PERSISTENT")) c->path_persistent = e[0] == '1';
     if (const char *e = getenv("VRT_PATH_POOL")) c->path_pool = e[0] != '0';
     if (const char *e = getenv("VRT_PATH_POOL_CHAIN")) c->path_chain = e[0] == '1';
@@ -663,6 +671,12 @@ void vrt_destroy(vrt_ctx *c) {
     for (auto p : c->path_acc) (void)hipFree(p);
     for (auto p : c->path_grp_counts) (void)hipFree(p);
     (void)hipFree(c->d_tile_cost); (void)hipFree(c->d_tile_order); (void)hipFree(c->d_tile_scratch);
+    if (c->mov_stream) (void)hipStreamSynchronize(c->mov_stream);   // (extra_stream[0]: destroyed with the others)
+    for (int k = 0; k < 2; k++) {
+        (void)hipFree(c->d_mov_cost[k]); (void)hipFree(c->d_mov_order[k]);
+        if (c->mov_frame_done[k]) (void)hipEventDestroy(c->mov_frame_done[k]);
+        if (c->mov_order_done[k]) (void)hipEventDestroy(c->mov_order_done[k]);
+    }
     for (auto st : c->side_stream)
         if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     for (auto &evs : c->side_ev)
@@ -698,18 +712,18 @@ const char *vrt_last_error(const vrt_ctx *ctx) { return ctx ? ctx->err.c_str() :
 
 // Whether a tile order made from camera a's frame, dilated over ~ 10 tiles each way, still serves camera b: the same projection,
 // the eye within a voxel and a half, every axis of the view within two degrees (a NaN camera is close to nothing).
-static bool cameras_close(const vrt_cam_data &a, const vrt_cam_data &b) {
+static bool cameras_close(const vrt_cam_data &a, const vrt_cam_data &b, float steps = 1.0f) {   // steps: camera steps the order is to hold for
     if (memcmp(a.inv_proj_mat, b.inv_proj_mat, sizeof a.inv_proj_mat) != 0 || memcmp(a.proj_size, b.proj_size, sizeof a.proj_size) != 0) return false;
     float d2 = 0.f;
     for (int k = 0; k < 3; k++) d2 += (a.pos[k] - b.pos[k]) * (a.pos[k] - b.pos[k]);
-    if (!(d2 <= 2.25f)) return false;
+    if (!(d2 <= 2.25f * steps * steps)) return false;
     for (int col = 0; col < 3; col++) {
         float dot = 0.f, na = 0.f, nb = 0.f;
         for (int k = 0; k < 3; k++) {
             const float x = a.inv_view_mat[4 * col + k], y = b.inv_view_mat[4 * col + k];
             dot += x * y; na += x * x; nb += y * y;
         }
-        if (!(dot >= 0.99939f * sqrtf(na * nb))) return false;
+        if (!(dot >= (steps > 1.5f ? 0.99756f : 0.99939f) * sqrtf(na * nb))) return false;   // cos 4 / 2 degrees
     }
     return true;
 }
@@ -919,6 +933,12 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     // (a tile's trips depend on the mode too — a primary-only frame has no shadow march: an order made from the other
     // mode's frame is a stale order, and the frame before a sort must be of the same kind)
     if (c->frame_mode != o.mode) c->view_gen++;
+    // (VRT_TILE_ORDER_MOVING=2) the order made beside the last frame is for the frame after it: this one may use the one before
+    c->mov_cur = c->mov_pend;
+    c->mov_pend = c->mov_new;
+    c->mov_new.valid = false;
+    const bool mov2 = c->tile_lpt_moving == 2u;
+    uint32_t mov_wb = 0;   // which of the two trips / order buffers this frame's trips go to
     if (lpt) {
         if (c->tile_buf_tiles != c->tiles_local) {
             const uint32_t chunks = (c->tiles_local + 63u) / 64u;
@@ -931,10 +951,29 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
         // an order is used by the very view it was made from, or — a dilated one — by a view a camera step away from it
         const bool exact = c->tile_order_valid && !c->order_dilated && c->order_view_gen == c->view_gen;
         const bool moving_ok = c->tile_lpt_moving && c->tiles_local == P.tiles_total && P.tiles_total % P.tiles_x == 0u;
-        const bool near = c->tile_order_valid && c->order_dilated && moving_ok &&
+        const bool near = !mov2 && c->tile_order_valid && c->order_dilated && moving_ok &&
                           c->view_gen - c->order_view_gen == c->cam_gen - c->order_cam_gen && cameras_close(c->order_cam, c->cam);
         if (!exact && !near) c->tile_order_valid = false;   // the order of another view: worse than none
         if (c->tile_order_valid) { P.tile_order = c->d_tile_order; c->ordered_frames++; }
+        if (mov2 && moving_ok) {
+            if (!c->d_mov_cost[0]) {
+                for (int k = 0; k < 2; k++) {
+                    HIP_TRY(c, hipMalloc(&c->d_mov_cost[k], (size_t)c->tiles_local * sizeof(uint32_t)));
+                    HIP_TRY(c, hipMalloc(&c->d_mov_order[k], (size_t)c->tiles_local * sizeof(uint32_t)));
+                    if (!c->mov_frame_done[k]) HIP_TRY(c, hipEventCreateWithFlags(&c->mov_frame_done[k], hipEventDisableTiming));
+                    if (!c->mov_order_done[k]) HIP_TRY(c, hipEventCreateWithFlags(&c->mov_order_done[k], hipEventDisableTiming));
+                }
+                // the stream of the second frame in flight — idle while frames go one at a time, and known to run beside the
+                // context's own (a stream made for the purpose shared its hardware queue: the order ran between the frames)
+                if (!c->extra_stream[0]) HIP_TRY(c, hipStreamCreateWithFlags(&c->extra_stream[0], hipStreamNonBlocking));
+                c->mov_stream = c->extra_stream[0];
+            }
+            mov_wb = c->mov_count & 1u;
+            // the order made from the frame before the last one: for a view two camera steps from it at most, nothing but the camera changed
+            const bool near2 = !c->tile_order_valid && c->mov_cur.valid && c->view_gen - c->mov_cur.view_gen == c->cam_gen - c->mov_cur.cam_gen &&
+                               cameras_close(c->mov_cur.cam, c->cam, 2.0f);
+            if (near2) { P.tile_order = c->d_mov_order[c->mov_cur.buf]; c->ordered_frames++; }
+        }
         if (!exact) {
             if (c->frame_view_gen == c->view_gen) tile_sort = true;   // the view has come to rest: this frame notes its trips
             else if (moving_ok) tile_sort = dilate = true;            // it moves: the next frame's order from this frame's trips, dilated
@@ -942,7 +981,13 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
         // an order made before a chunk was edited: kept for the edit's own frame, made again by the first frame behind it
         // that has no fresh edit in front of it (its launch reads the old order, the sort behind it writes the new one)
         if (exact && c->tile_order_stale && !edit_in_front) tile_sort = true;
-        if (tile_sort) P.tile_cost = c->d_tile_cost;
+        if (tile_sort) P.tile_cost = (dilate && mov2) ? c->d_mov_cost[mov_wb] : c->d_tile_cost;
+        // (the side stream's last reader of these trips / writer of this order buffer — two frames ago, or the order this frame
+        // launches in — has finished before the frame starts)
+        if (mov2 && c->mov_side && ((dilate && c->mov_order_recorded[mov_wb]) || P.tile_order == c->d_mov_order[mov_wb]))
+            HIP_TRY(c, hipStreamWaitEvent(f.st, c->mov_order_done[mov_wb], 0));
+        if (mov2 && c->mov_side && c->mov_cur.valid && P.tile_order == c->d_mov_order[c->mov_cur.buf] && c->mov_cur.buf != mov_wb)
+            HIP_TRY(c, hipStreamWaitEvent(f.st, c->mov_order_done[c->mov_cur.buf], 0));
     }
     c->frame_view_gen = c->view_gen;
     c->frame_mode = o.mode;
@@ -955,16 +1000,41 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
         if (rc) return rc;
     }
     if (tile_sort) {   // (the frame above read the old order and is over when this runs; the next frame starts after it)
-        if (dilate) vrt::g_exp.tile_order_moving(c->d_tile_cost, P.tiles_x, P.tiles_total / P.tiles_x, 1u, 2u, c->d_tile_scratch, c->d_tile_order, f.st);
+        bool made = true;
+        if (dilate && mov2) {
+            // beside the next frame: the side stream waits for this frame, sorts its trips, and says when the order is there
+            hipStream_t os = c->mov_side ? c->mov_stream : f.st;
+            if (c->mov_side) {
+                HIP_TRY(c, hipEventRecord(c->mov_frame_done[mov_wb], f.st));
+                HIP_TRY(c, hipStreamWaitEvent(os, c->mov_frame_done[mov_wb], 0));
+            }
+            made = vrt::g_exp.tile_order_blocks(c->d_mov_cost[mov_wb], P.tiles_x, P.tiles_total / P.tiles_x, 1u, c->mov_radius, c->d_mov_order[mov_wb], os,
+                                                 c->mov_side ? c->mov_threads : 1024u);
+            HIP_TRY(c, hipGetLastError());
+            if (c->mov_side) {
+                HIP_TRY(c, hipEventRecord(c->mov_order_done[mov_wb], os));
+                c->mov_order_recorded[mov_wb] = true;
+                c->mov_pending = true;
+            }
+            c->mov_new.valid = made;
+            c->mov_new.view_gen = c->view_gen;
+            c->mov_new.cam_gen = c->cam_gen;
+            c->mov_new.buf = mov_wb;
+            c->mov_new.cam = c->cam;
+            c->mov_count++;
+        } else {
+        if (dilate && c->tile_lpt_moving == 6u) vrt::g_exp.tile_order_moving(c->d_tile_cost, P.tiles_x, P.tiles_total / P.tiles_x, 1u, 2u, c->d_tile_scratch, c->d_tile_order, f.st);
+        else if (dilate) made = vrt::g_exp.tile_order_blocks(c->d_tile_cost, P.tiles_x, P.tiles_total / P.tiles_x, 1u, 2u, c->d_tile_order, f.st, 1024u);
         else
         vrt::launch_tile_order(c->d_tile_cost, c->tiles_local, 1u, c->d_tile_scratch, c->d_tile_order, f.st);   // classes of two trips
         HIP_TRY(c, hipGetLastError());
-        c->tile_order_valid = true;
+        c->tile_order_valid = made;   // (a frame of more blocks than the one-launch order holds keeps screen order)
         c->order_view_gen = c->view_gen;
         c->order_dilated = dilate;
         c->order_cam_gen = c->cam_gen;
         c->order_cam = c->cam;
         c->tile_order_stale = false;
+        }
     }
     c->rendered = true;
     c->flushed_at_call = false;   // (the next frame's first staged range may go out at its call again: vrt_uploads.hip)
@@ -979,6 +1049,10 @@ int vrt_synchronize(vrt_ctx *c) {
     if (!c) return VRT_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     QUIESCE(c);
+    if (c->mov_pending) {   // (the order being made beside the last frame touches nothing but its own buffers: only this call waits for it)
+        if (c->mov_stream) HIP_TRY(c, hipStreamSynchronize(c->mov_stream));
+        c->mov_pending = false;
+    }
     {
         const int rc = flush_staged(c);
         if (rc) return rc;

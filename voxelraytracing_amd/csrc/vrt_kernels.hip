@@ -15,6 +15,8 @@
 //   * the 256-bit liquid mask (and, for variants 1-2, the chunk-root table) is staged in LDS.
 #include <hip/hip_ext.h>
 
+#include <atomic>
+
 #include "vrt_tile.h"
 #include "vrt_exp.h"
 
