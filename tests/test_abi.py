@@ -90,4 +90,4 @@ def test_no_kernel_of_the_library_spills_registers():
     bad = {k: v for k, v in regs.items() if v["scratch_bytes"] or v["sgpr_spills"] or v["vgpr_spills"]}
     assert not bad, f"kernels that spill: {bad}"
     bounce = {k: v for k, v in regs.items() if "path_bounce_cells_kernel" in k}
-    assert len(bounce) == 2 and all(v["vgprs"] <= 64 for v in bounce.values()), bounce
+    assert len(bounce) == 3 and all(v["vgprs"] <= 64 for v in bounce.values()), bounce   # (direct x 256- / 320-ray pools, blocks x 256)

@@ -812,6 +812,23 @@ def test_compact_shards_without_the_derived_tables_stay_inside_their_records(c2_
         c.close()
 
 
+@pytest.mark.parametrize("k", ["4", "5"])
+def test_pool_depth_of_the_bounce_waves_does_not_change_the_frame(orc, monkeypatch, k):
+    """The bounce launch's waves keep 256 rays (VRT_PATH_POOL_K=4) or 320 (5: the default for small worlds with two frames in
+    flight, profiles/r05_pool_k5.txt): the same frame, one frame at a time and two in flight, one and several samples."""
+    sc = scenes.c4((320, 184), bounces=4)
+    r_rgb, r_ids, _, _ = orc.from_package_scene(sc).render(orc.MODE_PATH, *sc.size, spp=3, seed=11)
+    monkeypatch.setenv("VRT_PATH_POOL_K", k)
+    for in_flight in (1, 2):
+        gpu = gpu_for_scene(sc)
+        gpu.set_frames_in_flight(in_flight)
+        for _ in range(3):
+            gpu.render(MODE_PATH, spp=3, seed=11)
+        rgb, ids, _ = gpu.read_output()
+        assert_frame_parity(rgb, ids, r_rgb, r_ids, f"pool of {k} batches, {in_flight} in flight")
+        gpu.close()
+
+
 def test_persistent_path_kernel_gives_the_same_frames(orc, monkeypatch):
     """VRT_PATH_PERSISTENT=1: the path trace as one launch of persistent waves whose lanes are refilled in batches (built
     and measured, not the default) — bit for bit the frame of the launch-per-bounce kernels, whole and sharded."""

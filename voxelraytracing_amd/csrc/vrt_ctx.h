@@ -40,7 +40,7 @@ void launch_shadow(const FrameParams &P, uint32_t variant, bool stats, hipStream
 void launch_primary_shadow_fused(const FrameParams &P, uint32_t march, bool stats, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
 void launch_path_primary(const FrameParams &P, bool stats, bool literal, hipStream_t st);
 void launch_path_bounce(const FrameParams &P, bool stats, bool literal, hipStream_t st);
-void launch_path_bounce_cells(const FrameParams &P, uint32_t refill_at, uint32_t segments, uint32_t lds_pad, hipStream_t st);
+void launch_path_bounce_cells(const FrameParams &P, uint32_t refill_at, uint32_t segments, uint32_t lds_pad, uint32_t pool_batches, hipStream_t st);
 void launch_path_finish(Texel *out, uint32_t n, uint32_t spp, hipStream_t st);
 void launch_tile_order(const uint32_t *cost, uint32_t n, uint32_t shift, uint32_t *scratch, uint32_t *order, hipStream_t st);
 void launch_path_chain_finish(Texel *out, const Texel *acc, uint32_t n, uint32_t chain, bool first, bool last, uint32_t spp, hipStream_t st);
@@ -236,6 +236,7 @@ struct vrt_ctx {
     uint32_t path_samples = 8;     // VRT_PATH_SAMPLES_PER_CHAIN: samples a launch chain traces at once when spp > 1 (1: one, as round 1 did)
     vrt::Texel *path_acc[kMaxInFlight] = {nullptr, nullptr, nullptr, nullptr};   // ... their accumulation planes, per frame set
     size_t path_acc_texels[kMaxInFlight] = {0, 0, 0, 0}, path_buf_records[kMaxInFlight] = {0, 0, 0, 0}, path_cont_records[kMaxInFlight] = {0, 0, 0, 0};
+    uint32_t path_pool_batches = 0;   // VRT_PATH_POOL_K = 4 | 5: the bounce waves' pools; 0: 5 for small worlds with two frames in flight, else 4
     uint32_t path_lds_pad = 0;     // VRT_PATH_LDS_PAD (experiments build): bytes of LDS a bounce workgroup claims beyond its pools — fewer waves per CU
     uint32_t path_refill = 0, path_eject = ~0u;   // VRT_PATH_POOL_REFILL / _EJECT: the pool kernel's thresholds (experiments; 0 / ~0: defaults)
     uint32_t accel_builds = 0;

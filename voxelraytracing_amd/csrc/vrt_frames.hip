@@ -450,7 +450,8 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
                 P.last_bounce = 1u;
                 if (window) vrt::g_exp.path_bounce_window(P, segments, n_regions, samples, c->path_window_shape, c->path_window_lift, f.st);
                 else if (vrt::g_exp.path_bounce_cells) vrt::g_exp.path_bounce_cells(P, c->path_refill, segments, c->path_lds_pad, f.st);   // (a probe build)
-                else vrt::launch_path_bounce_cells(P, c->path_refill, segments, c->path_lds_pad, f.st);
+                else vrt::launch_path_bounce_cells(P, c->path_refill, segments, c->path_lds_pad,
+                                                   c->path_pool_batches ? c->path_pool_batches : (c->in_flight > 1u ? 5u : 4u), f.st);
                 b += segments - 1u;
             } else {
                 if (!old_pool) vrt::launch_path_bounce(P, kstats, literal, f.st);   // (a world without march cells: lane = path)
@@ -612,6 +613,7 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     if (const char *e = getenv("VRT_PATH_POOL_REFILL")) c->path_refill = (uint32_t)atoi(e);
     if (const char *e = getenv("VRT_PATH_POOL_EJECT")) c->path_eject = (uint32_t)atoi(e);
     if (const char *e = getenv("VRT_PATH_LDS_PAD")) { const long v = strtol(e, nullptr, 10); if (v >= 0 && v <= 45000) c->path_lds_pad = (uint32_t)v; }
+    if (const char *e = getenv("VRT_PATH_POOL_K")) { const int v = atoi(e); if (v == 4 || v == 5) c->path_pool_batches = (uint32_t)v; }
     if (const char *e = getenv("VRT_PATH_SAMPLES_PER_CHAIN")) { const int v = atoi(e); if (v >= 1 && v <= 16) c->path_samples = (uint32_t)v; }
     if (const char *e = getenv("VRT_TIMING_EVERY")) { const long v = strtol(e, nullptr, 10); if (v >= 1 && v <= 1000000) c->timing_every = (uint32_t)v; }
     memset(c->h_mats, 0, sizeof c->h_mats);

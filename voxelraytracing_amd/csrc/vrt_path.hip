@@ -100,7 +100,10 @@ __global__ void __launch_bounds__(256) path_bounce_kernel(FrameParams P) {
 
 
 
-template <bool DIRECT>
+// KB: batches of 64 rays in a wave's pool.  4 (256 rays, 32 waves per CU) everywhere but for small worlds with two frames in flight:
+// there 5 (320 rays, 28 waves per CU) — fewer dry tails per ray, and the four wave slots a CU keeps free let the next frame's primary
+// launch start beside this one: C4 + 2.8 % (one frame at a time - 2.2 %, C5 - 3.8 %: profiles/r05_pool_k5.txt)
+template <bool DIRECT, uint32_t KB>
 __attribute__((amdgpu_waves_per_eu(8, 8)))
 __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
     const FrameParams &K = L.P;
@@ -110,7 +113,7 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
     if (blockIdx.x == 0 && K.seg_clear) K.seg_clear[threadIdx.x * kSegStride] = 0u;   // kHitSegments == blockDim.x cursors
     __syncthreads();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    constexpr uint32_t E = kPoolEntries;
+    constexpr uint32_t E = KB * 64u, kWords = 4u * E;
 
     // this wave's paths: the workgroup takes up to 4 E records of its segment, split evenly over its waves
     const uint32_t seg = blockIdx.x % kHitSegments, part = blockIdx.x / kHitSegments;
@@ -142,14 +145,14 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
     uint32_t none = 0u;
     asm volatile("" : "+s"(none));
     const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, none));
-    float *pool = reinterpret_cast<float *>(smem + 8) + (wave + none) * kPoolWords;
-    uint16_t *order = reinterpret_cast<uint16_t *>(smem + 8 + 4u * kPoolWords) + (wave + none) * E;
+    float *pool = reinterpret_cast<float *>(smem + 8) + (wave + none) * kWords;
+    uint16_t *order = reinterpret_cast<uint16_t *>(smem + 8 + 4u * kWords) + (wave + none) * E;
     const float world_max = 0.0f + (float)P.world.size;
     const bool last_bounce = left == 1u;   // (the launch's last segment is the paths' last)
 
     // ---- A: the unit steps of every ray (nine divides, three square roots), full width ----
 #pragma unroll
-    for (uint32_t k = 0; k < kPoolBatches; k++) {
+    for (uint32_t k = 0; k < KB; k++) {
         const uint32_t i = k * 64u + lane;
         if (i < n) {
             const uint4 b = recs[in_at + P.in_cap + base + i];
@@ -356,10 +359,10 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
     // ---- between B and C: the rays that hit first, then the rays that missed (their end position is outside the world) ----
     uint32_t n_hit = 0u;
     {
-        bool hit[kPoolBatches];
-        uint32_t cnt[kPoolBatches];
+        bool hit[KB];
+        uint32_t cnt[KB];
 #pragma unroll
-        for (uint32_t k = 0; k < kPoolBatches; k++) {
+        for (uint32_t k = 0; k < KB; k++) {
             const uint32_t i = k * 64u + lane;
             hit[k] = false;
             if (i < n) {
@@ -372,7 +375,7 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
         }
         uint32_t at_hit = 0u, at_miss = n_hit;
 #pragma unroll
-        for (uint32_t k = 0; k < kPoolBatches; k++) {
+        for (uint32_t k = 0; k < KB; k++) {
             const uint32_t i = k * 64u + lane;
             const unsigned long long mh = __ballot(hit[k]), mm = __ballot(i < n && !hit[k]);
             if (hit[k]) order[at_hit + lanes_below(mh)] = (uint16_t)i;
@@ -533,15 +536,17 @@ void launch_path_primary(const FrameParams &P, bool stats, bool literal, hipStre
 
 // the pool kernel over the march cells (P.mblk): `segments` bounce segments in this one launch (every wave carries its own
 // survivors from one to the next; P.path_in / P.path_out are the two buffers it goes back and forth between)
-void launch_path_bounce_cells(const FrameParams &P, uint32_t refill_at, uint32_t segments, uint32_t lds_pad, hipStream_t st) {
+void launch_path_bounce_cells(const FrameParams &P, uint32_t refill_at, uint32_t segments, uint32_t lds_pad, uint32_t pool_batches, hipStream_t st) {
     if (P.tiles_local == 0 || segments == 0) return;
     const uint32_t refill = refill_at >= 1u && refill_at <= 64u ? refill_at : kPoolRefillAt;
-    const uint32_t parts = (P.in_seg_cap + 4u * kPoolEntries - 1u) / (4u * kPoolEntries);
+    const uint32_t kb = (pool_batches == 5u && P.march_direct) ? 5u : 4u, entries = kb * 64u;   // (320-ray pools: direct worlds only)
+    const uint32_t parts = (P.in_seg_cap + 4u * entries - 1u) / (4u * entries);
     const dim3 grid(kHitSegments * parts), block(256);
-    const size_t sh = 8u * 4u + 4u * kCellsPoolBytesPerWave + lds_pad;   // (lds_pad: the occupancy sweep of profiles/r04_path_occupancy_sweep.txt)
+    const size_t sh = 8u * 4u + 4u * (entries * 16u + entries * 2u) + lds_pad;   // per wave: the pool + a u16 order per entry (lds_pad: r04's occupancy sweep)
     const CellsLaunch L{P, refill, segments};
-    if (P.march_direct) hipLaunchKernelGGL(path_bounce_cells_kernel<true>, grid, block, sh, st, L);
-    else hipLaunchKernelGGL(path_bounce_cells_kernel<false>, grid, block, sh, st, L);
+    if (kb == 5u) hipLaunchKernelGGL((path_bounce_cells_kernel<true, 5u>), grid, block, sh, st, L);
+    else if (P.march_direct) hipLaunchKernelGGL((path_bounce_cells_kernel<true, 4u>), grid, block, sh, st, L);
+    else hipLaunchKernelGGL((path_bounce_cells_kernel<false, 4u>), grid, block, sh, st, L);
 }
 
 void launch_path_bounce(const FrameParams &P, bool stats, bool literal, hipStream_t st) {
