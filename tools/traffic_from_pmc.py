@@ -55,7 +55,7 @@ pick = {"primary_shadow_march": (["primary_shadow_wave_kernel<0, false, false, 4
         "primary_march": (["primary_tile_kernel<0, false, false, true>", "primary_tile_kernel<0, false, false, false>"], True),
         "shadow_march": (["shadow_kernel<0, false, false>"], True),
         "path_primary_march": (["path_primary_kernel<0, false, false, false, false>", "path_primary_kernel<0, false, false, true, false>"], False),
-        "path_bounce_marches": (["path_bounce_cells_kernel<true>(vrt::CellsLaunch)", "path_bounce_cells_kernel<false>(vrt::CellsLaunch)"], False)}
+        "path_bounce_marches": (["path_bounce_cells_kernel<true, 5u>(vrt::CellsLaunch)", "path_bounce_cells_kernel<true, 4u>(vrt::CellsLaunch)", "path_bounce_cells_kernel<false, 4u>(vrt::CellsLaunch)"], False)}
 frames = 8.0   # tools/pmc.sh: bench.py --steps 6 --warmup 2, standing camera, no extra legs
 kernels = {}
 for k, (names, use_mix) in pick.items():
