@@ -10,7 +10,7 @@ hit (config C2; scene, derived tables and ndc tables resident in HBM before the 
 the reference frame loop's whole seam (clientdesktop/src/main.rs:426-453: settings, camera, chunk_roots, world data,
 dispatch) with a camera that orbits slowly, so the frames in flight are different frames; `value_fixed_camera` is the
 same loop with the camera standing still and `value_1_in_flight` the standing camera with one launch at a time (a view
-at rest: its tiles are launched longest first; `--frames-in-flight 1` gives the orbiting one-at-a-time loop, screen order).
+at rest: its tiles are launched longest first; `--frames-in-flight 1` gives the orbiting one-at-a-time loop, a kept block order).
 
 N > 1: the frame is sharded by interleaved 8x8 screen tiles (total work fixed: "strong" scaling), one process per GPU
 over RCCL (under torch.distributed.run, or started by this script itself when WORLD_SIZE is not set), or — with
@@ -482,7 +482,7 @@ def main():
                 extras["avg_bounce_launches_ms_1_in_flight"] = k1.sum_ms_secondary / max(k1.frames, 1)
             if not fixed:
                 # ... and what a host that renders one moving-camera frame at a time gets: the orbit, the whole seam per frame,
-                # screen order (a tile order made for another view is worse than none)
+                # a block order kept while the camera stays within what its dilation covers (vrt.h: vrt_set_frames_in_flight)
                 frame_no[0] = 0
                 run_frames(gpu, fg, 50, False)
                 frame_no[0] = 0

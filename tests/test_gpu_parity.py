@@ -2,6 +2,7 @@
 
 Bar (BASELINE.json north_star): id words bit-exact, f32 radiance within 1e-4.
 """
+import math
 import numpy as np
 import pytest
 
@@ -925,13 +926,15 @@ def test_samples_per_launch_chain_do_not_change_the_frame(orc, monkeypatch, per_
 
 @pytest.mark.parametrize("form", ["1", "2", "6"])
 def test_tiles_ordered_under_a_moving_camera_are_the_same_frames(orc, monkeypatch, form):
-    """VRT_TILE_ORDER_MOVING=1 (round 5: ONE launch that sorts blocks of 4 x 4 tiles, launch_tile_order_blocks) / 6 (round 4: six
-    small launches, experiments build): a one-frame-at-a-time context keeps launching its tiles longest first while the camera MOVES — the order made
-    from the frame before, its trips dilated over the image motion of a camera step (vrt_kernels.hip:
-    launch_tile_order_moving).  A walk of small steps (the bench's orbit step: < 1 voxel, ~ 1 degree), a rest, a jump (screen
-    order again), more steps: every frame is the screen-order context's frame, the last one the oracle's; and the counter
-    says which frames were ordered."""
-    needs_experiments()                                # (built, measured, not chosen: profiles/r04_tile_order_moving.txt, r05_tile_order_moving.txt)
+    """A one-frame-at-a-time context keeps launching its tiles longest first while the camera MOVES.  Form 1, the default (round 5):
+    ONE launch sorts blocks of 4 x 4 tiles by their trips dilated over the image motion of several camera steps
+    (vrt_kernels.hip: launch_tile_order_blocks), and the order is kept while the camera stays within what the dilation covers.
+    Forms 2 (that launch beside the next frame, every frame) and 6 (round 4: six small launches behind every frame) are the
+    experiments build's.  A walk of small steps (the bench's orbit step: < 1 voxel, ~ 1 degree), a rest, a jump (screen order
+    again), more steps: every frame is the screen-order context's frame, the last one the oracle's; and the counter says which
+    frames were ordered."""
+    if form != "1":
+        needs_experiments()                            # (built, measured, not chosen: profiles/r04_tile_order_moving.txt, r05_tile_order_moving.txt)
     from voxelraytracing_amd import graphics as g
     sc = scenes.c2()
     monkeypatch.setenv("VRT_TILE_ORDER_MOVING", form)
@@ -970,13 +973,18 @@ def test_tiles_ordered_under_a_moving_camera_are_the_same_frames(orc, monkeypatc
     o.set_cam(cam)
     r_rgb, r_ids, _, _ = o.render(MODE_PRIMARY_SHADOW, 1920, 1080)
     assert_frame_parity(a_rgb, a_ids, r_rgb, r_ids, "tiles ordered under a moving camera")
-    # the default is round 3's rule: screen order whenever the view has changed
+    # the default is form 1; VRT_TILE_ORDER_MOVING=0 is round 3's rule: screen order whenever the view has changed
+    dflt = gpu_for_scene(sc)
+    monkeypatch.setenv("VRT_TILE_ORDER_MOVING", "0")
     old = gpu_for_scene(sc)
-    old.set_frames_in_flight(1)
-    for k in range(4):
-        old.write_cam_data(cam_at(k))
-        old.render(MODE_PRIMARY_SHADOW)
-    assert old.accel_info().ordered_frames == 0
+    monkeypatch.delenv("VRT_TILE_ORDER_MOVING")
+    for gpu in (dflt, old):
+        gpu.set_frames_in_flight(1)
+        for k in range(4):
+            gpu.write_cam_data(cam_at(k))
+            gpu.render(MODE_PRIMARY_SHADOW)
+    assert dflt.accel_info().ordered_frames == 3 and old.accel_info().ordered_frames == 0
+    dflt.close()
     for gpu in (mov, ref, old):
         gpu.close()
 
@@ -986,7 +994,6 @@ def test_block_order_on_other_frame_shapes(monkeypatch, size):
     """The one-launch order of a moving view (launch_tile_order_blocks) on a 4K frame (8 160 blocks: 96 KiB of LDS, opted in), on one
     whose tile rows and columns are not multiples of four, and on a single row of tiles: the frames of a walking camera equal the
     screen-order context's, and the order is really used."""
-    needs_experiments()
     from voxelraytracing_amd import graphics as g
     sc = scenes.c2(size)
     monkeypatch.setenv("VRT_TILE_ORDER_MOVING", "1")
@@ -1006,6 +1013,44 @@ def test_block_order_on_other_frame_shapes(monkeypatch, size):
         assert np.array_equal(a_ids, b_ids) and np.array_equal(a_rgb, b_rgb), k
     tiles = (size[0] // 8) * (size[1] // 8)
     assert mov.accel_info().ordered_frames == (4 if tiles >= 128 else 0)   # (a frame of fewer than 128 tiles is not ordered at all)
+    assert ref.accel_info().ordered_frames == 0
+    mov.close(); ref.close()
+
+
+@pytest.mark.parametrize("pace", ["walk", "run", "leap"])
+def test_a_kept_block_order_serves_the_frames_it_covers_and_no_others(monkeypatch, pace):
+    """The moving view's order is KEPT (vrt_frames.hip: hold_limits): a walk of the bench's orbit step for 30 frames is
+    ordered from its second frame on — the order is made again before the camera leaves what its dilation covers, never after —;
+    at 4 degrees a step an order serves a few frames and is made again; at 40 degrees and 10 voxels a step no order is ever used, and the
+    context stops asking for them.  Every frame is the screen-order context's."""
+    from voxelraytracing_amd import graphics as g
+    sc = scenes.c2((640, 360))
+    mov = gpu_for_scene(sc)
+    mov.set_frames_in_flight(1)
+    monkeypatch.setenv("VRT_TILE_ORDER", "0")
+    ref = gpu_for_scene(sc)
+    ref.set_frames_in_flight(1)
+    monkeypatch.delenv("VRT_TILE_ORDER")
+    step = {"walk": (0.3, 0.9, 0.6), "run": (0.5, 4.0, 1.5), "leap": (1.0, 40.0, 20.0)}[pace]
+    used, before = [], 0
+    for k in range(30):
+        cam = g.cam_data_create((sc.rot[0] + step[0] * (k % 7), sc.rot[1] + step[1] * k, 0.0), (sc.eye[0] + step[2] * math.cos(0.1 * k) * k / 3.0, sc.eye[1], sc.eye[2] - step[2] * k / 2.0),
+                                70.0, (640.0, 360.0))
+        for gpu in (mov, ref):
+            gpu.write_cam_data(cam)
+            gpu.render(MODE_PRIMARY_SHADOW)
+        a_rgb, a_ids, _ = mov.read_output()
+        b_rgb, b_ids, _ = ref.read_output()
+        assert np.array_equal(a_ids, b_ids) and np.array_equal(a_rgb, b_rgb), k
+        n = mov.accel_info().ordered_frames
+        used.append(n - before)
+        before = n
+    if pace == "walk":
+        assert used == [0] + [1] * 29, used
+    elif pace == "run":
+        assert 10 <= sum(used) <= 29 and used[0] == 0, used
+    else:
+        assert sum(used) == 0, used
     assert ref.accel_info().ordered_frames == 0
     mov.close(); ref.close()
 

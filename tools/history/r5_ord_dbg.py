@@ -1,6 +1,6 @@
 import ctypes as C, numpy as np, os, sys
 sys.path.insert(0, os.getcwd())
-os.environ["VRT_TILE_ORDER_MOVING"] = "1"   # (tools/ab/build_variant.sh orddbg "-DVRT_EXP_ORDDBG"; VRT_LIB=tools/ab/libvrt_orddbg.so)
+os.environ["VRT_TILE_ORDER_MOVING"] = "1"   # (history: the order kernel carried per-phase clock stamps under -DVRT_EXP_ORDDBG while it lived in the experiments build; they went when it became the product's)
 from voxelraytracing_amd import Gpu, MODE_PRIMARY_SHADOW, _ffi, scenes, graphics as g
 sc = scenes.c2()
 gpu = Gpu(sc.world.max_nodes(), sc.world.size_in_chunks(), sc.size)

@@ -5,7 +5,6 @@
 namespace vrt {
 void launch_primary_shadow_persistent(const FrameParams &P, uint32_t *heads, uint32_t n_cus, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
 void launch_tile_order_moving(uint32_t *cost, uint32_t tiles_x, uint32_t tiles_y, uint32_t shift, uint32_t radius, uint32_t *scratch, uint32_t *order, hipStream_t st);
-bool launch_tile_order_blocks(const uint32_t *cost, uint32_t tiles_x, uint32_t tiles_y, uint32_t shift, uint32_t radius, uint32_t *order, hipStream_t st, uint32_t threads);
 void launch_path_persistent(const FrameParams &P, uint32_t *heads, uint32_t n_cus, hipStream_t st);
 void launch_path_bounce_pool(const FrameParams &P, bool continuations, uint32_t refill_at, uint32_t eject_at, hipStream_t st);
 void launch_path_primary_grouped(const FrameParams &P, hipStream_t st);
@@ -17,7 +16,7 @@ struct Register {
     Register() {
         g_exp.primary_shadow_persistent = launch_primary_shadow_persistent;
         g_exp.tile_order_moving = launch_tile_order_moving;
-        g_exp.tile_order_blocks = launch_tile_order_blocks;
+        g_exp.tile_order_beside = true;
         g_exp.path_persistent = launch_path_persistent;
         g_exp.path_bounce_pool = launch_path_bounce_pool;
         g_exp.path_primary_grouped = launch_path_primary_grouped;

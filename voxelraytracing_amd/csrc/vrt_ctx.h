@@ -43,6 +43,7 @@ void launch_path_bounce(const FrameParams &P, bool stats, bool literal, hipStrea
 void launch_path_bounce_cells(const FrameParams &P, uint32_t refill_at, uint32_t segments, uint32_t lds_pad, uint32_t pool_batches, hipStream_t st);
 void launch_path_finish(Texel *out, uint32_t n, uint32_t spp, hipStream_t st);
 void launch_tile_order(const uint32_t *cost, uint32_t n, uint32_t shift, uint32_t *scratch, uint32_t *order, hipStream_t st);
+bool launch_tile_order_blocks(const uint32_t *cost, uint32_t tiles_x, uint32_t tiles_y, uint32_t shift, uint32_t radius, uint32_t *order, hipStream_t st, uint32_t threads);
 void launch_path_chain_finish(Texel *out, const Texel *acc, uint32_t n, uint32_t chain, bool first, bool last, uint32_t spp, hipStream_t st);
 void launch_quantize(const Texel *out, uint8_t *rgba8, uint32_t w, uint32_t h, hipStream_t st);
 void launch_assemble(const Texel *gathered, Texel *dst, uint32_t width, uint32_t tiles_x, uint32_t tiles_total,
@@ -254,13 +255,16 @@ struct vrt_ctx {
     uint32_t view_gen = 0;              // counts the changes of anything a tile's trips depend on
     uint32_t frame_view_gen = ~0u;      // ... as of the last frame rendered
     uint32_t order_view_gen = ~0u;      // ... as of the frame the order was made from
-    // ... and while the view MOVES: every such frame notes its trips, and the order for the next frame is made from them dilated
-    // over the image motion a camera step can cause — used by a frame whose camera is close to the one the trips were noted
-    // under and whose view differs from it in the camera only.  1 (VRT_TILE_ORDER_MOVING=1): round 5's ONE launch over blocks of
-    // 4 x 4 tiles (vrt_kernels.hip: launch_tile_order_blocks); 6: round 4's six small launches (experiments build: the frame's
-    // launch 112.4 -> 106.0 us, the six launches 17 us of the stream, profiles/r04_tile_order_moving.txt); 0: screen order while
-    // the view moves
-    uint32_t tile_lpt_moving = 0;
+    // ... and while the view MOVES (1, the default): a frame notes its trips, ONE launch behind it sorts blocks of 4 x 4 tiles by
+    // their trips dilated over `mov_radius` blocks (vrt_kernels.hip: launch_tile_order_blocks, ~ 17 us), and the order is KEPT for
+    // the frames that follow while their camera stays within what the dilation covers (hold_limits: ~ 8 of the bench's orbit steps)
+    // and nothing but the camera has changed; the frame that comes near the edge of that notes its trips for the next order.  A
+    // view that moves too fast for its orders to be used stops asking for them (mov_backoff).  One frame at a time, orbit:
+    // 112.8 -> 109.1 us per frame (profiles/r05_tile_order_moving.txt).  0 (VRT_TILE_ORDER_MOVING=0): screen order while the
+    // view moves.  Experiments build: 6 = round 4's six small launches behind every frame, 2 = the one launch beside the next frame.
+    uint32_t tile_lpt_moving = 1;
+    uint32_t order_uses = 0;            // frames that used the dilated order in d_tile_order
+    uint32_t mov_backoff = 0, mov_skip = 0;   // moving frames that go without asking for an order (doubles while orders go unused)
     // 2 (VRT_TILE_ORDER_MOVING=2): the order of a moving view made BESIDE the frame in between — frame k's trips are sorted on a
     // side stream while frame k + 1 runs, and frame k + 2 launches in that order (dilated over two camera steps): the order
     // costs the frames' stream nothing.  Two sets of trips / order buffers alternate; `mov_pend` is the order being made.
@@ -270,7 +274,8 @@ struct vrt_ctx {
     hipStream_t mov_stream = nullptr;
     hipEvent_t mov_frame_done[2] = {nullptr, nullptr}, mov_order_done[2] = {nullptr, nullptr};
     bool mov_order_recorded[2] = {false, false}, mov_pending = false, mov_side = true;   // (mov_side false: on the frames' own stream, for A/B)
-    uint32_t mov_count = 0, mov_radius = 3, mov_threads = 256;   // (a small workgroup finds room beside the frame's: VRT_TILE_ORDER_THREADS)
+    bool mov_radius_set = false, mov_any_size = false;
+    uint32_t mov_count = 0, mov_radius = 5, mov_threads = 256;   // (a small workgroup finds room beside the frame's: VRT_TILE_ORDER_THREADS)
     // vrt_present*: whether a window of (one_w x one_h) over a texture of the same size samples every texel at its centre
     uint32_t one_w = 0, one_h = 0;
     bool one_to_one = false;

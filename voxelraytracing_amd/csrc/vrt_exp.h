@@ -16,10 +16,10 @@ namespace vrt {
 struct ExpHooks {
     // primary + shadow as a persistent grid over per-XCD tile queues (vrt_render_opts.variant = 4)
     void (*primary_shadow_persistent)(const FrameParams &P, uint32_t *heads, uint32_t n_cus, hipStream_t st, hipEvent_t e0, hipEvent_t e1) = nullptr;
-    // the tile order of a moving view (VRT_TILE_ORDER_MOVING=1)
+    // the tile order of a moving view as round 4's six small launches behind every frame (VRT_TILE_ORDER_MOVING=6)
     void (*tile_order_moving)(uint32_t *cost, uint32_t tiles_x, uint32_t tiles_y, uint32_t shift, uint32_t radius, uint32_t *scratch, uint32_t *order, hipStream_t st) = nullptr;
-    // ... as ONE launch over blocks of 4 x 4 tiles (VRT_TILE_ORDER_MOVING=1), also made beside the next frame on a side stream (= 2)
-    bool (*tile_order_blocks)(const uint32_t *cost, uint32_t tiles_x, uint32_t tiles_y, uint32_t shift, uint32_t radius, uint32_t *order, hipStream_t st, uint32_t threads) = nullptr;
+    // ... the shipping one-launch order made beside the next frame on a side stream, every frame (VRT_TILE_ORDER_MOVING=2)
+    bool tile_order_beside = false;
     // the path trace as one launch of persistent waves (VRT_PATH_PERSISTENT=1)
     void (*path_persistent)(const FrameParams &P, uint32_t *heads, uint32_t n_cus, hipStream_t st) = nullptr;
     // the round-2 pool kernel over cell grid + bricks, with its straggler chain (VRT_PATH_CELLS=0, VRT_PATH_POOL_CHAIN=1)

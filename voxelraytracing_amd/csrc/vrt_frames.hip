@@ -597,12 +597,13 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
     }
     if (const char *e = getenv("VRT_TILE_ORDER")) c->tile_lpt = e[0] != '0';
     // switches of the experiments build (tools/ab/libvrt_exp.so): without its hooks (vrt_exp.h) the first seven select nothing
-    // (the orders of a moving view: built, measured, not chosen — profiles/r05_tile_order_moving.txt; the experiments build's hooks)
+    // (0: screen order while the view moves; 2, 6: the experiments build's forms — profiles/r05_tile_order_moving.txt)
     if (const char *e = getenv("VRT_TILE_ORDER_MOVING"))
-        c->tile_lpt_moving = e[0] == '6' ? (vrt::g_exp.tile_order_moving ? 6u : 0u) : !vrt::g_exp.tile_order_blocks ? 0u : e[0] == '2' ? 2u : e[0] != '0' ? 1u : 0u;
+        c->tile_lpt_moving = e[0] == '6' ? (vrt::g_exp.tile_order_moving ? 6u : 1u) : e[0] == '2' ? (vrt::g_exp.tile_order_beside ? 2u : 1u) : e[0] != '0' ? 1u : 0u;
+    c->mov_any_size = getenv("VRT_TILE_ORDER_MOVING") != nullptr;   // (asked for by name: also for frames larger than kMovingTilesMax)
     if (const char *e = getenv("VRT_TILE_ORDER_SIDE")) c->mov_side = e[0] != '0';
     if (const char *e = getenv("VRT_TILE_ORDER_THREADS")) { const int v = atoi(e); if (v >= 64 && v <= 1024) c->mov_threads = (uint32_t)v; }
-    if (const char *e = getenv("VRT_TILE_ORDER_RADIUS")) { const int v = atoi(e); if (v >= 1 && v <= 4) c->mov_radius = (uint32_t)v; }
+    if (const char *e = getenv("VRT_TILE_ORDER_RADIUS")) { const int v = atoi(e); if (v >= 1 && v <= 6) { c->mov_radius = (uint32_t)v; c->mov_radius_set = true; } }
     if (const char *e = getenv("VRT_PATH_PERSISTENT")) c->path_persistent = e[0] == '1';
     if (const char *e = getenv("VRT_PATH_POOL")) c->path_pool = e[0] != '0';
     if (const char *e = getenv("VRT_PATH_POOL_CHAIN")) c->path_chain = e[0] == '1';
@@ -712,22 +713,42 @@ void vrt_destroy(vrt_ctx *c) {
 
 const char *vrt_last_error(const vrt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
-// Whether a tile order made from camera a's frame, dilated over ~ 10 tiles each way, still serves camera b: the same projection,
-// the eye within a voxel and a half, every axis of the view within two degrees (a NaN camera is close to nothing).
-static bool cameras_close(const vrt_cam_data &a, const vrt_cam_data &b, float steps = 1.0f) {   // steps: camera steps the order is to hold for
+// Whether camera b is near camera a: the same projection, the eye within `voxels`, every axis of the view within the angle whose
+// cosine is `cos_angle` (a NaN camera is near nothing).
+static bool cameras_within(const vrt_cam_data &a, const vrt_cam_data &b, float voxels, float cos_angle) {
     if (memcmp(a.inv_proj_mat, b.inv_proj_mat, sizeof a.inv_proj_mat) != 0 || memcmp(a.proj_size, b.proj_size, sizeof a.proj_size) != 0) return false;
     float d2 = 0.f;
     for (int k = 0; k < 3; k++) d2 += (a.pos[k] - b.pos[k]) * (a.pos[k] - b.pos[k]);
-    if (!(d2 <= 2.25f * steps * steps)) return false;
+    if (!(d2 <= voxels * voxels)) return false;
     for (int col = 0; col < 3; col++) {
         float dot = 0.f, na = 0.f, nb = 0.f;
         for (int k = 0; k < 3; k++) {
             const float x = a.inv_view_mat[4 * col + k], y = b.inv_view_mat[4 * col + k];
             dot += x * y; na += x * x; nb += y * y;
         }
-        if (!(dot >= (steps > 1.5f ? 0.99756f : 0.99939f) * sqrtf(na * nb))) return false;   // cos 4 / 2 degrees
+        if (!(dot >= cos_angle * sqrtf(na * nb))) return false;
     }
     return true;
+}
+// Whether a tile order made from camera a's frame, dilated over ~ 10 tiles each way, still serves camera b `steps` camera steps on:
+// the eye within a voxel and a half per step, every axis of the view within two (four) degrees.
+static bool cameras_close(const vrt_cam_data &a, const vrt_cam_data &b, float steps = 1.0f) {
+    return cameras_within(a, b, 1.5f * steps, steps > 1.5f ? 0.99756f : 0.99939f);
+}
+// ... and the kept order of the default: a block order dilated over `radius` blocks of 32 pixels each way serves the views whose
+// image has moved by less — every axis of the view within three quarters of the angle that many pixels are (1080p at 70 degrees,
+// radius 5: 8.9 degrees), the eye within 1.3 voxels per block (6.5) — and is made again by the frame that passes three quarters
+// of that.  The bench's orbit (0.8 voxels and ~ 1 degree a step) is served for 8 steps: the best of the sweep in
+// profiles/r05_tile_order_moving.txt.
+constexpr uint32_t kMovingTilesMax = 40000u;
+struct HoldLimits { float voxels, cos_hold, cos_refresh; };
+static HoldLimits hold_limits(const vrt_cam_data &cam, uint32_t width, uint32_t height, uint32_t radius) {
+    const float ax = fabsf(cam.inv_proj_mat[0]), ay = fabsf(cam.inv_proj_mat[5]);   // the tangents of half the field of view
+    float per_rad = fminf(0.5f * (float)width / ax, 0.5f * (float)height / ay);    // pixels per radian at the image's centre
+    float angle = 0.75f * 32.0f * (float)radius / per_rad;
+    if (!(angle >= 0.0f) || !(per_rad > 0.0f)) angle = 0.0f;                         // (a projection that is not one: only the same camera is near)
+    angle = fminf(angle, 0.5f);
+    return HoldLimits{1.3f * (float)radius, cosf(angle), cosf(0.75f * angle)};
 }
 
 int vrt_set_camera(vrt_ctx *c, const vrt_cam_data *cam) {
@@ -950,13 +971,20 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
             c->tile_buf_tiles = c->tiles_local;
             c->tile_order_valid = false;
         }
-        // an order is used by the very view it was made from, or — a dilated one — by a view a camera step away from it
+        // an order is used by the very view it was made from, or — a dilated one — by a view whose camera the dilation still covers
         const bool exact = c->tile_order_valid && !c->order_dilated && c->order_view_gen == c->view_gen;
-        const bool moving_ok = c->tile_lpt_moving && c->tiles_local == P.tiles_total && P.tiles_total % P.tiles_x == 0u;
+        // (a 4K frame's order is 8 160 blocks to sort — ~ 50 us —, holds for half as many camera steps, and shortens a 354-us frame
+        // by the same ~ 5 us: 364 us per frame against 354 in screen order.  Frames of up to kMovingTilesMax tiles — 1080p: 32 400 — ask.)
+        const bool moving_ok = c->tile_lpt_moving && c->tiles_local == P.tiles_total && P.tiles_total % P.tiles_x == 0u &&
+                               (P.tiles_total <= kMovingTilesMax || c->mov_any_size);
+        const bool hold = c->tile_lpt_moving == 1u;   // (6: an order a frame, for the very next one)
+        const HoldLimits lim = hold_limits(c->cam, c->width, c->height, c->mov_radius);
         const bool near = !mov2 && c->tile_order_valid && c->order_dilated && moving_ok &&
-                          c->view_gen - c->order_view_gen == c->cam_gen - c->order_cam_gen && cameras_close(c->order_cam, c->cam);
+                          c->view_gen - c->order_view_gen == c->cam_gen - c->order_cam_gen &&
+                          (hold ? cameras_within(c->order_cam, c->cam, lim.voxels, lim.cos_hold) : cameras_close(c->order_cam, c->cam));
         if (!exact && !near) c->tile_order_valid = false;   // the order of another view: worse than none
         if (c->tile_order_valid) { P.tile_order = c->d_tile_order; c->ordered_frames++; }
+        if (near) c->order_uses++;
         if (mov2 && moving_ok) {
             if (!c->d_mov_cost[0]) {
                 for (int k = 0; k < 2; k++) {
@@ -978,7 +1006,12 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
         }
         if (!exact) {
             if (c->frame_view_gen == c->view_gen) tile_sort = true;   // the view has come to rest: this frame notes its trips
-            else if (moving_ok) tile_sort = dilate = true;            // it moves: the next frame's order from this frame's trips, dilated
+            else if (moving_ok && !hold) tile_sort = dilate = true;   // it moves: the next frame's order from this frame's trips, dilated
+            else if (moving_ok && !(near && cameras_within(c->order_cam, c->cam, 0.75f * lim.voxels, lim.cos_refresh))) {
+                // it moves and has no order, or is about to leave the one it has: this frame's trips, dilated, for the frames to come
+                if (c->mov_skip) c->mov_skip--;
+                else tile_sort = dilate = true;
+            }
         }
         // an order made before a chunk was edited: kept for the edit's own frame, made again by the first frame behind it
         // that has no fresh edit in front of it (its launch reads the old order, the sort behind it writes the new one)
@@ -1010,7 +1043,7 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
                 HIP_TRY(c, hipEventRecord(c->mov_frame_done[mov_wb], f.st));
                 HIP_TRY(c, hipStreamWaitEvent(os, c->mov_frame_done[mov_wb], 0));
             }
-            made = vrt::g_exp.tile_order_blocks(c->d_mov_cost[mov_wb], P.tiles_x, P.tiles_total / P.tiles_x, 1u, c->mov_radius, c->d_mov_order[mov_wb], os,
+            made = vrt::launch_tile_order_blocks(c->d_mov_cost[mov_wb], P.tiles_x, P.tiles_total / P.tiles_x, 1u, c->mov_radius_set ? c->mov_radius : 3u, c->d_mov_order[mov_wb], os,
                                                  c->mov_side ? c->mov_threads : 1024u);
             HIP_TRY(c, hipGetLastError());
             if (c->mov_side) {
@@ -1026,7 +1059,13 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
             c->mov_count++;
         } else {
         if (dilate && c->tile_lpt_moving == 6u) vrt::g_exp.tile_order_moving(c->d_tile_cost, P.tiles_x, P.tiles_total / P.tiles_x, 1u, 2u, c->d_tile_scratch, c->d_tile_order, f.st);
-        else if (dilate) made = vrt::g_exp.tile_order_blocks(c->d_tile_cost, P.tiles_x, P.tiles_total / P.tiles_x, 1u, 2u, c->d_tile_order, f.st, 1024u);
+        else if (dilate) {
+            made = vrt::launch_tile_order_blocks(c->d_tile_cost, P.tiles_x, P.tiles_total / P.tiles_x, 1u, c->mov_radius, c->d_tile_order, f.st, 1024u);
+            // orders that are not used — the view moves further per frame than they cover — are asked for less and less often
+            c->mov_backoff = c->order_dilated && c->order_uses < 2u ? (c->mov_backoff ? (c->mov_backoff < 64u ? c->mov_backoff * 2u : 64u) : 1u) : 0u;
+            c->mov_skip = c->mov_backoff;
+            c->order_uses = 0;
+        }
         else
         vrt::launch_tile_order(c->d_tile_cost, c->tiles_local, 1u, c->d_tile_scratch, c->d_tile_order, f.st);   // classes of two trips
         HIP_TRY(c, hipGetLastError());
