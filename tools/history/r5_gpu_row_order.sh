@@ -1,5 +1,6 @@
 #!/bin/bash
 # tools/r5/gpu_row_order.sh — the moving view's order once more, cheaper: made once in K camera steps (VRT_TILE_ORDER_EVERY) and, with
+# (history: VRT_TILE_ORDER_EVERY and the row-wise radius codes existed in the experiments build of commit 2325149+ only; the kept order that came of the sweep is the default now — tools/r5/gpu_kept_order.sh)
 # VRT_TILE_ORDER_RADIUS >= 100, by block ROWS (a turn of the view leaves a row's cost alone).  Experiments build, one frame at a time.
 mkdir -p gpurun_out
 run() {   # moving-mode every radius
