@@ -25,6 +25,8 @@ rows = [
     ("... one frame at a time, orbit", f["value_1_in_flight_orbit"], f["ms_per_step_1_in_flight_orbit"], None, f"`{R}_final_bench.json`"),
     ("... the client's real frame: 30^3-chunk grid, untagged `chunk_roots` rewrite, render + blit", f["operating_point"]["2_in_flight"]["value"],
      f["operating_point"]["2_in_flight"]["ms_per_frame"], None, f"`{R}_final_bench.json` (`operating_point`)"),
+    ("... the client's real frame, one frame at a time", f["operating_point"]["1_in_flight"]["value"],
+     f["operating_point"]["1_in_flight"]["ms_per_frame"], None, f"`{R}_final_bench.json` (`operating_point`)"),
     ("primary rays only", pr["value"], pr["ms_per_step"], fr(pr), f"`{R}_final_bench_primary.json`"),
     ("C3's shape on one GPU: 16^3 chunks", c3["value"], c3["ms_per_step"], fr(c3), f"`{R}_final_bench_c3shape.json`"),
     ("3840x2160 over C5's 32^3 world, primary + shadow", c5s["value"], c5s["ms_per_step"], fr(c5s), f"`{R}_final_bench_c5shape.json`"),
