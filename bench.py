@@ -361,7 +361,9 @@ def main():
         if args.root_weight > 0:
             root_weight = args.root_weight
         else:
-            tuning = {w0: trial(w0, batch) for w0 in (1, 2, 3, 4, 6, 8, 12, 16)}
+            # (32 and 128: the root keeps nearly the whole frame — the floor if the links turn out slower than the model's 60 GB/s,
+            # so that a sharded run is never much slower than one GPU)
+            tuning = {w0: trial(w0, batch) for w0 in (1, 2, 3, 4, 6, 8, 12, 16, 32, 128)}
             root_weight = min(tuning, key=lambda k: (tuning[k], k))
         if args.gather_batch == 0 and not rehearsal:
             batch_tuning = {b: trial(root_weight, b) for b in (1, 2, 4, 8)}
