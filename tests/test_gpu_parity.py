@@ -52,6 +52,35 @@ def test_c1_flat_matches_oracle(c1, orc, mode, variant):
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
+def test_a_world_no_chunk_of_which_has_arrived(orc, variant):
+    """The client's first frames (client/src/world.rs:259-295: the grid exists, `chunk_roots()` is all zeros until GiveChunkData
+    arrives — every chunk resolves to pool[0], the permanent air leaf, a free 32^3 cell): primary, primary + shadow and a
+    path-traced frame of a 4^3-chunk world without a single chunk, the camera inside and looking down across it — ids, per-pixel
+    step counts and the ray counts against the oracle (every ray crosses the grid in 32-voxel steps and leaves: sky everywhere)."""
+    from voxelraytracing_amd.world import ClientWorld
+    world = ClientWorld((2, 2, 2), 1 << 14, 4)
+    assert not np.any(world.chunk_roots())
+    sc = scenes._scene("empty 4^3", world, (160, 96), (64.5, 100.5, 64.5), (35.0, 20.0, 0.0), MODE_PRIMARY_SHADOW)
+    gpu = gpu_for_scene(sc)
+    o = orc.from_package_scene(sc)
+    for mode in (MODE_PRIMARY, MODE_PRIMARY_SHADOW):
+        gpu.render(mode, variant=variant, stats=True)
+        rgb, ids, _ = gpu.read_output()
+        r_rgb, r_ids, r_steps, st = o.render(mode, *sc.size, want_steps=True)
+        assert_frame_parity(rgb, ids, r_rgb, r_ids, f"empty world, mode {mode}")
+        assert np.array_equal(gpu.read_steps(), r_steps)
+        s = gpu.stats()
+        assert (s.primary_rays, s.secondary_rays, s.hits) == (st.primary_rays, st.secondary_rays, st.hits) == (160 * 96, 0, 0)
+        assert r_steps.max() <= 8 and r_steps.min() >= 1
+    if variant == 0:
+        gpu.render(MODE_PATH, spp=2, seed=5)
+        rgb, ids, _ = gpu.read_output()
+        r_rgb, r_ids, _, _ = o.render(MODE_PATH, *sc.size, spp=2, seed=5)
+        assert_frame_parity(rgb, ids, r_rgb, r_ids, "empty world, path trace")
+    gpu.close()
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("mode", [MODE_PRIMARY, MODE_PRIMARY_SHADOW])
 def test_c2_procedural_matches_oracle(c2_small, orc, mode, variant):
     gpu = gpu_for_scene(c2_small)
