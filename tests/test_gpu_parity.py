@@ -1048,7 +1048,7 @@ def test_block_order_on_other_frame_shapes(monkeypatch, size):
 
 @pytest.mark.parametrize("pace", ["walk", "run", "leap"])
 def test_a_kept_block_order_serves_the_frames_it_covers_and_no_others(monkeypatch, pace):
-    """The moving view's order is KEPT (vrt_frames.hip: hold_limits): a walk of the bench's orbit step for 30 frames is
+    """The moving view's order is KEPT (vrt_order.hip: hold_limits): a walk of the bench's orbit step for 30 frames is
     ordered from its second frame on — the order is made again before the camera leaves what its dilation covers, never after —;
     at 4 degrees a step an order serves a few frames and is made again; at 40 degrees and 10 voxels a step no order is ever used, and the
     context stops asking for them.  Every frame is the screen-order context's."""

@@ -1,5 +1,5 @@
 """tools/soak_order.py [seconds] [seed] — a long random session of a one-frame-at-a-time context whose tile order follows the view
-(the exact order of a view at rest, the KEPT block order of a moving one: csrc/vrt_frames.hip, hold_limits) against a context that
+(the exact order of a view at rest, the KEPT block order of a moving one: csrc/vrt_order.hip, hold_limits) against a context that
 always launches in screen order (VRT_TILE_ORDER=0): camera steps of every size (the bench's orbit step, strides, leaps), rests,
 voxel edits in front of frames, changes of settings, of the mode, of the number of frames in flight, resizes of the result texture —
 the same calls to both, and EVERY frame compared word for word.  Any order of the tiles is the same frame; what this looks for is an

@@ -257,7 +257,7 @@ struct vrt_ctx {
     uint32_t order_view_gen = ~0u;      // ... as of the frame the order was made from
     // ... and while the view MOVES (1, the default): a frame notes its trips, ONE launch behind it sorts blocks of 4 x 4 tiles by
     // their trips dilated over `mov_radius` blocks (vrt_kernels.hip: launch_tile_order_blocks, ~ 17 us), and the order is KEPT for
-    // the frames that follow while their camera stays within what the dilation covers (hold_limits: ~ 8 of the bench's orbit steps)
+    // the frames that follow while their camera stays within what the dilation covers (vrt_order.hip, hold_limits: ~ 8 of the bench's orbit steps)
     // and nothing but the camera has changed; the frame that comes near the edge of that notes its trips for the next order.  A
     // view that moves too fast for its orders to be used stops asking for them (mov_backoff).  One frame at a time, orbit:
     // 112.8 -> 109.1 us per frame (profiles/r05_tile_order_moving.txt).  0 (VRT_TILE_ORDER_MOVING=0): screen order while the
@@ -402,6 +402,11 @@ VRT_HIDDEN hipError_t zero_now(vrt_ctx *c, void *p, size_t bytes);
 VRT_HIDDEN int validate_frame(vrt_ctx *c);
 VRT_HIDDEN int ensure_ndc(vrt_ctx *c);
 VRT_HIDDEN void fill_uniforms(const vrt_ctx *c, vrt::FrameParams &P);
+// vrt_order.hip: the order a one-frame-at-a-time context launches its tiles in, around the frame's launch in vrt_render
+struct TileOrderPlan { bool sort = false, dilate = false, beside = false; uint32_t wb = 0; };
+VRT_HIDDEN int tile_order_before_frame(vrt_ctx *c, vrt::FrameParams &P, hipStream_t st, const vrt_render_opts &o, uint32_t variant, bool kstats,
+                                       bool edit_in_front, TileOrderPlan &plan);
+VRT_HIDDEN int tile_order_after_frame(vrt_ctx *c, const vrt::FrameParams &P, hipStream_t st, const TileOrderPlan &plan);
 // vrt_uploads.hip
 VRT_HIDDEN int alloc_roots(vrt_ctx *c, uint32_t world_size);
 VRT_HIDDEN int flush_staged(vrt_ctx *c);
