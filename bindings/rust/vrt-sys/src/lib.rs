@@ -90,6 +90,7 @@ pub const VRT_MAX_DEVICES: usize = 16;
 pub const VRT_FLAG_TILE_MAJOR: u32 = 1;
 pub const VRT_FLAG_ROW_MAJOR: u32 = 2;
 pub const VRT_FLAG_COMPACT: u32 = 4;
+pub const VRT_PRESENT_SKIP_TEXELS: u32 = 1;
 pub const VRT_FLAG_TEXEL_MESSAGES: u32 = 8;
 pub const VRT_FLAG_STAGED_MESSAGES: u32 = 16;
 pub const VRT_FLAG_POISON_MESSAGES: u32 = 32;
@@ -177,6 +178,7 @@ extern "C" {
     pub fn vrt_present(ctx: *mut vrt_ctx, crosshair: *const vrt_crosshair, screen_w: u32, screen_h: u32, rgba8: *mut u8) -> c_int;
     pub fn vrt_selftest_exact_math(device: i32, n: u32, seed: u32, mismatches: *mut u64) -> c_int;
     pub fn vrt_present_device(ctx: *mut vrt_ctx, crosshair: *const vrt_crosshair, screen_w: u32, screen_h: u32, rgba8_device: *mut *mut c_void, bytes: *mut u64) -> c_int;
+    pub fn vrt_set_presentation(ctx: *mut vrt_ctx, crosshair: *const vrt_crosshair, screen_w: u32, screen_h: u32, flags: u32) -> c_int;
     pub fn vrt_get_stats(ctx: *mut vrt_ctx, out: *mut vrt_stats) -> c_int;
     pub fn vrt_get_accel_info(ctx: *mut vrt_ctx, out: *mut vrt_accel_info) -> c_int;
     pub fn vrt_read_accel(ctx: *mut vrt_ctx, grid: *mut u32, bricks: *mut u16) -> c_int;

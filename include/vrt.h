@@ -149,8 +149,7 @@ typedef struct {
     uint32_t mode;     /* vrt_mode */
     uint32_t variant;  /* kernel variant: 0 = default (grid march over the derived cell grid / brick pool; primary +
                         * shadow fused into one launch), 1 = literal octree walk (the shader's text), 2 = ancestor-cache
-                        * octree walk, 3 = grid march with the shadow rays as a second launch, 4 = variant 0's work as a persistent grid
-                        * pulling tiles from per-XCD queues (primary + shadow frames only); DESIGN.md §Kernels */
+                        * octree walk, 3 = grid march with the shadow rays as a second launch; DESIGN.md §Kernels */
     uint32_t stats;    /* 1: also count steps / node visits this frame (slower; not for timing); 2: clock probe — the default
                         * primary + shadow kernel with s_memtime / s_memrealtime stamps around one wave in sixteen
                         * (vrt_stats.clock_*; the frame itself is the normal one) */
@@ -282,6 +281,21 @@ int vrt_present(vrt_ctx *ctx, const vrt_crosshair *crosshair, uint32_t screen_w,
  * interop (a 1080p frame is 8 MB of PCIe traffic otherwise).  vrt_synchronize before reading it from another stream. */
 int vrt_present_device(vrt_ctx *ctx, const vrt_crosshair *crosshair, uint32_t screen_w, uint32_t screen_h, void **rgba8_device,
                        uint64_t *bytes);
+
+/* The blit folded into the frame's own launch.  The reference's compute pass stores rgba8unorm (ray_tracer.wgsl:179) and its
+ * blit follows in the same submission, every frame (main.rs:452-454); here the frame is a 16-byte parity texel per pixel and
+ * vrt_present* a second launch that reads it again.  vrt_set_presentation declares what the frames that follow will be presented
+ * with: while the window has the texture's size, that size is whole 8x8 tiles, every pixel samples its own texel's centre (to
+ * 1e-4 of a texel: 1920x1080, 2560x1440, 3840x2160, ... — found once per size) and every tap of the pixels the crosshair can reach
+ * lies in the pixel's own tile, a plain primary / primary + shadow frame of a whole-frame context ALSO stores the window's
+ * pixel — fs_main's byte: the texel quantised, the crosshair blended in — into the screen buffer of its frame set, and
+ * vrt_present_device / vrt_present with the declared crosshair and size after such a frame launch nothing.  Every other frame,
+ * window size or crosshair takes the blit's own launch as before: the declaration never changes a result, only who stores it.
+ * flags: VRT_PRESENT_SKIP_TEXELS — such a frame stores the window's pixel ONLY (4 bytes per pixel written instead of 20): a
+ * host that presents and never reads back.  vrt_read_output, vrt_present* with another crosshair or size and vrt_assemble
+ * sources then find no texels for that frame and return VRT_ERR_STATE.  crosshair NULL: off (the default). */
+#define VRT_PRESENT_SKIP_TEXELS 1u
+int vrt_set_presentation(vrt_ctx *ctx, const vrt_crosshair *crosshair, uint32_t screen_w, uint32_t screen_h, uint32_t flags);
 
 int vrt_get_stats(vrt_ctx *ctx, vrt_stats *out);
 

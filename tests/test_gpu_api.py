@@ -245,6 +245,138 @@ def test_present_quantise_and_crosshair_blit(orc):
         gpu.present((0, 36))
 
 
+def _poison_texels(gpu):
+    """Overwrite the texel buffer of the last frame with 0xFF bytes (behind everything enqueued): a blit launched from here on
+    would show it."""
+    from voxelraytracing_amd import _ffi
+    gpu.synchronize()
+    ptr, nbytes = gpu.device_output()
+    hip_memset = _ffi.vrt().hipMemset
+    hip_memset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    assert hip_memset(ptr, 0xFF, nbytes) == 0
+
+
+@pytest.mark.parametrize("size", [(256, 144), (360, 120), (360, 200), (1920, 1080), (364, 100), (16380, 8)])
+def test_frames_presented_texel_for_texel_store_their_own_window_pixels(orc, size):
+    """Round 6 (vrt_set_presentation): the reference's compute pass stores rgba8unorm and its blit follows in the same submission
+    (ray_tracer.wgsl:179, main.rs:452-454); here, declared, the march kernel stores the window's pixel itself — the texel
+    quantised, fs_main's crosshair blended in from the lanes of the pixel's tile — and vrt_present* launches nothing.  The bytes are
+    the oracle's general bilinear blit for every crosshair; the texel buffer is overwritten before the present, so a blit that
+    did launch would show.  360 x 120 and 1920 x 1080 have samples 2e-6 beside their texel's centre INSIDE the crosshair's box
+    (columns 182, 185, rows 61, 63; columns 962-964): their taps come from the neighbouring lanes.  At 360 x 200 one such row's
+    tap lies in the tile above (row 104 takes 2e-6 of row 103), 364 columns are a ragged texture and 16 380 have a sample 5e-4
+    off: those frames cannot store their window pixels — the declaration changes nothing and the blit's own launch gives the
+    same bytes."""
+    w, h = size
+    sc = scenes.c2((w, h))
+    ref = gpu_for_scene(sc)
+    stores_its_pixels = size in ((256, 144), (360, 120), (1920, 1080))   # (for the crosshairs whose box is the small one around the centre)
+    kinds = [dict(style=0), dict(), dict(style=1, size=9.5, color=(1.0, 0.2, 0.1, 0.75)), dict(style=2, size=17.0, color=(0.0, 0.0, 0.0, 1.0))]
+    if w <= 400:
+        kinds += [dict(style=1, size=0.4), dict(style=2, size=-3.0), dict(style=1, size=float("nan")),
+                  dict(style=2, size=7.0, color=(float("nan"), 0.5, 0.5, 0.5)), dict(style=2, size=1.0e4, color=(0.3, 0.6, 0.9, 0.5))]
+    for mode, variant in ((MODE_PRIMARY_SHADOW, 0), (MODE_PRIMARY, 0), (MODE_PRIMARY, 1)):
+        if w > 400 and (mode, variant) != (MODE_PRIMARY_SHADOW, 0):
+            continue
+        ref.render(mode, variant=variant)
+        rgb, ids, _ = ref.read_output()
+        gpu = gpu_for_scene(sc)
+        for kw in kinds:
+            gpu.set_presentation((w, h), **kw)
+            for _ in range(3):   # (frames in flight alternate between the frame sets: each has its own screen buffer)
+                gpu.render(mode, variant=variant)
+            a_rgb, a_ids, _ = gpu.read_output()              # the texels are stored as ever
+            assert np.array_equal(a_ids, ids) and np.array_equal(a_rgb, rgb)
+            want = orc.present(rgb, (w, h), **kw)
+            small_box = kw.get("style", 2) == 0 or (0.0 < kw.get("size", 5.0) <= 17.0 and all(c == c for c in kw.get("color", (1.0,))))
+            if stores_its_pixels and small_box:
+                _poison_texels(gpu)
+            assert np.array_equal(gpu.present((w, h), **kw), want), (mode, variant, kw)
+        # another crosshair or size than the declared one: the blit's own launch, from the texels
+        gpu.set_presentation((w, h))
+        gpu.render(mode, variant=variant)
+        other = dict(style=1, size=6.0, color=(0.2, 0.9, 0.1, 0.5))
+        assert np.array_equal(gpu.present((w, h), **other), orc.present(rgb, (w, h), **other))
+        if w <= 400:
+            assert np.array_equal(gpu.present((w + 40, h + 8)), orc.present(rgb, (w + 40, h + 8)))
+        assert np.array_equal(gpu.present((w, h)), orc.present(rgb, (w, h)))   # (and the declared one again, blitted this time)
+        gpu.close()
+    ref.close()
+
+
+def test_presentation_only_frames_and_frames_that_cannot_store_their_pixels(orc):
+    """VRT_PRESENT_SKIP_TEXELS: a frame that stores its window pixels stores nothing else — it can be presented with the declared
+    crosshair, and everything that would need its texels says so.  Frames that cannot store window pixels (the path trace, stats
+    frames of the two-launch variants, sharded contexts) are untouched by the declaration.  A draw + present loop with frames in
+    flight gets every frame's own image."""
+    from voxelraytracing_amd import _ffi
+    sc = scenes.c2((320, 184))
+    ref = gpu_for_scene(sc)
+    ref.render(MODE_PRIMARY_SHADOW)
+    rgb, ids, _ = ref.read_output()
+    gpu = gpu_for_scene(sc)
+    gpu.set_presentation(skip_texels=True)
+    gpu.render(MODE_PRIMARY_SHADOW)
+    assert np.array_equal(gpu.present(), orc.present(rgb, sc.size))
+    with pytest.raises(VrtError):
+        gpu.read_output()
+    with pytest.raises(VrtError):
+        gpu.present(style=0)
+    with pytest.raises(VrtError):
+        gpu.present((400, 200))
+    gpu.render(MODE_PRIMARY_SHADOW, variant=3)               # two launches: texels, and the blit's own launch
+    a_rgb, a_ids, _ = gpu.read_output()
+    assert np.array_equal(a_ids, ids) and np.array_equal(a_rgb, rgb)
+    assert np.array_equal(gpu.present(), orc.present(rgb, sc.size))
+    gpu.render(MODE_PATH, spp=2, seed=5)                     # the path trace accumulates in its texels
+    ref.render(MODE_PATH, spp=2, seed=5)
+    p_rgb, p_ids, _ = ref.read_output()
+    a_rgb, a_ids, _ = gpu.read_output()
+    assert np.array_equal(a_ids, p_ids) and np.array_equal(a_rgb, p_rgb)
+    assert np.array_equal(gpu.present(), orc.present(p_rgb, sc.size))
+    gpu.set_presentation(off=True)
+    gpu.render(MODE_PRIMARY_SHADOW)
+    a_rgb, a_ids, _ = gpu.read_output()
+    assert np.array_equal(a_ids, ids) and np.array_equal(a_rgb, rgb)
+    gpu.close()
+    sh = gpu_for_scene(sc, shard_rank=1, shard_count=2)      # a shard's tiles are a message, not a window
+    sh.set_presentation()
+    sh.render(MODE_PRIMARY_SHADOW)
+    s_rgb, s_ids, _ = sh.read_output()
+    mine = s_ids != 0
+    assert mine.any() and np.array_equal(s_ids[mine], ids[mine]) and np.array_equal(s_rgb[mine], rgb[mine])
+    with pytest.raises(VrtError):
+        sh.present()
+    sh.close()
+    # the client's loop: draw, present, next frame — no wait in between; each of the frames in flight keeps its own image
+    for in_flight in (1, 2, 3):
+        gpu = gpu_for_scene(sc)
+        gpu.set_frames_in_flight(in_flight)
+        gpu.set_presentation(skip_texels=in_flight == 2)
+        cams = [g.cam_data_create((20.0 + 9 * k, 35.0 + 50 * k, 0.0), (sc.eye[0] + 2 * k, sc.eye[1] + k, sc.eye[2] - k), 70.0, (320.0, 184.0)) for k in range(5)]
+        want = []
+        for cam in cams:
+            ref.write_cam_data(cam)
+            ref.render(MODE_PRIMARY_SHADOW)
+            want.append(ref.present())
+        ptrs = []
+        for cam in cams:
+            gpu.write_cam_data(cam)
+            gpu.render(MODE_PRIMARY_SHADOW)
+            ptrs.append(gpu.present_device())
+        gpu.synchronize()
+        assert len({p for p, _ in ptrs[-in_flight:]}) == in_flight
+        hip_memcpy = _ffi.vrt().hipMemcpy
+        hip_memcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        for k in range(len(cams) - in_flight, len(cams)):
+            ptr, nbytes = ptrs[k]
+            host = np.empty(nbytes, dtype=np.uint8)
+            assert nbytes == 320 * 184 * 4 and hip_memcpy(host.ctypes.data, ptr, nbytes, 2) == 0
+            assert np.array_equal(host.reshape(184, 320, 4), want[k]), f"frame {k}, {in_flight} in flight"
+        gpu.close()
+    ref.close()
+
+
 @pytest.mark.parametrize("in_flight", [1, 2, 3])
 def test_present_device_follows_its_frame_without_waiting(orc, in_flight):
     """vrt_present_device enqueues the blit behind the frame it presents, on that frame's stream, into the screen buffer of

@@ -333,32 +333,6 @@ def test_batched_gather_frames_stay_apart(c2_small, orc):
         c.close()
 
 
-def test_persistent_grid_variant_gives_the_same_frames(c1, c2_small):
-    """Variant 4 — the default kernel's work pulled from per-XCD tile queues by a grid that just fills the chip — against
-    variant 0, whole and sharded (tile-major), several frames in a row (the queue heads are reset per frame)."""
-    needs_experiments()
-    for sc in (c1, c2_small):
-        gpu = gpu_for_scene(sc)
-        gpu.render(MODE_PRIMARY_SHADOW)
-        rgb, ids, _ = gpu.read_output()
-        n0 = gpu.stats().secondary_rays
-        for _ in range(3):
-            gpu.render(MODE_PRIMARY_SHADOW, variant=4)
-        rgb4, ids4, _ = gpu.read_output()
-        assert np.array_equal(ids4, ids) and np.array_equal(rgb4, rgb) and gpu.stats().secondary_rays == n0
-        with pytest.raises(g.VrtError):
-            gpu.render(MODE_PRIMARY, variant=4)
-        with pytest.raises(g.VrtError):
-            gpu.render(MODE_PRIMARY_SHADOW, variant=4, stats=True)
-    acc = np.zeros_like(ids)
-    for r in range(3):
-        sh = gpu_for_scene(c2_small, shard_rank=r, shard_count=3, root_weight=2)
-        sh.render(MODE_PRIMARY_SHADOW, variant=4)
-        acc |= sh.read_output()[1]
-        sh.close()
-    assert np.array_equal(acc, ids)
-
-
 def test_full_size_properties():
     """At BASELINE's full size (1920x1080, 8^3 world) check size-independent properties instead of the oracle:
     determinism, shadow pass only darkens launched pixels by exactly the factor, stats add up."""
@@ -859,45 +833,17 @@ def test_pool_depth_of_the_bounce_waves_does_not_change_the_frame(orc, monkeypat
         gpu.close()
 
 
-def test_persistent_path_kernel_gives_the_same_frames(orc, monkeypatch):
-    """VRT_PATH_PERSISTENT=1: the path trace as one launch of persistent waves whose lanes are refilled in batches (built
-    and measured, not the default) — bit for bit the frame of the launch-per-bounce kernels, whole and sharded."""
-    needs_experiments()
-    sc = scenes.c4((320, 184), bounces=4)
-    ref = gpu_for_scene(sc)
-    ref.render(MODE_PATH, spp=3, seed=11)
-    rgb, ids, _ = ref.read_output()
-    monkeypatch.setenv("VRT_PATH_PERSISTENT", "1")
-    gpu = gpu_for_scene(sc)
-    for _ in range(3):
-        gpu.render(MODE_PATH, spp=3, seed=11)
-    rgb2, ids2, _ = gpu.read_output()
-    assert np.array_equal(ids2, ids) and np.array_equal(rgb2, rgb)
-    r_rgb, r_ids, _, _ = orc.from_package_scene(sc).render(orc.MODE_PATH, *sc.size, spp=3, seed=11)
-    assert_frame_parity(rgb2, ids2, r_rgb, r_ids, "persistent path kernel")
-    acc_rgb, acc_ids = np.zeros_like(rgb), np.zeros_like(ids)
-    for r in range(3):
-        sh = gpu_for_scene(sc, shard_rank=r, shard_count=3, root_weight=2)
-        sh.render(MODE_PATH, spp=3, seed=11)
-        s_rgb, s_ids, _ = sh.read_output()
-        acc_rgb += s_rgb
-        acc_ids |= s_ids
-        sh.close()
-    assert np.array_equal(acc_ids, ids) and np.array_equal(acc_rgb, rgb)
-
-
-@pytest.mark.parametrize("env", [{"VRT_PATH_POOL": "0"}, {"VRT_PATH_CELLS": "0"}, {"VRT_PATH_CELLS": "0", "VRT_PATH_POOL_CHAIN": "1"},
-                                 {"VRT_PATH_CELLS": "0", "VRT_PATH_POOL_CHAIN": "1", "VRT_PATH_POOL_EJECT": "40"}] +
+@pytest.mark.parametrize("env", [{"VRT_PATH_POOL": "0"}, {"VRT_PATH_CELLS": "0"}] +
                                 [{"VRT_PATH_WINDOW": "1", "VRT_PATH_WINDOW_SHAPE": str(k)} for k in range(5)])
 def test_every_form_of_the_bounce_launch_gives_the_same_frames(orc, monkeypatch, env):
     """The default bounce launch is the pool kernel over the march cells (a wave refills its lanes from its own LDS pool of
-    rays; one 16-byte load per step).  VRT_PATH_POOL=0: lane = path for the whole kernel, the round-1 structure.
-    VRT_PATH_WINDOW=1 (round 5; built and measured, not the default: profiles/r05_window_ab.txt): the rays grouped by screen block,
-    the march cells around a group staged in LDS (shapes 0-3), or (shape 4) the pool kernel with its rays' state in global memory.
-    VRT_PATH_CELLS=0: the round-2 pool kernel over cell grid + bricks; with VRT_PATH_POOL_CHAIN=1 (built and measured, not the
-    default) its rays still marching when a wave's pool runs dry go to a chain of launches on a side stream.  All bit for
-    bit the same frame, with several samples (the chains join per sample), sharded, and with two frames in flight."""
-    needs_experiments()
+    rays; one 16-byte load per step).  VRT_PATH_POOL=0 / VRT_PATH_CELLS=0: lane = path for the whole kernel, one launch per
+    bounce, the round-1 structure (what worlds without march cells and stats frames run).
+    VRT_PATH_WINDOW=1 (round 5; built and measured, not the default: profiles/r05_window_ab.txt; the experiments build): the rays
+    grouped by screen block, the march cells around a group staged in LDS (shapes 0-3), or (shape 4) the pool kernel with its rays'
+    state in global memory.  All bit for bit the same frame, with several samples, sharded, and with two frames in flight."""
+    if "VRT_PATH_WINDOW" in env:
+        needs_experiments()
     sc = scenes.c4((320, 184), bounces=4)
     ref = gpu_for_scene(sc)
     ref.render(MODE_PATH, spp=3, seed=11)
@@ -953,23 +899,18 @@ def test_samples_per_launch_chain_do_not_change_the_frame(orc, monkeypatch, per_
     assert np.array_equal(ids1, o_ids) and np.array_equal(rgb1, o_rgb)
 
 
-@pytest.mark.parametrize("form", ["1", "2", "6"])
-def test_tiles_ordered_under_a_moving_camera_are_the_same_frames(orc, monkeypatch, form):
-    """A one-frame-at-a-time context keeps launching its tiles longest first while the camera MOVES.  Form 1, the default (round 5):
+def test_tiles_ordered_under_a_moving_camera_are_the_same_frames(orc, monkeypatch):
+    """A one-frame-at-a-time context keeps launching its tiles longest first while the camera MOVES (round 5):
     ONE launch sorts blocks of 4 x 4 tiles by their trips dilated over the image motion of several camera steps
     (vrt_kernels.hip: launch_tile_order_blocks), and the order is kept while the camera stays within what the dilation covers.
-    Forms 2 (that launch beside the next frame, every frame) and 6 (round 4: six small launches behind every frame) are the
-    experiments build's.  A walk of small steps (the bench's orbit step: < 1 voxel, ~ 1 degree), a rest, a jump (screen order
+    (An order per frame, in two forms, was measured slower and is gone: profiles/r04_tile_order_moving.txt, r05_tile_order_moving.txt.)
+    A walk of small steps (the bench's orbit step: < 1 voxel, ~ 1 degree), a rest, a jump (screen order
     again), more steps: every frame is the screen-order context's frame, the last one the oracle's; and the counter says which
     frames were ordered."""
-    if form != "1":
-        needs_experiments()                            # (built, measured, not chosen: profiles/r04_tile_order_moving.txt, r05_tile_order_moving.txt)
     from voxelraytracing_amd import graphics as g
     sc = scenes.c2()
-    monkeypatch.setenv("VRT_TILE_ORDER_MOVING", form)
     mov = gpu_for_scene(sc)
     mov.set_frames_in_flight(1)
-    monkeypatch.delenv("VRT_TILE_ORDER_MOVING")
     monkeypatch.setenv("VRT_TILE_ORDER", "0")
     ref = gpu_for_scene(sc)
     ref.set_frames_in_flight(1)
@@ -992,10 +933,7 @@ def test_tiles_ordered_under_a_moving_camera_are_the_same_frames(orc, monkeypatc
         ordered.append(mov.accel_info().ordered_frames)
     used = [b - a for a, b in zip([0] + ordered[:-1], ordered)]
     # the first frame has no order; every frame a step (or no step) from its predecessor has one; the frame after the jump has none
-    # (form 2: an order is made beside the NEXT frame and used by the one after it — the first two frames and the two after the jump
-    # have none, nor has the second frame of the rest: the order made behind the last moving frame is the third's, the exact one of
-    # the view at rest comes after its second frame)
-    want = [0, 1, 1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1] if form != "2" else [0, 0, 1, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1, 1]
+    want = [0, 1, 1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1]
     assert used == want, used
     assert ref.accel_info().ordered_frames == 0
     o = orc.from_package_scene(sc)

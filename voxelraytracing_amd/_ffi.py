@@ -106,6 +106,7 @@ VRT_SYMBOLS = {
     "vrt_present": (C.c_int, [_P, C.POINTER(Crosshair), C.c_uint32, C.c_uint32, _P]),
     "vrt_selftest_exact_math": (C.c_int, [C.c_int32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
     "vrt_present_device": (C.c_int, [_P, C.POINTER(Crosshair), C.c_uint32, C.c_uint32, C.POINTER(_P), C.POINTER(C.c_uint64)]),
+    "vrt_set_presentation": (C.c_int, [_P, C.POINTER(Crosshair), C.c_uint32, C.c_uint32, C.c_uint32]),
     "vrt_get_stats": (C.c_int, [_P, C.POINTER(Stats)]),
     "vrt_get_accel_info": (C.c_int, [_P, C.POINTER(AccelInfo)]),
     "vrt_read_accel": (C.c_int, [_P, _P, _P]),

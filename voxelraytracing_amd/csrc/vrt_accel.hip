@@ -313,13 +313,6 @@ struct ChunkNodes {
     }
 };
 
-#ifdef VRT_EXP_CHUNKDBG   // experiment (tools/chunk_probe.py): when the LAST thread of workgroup 0 passes each phase (shader clock; [8 + i]: 100 MHz clock)
-__device__ unsigned long long g_chunk_dbg[16];
-#define CHUNK_STAMP(i) do { if (blockIdx.x == 0 && (int)(threadIdx.x & 63u) == __ffsll((long long)__ballot(1)) - 1) { atomicMax(&g_chunk_dbg[i], (unsigned long long)__builtin_amdgcn_s_memtime()); \
-                                                   atomicMax(&g_chunk_dbg[8 + (i)], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } } while (0)
-#else
-#define CHUNK_STAMP(i) do { } while (0)
-#endif
 __global__ void __launch_bounds__(512) accel_chunks_kernel(const uint16_t *nodes, uint32_t n_nodes, const uint32_t *roots, uint32_t S,
                                                            uint32_t *grid, uint32_t *chunk_bricks, uint32_t *chunk_bases,
                                                            uint32_t *chunk_caps, uint32_t *tail, uint16_t *bricks, uint32_t brick_cap,
@@ -334,7 +327,6 @@ __global__ void __launch_bounds__(512) accel_chunks_kernel(const uint16_t *nodes
     // 14 us whatever its loops did; see tools/chunk_probe.py.  Hence buffer loads instead of a tail path per staged vector, the
     // liquid mask in LDS instead of a select chain per use, one place that reads a node, and no unrolling but the four cells the
     // last loop keeps in flight for its latency chain: 7.6 KB.)
-    CHUNK_STAMP(0);
     // (512 threads, not more: sixteen waves halve the lone kernel — 9.3 us, a lone edit 162.7 — but a workgroup that needs a
     // whole CU at once waits for one while frames are in flight: an edit before every frame 97 -> 107 us per frame, measured)
     const uint32_t chunk = list.chunk[blockIdx.x];
@@ -372,11 +364,9 @@ __global__ void __launch_bounds__(512) accel_chunks_kernel(const uint16_t *nodes
         const uint32_t v = t + 512u * j;
         if (v < vecs) reinterpret_cast<uint4 *>(s_raw)[v] = sw[j];
     }
-    CHUNK_STAMP(1);
     __syncthreads();
     if (t == 0 && (n_nodes & 1u) && n_nodes - 1u >= first && n_nodes - 1u - first < vecs * 8u) s_raw[n_nodes - 1u - first] = nodes[n_nodes - 1u];
     if (n_nodes & 1u) __syncthreads();   // (uniform)
-    CHUNK_STAMP(2);
     // node `idx` of the chunk, relative to its root: the one place that reads one (ChunkNodes above, spelled out once)
     const uint16_t *lds = s_raw + head;
     auto node_at = [&](uint32_t idx) __attribute__((always_inline)) -> uint32_t {
@@ -419,9 +409,7 @@ __global__ void __launch_bounds__(512) accel_chunks_kernel(const uint16_t *nodes
         }
         s_blk = blk;
     }
-    CHUNK_STAMP(3);
     __syncthreads();
-    CHUNK_STAMP(4);
     const bool own_block = s_blk >= 2u && s_blk < mc.cap;
     // what a cell writes — its entry of the cell grid and its march cell — in one place: a leaf cell's thread, or lane 0 of the
     // wave that did a split cell's brick
@@ -441,7 +429,6 @@ __global__ void __launch_bounds__(512) accel_chunks_kernel(const uint16_t *nodes
         const uint32_t m = stops(node & 0x7FFFu) ? 0u : 0xFFFFFFFFu;
         write_cell(t, make_uint4(leaf_entry(node, (32u >> depth) - 1u), 0u, m, m));
     }
-    CHUNK_STAMP(7);
     // The split cells: A WAVE PER CELL, A LANE PER VOXEL of its brick.  (One thread per cell — round 3 — had the threads of the
     // split cells walk 72 nodes and classify 64 voxels each, alone in their waves, while the threads of the leaf cells were
     // done.)  Lane e = x | y << 2 | z << 4 reads its depth-4 node — eight different ones per wave — and, below a split one, its
@@ -509,21 +496,7 @@ __global__ void __launch_bounds__(512) accel_chunks_kernel(const uint16_t *nodes
         // frames are later on this very stream, and frames of other sets that shared it were waited for, update_tables)
         if (mine) write_cell(my_ct, make_uint4(0x80000000u | (my_brick * 64u), my_size2, my_pass_lo, my_pass_hi));
     }
-    CHUNK_STAMP(6);
 }
-#ifdef VRT_EXP_CHUNKDBG
-}  // namespace
-}  // namespace vrt
-extern "C" void vrt_exp_chunk_dbg(unsigned long long *out) {   // read and reset
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(vrt::g_chunk_dbg), sizeof(unsigned long long) * 16);
-    void *p = nullptr;
-    (void)hipGetSymbolAddress(&p, HIP_SYMBOL(vrt::g_chunk_dbg));
-    (void)hipMemset(p, 0, sizeof(unsigned long long) * 16);
-}
-namespace vrt {
-namespace {
-#endif
 
 // Upload of a staged range: the pinned ring is mapped into the device's address space, so a kernel reads it over PCIe and
 // writes the resident buffer — a launch like any other on the stream, where hipMemcpyAsync makes the host wait for the

@@ -40,7 +40,7 @@ void launch_shadow(const FrameParams &P, uint32_t variant, bool stats, hipStream
 void launch_primary_shadow_fused(const FrameParams &P, uint32_t march, bool stats, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
 void launch_path_primary(const FrameParams &P, bool stats, bool literal, hipStream_t st);
 void launch_path_bounce(const FrameParams &P, bool stats, bool literal, hipStream_t st);
-void launch_path_bounce_cells(const FrameParams &P, uint32_t refill_at, uint32_t segments, uint32_t lds_pad, uint32_t pool_batches, hipStream_t st);
+void launch_path_bounce_cells(const FrameParams &P, uint32_t refill_at, uint32_t segments, uint32_t pool_batches, hipStream_t st);
 void launch_path_finish(Texel *out, uint32_t n, uint32_t spp, hipStream_t st);
 void launch_tile_order(const uint32_t *cost, uint32_t n, uint32_t shift, uint32_t *scratch, uint32_t *order, hipStream_t st);
 bool launch_tile_order_blocks(const uint32_t *cost, uint32_t tiles_x, uint32_t tiles_y, uint32_t shift, uint32_t radius, uint32_t *order, hipStream_t st, uint32_t threads);
@@ -120,10 +120,6 @@ struct vrt_ctx {
     uint32_t *extra_blk[kMaxInFlight - 1] = {nullptr, nullptr, nullptr};
     uint4 *extra_path[kMaxInFlight - 1] = {nullptr, nullptr, nullptr};                   // path mode: its own path buffers
     unsigned long long *extra_counters[kMaxInFlight - 1] = {nullptr, nullptr, nullptr};  // ... and segment cursors
-    // path mode, straggler chain (launch_path_frame): per frame set [0] = the context's own, [k] = extra set k - 1
-    uint4 *path_cont[kMaxInFlight] = {nullptr, nullptr, nullptr, nullptr};        // kContSets x 4 planes
-    hipStream_t side_stream[kMaxInFlight] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t side_ev[kMaxInFlight][6] = {};                                     // [0..3] bounce launch done, [4] chain done, [5] frame start
     uint32_t in_flight = 2;        // vrt_set_frames_in_flight
     bool alt_pending = false;      // frames may still be running on the extra streams
     bool own_pending = false;      // ... or on own_stream while the caller's stream is the context's stream (VRT_RENDER_OWN_STREAMS)
@@ -159,8 +155,6 @@ struct vrt_ctx {
     uint32_t *last_blk = nullptr;
     uint4 *d_hits = nullptr;
     uint32_t *d_blk_counts = nullptr;  // hit records per primary workgroup
-    uint32_t *d_heads = nullptr;   // variant 4: the per-XCD queue heads (8 x 64 B)
-    uint32_t n_cus = 0;
     uint32_t n_blocks = 0;
     uint32_t n_counts = 0;          // entries of blk_counts the last primary + shadow frame wrote
     uint4 *d_path = nullptr;  // path mode: 2 buffers x 3 planes x (kHitSegments * hit_seg_cap) records, lazily allocated
@@ -222,10 +216,8 @@ struct vrt_ctx {
     // costs the host 13 us, one without 4 us (tools/host_cost.py) — nothing on one device, the frame period of a
     // multi-device context that issues to eight from one thread.
     uint32_t timing_every = 8, frame_no = 0;
-    bool path_persistent = false;  // VRT_PATH_PERSISTENT=1: plain path frames as one persistent launch instead of one launch per bounce
-    bool path_pool = true;         // VRT_PATH_POOL=0: bounce launches with lane = path (the round-1 structure) instead of the pool kernel
-    bool path_chain = false;       // VRT_PATH_POOL_CHAIN=1: the pool kernel's stragglers go to a chain of launches on a side stream
-    bool path_cells = true;        // VRT_PATH_CELLS=0: the pool kernel over cell grid + bricks instead of the one over the march cells
+    bool path_pool = true;         // VRT_PATH_POOL=0 / VRT_PATH_CELLS=0: bounce launches with lane = path (the round-1 structure) instead of the
+    bool path_cells = true;        // pool kernel over the march cells (tests: the two structures hold each other's frames)
     // VRT_PATH_WINDOW=1 (experiments build; built and measured in round 5, not chosen: profiles/r05_window_*): the bounce launch over
     // LDS-staged windows of march cells (experiments/vrt_path_window.hip).  Per frame set: the regions' counts (two 16-byte planes
     // of per-ray state lie behind the path buffer's six)
@@ -236,10 +228,9 @@ struct vrt_ctx {
     size_t path_grp_regions[kMaxInFlight] = {0, 0, 0, 0};
     uint32_t path_samples = 8;     // VRT_PATH_SAMPLES_PER_CHAIN: samples a launch chain traces at once when spp > 1 (1: one, as round 1 did)
     vrt::Texel *path_acc[kMaxInFlight] = {nullptr, nullptr, nullptr, nullptr};   // ... their accumulation planes, per frame set
-    size_t path_acc_texels[kMaxInFlight] = {0, 0, 0, 0}, path_buf_records[kMaxInFlight] = {0, 0, 0, 0}, path_cont_records[kMaxInFlight] = {0, 0, 0, 0};
+    size_t path_acc_texels[kMaxInFlight] = {0, 0, 0, 0}, path_buf_records[kMaxInFlight] = {0, 0, 0, 0};
     uint32_t path_pool_batches = 0;   // VRT_PATH_POOL_K = 4 | 5: the bounce waves' pools; 0: 5 for small worlds with two frames in flight, else 4
-    uint32_t path_lds_pad = 0;     // VRT_PATH_LDS_PAD (experiments build): bytes of LDS a bounce workgroup claims beyond its pools — fewer waves per CU
-    uint32_t path_refill = 0, path_eject = ~0u;   // VRT_PATH_POOL_REFILL / _EJECT: the pool kernel's thresholds (experiments; 0 / ~0: defaults)
+    uint32_t path_refill = 0;      // VRT_PATH_POOL_REFILL: idle lanes that send a bounce wave back to its pool (0: the default, 16)
     uint32_t accel_builds = 0;
     // longest tiles first (vrt_kernels.hip: tile_order_*), for a context that renders one frame at a time
     // (vrt_set_frames_in_flight(1)) and whose view is at rest: the second plain frame of an unchanged view (camera, settings,
@@ -261,24 +252,24 @@ struct vrt_ctx {
     // and nothing but the camera has changed; the frame that comes near the edge of that notes its trips for the next order.  A
     // view that moves too fast for its orders to be used stops asking for them (mov_backoff).  One frame at a time, orbit:
     // 112.8 -> 109.1 us per frame (profiles/r05_tile_order_moving.txt).  0 (VRT_TILE_ORDER_MOVING=0): screen order while the
-    // view moves.  Experiments build: 6 = round 4's six small launches behind every frame, 2 = the one launch beside the next frame.
+    // view moves.
     uint32_t tile_lpt_moving = 1;
     uint32_t order_uses = 0;            // frames that used the dilated order in d_tile_order
     uint32_t mov_backoff = 0, mov_skip = 0;   // moving frames that go without asking for an order (doubles while orders go unused)
-    // 2 (VRT_TILE_ORDER_MOVING=2): the order of a moving view made BESIDE the frame in between — frame k's trips are sorted on a
-    // side stream while frame k + 1 runs, and frame k + 2 launches in that order (dilated over two camera steps): the order
-    // costs the frames' stream nothing.  Two sets of trips / order buffers alternate; `mov_pend` is the order being made.
-    struct MovingOrder { bool valid = false; uint32_t view_gen = 0, cam_gen = 0, buf = 0; vrt_cam_data cam{}; };
-    MovingOrder mov_new, mov_pend, mov_cur;   // made behind the last frame -> being made beside this one -> this frame's
-    uint32_t *d_mov_cost[2] = {nullptr, nullptr}, *d_mov_order[2] = {nullptr, nullptr};
-    hipStream_t mov_stream = nullptr;
-    hipEvent_t mov_frame_done[2] = {nullptr, nullptr}, mov_order_done[2] = {nullptr, nullptr};
-    bool mov_order_recorded[2] = {false, false}, mov_pending = false, mov_side = true;   // (mov_side false: on the frames' own stream, for A/B)
-    bool mov_radius_set = false, mov_any_size = false;
-    uint32_t mov_count = 0, mov_radius = 5, mov_threads = 256;   // (a small workgroup finds room beside the frame's: VRT_TILE_ORDER_THREADS)
+    bool mov_any_size = false;          // VRT_TILE_ORDER_MOVING set by name: also frames of more than kMovingTilesMax tiles
+    uint32_t mov_radius = 5;            // VRT_TILE_ORDER_RADIUS: blocks the order is dilated over
     // vrt_present*: whether a window of (one_w x one_h) over a texture of the same size samples every texel at its centre
     uint32_t one_w = 0, one_h = 0;
     bool one_to_one = false;
+    // vrt_set_presentation: the declared crosshair / window / flags; whether frames of (pres_for_w x pres_for_h) can store their own
+    // window pixels (found once per size and declaration) and the crosshair's box; which frame sets' screen buffers hold the
+    // image their last frame stored itself; whether the last frame stored one, and whether it stored texels at all
+    bool pres_on = false;
+    vrt_crosshair pres_ch{};
+    uint32_t pres_w = 0, pres_h = 0, pres_flags = 0;
+    uint32_t pres_for_w = 0, pres_for_h = 0, pres_box[4] = {0, 0, 0, 0};
+    bool pres_fusable = false;
+    bool last_fused = false, last_has_texels = true;
     uint32_t ordered_frames = 0;        // frames launched in an order (vrt_accel_info.ordered_frames)
     bool order_dilated = false;         // the order in d_tile_order is a dilated one
     uint32_t cam_gen = 0, order_cam_gen = 0;   // counts the changes of the camera (each is a change of the view too)
@@ -349,8 +340,7 @@ struct vrt_ctx {
 static constexpr size_t kSegBytes = (size_t)vrt::kHitSegments * vrt::kSegStride * sizeof(uint32_t);
 // three sets of segment cursors: launch g of a path frame appends to set g % 3, reads set (g - 1) % 3 and clears set
 // (g + 1) % 3 for its successor, so no memset sits between two launches
-static constexpr uint32_t kContSets = 4;   // straggler-chain record sets of a path frame (one per bounce launch; more bounces: no chain)
-static constexpr size_t kCounterBytes = vrt::kCtrCount * sizeof(unsigned long long) + (3 + kContSets) * kSegBytes;   // 3 path cursor sets + the chain's
+static constexpr size_t kCounterBytes = vrt::kCtrCount * sizeof(unsigned long long) + 3 * kSegBytes;   // + the path trace's 3 cursor sets
 
 enum EvKind : uint8_t { kEvNone = 0, kEvOneKernel = 1, kEvTwoKernels = 2, kEvRecorded = 3 };
 
@@ -402,8 +392,11 @@ VRT_HIDDEN hipError_t zero_now(vrt_ctx *c, void *p, size_t bytes);
 VRT_HIDDEN int validate_frame(vrt_ctx *c);
 VRT_HIDDEN int ensure_ndc(vrt_ctx *c);
 VRT_HIDDEN void fill_uniforms(const vrt_ctx *c, vrt::FrameParams &P);
+// vrt_present.hip: whether this frame can store its own window pixels (vrt_set_presentation) and, then, its screen buffer
+VRT_HIDDEN bool presentation_fusable(vrt_ctx *c);
+VRT_HIDDEN int screen_buffer_for_frame(vrt_ctx *c, uint32_t slot, hipStream_t st, uint32_t screen_w, uint32_t screen_h);
 // vrt_order.hip: the order a one-frame-at-a-time context launches its tiles in, around the frame's launch in vrt_render
-struct TileOrderPlan { bool sort = false, dilate = false, beside = false; uint32_t wb = 0; };
+struct TileOrderPlan { bool sort = false, dilate = false; };
 VRT_HIDDEN int tile_order_before_frame(vrt_ctx *c, vrt::FrameParams &P, hipStream_t st, const vrt_render_opts &o, uint32_t variant, bool kstats,
                                        bool edit_in_front, TileOrderPlan &plan);
 VRT_HIDDEN int tile_order_after_frame(vrt_ctx *c, const vrt::FrameParams &P, hipStream_t st, const TileOrderPlan &plan);

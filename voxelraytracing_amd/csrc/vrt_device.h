@@ -53,13 +53,8 @@ struct FrameParams {
     const uint32_t *seg_in;  // segment counters of path_in
     uint32_t *seg_clear;     // the counter set the NEXT launch of the frame appends to: this launch zeroes it (nobody reads it meanwhile)
     uint32_t path_cap;       // entries per plane = kHitSegments * hit_seg_cap
-    // Records of the straggler chain of the pool bounce kernel (vrt_path.hip): four planes {slot, origin} {dir, rng}
-    // {throughput, 0} {pos, steps taken | exit faces << 16 | kContFresh}, segmented like the paths and as large (a path is
-    // in exactly one place).  A bounce launch appends the rays it hands on; a straggler launch appends its survivors.
     uint32_t in_seg_cap;     // capacity of one segment of path_in (hit_seg_cap)
     uint32_t in_cap;         // entries per plane of path_in; path_cap is path_out's
-    uint4 *cont_out;         // null: a bounce launch marches every ray to its end / a straggler launch has no survivors
-    uint32_t *cont_counts;   // segment counters of cont_out
     uint32_t spp, sample, seed;
     // several samples per launch chain (plain frames with spp > 1): the primary launch traces samples sample .. sample +
     // chain - 1 of every pixel, sample s into its own plane of `acc` ({light, id} at [s - sample][slot]); the bounce launches
@@ -85,6 +80,12 @@ struct FrameParams {
     uint32_t tile_major;     // output slots are [t_local][64] (sharded, or VRT_FLAG_TILE_MAJOR) instead of row-major
     uint32_t compact;        // VRT_FLAG_COMPACT: a slot is an 8-byte record {id word | kIdNormYNeg, water_dist} instead of a texel
     uint32_t finite_settings;  // 1: every Settings float is finite (lets hits skip the sky term exactly)
+    // vrt_set_presentation: the frame is presented 1:1 — its march kernel also stores the window's rgba8 pixel (vrt_tile.h:
+    // store_screen) into the frame set's screen buffer; null: the blit is its own launch (vrt_present*)
+    uint32_t *screen;
+    uint32_t screen_only;    // VRT_PRESENT_SKIP_TEXELS: ... and no 16-byte texel
+    uint32_t present_box[4]; // [x0, x1) x [y0, y1): the pixels the crosshair's mask can reach (x0 >= x1: none)
+    vrt_crosshair crosshair;
     vrt_cam_data cam;
     vrt_settings settings;
     vrt_world_data world;
@@ -106,7 +107,6 @@ struct FrameParams {
 // per workgroup in LDS instead: vrt_kernels.hip.)
 constexpr uint32_t kHitSegments = 256;
 constexpr uint32_t kSegStride = 16;  // u32 words between counters (64 B)
-constexpr uint32_t kContFresh = 0x80000000u;   // plane 3, w: not a ray in mid-march but a path's next segment, to be started
 
 enum Counter : int {
     kCtrHitCount = 0,       // unused by the kernels (the host sums the segment counters)

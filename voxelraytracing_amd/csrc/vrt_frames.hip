@@ -65,13 +65,9 @@ static int alloc_output(vrt_ctx *c) {
     for (auto &p : c->extra_out) { (void)hipFree(p); p = nullptr; }
     for (auto &p : c->extra_blk) { (void)hipFree(p); p = nullptr; }
     for (auto &p : c->extra_path) { (void)hipFree(p); p = nullptr; }
-    for (auto &p : c->path_cont) { (void)hipFree(p); p = nullptr; }
     for (auto &p : c->path_acc) { (void)hipFree(p); p = nullptr; }
     for (auto &p : c->path_grp_counts) { (void)hipFree(p); p = nullptr; }
     for (auto &n : c->path_grp_regions) n = 0;
-    if (c->mov_stream) (void)hipStreamSynchronize(c->mov_stream);
-    for (int k = 0; k < 2; k++) { (void)hipFree(c->d_mov_cost[k]); (void)hipFree(c->d_mov_order[k]); c->d_mov_cost[k] = c->d_mov_order[k] = nullptr; c->mov_order_recorded[k] = false; }
-    c->mov_new.valid = c->mov_pend.valid = c->mov_cur.valid = false;
     (void)hipFree(c->d_tile_cost); c->d_tile_cost = nullptr;
     (void)hipFree(c->d_tile_order); c->d_tile_order = nullptr;
     (void)hipFree(c->d_tile_scratch); c->d_tile_scratch = nullptr;
@@ -79,7 +75,6 @@ static int alloc_output(vrt_ctx *c) {
     c->tile_order_valid = false;
     for (auto &n : c->path_acc_texels) n = 0;
     for (auto &n : c->path_buf_records) n = 0;
-    for (auto &n : c->path_cont_records) n = 0;
     layout_tiles(c);
     const size_t n = c->slots ? c->slots : 1;
     HIP_TRY(c, hipMalloc(&c->own_out, n * sizeof(vrt::Texel)));
@@ -102,6 +97,8 @@ static int alloc_output(vrt_ctx *c) {
     c->last_out = c->own_out;
     c->last_blk = c->d_blk_counts;
     c->rendered = false;
+    c->last_fused = false;
+    c->last_has_texels = true;
     return VRT_OK;
 }
 
@@ -306,29 +303,6 @@ static int next_events(vrt_ctx *c, std::array<hipEvent_t, 4> **ev, uint8_t **kin
 static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f, const vrt_render_opts &o, bool kstats, bool literal,
                              std::array<hipEvent_t, 4> &ev, uint8_t &ev_kind) {
     const uint32_t spp = o.spp ? o.spp : 1u, bounces = c->settings.max_ray_bounces;
-    if (bounces > 0 && !kstats && !literal && P.grid && c->path_persistent && vrt::g_exp.path_persistent) {
-        // VRT_PATH_PERSISTENT=1 (built and measured, not the default: 10.8 against 13.0 Grays/s on C4):
-        // persistent waves whose lanes own pixels and are refilled in batches (vrt_path.hip); one launch per frame
-        // whatever spp and the bounce count are, no path buffers.  The tile queues' eight heads live at the start of this
-        // frame set's segment-counter area (zeroed with the counters just before).
-        if (!c->n_cus) {
-            hipDeviceProp_t prop;
-            HIP_TRY(c, hipGetDeviceProperties(&prop, c->device));
-            c->n_cus = (uint32_t)prop.multiProcessorCount;
-        }
-        P.spp = spp;
-        P.seed = o.seed;
-        if (ev[0]) HIP_TRY(c, hipEventRecord(ev[0], f.st));
-        vrt::g_exp.path_persistent(P, P.seg_counts, c->n_cus, f.st);
-        HIP_TRY(c, hipGetLastError());
-        if (ev[0]) {
-            HIP_TRY(c, hipEventRecord(ev[1], f.st));
-            HIP_TRY(c, hipEventRecord(ev[3], f.st));
-            ev_kind = kEvRecorded;
-        }
-        c->last_spp = spp;
-        return VRT_OK;
-    }
     // Several samples per launch chain (plain frames, spp > 1): every launch of the chain carries `samples` times the rays —
     // 2.7 rays per lane are not enough to cover a bounce launch's tail — and a frame of 16 spp is 4 x 4
     // launches instead of 16 x 4.  Each sample accumulates into its own plane; the chain's finishing pass adds the planes
@@ -363,16 +337,10 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
     P.path_cap = (uint32_t)cap;
     P.in_cap = (uint32_t)cap;
     P.in_seg_cap = seg_cap;
-    P.cont_out = nullptr;
-    P.cont_counts = nullptr;
     P.spp = spp;
     P.seed = o.seed;
-    // Bounce launches over the derived tables use the pool kernel (vrt_path.hip).  With up to kContSets of them per sample
-    // they hand the rays still marching when a wave's pool runs dry to a *straggler chain* on a side stream: launch S(b)
-    // marches what bounce launch b handed on plus the next segments of S(b - 1)'s own survivors, while bounce launch
-    // b + 1 already runs — the few rays that graze the terrain for a hundred steps, which every bounce launch used to
-    // wait for, are off the frame's critical path.  A path is in exactly one of the two chains, so nothing is shared but
-    // the record sets' cursors (atomics).  The chains join at the end of every sample.
+    // Bounce launches over the derived tables with march cells: every later segment of the frame in ONE launch of the pool
+    // kernel (vrt_path.hip); worlds without march cells, stats frames and the literal march: one lane = path launch per bounce.
     const bool pool = !kstats && !literal && P.grid && bounces > 1 && c->path_pool;
     const bool cells = pool && P.mblk && c->path_cells;
     // ... and among those the window launch (vrt_path_window.hip): the primary launch compacts each workgroup's survivors into
@@ -396,27 +364,6 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
         P.blk_w = nw == 4u ? 4u : 8u;
         P.blk_h = nw == 16u ? 8u : 4u;
     }
-    // (the round-2 pool kernel and its straggler chain on a side stream: the experiments build)
-    const bool old_pool = pool && !cells && vrt::g_exp.path_bounce_pool;
-    const bool chain = old_pool && bounces - 1u <= kContSets && c->path_chain;
-    uint32_t *cont_seg[kContSets];
-    for (uint32_t i = 0; i < kContSets; i++) cont_seg[i] = P.seg_counts + (3 + i) * kSegWords;
-    hipStream_t side = nullptr;
-    hipEvent_t *sev = c->side_ev[f.slot];
-    if (chain) {
-        if (c->path_cont_records[f.slot] < cap) {
-            (void)hipFree(c->path_cont[f.slot]);
-            c->path_cont[f.slot] = nullptr; c->path_cont_records[f.slot] = 0;
-            HIP_TRY(c, hipMalloc(&c->path_cont[f.slot], (size_t)kContSets * 4 * cap * sizeof(uint4)));
-            c->path_cont_records[f.slot] = cap;
-        }
-        if (!c->side_stream[f.slot]) HIP_TRY(c, hipStreamCreateWithFlags(&c->side_stream[f.slot], hipStreamNonBlocking));
-        for (int i = 0; i < 6; i++)
-            if (!sev[i]) HIP_TRY(c, hipEventCreateWithFlags(&sev[i], hipEventDisableTiming));
-        side = c->side_stream[f.slot];
-    }
-    uint4 *cont = c->path_cont[f.slot];
-    (void)cont;
     const bool timed = ev[0] != nullptr;
     if (timed) HIP_TRY(c, hipEventRecord(ev[0], f.st));
     if (bounces == 0) HIP_TRY(c, hipMemsetAsync(f.out, 0, (size_t)c->slots * sizeof(vrt::Texel), f.st));
@@ -425,9 +372,6 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
     for (uint32_t smp = 0; smp < spp && bounces > 0; smp += samples) {
         P.sample = smp;
         P.chain = spp - smp < samples ? spp - smp : samples;
-        // (the chain's cursors are zero at the start of a frame — vrt_render cleared the counters — and again for every
-        // further sample; the chains have joined by then)
-        if (chain && smp > 0) HIP_TRY(c, hipMemsetAsync(cont_seg[0], 0, kContSets * kSegBytes, f.st));
         for (uint32_t b = 0; b < bounces; b++, g++) {
             P.seg_counts = seg[g % 3u];
             P.seg_in = seg[(g + 2u) % 3u];
@@ -435,55 +379,23 @@ static int launch_path_frame(vrt_ctx *c, vrt::FrameParams &P, const FrameSet &f,
             P.path_out = buf[g & 1u];
             P.path_in = buf[(g + 1u) & 1u];
             P.last_bounce = b + 1 == bounces;
-            P.cont_out = nullptr;
-            P.cont_counts = nullptr;
             // one sample per pixel: the lane that ends a path has the pixel's final value (x / 1 = x) — no finishing pass
             if (b == 0) {
                 if (window) vrt::g_exp.path_primary_grouped(P, f.st);
                 else vrt::launch_path_primary(P, kstats, literal, f.st);
-            } else if (!pool) {
-                vrt::launch_path_bounce(P, kstats, literal, f.st);
             } else if (cells) {
                 // every bounce segment that is left in ONE launch: the waves carry their own survivors from one to the next
                 // (one cursor set, one swap of the path buffers per LAUNCH: g counts launches)
                 const uint32_t segments = bounces - b;
                 P.last_bounce = 1u;
                 if (window) vrt::g_exp.path_bounce_window(P, segments, n_regions, samples, c->path_window_shape, c->path_window_lift, f.st);
-                else if (vrt::g_exp.path_bounce_cells) vrt::g_exp.path_bounce_cells(P, c->path_refill, segments, c->path_lds_pad, f.st);   // (a probe build)
-                else vrt::launch_path_bounce_cells(P, c->path_refill, segments, c->path_lds_pad,
-                                                   c->path_pool_batches ? c->path_pool_batches : (c->in_flight > 1u ? 5u : 4u), f.st);
+                else vrt::launch_path_bounce_cells(P, c->path_refill, segments, c->path_pool_batches ? c->path_pool_batches : (c->in_flight > 1u ? 5u : 4u), f.st);
                 b += segments - 1u;
             } else {
-                if (!old_pool) vrt::launch_path_bounce(P, kstats, literal, f.st);   // (a world without march cells: lane = path)
-                else {
-                if (chain) {
-                    P.cont_out = cont + (size_t)(b - 1u) * 4 * cap;
-                    P.cont_counts = cont_seg[b - 1u];
-                }
-                vrt::g_exp.path_bounce_pool(P, false, c->path_refill, c->path_eject, f.st);
-                if (chain) {
-                    HIP_TRY(c, hipGetLastError());
-                    // S(b): after bounce launch b (its hand-overs) and S(b - 1) (stream order: its survivors)
-                    HIP_TRY(c, hipEventRecord(sev[b - 1u], f.st));
-                    HIP_TRY(c, hipStreamWaitEvent(side, sev[b - 1u], 0));
-                    vrt::FrameParams Q = P;
-                    Q.path_in = P.cont_out;
-                    Q.seg_in = P.cont_counts;
-                    Q.seg_clear = nullptr;
-                    Q.path_out = nullptr;
-                    Q.seg_counts = nullptr;
-                    Q.cont_out = P.last_bounce ? nullptr : cont + (size_t)b * 4 * cap;
-                    Q.cont_counts = P.last_bounce ? nullptr : cont_seg[b];
-                    vrt::g_exp.path_bounce_pool(Q, true, c->path_refill, 0u, side);
-                }
-                }
+                vrt::launch_path_bounce(P, kstats, literal, f.st);   // (no march cells, a stats frame, the literal march: lane = path)
             }
             HIP_TRY(c, hipGetLastError());
             if (first) { if (timed) HIP_TRY(c, hipEventRecord(ev[1], f.st)); first = false; }
-        }
-        if (chain) {   // the sample's two chains join
-            HIP_TRY(c, hipEventRecord(sev[4], side));
-            HIP_TRY(c, hipStreamWaitEvent(f.st, sev[4], 0));
         }
         if (planes) {
             vrt::launch_path_chain_finish(frame_out, c->path_acc[f.slot], c->slots, P.chain, smp == 0u, smp + P.chain >= spp, spp, f.st);
@@ -509,21 +421,6 @@ static int launch_march_frame(vrt_ctx *c, const vrt::FrameParams &P, const Frame
                               std::array<hipEvent_t, 4> &ev, uint8_t &ev_kind) {
     if (!c->tiles_local) return VRT_OK;  // an empty shard
     const uint32_t march = variant == 3u ? 0u : variant;  // variant 3 = the grid march in two launches
-    if (variant == 4u) {   // (the persistent grid of the experiments build: variant_supported() refuses it elsewhere)
-        if (!vrt::g_exp.primary_shadow_persistent) return fail(c, VRT_ERR_INVALID_ARG, "vrt_render: variant 4 (the persistent grid) is in the experiments build only");
-        if (!c->d_heads) {
-            HIP_TRY(c, hipMalloc(&c->d_heads, 8 * 64));
-            hipDeviceProp_t prop;
-            HIP_TRY(c, hipGetDeviceProperties(&prop, c->device));
-            c->n_cus = (uint32_t)prop.multiProcessorCount;
-        }
-        HIP_TRY(c, hipMemsetAsync(c->d_heads, 0, 8 * 64, f.st));
-        c->n_counts = c->tiles_local;
-        vrt::g_exp.primary_shadow_persistent(P, c->d_heads, c->n_cus, f.st, ev[0], ev[1]);
-        HIP_TRY(c, hipGetLastError());
-        if (ev[0]) ev_kind = kEvOneKernel;
-        return VRT_OK;
-    }
     // primary + shadow in one launch: the default march, and — on a context whose pixel slots are 8-byte records — the
     // octree walk it falls back to when the world is too large for the derived tables (the two-launch kernels store and
     // re-read 16-byte texels, which such a buffer has no room for)
@@ -596,24 +493,17 @@ int vrt_create(const vrt_config *cfg, vrt_ctx **out) {
         if (v >= 0 && v <= (long)kMarchDirectMaxS) c->march_direct_max_s = (uint32_t)v;
     }
     if (const char *e = getenv("VRT_TILE_ORDER")) c->tile_lpt = e[0] != '0';
-    // switches of the experiments build (tools/ab/libvrt_exp.so): without its hooks (vrt_exp.h) the first seven select nothing
-    // (0: screen order while the view moves; 2, 6: the experiments build's forms — profiles/r05_tile_order_moving.txt)
-    if (const char *e = getenv("VRT_TILE_ORDER_MOVING"))
-        c->tile_lpt_moving = e[0] == '6' ? (vrt::g_exp.tile_order_moving ? 6u : 1u) : e[0] == '2' ? (vrt::g_exp.tile_order_beside ? 2u : 1u) : e[0] != '0' ? 1u : 0u;
+    // (0: screen order while the view moves — profiles/r05_tile_order_moving.txt)
+    if (const char *e = getenv("VRT_TILE_ORDER_MOVING")) c->tile_lpt_moving = e[0] != '0' ? 1u : 0u;
     c->mov_any_size = getenv("VRT_TILE_ORDER_MOVING") != nullptr;   // (asked for by name: also for frames larger than kMovingTilesMax)
-    if (const char *e = getenv("VRT_TILE_ORDER_SIDE")) c->mov_side = e[0] != '0';
-    if (const char *e = getenv("VRT_TILE_ORDER_THREADS")) { const int v = atoi(e); if (v >= 64 && v <= 1024) c->mov_threads = (uint32_t)v; }
-    if (const char *e = getenv("VRT_TILE_ORDER_RADIUS")) { const int v = atoi(e); if (v >= 1 && v <= 6) { c->mov_radius = (uint32_t)v; c->mov_radius_set = true; } }
-    if (const char *e = getenv("VRT_PATH_PERSISTENT")) c->path_persistent = e[0] == '1';
+    if (const char *e = getenv("VRT_TILE_ORDER_RADIUS")) { const int v = atoi(e); if (v >= 1 && v <= 6) c->mov_radius = (uint32_t)v; }
     if (const char *e = getenv("VRT_PATH_POOL")) c->path_pool = e[0] != '0';
-    if (const char *e = getenv("VRT_PATH_POOL_CHAIN")) c->path_chain = e[0] == '1';
     if (const char *e = getenv("VRT_PATH_CELLS")) c->path_cells = e[0] != '0';
+    // (the experiments build, tools/ab/libvrt_exp.so: without its hooks — vrt_exp.h — the next three select nothing)
     if (const char *e = getenv("VRT_PATH_WINDOW")) c->path_window = e[0] == '1';
     if (const char *e = getenv("VRT_PATH_WINDOW_SHAPE")) { const int v = atoi(e); if (v >= 0 && v <= 4) c->path_window_shape = (uint32_t)v; }
     if (const char *e = getenv("VRT_PATH_WINDOW_LIFT")) { const int v = atoi(e); if (v >= -64 && v <= 64) c->path_window_lift = v; }
     if (const char *e = getenv("VRT_PATH_POOL_REFILL")) c->path_refill = (uint32_t)atoi(e);
-    if (const char *e = getenv("VRT_PATH_POOL_EJECT")) c->path_eject = (uint32_t)atoi(e);
-    if (const char *e = getenv("VRT_PATH_LDS_PAD")) { const long v = strtol(e, nullptr, 10); if (v >= 0 && v <= 45000) c->path_lds_pad = (uint32_t)v; }
     if (const char *e = getenv("VRT_PATH_POOL_K")) { const int v = atoi(e); if (v == 4 || v == 5) c->path_pool_batches = (uint32_t)v; }
     if (const char *e = getenv("VRT_PATH_SAMPLES_PER_CHAIN")) { const int v = atoi(e); if (v >= 1 && v <= 16) c->path_samples = (uint32_t)v; }
     if (const char *e = getenv("VRT_TIMING_EVERY")) { const long v = strtol(e, nullptr, 10); if (v >= 1 && v <= 1000000) c->timing_every = (uint32_t)v; }
@@ -670,21 +560,9 @@ void vrt_destroy(vrt_ctx *c) {
     for (auto p : c->extra_blk) (void)hipFree(p);
     for (auto p : c->extra_path) (void)hipFree(p);
     for (auto p : c->extra_counters) (void)hipFree(p);
-    for (auto p : c->path_cont) (void)hipFree(p);
     for (auto p : c->path_acc) (void)hipFree(p);
     for (auto p : c->path_grp_counts) (void)hipFree(p);
     (void)hipFree(c->d_tile_cost); (void)hipFree(c->d_tile_order); (void)hipFree(c->d_tile_scratch);
-    if (c->mov_stream) (void)hipStreamSynchronize(c->mov_stream);   // (extra_stream[0]: destroyed with the others)
-    for (int k = 0; k < 2; k++) {
-        (void)hipFree(c->d_mov_cost[k]); (void)hipFree(c->d_mov_order[k]);
-        if (c->mov_frame_done[k]) (void)hipEventDestroy(c->mov_frame_done[k]);
-        if (c->mov_order_done[k]) (void)hipEventDestroy(c->mov_order_done[k]);
-    }
-    for (auto st : c->side_stream)
-        if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
-    for (auto &evs : c->side_ev)
-        for (auto ev : evs)
-            if (ev) (void)hipEventDestroy(ev);
     (void)hipFree(c->d_nodes); (void)hipFree(c->d_roots); (void)hipFree(c->d_mats); (void)hipFree(c->own_out);
     (void)hipFree(c->d_hits); (void)hipFree(c->d_counters); (void)hipFree(c->d_steps); (void)hipFree(c->d_rgba8); (void)hipFree(c->d_path);
     (void)hipFree(c->d_blk_counts); (void)hipFree(c->d_clock);
@@ -701,7 +579,7 @@ void vrt_destroy(vrt_ctx *c) {
         for (auto ev : evs)
             if (ev) (void)hipEventDestroy(ev);
     if (c->ev_frames) (void)hipEventDestroy(c->ev_frames);
-    if (c->ev_upload) (void)hipEventDestroy(c->ev_upload); (void)hipFree(c->d_ndc); for (uint8_t *p : c->d_screen) (void)hipFree(p); (void)hipFree(c->d_heads);
+    if (c->ev_upload) (void)hipEventDestroy(c->ev_upload); (void)hipFree(c->d_ndc); for (uint8_t *p : c->d_screen) (void)hipFree(p);
     for (auto &t : c->ev_pool)
         for (auto &ev : t)
             if (ev) (void)hipEventDestroy(ev);
@@ -762,8 +640,6 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     if (o.stats > 2u) return fail(c, VRT_ERR_INVALID_ARG, "vrt_render: stats %u (0, 1 = count steps, 2 = clock probe)", o.stats);
     if (o.stats == 2u && (o.mode != VRT_MODE_PRIMARY_SHADOW || (o.variant != 0u)))
         return fail(c, VRT_ERR_INVALID_ARG, "vrt_render: the clock probe (stats = 2) is a build of the default primary + shadow kernel");
-    if (o.variant == 4u && (o.mode != VRT_MODE_PRIMARY_SHADOW || o.stats))
-        return fail(c, VRT_ERR_INVALID_ARG, "vrt_render: variant 4 (persistent grid) renders plain primary + shadow frames only");
     if (!vrt::variant_supported(o.variant)) return fail(c, VRT_ERR_INVALID_ARG, "vrt_render: unknown kernel variant %u", o.variant);
     int rc;
     {
@@ -796,15 +672,15 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     // material table that flags voxel 0 as liquid — nothing the reference's data packs do — is traced by the literal march.
     const bool air_liquid = c->h_mats[0].is_liquid == 1u;
     if (air_liquid) {
-        if (c->compact || o.variant == 4u)
+        if (c->compact)
             return fail(c, VRT_ERR_STATE, "vrt_render: materials[0].is_liquid == 1 (air flagged liquid) is traced by the literal march only");
         variant = 1u;
     }
-    if (variant == 0u || variant == 3u || variant == 4u || (o.mode == VRT_MODE_PATH && !air_liquid)) {
+    if (variant == 0u || variant == 3u || (o.mode == VRT_MODE_PATH && !air_liquid)) {
         VRT_PROF(9, "  ensure_accel_world");
         rc = ensure_accel_world(c);
         if (rc) return rc;
-        if (!c->accel_ok && (variant == 0u || variant == 3u || variant == 4u)) variant = 2u;  // world too large for the tables: walk the octree
+        if (!c->accel_ok && (variant == 0u || variant == 3u)) variant = 2u;  // world too large for the tables: walk the octree
     }
     // per-lane iteration counts exist in the STATS kernels only; the step-count debug view (F2 in the reference,
     // main.rs:368-370) needs them, so it runs those kernels too
@@ -826,7 +702,7 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     }
 
     // this frame's table set, brought up to date on its own stream (which waits for the uploads so far first)
-    const bool wants_tables = variant == 0u || variant == 3u || variant == 4u || (o.mode == VRT_MODE_PATH && !air_liquid);
+    const bool wants_tables = variant == 0u || variant == 3u || (o.mode == VRT_MODE_PATH && !air_liquid);
     constexpr uint32_t kQuietFrames = 64;
     if (c->tables_split && ++c->quiet_frames > kQuietFrames && c->tabs[0].dirty_chunks.empty()) {
         c->tables_split = false;   // no edit for a while: everybody reads tabs[0] again; the other sets go stale
@@ -885,6 +761,20 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     P.steps = o.stats == 1u ? c->d_steps : nullptr;
     P.clock = o.stats == 2u ? c->d_clock : nullptr;
     fill_uniforms(c, P);
+    // vrt_set_presentation: a frame whose kernel finishes its pixels through store_pixel (every primary-only frame; primary + shadow
+    // in one launch) and whose window samples texel for texel also stores the window's image, into its frame set's screen buffer
+    const bool one_launch_shadow = o.mode == VRT_MODE_PRIMARY_SHADOW && (variant == 0u || (variant == 2u && c->compact));
+    const bool fuse_present = (o.mode == VRT_MODE_PRIMARY || one_launch_shadow) && c->tiles_local && presentation_fusable(c);
+    if (fuse_present) {
+        rc = screen_buffer_for_frame(c, f.slot, f.st, c->width, c->height);
+        if (rc) return rc;
+        P.screen = reinterpret_cast<uint32_t *>(c->d_screen[f.slot]);
+        P.screen_only = (c->pres_flags & VRT_PRESENT_SKIP_TEXELS) ? 1u : 0u;
+        memcpy(P.present_box, c->pres_box, sizeof P.present_box);
+        P.crosshair = c->pres_ch;
+    }
+    c->last_fused = fuse_present;
+    c->last_has_texels = !(fuse_present && P.screen_only);
 
     std::array<hipEvent_t, 4> *ev = nullptr;
     uint8_t *ev_kind = nullptr;
@@ -937,10 +827,6 @@ int vrt_synchronize(vrt_ctx *c) {
     if (!c) return VRT_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     QUIESCE(c);
-    if (c->mov_pending) {   // (the order being made beside the last frame touches nothing but its own buffers: only this call waits for it)
-        if (c->mov_stream) HIP_TRY(c, hipStreamSynchronize(c->mov_stream));
-        c->mov_pending = false;
-    }
     {
         const int rc = flush_staged(c);
         if (rc) return rc;
@@ -958,6 +844,7 @@ int vrt_read_output(vrt_ctx *c, float *rgb, uint32_t *ids, uint8_t *rgba8) {
     if (!c) return VRT_ERR_INVALID_ARG;
     if (!c->rendered) return fail(c, VRT_ERR_STATE, "vrt_read_output: nothing rendered yet");
     if (c->compact) return fail(c, VRT_ERR_STATE, "vrt_read_output: a VRT_FLAG_COMPACT context holds 8-byte records, not texels (vrt_assemble_compact shades them)");
+    if (!c->last_has_texels) return fail(c, VRT_ERR_STATE, "vrt_read_output: the last frame stored its window pixels only (vrt_set_presentation with VRT_PRESENT_SKIP_TEXELS)");
     HIP_TRY(c, hipSetDevice(c->device));
     QUIESCE(c);
     const size_t npix = (size_t)c->width * c->height;

@@ -170,7 +170,7 @@ static int grp_render_frame(vrt_ctx *c, const vrt_render_opts *opts, bool &issue
     if (!g->texels && (o.mode == VRT_MODE_PATH || (o.variant != 0u && o.variant != 2u)))
         return fail(c, VRT_ERR_STATE, "vrt_render: this multi-device context exchanges 8-byte records (primary(+shadow) frames of the default "
                     "march); create it with VRT_FLAG_TEXEL_MESSAGES for the path trace and the other marches");
-    if (o.stats == 2u || o.variant == 4u) return fail(c, VRT_ERR_INVALID_ARG, "vrt_render: no clock probe / persistent grid on a multi-device context");
+    if (o.stats == 2u) return fail(c, VRT_ERR_INVALID_ARG, "vrt_render: no clock probe on a multi-device context");
     const uint32_t n = (uint32_t)g->dev.size();
     const bool plain = o.stats == 0u && root->settings.show_step_count != 1u;
     if (!plain || g->in_flight == 1u || g->last_was_stats) {   // a stats frame (counters are read back) stands alone

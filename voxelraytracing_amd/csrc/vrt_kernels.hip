@@ -11,7 +11,7 @@
 //   * the step arithmetic is branch-free and algebraically reduced where the reduction is bit-exact;
 //   * primary + shadow is one launch with no cooperation between waves: a lane marches its pixel's shadow ray right
 //     after its primary ray and stores one 16-byte texel {r,g,b,id} (a wave stores 1 KiB contiguously); the two-launch
-//     form with a workgroup-compacted hit buffer in HBM is variant 3, a persistent grid over per-XCD tile queues variant 4;
+//     form with a workgroup-compacted hit buffer in HBM is variant 3;
 //   * the 256-bit liquid mask (and, for variants 1-2, the chunk-root table) is staged in LDS.
 #include <hip/hip_ext.h>
 
@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(256) primary_tile_kernel(FrameParams P) {
             if (launch) id |= VRT_ID_SHADOW_RAY;
         }
         if (SHADOW) P.out[slot] = make_uint4(__float_as_uint(color.x), __float_as_uint(color.y), __float_as_uint(color.z), id);
-        else store_pixel(P, slot, color, id, R);   // (the two-launch shadow kernel read-modify-writes texels: no compact form)
+        else store_pixel(P, slot, px, py, color, id, R);   // (the two-launch shadow kernel read-modify-writes texels: no compact form)
 
         if (SHADOW) {
             // Compaction of the solid hits into the workgroup's own 256-record slice of the hit buffer: ballot +
@@ -468,13 +468,19 @@ bool launch_tile_order_blocks(const uint32_t *cost, uint32_t tiles_x, uint32_t t
     if (!nb || nb > kOrderBlocksMax || bw > 255u || bh > 255u || radius > kOrderRadiusMax) return false;
     const uint32_t chunks = (nb + 63u) / 64u;
     const size_t lds = ((size_t)3 * nb + (size_t)kCostClasses * chunks) * sizeof(uint32_t);   // 4K: 96 + 32 KiB
-    static std::atomic<uint64_t> opted_in{0};   // (> 64 KiB of dynamic LDS needs opting in, once per device)
+    // (> 48 KiB of dynamic LDS needs opting in, once per device — with the kernel's MAXIMUM, kOrderBlocksMax blocks, so that a later,
+    // larger frame on the same device needs nothing more: 128 KiB of gfx950's 160)
+    static std::atomic<uint64_t> opted_in{0};
     if (lds > 48u * 1024u) {
+        constexpr size_t kLdsMax = ((size_t)3 * kOrderBlocksMax + (size_t)kCostClasses * (kOrderBlocksMax / 64u)) * sizeof(uint32_t);
         int dev = 0;
         (void)hipGetDevice(&dev);
         const uint64_t bit = (unsigned)dev < 64u ? 1ull << dev : 0ull;
-        if (!(opted_in.load(std::memory_order_relaxed) & bit)) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(tile_order_blocks_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+        if (!bit || !(opted_in.load(std::memory_order_relaxed) & bit)) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(tile_order_blocks_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax) != hipSuccess) {
+                (void)hipGetLastError();
+                return false;
+            }
             opted_in.fetch_or(bit, std::memory_order_relaxed);
         }
     }
@@ -504,7 +510,6 @@ __global__ void quantize_rgba8_kernel(const Texel *out, uint8_t *rgba8, uint32_t
 
 // Presentation: fs_main of screen_shader.wgsl:43-65 over the rgba8unorm result texture (ray_tracer.wgsl:179), one lane
 // per screen pixel: the sampler's (bilinear) sample of the texture at the pixel centre, crosshair mask, blend, unorm8 store.
-__device__ __forceinline__ uint32_t unorm8(float x) { return (uint32_t)rintf(vclamp(x, 0.0f, 1.0f) * 255.0f) & 0xFFu; }
 
 // decoded[q] = q / 255 as the sampler decodes an rgba8unorm texel, a table of the workgroup (256 threads, a correctly rounded divide each):
 // a sample took twelve such divides — ~ 130 of the general blit's ~ 250 instructions per pixel, 68 us for a 4K window
@@ -520,64 +525,19 @@ __device__ __forceinline__ void present_tap(const Texel *tex, size_t i, bool cov
 
 __device__ __forceinline__ uint32_t present_pixel(const Texel *tex, uint32_t w, uint32_t h, uint32_t cov_w, uint32_t cov_h, uint32_t screen_w, uint32_t screen_h,
                                                    const vrt_crosshair &ch, uint32_t sx, uint32_t sy, const float *decoded, bool in_box) {
-    // in_box: the pixel is within the host's box around the crosshair (a pixel wider than the mask can reach, vrt_present.hip) —
-    // outside it the mask is zero without being computed
-    const float ssx = (float)screen_w, ssy = (float)screen_h;
-    const float cx = ssx * 0.5f, cy = ssy * 0.5f;
-    const float u = ((float)sx + 0.5f) / ssx, v = ((float)sy + 0.5f) / ssy;
-    const float px = u * ssx, py = v * ssy;
-    // (uniform) outside the crosshair the blend is x * 1 + c * 0 = x — for a FINITE colour c (x >= 0: adding -0 changes nothing
-    // either); a crosshair whose colour is not a number takes the blend everywhere, as the shader would
-    const bool colour_finite = ((__float_as_uint(ch.color[0]) & 0x7F800000u) != 0x7F800000u) && ((__float_as_uint(ch.color[1]) & 0x7F800000u) != 0x7F800000u) &&
-                               ((__float_as_uint(ch.color[2]) & 0x7F800000u) != 0x7F800000u);
-    float mask = 0.0f;
-    if (in_box && ch.style == 1u) {
-        const float dx = cx - px, dy = cy - py;
-        mask = (sqrtf(dx * dx + dy * dy) < ch.size ? 1.0f : 0.0f) * ch.color[3];
-    }
-    if (in_box && ch.style == 2u) {
-        const float dx = fabsf(cx - px), dy = fabsf(cy - py);
-        const float wd = ch.size * 0.25f;
-        mask = (((dx < ch.size && dy < wd) || (dy < ch.size && dx < wd)) ? 1.0f : 0.0f) * ch.color[3];
-    }
-    // textureSample through the reference's sampler (texture.rs:31-44): lod clamped to [1, 1] => the minification filter,
-    // Linear, at every window size (oracle/vrt_oracle.c:orc_present spells the rule out); bilinear in f32, ClampToEdge
-    const float ut = u * (float)w - 0.5f, vt = v * (float)h - 0.5f;
-    const float fu = floorf(ut), fv = floorf(vt);
-    const float a = ut - fu, b = vt - fv;
-    const int x0 = min(max((int)fu, 0), (int)w - 1), x1 = min(max((int)fu + 1, 0), (int)w - 1);
-    const int y0 = min(max((int)fv, 0), (int)h - 1), y1 = min(max((int)fv + 1, 0), (int)h - 1);
+    // (the sample's taps and weights, the crosshair's mask and the blend: vrt_tile.h, shared with the march kernels' own store)
+    const PresentSample S = present_sample(w, h, screen_w, screen_h, ch, sx, sy, in_box);
     // alpha: 1 where the compute pass stored a texel, 0 beyond its workgroups (all of it when w and h are multiples of 8)
-    float v00[4];
-    present_tap(tex, (size_t)y0 * w + x0, (uint32_t)x0 < cov_w && (uint32_t)y0 < cov_h, decoded, v00);
-    float texel[4];
-    if (a == 0.0f && b == 0.0f) {
-        // The sample is at a texel's centre: the other three taps have weight zero, and x * 1 + y * 0 is x for the finite x and y a
-        // decoded unorm8 is — one tap instead of four (every pixel of a window of the texture's size that present_plain_kernel
-        // does not take)
-#pragma unroll
-        for (int k = 0; k < 4; k++) texel[k] = v00[k];
-    } else {
-        float v10[4], v01[4], v11[4];
-        present_tap(tex, (size_t)y0 * w + x1, (uint32_t)x1 < cov_w && (uint32_t)y0 < cov_h, decoded, v10);
-        present_tap(tex, (size_t)y1 * w + x0, (uint32_t)x0 < cov_w && (uint32_t)y1 < cov_h, decoded, v01);
-        present_tap(tex, (size_t)y1 * w + x1, (uint32_t)x1 < cov_w && (uint32_t)y1 < cov_h, decoded, v11);
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const float top = v00[k] * (1.0f - a) + v10[k] * a, bot = v01[k] * (1.0f - a) + v11[k] * a;
-            texel[k] = top * (1.0f - b) + bot * b;
-        }
+    float v00[4], v10[4] = {0.f, 0.f, 0.f, 0.f}, v01[4] = {0.f, 0.f, 0.f, 0.f}, v11[4] = {0.f, 0.f, 0.f, 0.f};
+    present_tap(tex, (size_t)S.y0 * w + S.x0, (uint32_t)S.x0 < cov_w && (uint32_t)S.y0 < cov_h, decoded, v00);
+    if (!(S.a == 0.0f && S.b == 0.0f)) {
+        // (a sample at a texel's centre looks at one tap instead of four: every pixel of a window of the texture's size that
+        // present_plain_kernel does not take)
+        present_tap(tex, (size_t)S.y0 * w + S.x1, (uint32_t)S.x1 < cov_w && (uint32_t)S.y0 < cov_h, decoded, v10);
+        present_tap(tex, (size_t)S.y1 * w + S.x0, (uint32_t)S.x0 < cov_w && (uint32_t)S.y1 < cov_h, decoded, v01);
+        present_tap(tex, (size_t)S.y1 * w + S.x1, (uint32_t)S.x1 < cov_w && (uint32_t)S.y1 < cov_h, decoded, v11);
     }
-    uint32_t q = 0u;
-    if (mask == 0.0f && colour_finite) {   // unorm8(x * 1 + c * 0) = unorm8(x)
-#pragma unroll
-        for (int k = 0; k < 4; k++) q |= unorm8(texel[k]) << (8 * k);
-        return q;
-    }
-    const float cc[4] = {ch.color[0], ch.color[1], ch.color[2], 1.0f};
-#pragma unroll
-    for (int k = 0; k < 4; k++) q |= unorm8(texel[k] * (1.0f - mask) + cc[k] * mask) << (8 * k);
-    return q;
+    return present_blend(S, ch, v00, v10, v01, v11);
 }
 
 
@@ -719,9 +679,8 @@ static void launch_shadow_t(const FrameParams &P, bool stats, hipStream_t st, hi
 
 // variant 0: grid march over the derived cell grid / brick pool (needs P.grid), primary + shadow fused into one launch;
 // 1: literal octree walk; 2: ancestor-cache octree walk; 3: grid march, shadow rays as a second launch from a hit buffer
-// in HBM (the wavefront form the path trace is built from); 4: variant 0's work as a persistent grid pulling tiles from
-// per-XCD queues (primary + shadow frames only)
-bool variant_supported(uint32_t variant) { return variant <= 3u || (variant == 4u && g_exp.primary_shadow_persistent != nullptr); }   // (4, the persistent grid: the experiments build)
+// in HBM (the wavefront form the path trace is built from)
+bool variant_supported(uint32_t variant) { return variant <= 3u; }
 
 
 // One launch for primary + shadow; blk_counts gets one launched-ray count per tile.  march 0 = the grid march (variant 0);

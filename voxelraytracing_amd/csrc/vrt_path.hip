@@ -536,13 +536,13 @@ void launch_path_primary(const FrameParams &P, bool stats, bool literal, hipStre
 
 // the pool kernel over the march cells (P.mblk): `segments` bounce segments in this one launch (every wave carries its own
 // survivors from one to the next; P.path_in / P.path_out are the two buffers it goes back and forth between)
-void launch_path_bounce_cells(const FrameParams &P, uint32_t refill_at, uint32_t segments, uint32_t lds_pad, uint32_t pool_batches, hipStream_t st) {
+void launch_path_bounce_cells(const FrameParams &P, uint32_t refill_at, uint32_t segments, uint32_t pool_batches, hipStream_t st) {
     if (P.tiles_local == 0 || segments == 0) return;
     const uint32_t refill = refill_at >= 1u && refill_at <= 64u ? refill_at : kPoolRefillAt;
     const uint32_t kb = (pool_batches == 5u && P.march_direct) ? 5u : 4u, entries = kb * 64u;   // (320-ray pools: direct worlds only)
     const uint32_t parts = (P.in_seg_cap + 4u * entries - 1u) / (4u * entries);
     const dim3 grid(kHitSegments * parts), block(256);
-    const size_t sh = 8u * 4u + 4u * (entries * 16u + entries * 2u) + lds_pad;   // per wave: the pool + a u16 order per entry (lds_pad: r04's occupancy sweep)
+    const size_t sh = 8u * 4u + 4u * (entries * 16u + entries * 2u);   // per wave: the pool + a u16 order per entry
     const CellsLaunch L{P, refill, segments};
     if (kb == 5u) hipLaunchKernelGGL((path_bounce_cells_kernel<true, 5u>), grid, block, sh, st, L);
     else if (P.march_direct) hipLaunchKernelGGL((path_bounce_cells_kernel<true, 4u>), grid, block, sh, st, L);

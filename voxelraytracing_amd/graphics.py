@@ -178,6 +178,14 @@ class Gpu:
         self._ck(self._lib.vrt_present_device(self._h, C.byref(ch), sw, sh, C.byref(ptr), C.byref(nb)))
         return ptr.value, nb.value
 
+    def set_presentation(self, screen_size=None, color=(1.0, 1.0, 1.0, 0.33), style: int = 2, size: float = 5.0, skip_texels: bool = False, off: bool = False):
+        """vrt_set_presentation: the frames that follow are presented to a window of screen_size under this crosshair — when the window
+        samples the texture texel for texel their march kernel stores the window's image itself and present / present_device with the
+        same crosshair and size launch nothing (main.rs:452-454 in one launch).  skip_texels: such frames store the image only."""
+        sw, sh = screen_size or self.result_size
+        ch = _ffi.Crosshair((C.c_float * 4)(*color), style, size)
+        self._ck(self._lib.vrt_set_presentation(self._h, None if off else C.byref(ch), sw, sh, 1 if skip_texels else 0))
+
     def read_steps(self) -> np.ndarray:
         w, h = self.result_size
         a = np.empty((h, w), dtype=np.uint32)
