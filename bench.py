@@ -402,7 +402,7 @@ def main():
         gpu.write_cam_data(cam)
         if fg is not None:
             fg.bind(gpu, 0)
-        gpu.render(MODE, stats=True, **(dict(rkw, variant=0) if rkw.get("variant") == 4 else rkw))   # (the persistent grid has no stats form)
+        gpu.render(MODE, stats=True, **rkw)
         return gpu.stats()
     orbit_rays = []
     for rot, eye in cams:
@@ -543,17 +543,24 @@ def main():
                                     f"{w_op.populated_count()} chunks with nodes", "frames": 400,
                            "per_frame": "vrt_set_settings, vrt_set_camera, vrt_write_chunk_roots (untagged, a fresh 27 000-entry table), vrt_set_world, "
                                         "vrt_render (primary + shadow), vrt_present_device at the frame's size"}
-        for nf in (1, 2):
-            gp.set_frames_in_flight(nf)
-            client_frames(100)
-            gp.synchronize()
-            t0 = time.perf_counter()
-            client_frames(400)
-            t_host = time.perf_counter() - t0
-            gp.synchronize()
-            t_all = time.perf_counter() - t0
-            operating_point[f"{nf}_in_flight"] = {"ms_per_frame": t_all / 400 * 1e3, "host_us_per_frame": t_host / 400 * 1e6,
-                                                  "value": sum(rays_op[i % ORBIT] for i in range(400)) / t_all / 1e6, "unit": "Mrays/s"}
+        # the window has the texture's size (the reference keeps its texture at 1080 rows and the window's aspect, main.rs:255-262):
+        # declared (vrt_set_presentation), the frame's own launch stores the window's image and vrt_present_device launches nothing —
+        # `*_in_flight`; `*_blit_launch`: undeclared, the blit as a launch of its own (rounds 4-5); `*_window_only`: declared with
+        # VRT_PRESENT_SKIP_TEXELS (no 16-byte texel: a client that never reads back)
+        operating_point["per_frame"] += " (declared with vrt_set_presentation: the frame's launch stores the window's pixels, the present call launches nothing)"
+        for tag, decl in (("", dict()), ("_blit_launch", dict(off=True)), ("_window_only", dict(skip_texels=True))):
+            gp.set_presentation((args.width, args.height), **decl)
+            for nf in (1, 2):
+                gp.set_frames_in_flight(nf)
+                client_frames(100)
+                gp.synchronize()
+                t0 = time.perf_counter()
+                client_frames(400)
+                t_host = time.perf_counter() - t0
+                gp.synchronize()
+                t_all = time.perf_counter() - t0
+                operating_point[f"{nf}_in_flight{tag}"] = {"ms_per_frame": t_all / 400 * 1e3, "host_us_per_frame": t_host / 400 * 1e6,
+                                                           "value": sum(rays_op[i % ORBIT] for i in range(400)) / t_all / 1e6, "unit": "Mrays/s"}
         gp.close()
 
     one_gpu_ms = [None]   # N > 1: the unsharded frame on this rank's GPU, timed off the clock (config.expected_scaling's input)
@@ -609,7 +616,7 @@ def main():
     b_primary, b_shadow, b_fused = algorithmic_bytes(st)  # rank 0's own launches (its shard when N > 1), fixed-camera frame
     ms_p = kst.sum_ms_primary / max(kst.frames, 1)
     ms_s = kst.sum_ms_secondary / max(kst.frames, 1)
-    fused = args.mode == "shadow" and args.variant in (0, 4) and ms_s == 0.0  # one launch: no second kernel was timed
+    fused = args.mode == "shadow" and args.variant == 0 and ms_s == 0.0  # one launch: no second kernel was timed
     if fused:
         dom_name, dom_bytes, dom_ms = "primary_shadow_march", b_fused, ms_p
     elif args.mode == "path":   # not the headline: first launch vs all bounce launches + finish; bytes as for shadow rays
@@ -797,6 +804,9 @@ def main():
                    "root_weight": root_weight, "root_weight_tuning_ms_per_frame": tuning,
                    "frames_per_gather": batch, "frames_per_gather_tuning_ms_per_frame": batch_tuning,
                    "frames_in_flight": args.frames_in_flight, "clock_settle": settle,
+                   # (scalars, so that they survive in the driver's `parsed.config`: which window `value` / `ms_per_step` are of)
+                   "steps_requested": args.steps, "steps_timed": steps_timed, "value_requested_steps": requested["value"],
+                   "ms_per_step_requested_steps": requested["ms_per_step"], "value_window": "requested steps" if steps_timed == args.steps else "second window of steps_timed frames",
                    "kernel_variant": args.variant, "derived_tables": derived,
                    # N > 1: what this split should give, term by term, from the unsharded frame timed on this GPU in this run —
                    # stated so that the measured line can be read against it (shard.expected_scaling)

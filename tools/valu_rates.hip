@@ -73,6 +73,16 @@ KERNEL(k_pk_mul_f32, "v_pk_mul_f32 v[20:21], v[20:21], v[22:23]\n v_pk_mul_f32 v
 KERNEL(k_sub_f32_lit, "v_add_f32 %0, 0xcb000000, %0\n v_add_f32 %2, 0xcb000000, %2\n v_add_f32 %3, 0xcb000000, %3\n v_add_f32 %4, 0xcb000000, %4\n v_add_f32 %5, 0xcb000000, %5\n v_add_f32 %6, 0xcb000000, %6\n v_add_f32 %7, 0xcb000000, %7\n v_add_f32 %1, 0xcb000000, %1\n")
 KERNEL(k_cndmask_lit, "v_cndmask_b32 %0, 0, %1, vcc\n v_cndmask_b32 %2, 0, %1, vcc\n v_cndmask_b32 %3, 0, %1, vcc\n v_cndmask_b32 %4, 0, %1, vcc\n v_cndmask_b32 %5, 0, %1, vcc\n v_cndmask_b32 %6, 0, %1, vcc\n v_cndmask_b32 %7, 0, %1, vcc\n v_cndmask_b32 %0, 0, %2, vcc\n")
 KERNEL(k_cmp_sgpr_f32, "v_cmp_eq_f32 s[10:11], %0, %1\n v_cmp_eq_f32 s[12:13], %2, %1\n v_cmp_eq_f32 s[14:15], %3, %1\n v_cmp_eq_f32 s[16:17], %4, %1\n v_cmp_eq_f32 s[10:11], %5, %1\n v_cmp_eq_f32 s[12:13], %6, %1\n v_cmp_eq_f32 s[14:15], %7, %1\n v_cmp_eq_f32 s[16:17], %0, %2\n")
+// round 6: the path trace's RNG (two 32 x 32 multiplies per draw: path_tracer.wgsl:56-61) and the general division's scaffolding
+KERNEL(k_mul_lo_u32, "v_mul_lo_u32 %8, %8, %9\n v_mul_lo_u32 %9, %9, %10\n v_mul_lo_u32 %10, %10, %11\n v_mul_lo_u32 %11, %11, %8\n v_mul_lo_u32 %8, %8, %10\n v_mul_lo_u32 %9, %9, %11\n v_mul_lo_u32 %10, %10, %8\n v_mul_lo_u32 %11, %11, %9\n")
+KERNEL(k_mul_hi_u32, "v_mul_hi_u32 %8, %8, %9\n v_mul_hi_u32 %9, %9, %10\n v_mul_hi_u32 %10, %10, %11\n v_mul_hi_u32 %11, %11, %8\n v_mul_hi_u32 %8, %8, %10\n v_mul_hi_u32 %9, %9, %11\n v_mul_hi_u32 %10, %10, %8\n v_mul_hi_u32 %11, %11, %9\n")
+KERNEL(k_mad_u64_u32, "v_mad_u64_u32 v[20:21], vcc, %8, %9, v[22:23]\n v_mad_u64_u32 v[24:25], vcc, %9, %10, v[22:23]\n v_mad_u64_u32 v[26:27], vcc, %10, %11, v[22:23]\n v_mad_u64_u32 v[28:29], vcc, %11, %8, v[22:23]\n v_mad_u64_u32 v[20:21], vcc, %8, %10, v[24:25]\n v_mad_u64_u32 v[24:25], vcc, %9, %11, v[26:27]\n v_mad_u64_u32 v[26:27], vcc, %10, %8, v[28:29]\n v_mad_u64_u32 v[28:29], vcc, %11, %9, v[20:21]\n")
+KERNEL(k_mul_u24, "v_mul_u32_u24 %8, %8, %9\n v_mul_u32_u24 %9, %9, %10\n v_mul_u32_u24 %10, %10, %11\n v_mul_u32_u24 %11, %11, %8\n v_mul_u32_u24 %8, %8, %10\n v_mul_u32_u24 %9, %9, %11\n v_mul_u32_u24 %10, %10, %8\n v_mul_u32_u24 %11, %11, %9\n")
+KERNEL(k_div_scale, "v_div_scale_f32 %0, vcc, %0, %1, %2\n v_div_scale_f32 %2, vcc, %2, %1, %3\n v_div_scale_f32 %3, vcc, %3, %1, %4\n v_div_scale_f32 %4, vcc, %4, %1, %5\n v_div_scale_f32 %5, vcc, %5, %1, %6\n v_div_scale_f32 %6, vcc, %6, %1, %7\n v_div_scale_f32 %7, vcc, %7, %1, %0\n v_div_scale_f32 %0, vcc, %0, %2, %3\n")
+KERNEL(k_div_fmas, "v_div_fmas_f32 %0, %0, %1, %2\n v_div_fmas_f32 %2, %2, %1, %3\n v_div_fmas_f32 %3, %3, %1, %4\n v_div_fmas_f32 %4, %4, %1, %5\n v_div_fmas_f32 %5, %5, %1, %6\n v_div_fmas_f32 %6, %6, %1, %7\n v_div_fmas_f32 %7, %7, %1, %0\n v_div_fmas_f32 %0, %0, %2, %3\n")
+KERNEL(k_pk_fma_f32, "v_pk_fma_f32 v[20:21], v[20:21], v[22:23], v[24:25]\n v_pk_fma_f32 v[24:25], v[24:25], v[22:23], v[26:27]\n v_pk_fma_f32 v[26:27], v[26:27], v[22:23], v[28:29]\n v_pk_fma_f32 v[28:29], v[28:29], v[22:23], v[20:21]\n v_pk_fma_f32 v[20:21], v[20:21], v[24:25], v[26:27]\n v_pk_fma_f32 v[24:25], v[24:25], v[26:27], v[28:29]\n v_pk_fma_f32 v[26:27], v[26:27], v[28:29], v[20:21]\n v_pk_fma_f32 v[28:29], v[28:29], v[20:21], v[24:25]\n")
+KERNEL(k_cvt_f32_u32, "v_cvt_f32_u32 %0, %8\n v_cvt_f32_u32 %2, %9\n v_cvt_f32_u32 %3, %10\n v_cvt_f32_u32 %4, %11\n v_cvt_f32_u32 %5, %8\n v_cvt_f32_u32 %6, %9\n v_cvt_f32_u32 %7, %10\n v_cvt_f32_u32 %1, %11\n")
+KERNEL(k_bpermute, "ds_bpermute_b32 %0, %8, %0\n ds_bpermute_b32 %2, %8, %2\n ds_bpermute_b32 %3, %8, %3\n ds_bpermute_b32 %4, %8, %4\n s_waitcnt lgkmcnt(0)\n ds_bpermute_b32 %5, %8, %5\n ds_bpermute_b32 %6, %8, %6\n ds_bpermute_b32 %7, %8, %7\n")
 // scalar instructions: alone, and interleaved one to one with simple VALU (does the scalar stream ride along for free?)
 KERNEL(k_salu, "s_and_b64 s[10:11], s[10:11], s[12:13]\n s_or_b64 s[12:13], s[12:13], s[14:15]\n s_xor_b64 s[14:15], s[14:15], s[16:17]\n s_and_b64 s[16:17], s[16:17], s[10:11]\n s_or_b64 s[10:11], s[10:11], s[14:15]\n s_andn2_b64 s[12:13], s[12:13], s[16:17]\n s_xor_b64 s[14:15], s[14:15], s[10:11]\n s_and_b64 s[16:17], s[16:17], s[12:13]\n")
 KERNEL(k_salu_valu, "s_and_b64 s[10:11], s[10:11], s[12:13]\n v_add_f32 %0, %0, %1\n s_or_b64 s[12:13], s[12:13], s[14:15]\n v_add_f32 %2, %2, %1\n s_xor_b64 s[14:15], s[14:15], s[16:17]\n v_add_f32 %3, %3, %1\n s_and_b64 s[16:17], s[16:17], s[10:11]\n v_add_f32 %4, %4, %1\n")
@@ -154,6 +164,7 @@ int main() {
     RUN(k_bfi_b32); RUN(k_mad_u24); RUN(k_mad_i24); RUN(k_max3_u32); RUN(k_div_fixup); RUN(k_pk_add_f32);
     RUN(k_sqrt_f32); RUN(k_rcp_f32);
     RUN(k_bitop3); RUN(k_bitop3_2src); RUN(k_setreg_add); RUN(k_bfe_u32); RUN(k_lshl_add); RUN(k_fmac_f32); RUN(k_pk_mul_f32); RUN(k_sub_f32_lit); RUN(k_cndmask_lit); RUN(k_cmp_sgpr_f32);
+    RUN(k_mul_lo_u32); RUN(k_mul_hi_u32); RUN(k_mad_u64_u32); RUN(k_mul_u24); RUN(k_div_scale); RUN(k_div_fmas); RUN(k_pk_fma_f32); RUN(k_cvt_f32_u32); RUN(k_bpermute);
     RUN(k_salu); RUN(k_salu_valu); RUN(k_nop);
     RUN(k_fma_lanes_0_15); RUN(k_fma_lanes_0_31); RUN(k_fma_every_4th); RUN(k_fma_one_in_16); RUN(k_min3_lanes_0_15); RUN(k_min3_lanes_0_31); RUN(k_min3_every_4th);
     return 0;

@@ -18,6 +18,7 @@
 #include <atomic>
 
 #include "vrt_tile.h"
+#include "vrt_path_common.h"   // (vrt_selftest_exact_math: the RNG's logarithm and direction, both forms)
 #include "vrt_exp.h"
 
 namespace vrt {
@@ -779,6 +780,20 @@ __device__ __forceinline__ float st_float(uint32_t h, uint32_t lo, uint32_t hi) 
 }
 __device__ __noinline__ float st_div_general(float n, float d) { return n / d; }
 __device__ __noinline__ float st_sqrt_general(float x) { return sqrtf(x); }
+// rng_next_dir (vrt_path_common.h) as the text has it: the general division inside the logarithm, sqrtf, the general normalise
+__device__ __forceinline__ float st_rng_norm_general(uint32_t &state) {
+    const float u1 = rng_next(state);
+    float u2 = rng_next(state);
+    if (u2 < 1.0e-10f) u2 = 1.0e-10f;
+    return st_sqrt_general(-2.0f * vlog_t<false>(u2)) * vcos2pi(u1);
+}
+__device__ __forceinline__ V3 st_rng_dir_general(uint32_t &state) {
+    const float x = st_rng_norm_general(state);
+    const float y = st_rng_norm_general(state);
+    const float z = st_rng_norm_general(state);
+    const float len = st_sqrt_general(x * x + y * y + z * z);
+    return V3{st_div_general(x, len), st_div_general(y, len), st_div_general(z, len)};
+}
 
 __global__ void selftest_exact_math_kernel(uint32_t n, uint32_t seed, unsigned long long *mismatches) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -804,6 +819,15 @@ __global__ void selftest_exact_math_kernel(uint32_t n, uint32_t seed, unsigned l
         const float len = st_sqrt_general(vdot(v, v));
         const V3 ng{st_div_general(v.x, len), st_div_general(v.y, len), st_div_general(v.z, len)};
         bad += __float_as_uint(nn.x) != __float_as_uint(ng.x) || __float_as_uint(nn.y) != __float_as_uint(ng.y) || __float_as_uint(nn.z) != __float_as_uint(ng.z);
+        // the path trace's logarithm, its division with and without the scaffolding: the first 2^23 indices run through every
+        // mantissa (the division sees nothing else of x), the rest through the exponents a draw can have (1e-10 .. 1)
+        const float xl = i < (1u << 23) ? __uint_as_float(0x3F000000u | i) : fabsf(st_float(h1, 93u, 126u));
+        bad += __float_as_uint(vlog_t<true>(xl)) != __float_as_uint(vlog_t<false>(xl));
+        bad += __float_as_uint(vlog_t<true>(1.0f)) != __float_as_uint(vlog_t<false>(1.0f));
+        // ... and a whole direction draw from a random state
+        uint32_t sa = h2, sb = h2;
+        const V3 da = rng_next_dir(sa), db = st_rng_dir_general(sb);
+        bad += sa != sb || __float_as_uint(da.x) != __float_as_uint(db.x) || __float_as_uint(da.y) != __float_as_uint(db.y) || __float_as_uint(da.z) != __float_as_uint(db.z);
     }
     if (bad) atomicAdd(mismatches, (unsigned long long)bad);
 }

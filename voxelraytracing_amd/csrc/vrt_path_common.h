@@ -17,16 +17,23 @@ __device__ __forceinline__ float rng_next(uint32_t &state) {
 }
 
 // ln(x), x normal > 0: x = m * 2^e with m in (sqrt(1/2), sqrt(2)], ln m = 2 atanh((m-1)/(m+1))
-__device__ __forceinline__ float vlog(float x) {
+// BANDED: the one division without the general sequence's scaffolding (vrt_march.h: rcp_refined / div_refined).  Its operands are
+// always inside what that needs: m + 1 in [1.70, 2.42]; m - 1 is zero — +0 / d is +0 from either form — or of magnitude >= 2^-24
+// (m is a binary32 in (0.707, 1.4143]).  So there is no choice to make per wave: 8 instructions for 11, 25 issue cycles for 40.
+// vrt_selftest_exact_math runs both forms over every mantissa.
+template <bool BANDED>
+__device__ __forceinline__ float vlog_t(float x) {
     const uint32_t b = __float_as_uint(x);
     int e = (int)(b >> 23) - 127;
     float m = __uint_as_float((b & 0x007FFFFFu) | 0x3F800000u);
     if (m > 1.41421354f) { m = m * 0.5f; e += 1; }
-    const float s = (m - 1.0f) / (m + 1.0f);
+    const float num = m - 1.0f, den = m + 1.0f;
+    const float s = BANDED ? div_refined(num, den, rcp_refined(den)) : num / den;
     const float z = s * s;
     const float p = z * (0.333333343f + z * (0.2f + z * (0.142857149f + z * (0.111111112f + z * 0.0909090936f))));
     return (float)e * 0.693147182f + (s + s * p) * 2.0f;
 }
+__device__ __forceinline__ float vlog(float x) { return vlog_t<true>(x); }
 
 // cos(2*pi*u), u in [0,1]
 __device__ __forceinline__ float vcos2pi(float u) {
@@ -40,19 +47,26 @@ __device__ __forceinline__ float vcos2pi(float u) {
     return qi == 0 ? cs : (qi == 1 ? -sn : (qi == 2 ? -cs : sn));
 }
 
-// rng_next_norm / rng_next_dir, path_tracer.wgsl:62-72
-__device__ __forceinline__ float rng_next_norm(uint32_t &state) {
-    const float u1 = rng_next(state);
-    float u2 = rng_next(state);
-    if (u2 < 1.0e-10f) u2 = 1.0e-10f;
-    const float rho = sqrtf(-2.0f * vlog(u2));
-    return rho * vcos2pi(u1);
+// rng_next_norm / rng_next_dir, path_tracer.wgsl:62-72: three normal deviates rho * cos(2 pi u1), rho = sqrt(-2 ln u2), drawn in
+// the shader's order (u1, u2 of x, then of y, then of z), and their direction.  The three square roots take vrt_march.h's banded
+// form — v_sqrt_f32 and one ulp either way — when every lane's three arguments are in its range (one ballot for the three): an
+// argument is -0 when u2 rounds to 1 (a draw in 2^25), else >= 1.19e-7.  Same operations on the same values as the texts below.
+__device__ __forceinline__ float rng_next_u2(uint32_t &state) {
+    const float u2 = rng_next(state);
+    return u2 < 1.0e-10f ? 1.0e-10f : u2;
 }
 __device__ __forceinline__ V3 rng_next_dir(uint32_t &state) {
-    const float x = rng_next_norm(state);
-    const float y = rng_next_norm(state);
-    const float z = rng_next_norm(state);
-    return normalize_wave(V3{x, y, z});
+    const float u1x = rng_next(state), tx = -2.0f * vlog(rng_next_u2(state));
+    const float u1y = rng_next(state), ty = -2.0f * vlog(rng_next_u2(state));
+    const float u1z = rng_next(state), tz = -2.0f * vlog(rng_next_u2(state));
+    constexpr float kSqrtBandLo = 1.0e-28f;   // (sqrt_banded's range is [2^-96, inf); the arguments are <= 46.1)
+    float rx, ry, rz;
+    if (__ballot(!(min3_f32(tx, ty, tz) >= kSqrtBandLo)) == 0ull) {
+        rx = sqrt_banded(tx); ry = sqrt_banded(ty); rz = sqrt_banded(tz);
+    } else {
+        rx = sqrtf(tx); ry = sqrtf(ty); rz = sqrtf(tz);
+    }
+    return normalize_wave(V3{rx * vcos2pi(u1x), ry * vcos2pi(u1y), rz * vcos2pi(u1z)});
 }
 
 // The material colour of a hit after face shading (ray_tracer.wgsl:296-314) — shade()'s first half.
