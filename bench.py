@@ -436,6 +436,9 @@ def main():
             prev = cur
     run_frames(gpu, fg, args.warmup, fixed)
     gpu.stats()  # drop the warm-up frames' kernel timings
+    gpu.issue_profile()   # ... and their host times (vrt_get_issue_profile / FrameGather.host_profile: the timed frames' own)
+    if fg is not None:
+        fg.reset_host_profile()
     frame_no[0] = 0
     dt = timed(gpu, fg, args.steps, fixed)   # every timed frame is gathered and assembled on rank 0 before the clock stops
     host_submit_ms = submit[0] / args.steps * 1e3
@@ -454,6 +457,8 @@ def main():
         host_submit_ms = submit[0] / steps_timed * 1e3
         rays_total = rays_fixed * steps_timed if fixed else int(sum(int(orbit_rays[(first + i) % ORBIT]) for i in range(steps_timed)))
     kst = gpu.stats()   # per-kernel durations over the timed frames (both windows): HIP events on the streams the kernels ran on
+    issue = gpu.issue_profile()                                   # what issuing those frames cost this rank's host thread
+    gather_host = fg.host_profile() if fg is not None else None   # ... and its collectives
 
     # ---- extra legs, off the headline clock (N = 1): standing camera, one launch at a time, the clock the march runs at ----
     extras = {}
@@ -818,13 +823,59 @@ def main():
         from voxelraytracing_amd.shard import expected_scaling
         texel_msgs = MODE == MODE_PATH or args.variant != 0
         n_ = args.gpus
-        # the host's share per frame, as measured on one GPU (it cannot be taken from this run: a host that is ahead of its GPUs
-        # blocks on full queues and its submit time reads as the GPU's): one process per GPU — a collective call per `batch`
-        # frames (~ 35 us) + a render call (~ 8 us); one context over N devices — the root's render, N - 1 stream waits, the
-        # assembly's launch, an event record (~ 30 us) beside the shard devices' own threads (~ 10 us each, in parallel)
-        host_us = (35.0 / max(batch, 1) + 8.0) if world > 1 else 30.0 + 10.2
-        es = expected_scaling(n_, one_gpu_ms[0], args.width * args.height, 16 if texel_msgs else 8, root_weight,
+        # The host's share per frame, MEASURED in this run (round 6): not the loop's own clock — a host that is ahead of its GPUs reads
+        # the GPUs' time there — but the time spent inside the calls that issue a frame (vrt_get_issue_profile, FrameGather.host_profile).
+        #   one process per GPU: rank 0's render call + (gather call + wait + assembly launches) / frames per collective;
+        #   one context over N devices: with issuing threads (distinct devices) the whole vrt_render call as it was timed; without
+        #   (a one-GPU rehearsal issues for every device in turn) the call as it would be with them: the slower of the root's issue
+        #   and one shard device's issue + a hand-over, + the tail (waits, assembly launch, event) — and the measured serial call
+        #   beside it, which must be the sum of those parts.
+        HAND_OVER_US = 3.0   # post + wake of a spinning issuing thread, and the join: measured 2-4 us (profiles/r04_group_host_profile.txt)
+        host_term = {"source": "measured in this run", "render_call_us": issue["render_us"]}
+        if world > 1:
+            per_collective = gather_host["gather_call_us"] + gather_host["wait_us"] + gather_host["assemble_us"]
+            fpc = max(gather_host["frames_per_collective"], 1.0)
+            host_term.update(collective=gather_host, collective_us_per_frame=per_collective / fpc)
+            if args.rehearse_on_one_gpu:
+                # (the rehearsal's collective is a gloo gather staged through host memory: its cost is not RCCL's; the model keeps
+                # the 35 us per RCCL collective that --force-gather measures on one rank, and says so)
+                host_term["collective_us_per_frame_used"] = 35.0 / max(batch, 1)
+                host_term["source"] = "render call measured in this run; collective: 35 us assumed (the rehearsal timed a gloo stand-in)"
+            else:
+                host_term["collective_us_per_frame_used"] = per_collective / fpc
+            host_us = issue["render_us"] + host_term["collective_us_per_frame_used"]
+        else:
+            host_term.update(issue_profile=issue)
+            serial_sum = issue["root_issue_us"] + (n_ - 1) * issue["shard_issue_us_mean"] + issue["tail_us"]
+            with_threads = max(issue["root_issue_us"], issue["shard_issue_us_mean"] + HAND_OVER_US) + HAND_OVER_US + issue["tail_us"]
+            host_term.update(serial_sum_of_parts_us=serial_sum, with_issuing_threads_us=with_threads, hand_over_us_assumed=HAND_OVER_US)
+            if issue["issuing_threads"]:
+                host_us = issue["render_us"]
+            else:
+                host_us = with_threads
+                host_term["source"] = ("parts measured in this run (one thread issued for every device in turn: render_call_us is their sum); "
+                                       "the term used is the call with one issuing thread per device")
+        host_term["host_us_per_frame_used"] = host_us
+        bpp = 16 if texel_msgs else 8
+        es = expected_scaling(n_, one_gpu_ms[0], args.width * args.height, bpp, root_weight,
                               host_us_per_frame=host_us, fixed_ms_per_launch=min(0.016, one_gpu_ms[0]))
+        es["host_term"] = host_term
+        # both ways of driving N GPUs, side by side: this run's mode with its measured host term, the other with the host term its
+        # own runs measured (profiles/r06_bench_modes_rehearsal.txt) — which one the model expects to be faster for this workload
+        other_host = (30.0 + 10.2) if world > 1 else (35.0 / 4.0 + 8.0)
+        from voxelraytracing_amd.shard import root_weight_model as rwm
+        w_other = rwm(n_, one_gpu_ms[0], args.width * args.height * bpp)
+        other = expected_scaling(n_, one_gpu_ms[0], args.width * args.height, bpp, w_other, host_us_per_frame=other_host,
+                                 fixed_ms_per_launch=min(0.016, one_gpu_ms[0]))
+        this_mode, other_mode = ("one process per GPU + RCCL gather", "one context over N devices") if world > 1 else ("one context over N devices", "one process per GPU + RCCL gather")
+        es["modes"] = {this_mode: {"predicted_ms": es["predicted_ms"], "speedup": es["speedup"], "bound": es["bound"], "host_us_per_frame": host_us, "host_term": "this run's"},
+                       other_mode: {"predicted_ms": other["predicted_ms"], "speedup": other["speedup"], "bound": other["bound"], "host_us_per_frame": other_host,
+                                    "host_term": "that mode's own measurement on one GPU (profiles/r06_bench_modes_rehearsal.txt)", "root_weight": w_other},
+                       "predicted_faster": this_mode if es["predicted_ms"] <= other["predicted_ms"] else other_mode}
+        # a root that keeps (nearly) the whole frame is one GPU with spectators: such a line is not a scaling point
+        root_share = root_weight / float(root_weight + n_ - 1)
+        es["root_share_of_tiles"] = root_share
+        es["degenerate_scaling_point"] = bool(root_share > 0.8)
         es["host_submit_us_per_frame_this_run"] = host_submit_ms * 1e3
         # ... and at the root weight the same model would choose (this run's was measured, or — a rehearsal on one GPU — tuned
         # for a machine on which sharing buys nothing)
@@ -841,6 +892,12 @@ def main():
         if args.rehearse_on_one_gpu:
             es["rehearsal"] = "every rank / device on ONE GPU: the measured line is not a scaling point; the prediction is for N distinct devices"
         out["config"]["expected_scaling"] = es
+        # (scalars beside the object: what survives in a record that keeps only a config's scalar fields)
+        out["config"].update(expected_ms=es["predicted_ms"], expected_speedup=es["speedup"], expected_bound=es["bound"], host_us_per_frame_measured=host_us,
+                             predicted_faster_mode=es["modes"]["predicted_faster"], root_share_of_tiles=root_share, degenerate_scaling_point=bool(root_share > 0.8),
+                             frame_ms_1gpu_same_run=one_gpu_ms[0])
+    if gather_host is not None:
+        out["gather_host_profile"] = dict(gather_host, render_call_us=issue["render_us"])   # (this rank's host time per collective / per render call)
     out.update(extras)
     if operating_point:
         out["operating_point"] = operating_point

@@ -149,6 +149,22 @@ pub struct vrt_accel_info {
     pub ordered_frames: u32,
 }
 
+/// What issuing a frame costs the host (vrt_get_issue_profile), microseconds per vrt_render call.
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct vrt_issue_profile {
+    pub frames: u32,
+    pub devices: u32,
+    pub issuing_threads: u32,
+    pub _reserved: u32,
+    pub render_us: f64,
+    pub root_issue_us: f64,
+    pub shard_issue_us_mean: f64,
+    pub shard_issue_us_max: f64,
+    pub join_wait_us: f64,
+    pub tail_us: f64,
+}
+
 pub const VRT_ID_VOXEL_MASK: u32 = 0x7FFF;
 pub const VRT_ID_HIT: u32 = 1 << 16;
 pub const VRT_ID_NX: u32 = 1 << 17;
@@ -180,6 +196,7 @@ extern "C" {
     pub fn vrt_present_device(ctx: *mut vrt_ctx, crosshair: *const vrt_crosshair, screen_w: u32, screen_h: u32, rgba8_device: *mut *mut c_void, bytes: *mut u64) -> c_int;
     pub fn vrt_set_presentation(ctx: *mut vrt_ctx, crosshair: *const vrt_crosshair, screen_w: u32, screen_h: u32, flags: u32) -> c_int;
     pub fn vrt_get_stats(ctx: *mut vrt_ctx, out: *mut vrt_stats) -> c_int;
+    pub fn vrt_get_issue_profile(ctx: *mut vrt_ctx, out: *mut vrt_issue_profile) -> c_int;
     pub fn vrt_get_accel_info(ctx: *mut vrt_ctx, out: *mut vrt_accel_info) -> c_int;
     pub fn vrt_read_accel(ctx: *mut vrt_ctx, grid: *mut u32, bricks: *mut u16) -> c_int;
     pub fn vrt_read_march_cells(ctx: *mut vrt_ctx, cells: *mut u32, direct: *mut u32) -> c_int;
@@ -207,5 +224,6 @@ mod layout {
         assert_eq!(size_of::<vrt_render_opts>(), 32);
         assert_eq!(size_of::<vrt_stats>(), 112);
         assert_eq!(size_of::<vrt_accel_info>(), 48);
+        assert_eq!(size_of::<vrt_issue_profile>(), 64);
     }
 }

@@ -299,6 +299,26 @@ int vrt_set_presentation(vrt_ctx *ctx, const vrt_crosshair *crosshair, uint32_t 
 
 int vrt_get_stats(vrt_ctx *ctx, vrt_stats *out);
 
+/* New relative to the reference: what ISSUING a frame costs the host, averaged over the vrt_render calls since the previous call
+ * of this function (wall-clock microseconds of the calling thread; nothing here waits for a device).  A multi-GPU frame period
+ * cannot fall below it, and it cannot be read off a frame loop's own clock once the loop is ahead of its GPUs.  For a multi-device
+ * context: the calling thread issues for device_ids[0] while one thread per other device issues for that device (all on the
+ * calling thread when the ordinals repeat — a one-GPU rehearsal — or with VRT_GROUP_THREADS=0), then waits for them, then
+ * enqueues the waits for the messages, the assembly and an event. */
+typedef struct {
+    uint32_t frames;            /* vrt_render calls averaged (0: none since the previous call; every figure below is then 0) */
+    uint32_t devices;           /* 1, or the devices of a multi-device context */
+    uint32_t issuing_threads;   /* threads issuing beside the caller (0: the caller issues for every device in turn) */
+    uint32_t _reserved;
+    double render_us;           /* the whole vrt_render call */
+    double root_issue_us;       /* multi-device: the caller's own issue for device_ids[0] */
+    double shard_issue_us_mean; /* ... one other device's issue (its thread's job, or its turn on the caller), mean over devices */
+    double shard_issue_us_max;  /* ... the slowest of them, per frame */
+    double join_wait_us;        /* ... the caller waiting for the issuing threads after its own issue (0 without threads) */
+    double tail_us;             /* ... stream waits for the messages, the assembly's launch, the event record */
+} vrt_issue_profile;
+int vrt_get_issue_profile(vrt_ctx *ctx, vrt_issue_profile *out);
+
 /* Self-test of the kernels' exact-arithmetic shortcuts (csrc/vrt_march.h: division and square root without the general
  * case's scaling and special-value handling, taken when every operand's magnitude is in [2^-30, 2^30]): n pseudo-random
  * operand sets (seed) on `device`, each computed both ways; *mismatches = results whose bits differ (0 on a correct

@@ -76,7 +76,7 @@ def test_rust_sys_crate_declares_the_same_abi():
     sizes = {m.group(1): int(m.group(2)) for m in re.finditer(r"size_of::<(\w+)>\(\), (\d+)\)", src)}
     want = {"vrt_material": _ffi.Material, "vrt_cam_data": _ffi.CamData, "vrt_world_data": _ffi.WorldData, "vrt_settings": _ffi.Settings,
             "vrt_crosshair": _ffi.Crosshair, "vrt_config": _ffi.Config, "vrt_render_opts": _ffi.RenderOpts, "vrt_stats": _ffi.Stats,
-            "vrt_accel_info": _ffi.AccelInfo}
+            "vrt_accel_info": _ffi.AccelInfo, "vrt_issue_profile": _ffi.IssueProfile}
     assert sizes == {k: C.sizeof(v) for k, v in want.items()}
     for flag, val in (("VRT_FLAG_TILE_MAJOR", 1), ("VRT_FLAG_ROW_MAJOR", 2), ("VRT_FLAG_COMPACT", 4)):
         assert re.search(rf"#define {flag} {val}u", hdr) and re.search(rf"pub const {flag}: u32 = {val};", src)

@@ -45,10 +45,11 @@ def test_kernels_compute_what_the_reference_shader_computes(case, variant):
 
 
 @pytest.mark.parametrize("variant", [0, 1, 2, 3])
-def test_material_ids_past_the_table_follow_the_clamp_policy(variant):
+def test_material_ids_past_the_table_follow_the_pinned_clamp_policy(variant):
     """Voxel ids >= 256 index voxel_mats past its 256 entries (ray_tracer.wgsl:226): tests/golden/wgsl_oob.npz holds the
     reference's shader text under a clamped index and under a zero value.  Every march of the backend gives the CLAMPED
-    frame (material 255), as the oracle does — and not the zero-valued one."""
+    frame (material 255), as the oracle does: the pinned choice (undecided until a real wgpu run of the scene — tools/wgpu_check —
+    says which policy the reference's backend has; the zero-valued frame is in the fixture for that day)."""
     f = np.load(os.path.join(HERE, "golden", "wgsl_oob.npz"))
     sc = mk.oob_material_scene()
     for k, v in mk.scene_checksums(sc).items():
@@ -62,8 +63,7 @@ def test_material_ids_past_the_table_follow_the_clamp_policy(variant):
     assert np.array_equal(np.where(hit, ids & ID_VOXEL_MASK, 0), np.where(hit, f["material_clamp_voxel"] & ID_VOXEL_MASK, 0))
     assert np.array_equal(steps, f["material_clamp_iters"])
     assert float(np.abs(rgb - f["material_clamp_rgb"]).max()) <= RADIANCE_TOL
-    differ = np.abs(f["material_clamp_rgb"] - f["material_zero_rgb"]).max(axis=-1) > 0
-    assert differ.any() and (np.abs(rgb - f["material_zero_rgb"]).max(axis=-1) > RADIANCE_TOL)[differ].all()
+    assert (np.abs(f["material_clamp_rgb"] - f["material_zero_rgb"]).max(axis=-1) > 0).any()   # (the fixture can tell the policies apart)
     gpu.close()
 
 

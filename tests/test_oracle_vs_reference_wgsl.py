@@ -122,12 +122,14 @@ def test_present_is_the_reference_fragment_shader(orc):
             assert (want != np.rint(np.clip(f["img0"], 0.0, 1.0) * 255.0).astype(np.uint8)).any()
 
 
-def test_reads_past_an_arrays_end_follow_the_clamp_policy(orc):
+def test_reads_past_an_arrays_end_follow_the_pinned_clamp_policy(orc):
     """The two reads of ray_tracer.wgsl that can go past their arrays (voxel_mats[voxel] for ids >= 256, :226; chunk_roots_[idx]
     past the table, :121-124) under the two things WGSL lets an implementation do: tests/golden/wgsl_oob.npz holds what the
     reference's shader text computes with the index CLAMPED and with a ZERO value.  The oracle implements the clamp (its
-    header says so; the kernels do too: tests/test_gpu_reference_wgsl.py) — this test pins that choice and shows that the
-    fixture can tell the two apart, so that one run of the same two scenes through a real wgpu settles which the reference gets."""
+    header says so; the kernels do too: tests/test_gpu_reference_wgsl.py).  That is a PINNED CHOICE, NOT A DECISION: which of the two
+    the reference's own runs get depends on its backend (Metal / DX12 clamp; Vulkan with robustBufferAccess2 may return zero), so the
+    test holds the oracle to the clamped frame and only shows that the fixture can tell the two apart — one run of the same two
+    scenes through a real wgpu (tools/wgpu_check prints which policy it sees) settles it."""
     f = np.load(os.path.join(GOLD, "wgsl_oob.npz"))
     sc = mk.oob_material_scene()
     sc2, wd2 = mk.oob_chunk_scene()
@@ -145,5 +147,4 @@ def test_reads_past_an_arrays_end_follow_the_clamp_policy(orc):
         assert float(np.abs(rgb - f[f"{name}_clamp_rgb"]).max()) <= 1e-6
         differ = np.abs(f[f"{name}_clamp_rgb"] - f[f"{name}_zero_rgb"]).max(axis=-1) > 0
         assert differ.any(), f"{name}: the fixture cannot tell the two policies apart"
-        assert (np.abs(rgb - f[f"{name}_zero_rgb"]).max(axis=-1) > 1e-6)[differ].all(), f"{name}: the oracle follows the zero policy somewhere"
     assert {255, 256, 300, 1000, 32767} <= set(f["material_clamp_voxel"].reshape(-1).tolist())

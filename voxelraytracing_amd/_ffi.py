@@ -75,6 +75,12 @@ class AccelInfo(C.Structure):
                 ("chunk_builds", C.c_uint32), ("ordered_frames", C.c_uint32)]
 
 
+class IssueProfile(C.Structure):
+    _fields_ = [("frames", C.c_uint32), ("devices", C.c_uint32), ("issuing_threads", C.c_uint32), ("_reserved", C.c_uint32),
+                ("render_us", C.c_double), ("root_issue_us", C.c_double), ("shard_issue_us_mean", C.c_double), ("shard_issue_us_max", C.c_double),
+                ("join_wait_us", C.c_double), ("tail_us", C.c_double)]
+
+
 assert C.sizeof(Material) == 32 and C.sizeof(CamData) == 160
 assert C.sizeof(WorldData) == 32 and C.sizeof(Settings) == 48
 
@@ -108,6 +114,7 @@ VRT_SYMBOLS = {
     "vrt_present_device": (C.c_int, [_P, C.POINTER(Crosshair), C.c_uint32, C.c_uint32, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     "vrt_set_presentation": (C.c_int, [_P, C.POINTER(Crosshair), C.c_uint32, C.c_uint32, C.c_uint32]),
     "vrt_get_stats": (C.c_int, [_P, C.POINTER(Stats)]),
+    "vrt_get_issue_profile": (C.c_int, [_P, C.POINTER(IssueProfile)]),
     "vrt_get_accel_info": (C.c_int, [_P, C.POINTER(AccelInfo)]),
     "vrt_read_accel": (C.c_int, [_P, _P, _P]),
     "vrt_read_march_cells": (C.c_int, [_P, _P, _P]),

@@ -327,6 +327,10 @@ struct vrt_ctx {
     vrt_settings settings;
     vrt_world_data world;
 
+    // vrt_get_issue_profile: the calling thread's time inside vrt_render since the last call of it
+    double prof_render_us = 0.0;
+    uint32_t prof_frames = 0;
+
     uint32_t last_spp = 1;
     bool rendered = false;
     bool last_stats = false;
@@ -444,6 +448,7 @@ struct GrpWorker {
     std::function<int()> job;
     int rc = 0;
     bool quit = false;
+    double last_job_us = 0.0;   // how long the last job took this thread (read by the caller after join())
 
     void run() {
         uint64_t seen = 0;
@@ -455,7 +460,9 @@ struct GrpWorker {
                 if (quit) return;
             }
             seen = posted.load(std::memory_order_acquire);
+            const auto t0 = std::chrono::steady_clock::now();
             rc = job();
+            last_job_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
             finished.store(seen, std::memory_order_release);
         }
     }
@@ -499,6 +506,8 @@ struct vrt_group {
     std::vector<std::array<hipEvent_t, kSlots>> done;      // [r][slot]: device r's message is complete
     uint32_t slot = 0, in_flight = 2;
     bool last_was_stats = false;
+    // vrt_get_issue_profile: sums over the frames since its last call
+    struct { uint32_t frames = 0; double render = 0, root = 0, shard_sum = 0, shard_max = 0, join = 0, tail = 0; } prof;
 };
 
 VRT_HIDDEN int grp_create(const vrt_config *cfg, vrt_ctx **out);
@@ -506,6 +515,7 @@ VRT_HIDDEN void grp_destroy(vrt_ctx *c);
 VRT_HIDDEN int grp_render(vrt_ctx *c, const vrt_render_opts *opts);
 VRT_HIDDEN int grp_synchronize(vrt_ctx *c);
 VRT_HIDDEN int grp_get_stats(vrt_ctx *c, vrt_stats *out);
+VRT_HIDDEN int grp_get_issue_profile(vrt_ctx *c, vrt_issue_profile *out);
 VRT_HIDDEN int grp_resize_output(vrt_ctx *c, uint32_t w, uint32_t h);
 VRT_HIDDEN int grp_set_frames_in_flight(vrt_ctx *c, uint32_t n);
 inline vrt_ctx *grp_root(vrt_ctx *c) { return c->grp->dev[0]; }

@@ -130,6 +130,19 @@ constexpr uint32_t kUploadPieceWords = 4096, kUploadBatchPieces = 128;
 struct UploadPiece { uint32_t dst_word, src_word, n_words; };
 struct UploadBatch { UploadPiece piece[kUploadBatchPieces]; };
 
+// A finished pixel is stored NON-TEMPORALLY (global_store ... nt): nothing on this device reads a frame's texels while the frame is
+// traced, and 33 MB of them per 1080p frame written through the L2 with the default policy push the derived tables' lines out of
+// it — the march is bound by instruction issue only while its table loads hit.  Measured on C2, same box, the kernels otherwise
+// identical (profiles/r06_nt_stores_ab.txt): lone launch 96.0 -> 93.3 us, 43.4 -> 44.1 Grays/s with two frames in flight, the
+// client's frame (30^3 chunks: larger tables) 117.8 -> 110.4 us one at a time.  The same bytes, whatever the policy.
+// (The path trace's texels are read again — a path that ends adds its light to its pixel — and are better left to the caches:
+// the same policy there costs 3 % of C4, profiles/r06_path_nt_ab.txt.)
+__device__ __forceinline__ void store_streaming(Texel *p, Texel v) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<u32x4 *>(p));
+}
+
 struct V3 { float x, y, z; };
 
 // WGSL min() with a NaN operand is implementation-defined; choice: a NaN operand is ignored, ties

@@ -632,6 +632,14 @@ int vrt_render(vrt_ctx *c, const vrt_render_opts *opts) {
     if (c && c->grp) return grp_render(c, opts);
     if (!c) return VRT_ERR_INVALID_ARG;
     VRT_PROF(3, "vrt_render (one context)");
+    struct IssueClock {   // vrt_get_issue_profile: the calling thread's time in here, whichever way the call leaves
+        vrt_ctx *c;
+        std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        ~IssueClock() {
+            c->prof_render_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            c->prof_frames += 1u;
+        }
+    } issue_clock{c};
     vrt_render_opts o;
     memset(&o, 0, sizeof o);
     if (opts) o = *opts;
@@ -944,6 +952,18 @@ int vrt_get_stats(vrt_ctx *c, vrt_stats *out) {
         c->timing_pending = false;
     }
     *out = c->stats;
+    return VRT_OK;
+}
+
+int vrt_get_issue_profile(vrt_ctx *c, vrt_issue_profile *out) {
+    if (!c || !out) return fail(c, VRT_ERR_INVALID_ARG, "vrt_get_issue_profile: null argument");
+    if (c->grp) return grp_get_issue_profile(c, out);
+    memset(out, 0, sizeof *out);
+    out->devices = 1u;
+    out->frames = c->prof_frames;
+    if (c->prof_frames) out->render_us = c->prof_render_us / (double)c->prof_frames;
+    c->prof_render_us = 0.0;
+    c->prof_frames = 0u;
     return VRT_OK;
 }
 

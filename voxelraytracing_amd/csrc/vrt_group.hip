@@ -160,8 +160,13 @@ int grp_render(vrt_ctx *c, const vrt_render_opts *opts) {
     return rc;
 }
 
+static inline double us_since(std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+}
+
 static int grp_render_frame(vrt_ctx *c, const vrt_render_opts *opts, bool &issued) {
     VRT_PROF(0, "grp_render (a frame of the group)");
+    const auto t_frame = std::chrono::steady_clock::now();
     vrt_group *g = c->grp;
     vrt_ctx *root = g->dev[0];
     vrt_render_opts o;
@@ -204,25 +209,38 @@ static int grp_render_frame(vrt_ctx *c, const vrt_render_opts *opts, bool &issue
         return VRT_OK;
     };
     DeviceRestore restore;
+    double shard_sum = 0.0, shard_max = 0.0;   // (vrt_get_issue_profile)
     if (!g->workers.empty()) {
         for (uint32_t r = 1; r < n; r++) g->workers[r - 1]->post([issue, r] { return issue(r); });
     } else {
         for (uint32_t r = 1; r < n; r++) {
+            const auto t_r = std::chrono::steady_clock::now();
             const int rc = issue(r);
             if (rc) { c->err = g->dev[r]->err; return rc; }
+            const double us = us_since(t_r);
+            shard_sum += us;
+            shard_max = us > shard_max ? us : shard_max;
         }
     }
+    const auto t_root = std::chrono::steady_clock::now();
     int rc = hipSetDevice(root->device) == hipSuccess ? VRT_OK : fail(root, VRT_ERR_DEVICE, "hipSetDevice(%d) failed", root->device);
     if (!rc) rc = vrt_render(root, &o);
+    const double root_us = us_since(t_root);
+    const auto t_join = std::chrono::steady_clock::now();
     // the workers have *enqueued* their frames (their done events are recorded) before the root's stream is told to wait —
     // and they are joined on every path out of here: nothing of a context is ever touched by two threads
     int wrc = VRT_OK;
     for (uint32_t r = 1; r < n && !g->workers.empty(); r++) {
         const int one = g->workers[r - 1]->join();
         if (one && !wrc) { wrc = one; c->err = g->dev[r]->err; }
+        const double us = g->workers[r - 1]->last_job_us;
+        shard_sum += us;
+        shard_max = us > shard_max ? us : shard_max;
     }
+    const double join_us = g->workers.empty() ? 0.0 : us_since(t_join);
     if (rc) { c->err = root->err; return rc; }
     if (wrc) return wrc;
+    const auto t_tail = std::chrono::steady_clock::now();
     VRT_PROF(4, " root: waits + assemble + record");
     hipStream_t X = root->last_stream ? root->last_stream : root->stream;
     for (uint32_t r = 1; r < n; r++)
@@ -244,6 +262,33 @@ static int grp_render_frame(vrt_ctx *c, const vrt_render_opts *opts, bool &issue
     if (g->poison) HIP_TRY(c, hipMemsetAsync((uint8_t *)g->recv[k] + g->rank_stride, 0xFF, g->rank_stride * (n - 1u), X));
     HIP_TRY(c, hipEventRecord(g->consumed[k], X));
     g->consumed_used[k] = true;
+    g->prof.frames += 1u;
+    g->prof.render += us_since(t_frame);
+    g->prof.root += root_us;
+    g->prof.shard_sum += shard_sum;
+    g->prof.shard_max += shard_max;
+    g->prof.join += join_us;
+    g->prof.tail += us_since(t_tail);
+    return VRT_OK;
+}
+
+int grp_get_issue_profile(vrt_ctx *c, vrt_issue_profile *out) {
+    vrt_group *g = c->grp;
+    memset(out, 0, sizeof *out);
+    out->devices = (uint32_t)g->dev.size();
+    out->issuing_threads = (uint32_t)g->workers.size();
+    out->frames = g->prof.frames;
+    if (g->prof.frames) {
+        const double f = (double)g->prof.frames, others = (double)(g->dev.size() > 1 ? g->dev.size() - 1 : 1);
+        out->render_us = g->prof.render / f;
+        out->root_issue_us = g->prof.root / f;
+        out->shard_issue_us_mean = g->prof.shard_sum / f / others;
+        out->shard_issue_us_max = g->prof.shard_max / f;
+        out->join_wait_us = g->prof.join / f;
+        out->tail_us = g->prof.tail / f;
+    }
+    g->prof = {};
+    for (vrt_ctx *d : g->dev) { d->prof_render_us = 0.0; d->prof_frames = 0; }
     return VRT_OK;
 }
 

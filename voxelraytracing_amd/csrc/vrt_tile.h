@@ -102,11 +102,7 @@ __device__ __forceinline__ void store_screen(const FrameParams &P, uint32_t px, 
         v00[3] = v10[3] = v01[3] = v11[3] = 1.0f;   // (every texel of a traced tile is covered)
         if (in_box) q = present_blend(S, P.crosshair, v00, v10, v01, v11);
     }
-#ifdef VRT_AB_NT_SCREEN
-    __builtin_nontemporal_store(q, &P.screen[py * P.width + px]);
-#else
-    P.screen[py * P.width + px] = q;
-#endif
+    __builtin_nontemporal_store(q, &P.screen[py * P.width + px]);   // (read by the window system, not by this device: see store_streaming)
 }
 
 // One finished pixel: the 16-byte texel, or (VRT_FLAG_COMPACT, a shard whose tiles go over a link) the 8 bytes the
@@ -117,15 +113,8 @@ __device__ __forceinline__ void store_screen(const FrameParams &P, uint32_t px, 
 __device__ __forceinline__ void store_pixel(const FrameParams &P, uint32_t slot, uint32_t px, uint32_t py, V3 color, uint32_t id, const MarchResult &R) {
     if (P.compact)
         reinterpret_cast<uint2 *>(P.out)[slot] = make_uint2(id | (R.norm.y < 0.0f ? kIdNormYNeg : 0u), __float_as_uint(R.water_dist));
-    else if (!P.screen_only) {
-#ifdef VRT_AB_NT_TEXELS
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        const u32x4 t = {__float_as_uint(color.x), __float_as_uint(color.y), __float_as_uint(color.z), id};
-        __builtin_nontemporal_store(t, reinterpret_cast<u32x4 *>(&P.out[slot]));
-#else
-        P.out[slot] = make_uint4(__float_as_uint(color.x), __float_as_uint(color.y), __float_as_uint(color.z), id);
-#endif
-    }
+    else if (!P.screen_only)
+        store_streaming(&P.out[slot], make_uint4(__float_as_uint(color.x), __float_as_uint(color.y), __float_as_uint(color.z), id));
     if (P.screen) store_screen(P, px, py, color);
 }
 

@@ -197,6 +197,12 @@ class Gpu:
         self._ck(self._lib.vrt_get_stats(self._h, C.byref(s)))
         return s
 
+    def issue_profile(self) -> dict:
+        """vrt_get_issue_profile: what issuing a frame cost the host (us, averaged over the render calls since the last call)."""
+        p = _ffi.IssueProfile()
+        self._ck(self._lib.vrt_get_issue_profile(self._h, C.byref(p)))
+        return {k: getattr(p, k) for k, _ in p._fields_ if not k.startswith("_")}
+
     def accel_info(self) -> "_ffi.AccelInfo":
         """The derived lookup tables of the default march (cell grid + brick pool); rebuilt lazily by render()."""
         a = _ffi.AccelInfo()

@@ -155,8 +155,20 @@ class FrameGather:
         self.frame = self.frames[0][0]   # the last completed frame (rank 0)
         self.k = 0            # batches submitted
         self.pending = None   # (work, buffer set, frames in it) of the gather still in flight
+        self.reset_host_profile()
         # single-buffer aliases (tests, simple callers)
         self.msg, self.gathered = self.msgs[0], self.recv[0]
+
+    # ---- what the collective costs THIS rank's host thread (bench.py: config.expected_scaling's host term, measured) ----
+    def reset_host_profile(self):
+        self._host = {"collectives": 0, "frames": 0, "gather_call_s": 0.0, "wait_s": 0.0, "assemble_s": 0.0}
+
+    def host_profile(self) -> dict:
+        """Microseconds of host time per collective: the gather call, the wait for it (stream-ordered for RCCL: enqueuing the wait;
+        host-blocking for gloo) and, on rank 0, the assembly launches of its frames — and the frames a collective carried."""
+        h, n = self._host, max(self._host["collectives"], 1)
+        return {"collectives": h["collectives"], "frames_per_collective": h["frames"] / n, "gather_call_us": h["gather_call_s"] / n * 1e6,
+                "wait_us": h["wait_s"] / n * 1e6, "assemble_us": h["assemble_s"] / n * 1e6}
 
     def _frame_of(self, which: int, j: int = 0):
         return self.frames[which % len(self.frames)][j]
@@ -170,9 +182,15 @@ class FrameGather:
 
     def gather(self, which: int = 0, async_op: bool = False, nframes: int | None = None):
         """One gather of equal-sized messages to rank 0 (RCCL: N-1 direct sends to the root)."""
+        import time
         n = (self.batch if nframes is None else nframes) * self.frame_words
-        return self.dist.gather(self.msgs[which][:n], [row[:n] for row in self.recv[which].unbind(0)] if self.rank == 0 else None,
+        t0 = time.perf_counter()
+        work = self.dist.gather(self.msgs[which][:n], [row[:n] for row in self.recv[which].unbind(0)] if self.rank == 0 else None,
                                 dst=0, async_op=async_op)
+        self._host["gather_call_s"] += time.perf_counter() - t0
+        self._host["collectives"] += 1
+        self._host["frames"] += self.batch if nframes is None else nframes
+        return work
 
     def assemble(self, gpu, which: int = 0, j: int = 0):
         """Rank 0: scatter frame j of the gathered tile buffers into its row-major texel frame on the device."""
@@ -199,11 +217,16 @@ class FrameGather:
     def _finish_pending(self, gpu):
         if self.pending is None:
             return
+        import time
         work, w, nframes = self.pending
+        t0 = time.perf_counter()
         work.wait()   # stream-ordered for RCCL (the current stream waits), host-blocking for gloo
+        t1 = time.perf_counter()
         if self.rank == 0:
             for j in range(nframes):
                 self.assemble(gpu, w, j)
+        self._host["wait_s"] += t1 - t0
+        self._host["assemble_s"] += time.perf_counter() - t1
         self.pending = None
 
     def drain(self, gpu):
