@@ -536,9 +536,13 @@ def main():
             s_ = gp.stats()
             rays_op.append(s_.primary_rays + s_.secondary_rays)
 
+        decl = [None]
+
         def client_frames(n):
             for i in range(n):
                 gp.write_settings(sc.settings)                       # main.rs:428
+                if decl[0] is not None:
+                    gp.set_presentation((args.width, args.height), **decl[0])   # :429-432 — screen_size + crosshair, every frame as the reference writes them
                 gp.write_cam_data(cams_op[i % ORBIT])                # :439
                 gp.write_chunk_roots(w_op.chunk_roots())             # :446 — a fresh table, no tag: the backend compares 27 000 roots
                 gp.write_world_data(wd_op)                           # :447-449
@@ -546,15 +550,16 @@ def main():
                 gp.present_device((args.width, args.height))         # :454
         operating_point = {"world": f"{S_OP}^3 chunks around player chunk {player} (main.rs:199), world.min {tuple(w_op.min_voxel())}, "
                                     f"{w_op.populated_count()} chunks with nodes", "frames": 400,
-                           "per_frame": "vrt_set_settings, vrt_set_camera, vrt_write_chunk_roots (untagged, a fresh 27 000-entry table), vrt_set_world, "
+                           "per_frame": "vrt_set_settings, vrt_set_presentation (the blit's screen_size + crosshair uniforms), vrt_set_camera, vrt_write_chunk_roots (untagged, a fresh 27 000-entry table), vrt_set_world, "
                                         "vrt_render (primary + shadow), vrt_present_device at the frame's size"}
         # the window has the texture's size (the reference keeps its texture at 1080 rows and the window's aspect, main.rs:255-262):
         # declared (vrt_set_presentation), the frame's own launch stores the window's image and vrt_present_device launches nothing —
         # `*_in_flight`; `*_blit_launch`: undeclared, the blit as a launch of its own (rounds 4-5); `*_window_only`: declared with
         # VRT_PRESENT_SKIP_TEXELS (no 16-byte texel: a client that never reads back)
         operating_point["per_frame"] += " (declared with vrt_set_presentation: the frame's launch stores the window's pixels, the present call launches nothing)"
-        for tag, decl in (("", dict()), ("_blit_launch", dict(off=True)), ("_window_only", dict(skip_texels=True))):
-            gp.set_presentation((args.width, args.height), **decl)
+        for tag, d_ in (("", dict()), ("_blit_launch", None), ("_window_only", dict(skip_texels=True))):
+            decl[0] = d_
+            gp.set_presentation((args.width, args.height), **(d_ if d_ is not None else dict(off=True)))
             for nf in (1, 2):
                 gp.set_frames_in_flight(nf)
                 client_frames(100)

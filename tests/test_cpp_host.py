@@ -28,7 +28,8 @@ def test_cpp_frame_loop_matches_python_and_oracle(tmp_path, orc):
     raw = np.fromfile(out, dtype=np.uint32)
     w, h = int(raw[0]), int(raw[1])
     ids = raw[2:2 + w * h].reshape(h, w)
-    rgb = raw[2 + w * h:].view(np.float32).reshape(h, w, 3)
+    rgb = raw[2 + w * h:2 + 4 * w * h].view(np.float32).reshape(h, w, 3)
+    image = raw[2 + 4 * w * h:].view(np.uint8).reshape(h, w, 4)   # ScreenShader::encode_pass: the window's image under the default crosshair
 
     sc = scenes.c1_flat((256, 256))   # same world, Player at (32.5,16.5,60.5) -> cam_pos y+4, rot (15,0,0)
     assert sc.eye == (32.5, 20.5, 60.5)
@@ -40,6 +41,7 @@ def test_cpp_frame_loop_matches_python_and_oracle(tmp_path, orc):
     assert np.array_equal(ids, p_ids) and np.array_equal(rgb, p_rgb)
     r_rgb, r_ids, _, _ = orc.from_package_scene(sc).render(orc.MODE_PRIMARY_SHADOW, 256, 256)
     assert_frame_parity(rgb, ids, r_rgb, r_ids, "C++ frame loop")
+    assert np.array_equal(image, orc.present(rgb, (w, h)))
     # Player::facing == axis_rot_to_ray (client/src/player.rs:72-78)
     fx, fy, fz = (float(t) for t in r.stdout.split("facing")[1].split())
     import math

@@ -68,12 +68,17 @@ int main(int argc, char **argv) {
         settings.sky_color[0] = 0.81f; settings.sky_color[1] = 0.93f; settings.sky_color[2] = 1.0f;
         settings.sun_pos[0] = 10000.0f; settings.sun_pos[1] = 20000.0f; settings.sun_pos[2] = 5000.0f;
 
-        auto draw_frame = [&](const PixelShader &shader) {  // main.rs:426-453
+        const Crosshair crosshair;   // Default::default(), main.rs:183
+        ScreenShader::View view;
+        auto draw_frame = [&](const PixelShader &shader) {  // main.rs:426-454
             res.buffers.write_settings(gpu, settings);
+            res.buffers.write_screen_size(gpu, {(float)W, (float)H});   // main.rs:429-431 (the result texture's size)
+            res.buffers.write_crosshair(gpu, crosshair);               // :432
             res.buffers.write_cam_data(gpu, CamData::create(player.rot, player.cam_pos(), player.fov, {(float)W, (float)H}));
             res.buffers.chunk_roots.write(gpu, 0, world.chunk_roots(), world.roots_generation());
             res.buffers.write_world_data(gpu, WorldData::from(world));
             shader.encode_pass(gpu, {W / 8, H / 8});
+            view = res.screen_shader.encode_pass(gpu, crosshair, {W, H});   // :454
         };
         draw_frame(res.ray_tracer);
 
@@ -95,6 +100,11 @@ int main(int argc, char **argv) {
         std::fwrite(&W, 4, 1, f); std::fwrite(&H, 4, 1, f);
         std::fwrite(ids.data(), 4, ids.size(), f);
         std::fwrite(rgb.data(), 4, rgb.size(), f);
+        // the window's image of the last frame (left on the device by the blit — here: stored by the frame's own launch)
+        std::vector<uint8_t> image((size_t)W * H * 4);
+        gpu.check(vrt_present(gpu.ctx(), &crosshair, W, H, image.data()));
+        if (view.bytes != image.size() || !view.rgba8_device) throw GpuError("ScreenShader::encode_pass returned no image");
+        std::fwrite(image.data(), 1, image.size(), f);
         std::fclose(f);
         const Vec3 fc = player.facing();
         std::printf("frame_loop ok %ux%u facing %.6f %.6f %.6f\n", W, H, fc.x, fc.y, fc.z);

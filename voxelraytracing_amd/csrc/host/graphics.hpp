@@ -149,11 +149,26 @@ struct ChunkRootsBuffer {
     }
 };
 
+// Crosshair, mod.rs:63-80 (the C ABI's struct is its layout; the defaults are Default::default()'s)
+struct Crosshair : vrt_crosshair {
+    Crosshair() : vrt_crosshair{{1.0f, 1.0f, 1.0f, 0.33f}, 2u, 5.0f, {0u, 0u}} {}
+};
+
 // Buffers, shader.rs:43-81. SimpleBuffer<T>::write becomes a typed setter.
 struct Buffers {
     NodeBuffer nodes;
     ChunkRootsBuffer chunk_roots;
+    // the blit's two uniforms (shader.rs:51-52): the reference writes them every frame (main.rs:429-432) in front of its two passes.
+    // Together they are vrt_set_presentation's declaration — an unchanged one costs a compare — under which a frame whose window has
+    // the texture's size stores the window's image in its own launch.  present_flags: VRT_PRESENT_SKIP_TEXELS for a client that
+    // never reads the f32 frame back.
+    mutable float screen_size_[2] = {0.0f, 0.0f};
+    uint32_t present_flags = 0u;
     Buffers(uint32_t max_nodes, uint32_t world_size) : nodes(max_nodes), chunk_roots{world_size * world_size * world_size} {}
+    void write_screen_size(const Gpu &, const float (&size)[2]) const { screen_size_[0] = size[0]; screen_size_[1] = size[1]; }
+    void write_crosshair(const Gpu &g, const Crosshair &c) const {
+        g.check(vrt_set_presentation(g.ctx(), &c, (uint32_t)screen_size_[0], (uint32_t)screen_size_[1], present_flags));
+    }
     void write_cam_data(const Gpu &g, const CamData &c) const { g.check(vrt_set_camera(g.ctx(), &c)); }
     void write_settings(const Gpu &g, const Settings &s) const { g.check(vrt_set_settings(g.ctx(), &s)); }
     void write_world_data(const Gpu &g, const WorldData &w) const { g.check(vrt_set_world(g.ctx(), &w)); }
@@ -177,12 +192,25 @@ struct PixelShader {
     }
 };
 
+// ScreenShader, shader.rs:216-294: encode_pass(encoder, view) blits the result texture into the window's image under the crosshair.
+// Here the image stays on the device (vrt_present_device: the pointer a window system takes through interop), enqueued behind the
+// frame — or, declared through Buffers::write_screen_size / write_crosshair, already stored by the frame's own launch.
+struct ScreenShader {
+    struct View { void *rgba8_device = nullptr; uint64_t bytes = 0; };
+    View encode_pass(const Gpu &g, const Crosshair &c, UVec2 window) const {
+        View v;
+        g.check(vrt_present_device(g.ctx(), &c, window.x, window.y, &v.rgba8_device, &v.bytes));
+        return v;
+    }
+};
+
 // GpuResources, mod.rs:145-212
 struct GpuResources {
     UVec2 result_size;
     Buffers buffers;
     PixelShader ray_tracer{VRT_MODE_PRIMARY};
     PixelShader shadow_tracer{VRT_MODE_PRIMARY_SHADOW};
+    ScreenShader screen_shader;
     GpuResources(UVec2 result_size_, uint32_t max_nodes, uint32_t world_size) : result_size(result_size_), buffers(max_nodes, world_size) {}
     void use_new_world_size(const Gpu &g, uint32_t world_size) { buffers.resize_chunk_buffer(g, world_size); }
     void resize_result_texture(const Gpu &g, UVec2 new_size) { g.check(vrt_resize_output(g.ctx(), new_size.x, new_size.y)); result_size = new_size; }

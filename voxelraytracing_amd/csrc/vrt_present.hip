@@ -177,6 +177,9 @@ int vrt_set_presentation(vrt_ctx *c, const vrt_crosshair *crosshair, uint32_t sc
     if (flags & ~VRT_PRESENT_SKIP_TEXELS) return fail(c, VRT_ERR_INVALID_ARG, "vrt_set_presentation: unknown flags 0x%x", flags);
     if (crosshair && (screen_w == 0u || screen_h == 0u || (uint64_t)screen_w * screen_h > (1ull << 28)))
         return fail(c, VRT_ERR_INVALID_ARG, "vrt_set_presentation: screen %ux%u out of range", screen_w, screen_h);
+    // (the reference writes its blit's uniforms every frame, main.rs:429-432: an unchanged declaration is a compare)
+    if (crosshair && c->pres_on && c->pres_w == screen_w && c->pres_h == screen_h && c->pres_flags == flags && memcmp(crosshair, &c->pres_ch, sizeof *crosshair) == 0)
+        return VRT_OK;
     c->pres_on = crosshair != nullptr;
     if (crosshair) c->pres_ch = *crosshair;
     c->pres_w = screen_w; c->pres_h = screen_h; c->pres_flags = flags;
