@@ -852,7 +852,10 @@ def main():
         else:
             host_term.update(issue_profile=issue)
             serial_sum = issue["root_issue_us"] + (n_ - 1) * issue["shard_issue_us_mean"] + issue["tail_us"]
-            with_threads = max(issue["root_issue_us"], issue["shard_issue_us_mean"] + HAND_OVER_US) + HAND_OVER_US + issue["tail_us"]
+            # (with issuing threads every thread makes its own message's stream wait — vrt_group.hip: frame_stream — so the caller's tail
+            # keeps only the assembly's launch and the event record)
+            one_wait = issue["message_waits_us"] / max(n_ - 1, 1)
+            with_threads = max(issue["root_issue_us"], issue["shard_issue_us_mean"] + one_wait + HAND_OVER_US) + HAND_OVER_US + (issue["tail_us"] - issue["message_waits_us"])
             host_term.update(serial_sum_of_parts_us=serial_sum, with_issuing_threads_us=with_threads, hand_over_us_assumed=HAND_OVER_US)
             if issue["issuing_threads"]:
                 host_us = issue["render_us"]

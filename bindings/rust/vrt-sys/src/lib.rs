@@ -163,6 +163,7 @@ pub struct vrt_issue_profile {
     pub shard_issue_us_max: f64,
     pub join_wait_us: f64,
     pub tail_us: f64,
+    pub message_waits_us: f64,
 }
 
 pub const VRT_ID_VOXEL_MASK: u32 = 0x7FFF;
@@ -224,6 +225,6 @@ mod layout {
         assert_eq!(size_of::<vrt_render_opts>(), 32);
         assert_eq!(size_of::<vrt_stats>(), 112);
         assert_eq!(size_of::<vrt_accel_info>(), 48);
-        assert_eq!(size_of::<vrt_issue_profile>(), 64);
+        assert_eq!(size_of::<vrt_issue_profile>(), 72);
     }
 }

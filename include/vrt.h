@@ -315,7 +315,9 @@ typedef struct {
     double shard_issue_us_mean; /* ... one other device's issue (its thread's job, or its turn on the caller), mean over devices */
     double shard_issue_us_max;  /* ... the slowest of them, per frame */
     double join_wait_us;        /* ... the caller waiting for the issuing threads after its own issue (0 without threads) */
-    double tail_us;             /* ... stream waits for the messages, the assembly's launch, the event record */
+    double tail_us;             /* ... behind the join: [the stream waits for the messages,] the assembly's launch, the event record */
+    double message_waits_us;    /* ... of tail_us, the N - 1 stream waits for the messages when the caller makes them (no issuing threads:
+                                 * with threads every thread makes its own, inside its job) */
 } vrt_issue_profile;
 int vrt_get_issue_profile(vrt_ctx *ctx, vrt_issue_profile *out);
 

@@ -9,7 +9,7 @@ show() { python -c "
 import json,sys
 d=json.loads(open('$1').readline()); e=d['config'].get('expected_scaling') or {}; h=e.get('host_term') or {}; ip=h.get('issue_profile') or {}
 s='$2 %d Mrays/s %.4f ms; one GPU %.4f ms; predicted for N devices %.4f ms = x %.2f bound %s; host: loop %.1f us/frame, render call %.1f us' % (d['value'], d['ms_per_step'], e.get('frame_ms_1gpu_measured_in_this_run',0), e.get('predicted_ms',0), e.get('speedup',0), e.get('bound'), d['host_submit_ms_per_step']*1e3, h.get('render_call_us',0))
-if ip: s+=' = root %.1f + %d x shard %.1f (max %.1f) + join %.1f + tail %.1f [sum of parts %.1f]; with issuing threads %.1f; threads %d' % (ip['root_issue_us'], ip['devices']-1, ip['shard_issue_us_mean'], ip['shard_issue_us_max'], ip['join_wait_us'], ip['tail_us'], h.get('serial_sum_of_parts_us',0), h.get('with_issuing_threads_us',0), ip['issuing_threads'])
+if ip: s+=' = root %.1f + %d x shard %.1f (max %.1f) + join %.1f + tail %.1f (of it %.1f the message waits) [sum of parts %.1f]; with issuing threads %.1f; threads %d' % (ip['root_issue_us'], ip['devices']-1, ip['shard_issue_us_mean'], ip['shard_issue_us_max'], ip['join_wait_us'], ip['tail_us'], ip['message_waits_us'], h.get('serial_sum_of_parts_us',0), h.get('with_issuing_threads_us',0), ip['issuing_threads'])
 c=h.get('collective')
 if c: s+='; collective: gather call %.1f + wait %.1f + assemble %.1f us per %.1f frames' % (c['gather_call_us'], c['wait_us'], c['assemble_us'], c['frames_per_collective'])
 s+='; term used %.1f us; faster by the model: %s' % (h.get('host_us_per_frame_used',0), (e.get('modes') or {}).get('predicted_faster'))

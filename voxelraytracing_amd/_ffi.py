@@ -78,7 +78,7 @@ class AccelInfo(C.Structure):
 class IssueProfile(C.Structure):
     _fields_ = [("frames", C.c_uint32), ("devices", C.c_uint32), ("issuing_threads", C.c_uint32), ("_reserved", C.c_uint32),
                 ("render_us", C.c_double), ("root_issue_us", C.c_double), ("shard_issue_us_mean", C.c_double), ("shard_issue_us_max", C.c_double),
-                ("join_wait_us", C.c_double), ("tail_us", C.c_double)]
+                ("join_wait_us", C.c_double), ("tail_us", C.c_double), ("message_waits_us", C.c_double)]
 
 
 assert C.sizeof(Material) == 32 and C.sizeof(CamData) == 160

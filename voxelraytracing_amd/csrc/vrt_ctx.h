@@ -506,8 +506,15 @@ struct vrt_group {
     std::vector<std::array<hipEvent_t, kSlots>> done;      // [r][slot]: device r's message is complete
     uint32_t slot = 0, in_flight = 2;
     bool last_was_stats = false;
+    // The stream device 0's share of the current frame was enqueued on, published by the calling thread once its own vrt_render has
+    // returned: every issuing thread then makes that stream wait for ITS message itself (one hipStreamWaitEvent each, in parallel)
+    // instead of the caller making N - 1 of them in turn behind the join — they were ~ 6 us each, the part of the caller's frame that
+    // grew with N (profiles/r06_bench_modes_rehearsal.txt: 10 / 20 / 48 us at N = 2 / 4 / 8).  nullptr: not yet; kNoFrameStream: the
+    // root's render failed, nobody waits for anything.
+    std::atomic<hipStream_t> frame_stream{nullptr};
+    static inline hipStream_t no_frame_stream() { return reinterpret_cast<hipStream_t>(static_cast<uintptr_t>(1)); }
     // vrt_get_issue_profile: sums over the frames since its last call
-    struct { uint32_t frames = 0; double render = 0, root = 0, shard_sum = 0, shard_max = 0, join = 0, tail = 0; } prof;
+    struct { uint32_t frames = 0; double render = 0, root = 0, shard_sum = 0, shard_max = 0, join = 0, tail = 0, waits = 0; } prof;
 };
 
 VRT_HIDDEN int grp_create(const vrt_config *cfg, vrt_ctx **out);

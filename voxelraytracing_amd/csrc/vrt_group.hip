@@ -188,7 +188,9 @@ static int grp_render_frame(vrt_ctx *c, const vrt_render_opts *opts, bool &issue
     issued = true;
     o.flags |= VRT_RENDER_OWN_STREAMS;   // every device's frame runs on that context's in-flight streams, into the buffer bound here
     // what is issued to device r >= 1 for this frame — by its worker thread, or here
-    auto issue = [g, k, o, root](uint32_t r) -> int {
+    const bool threaded = !g->workers.empty();
+    g->frame_stream.store(nullptr, std::memory_order_release);
+    auto issue = [g, k, o, root, threaded](uint32_t r) -> int {
         VRT_PROF(1, " issue to a shard device");
         vrt_ctx *d = g->dev[r];
         if (hipSetDevice(d->device) != hipSuccess) return fail(d, VRT_ERR_DEVICE, "hipSetDevice(%d) failed", d->device);
@@ -206,6 +208,14 @@ static int grp_render_frame(vrt_ctx *c, const vrt_render_opts *opts, bool &issue
         VRT_PROF(2, "  record done");
         if (d->tiles_local && hipEventRecord(g->done[r][k], d->last_stream) != hipSuccess)
             return fail(d, VRT_ERR_DEVICE, "hipEventRecord failed on device %d", d->device);
+        if (threaded) {
+            // this thread, not the caller, tells device 0's frame stream to wait for this message — once the caller has enqueued
+            // its own share there (the wait must come behind it: device 0's tiles do not wait for anybody's message)
+            hipStream_t x;
+            while ((x = g->frame_stream.load(std::memory_order_acquire)) == nullptr) __builtin_ia32_pause();
+            if (d->tiles_local && x != vrt_group::no_frame_stream() && hipStreamWaitEvent(x, g->done[r][k], 0) != hipSuccess)
+                return fail(d, VRT_ERR_DEVICE, "hipStreamWaitEvent failed for device %d's message", d->device);
+        }
         return VRT_OK;
     };
     DeviceRestore restore;
@@ -225,6 +235,8 @@ static int grp_render_frame(vrt_ctx *c, const vrt_render_opts *opts, bool &issue
     const auto t_root = std::chrono::steady_clock::now();
     int rc = hipSetDevice(root->device) == hipSuccess ? VRT_OK : fail(root, VRT_ERR_DEVICE, "hipSetDevice(%d) failed", root->device);
     if (!rc) rc = vrt_render(root, &o);
+    hipStream_t X = root->last_stream ? root->last_stream : root->stream;
+    g->frame_stream.store(rc ? vrt_group::no_frame_stream() : X, std::memory_order_release);   // (the issuing threads go on from here)
     const double root_us = us_since(t_root);
     const auto t_join = std::chrono::steady_clock::now();
     // the workers have *enqueued* their frames (their done events are recorded) before the root's stream is told to wait —
@@ -242,9 +254,10 @@ static int grp_render_frame(vrt_ctx *c, const vrt_render_opts *opts, bool &issue
     if (wrc) return wrc;
     const auto t_tail = std::chrono::steady_clock::now();
     VRT_PROF(4, " root: waits + assemble + record");
-    hipStream_t X = root->last_stream ? root->last_stream : root->stream;
-    for (uint32_t r = 1; r < n; r++)
-        if (g->dev[r]->tiles_local) HIP_TRY(c, hipStreamWaitEvent(X, g->done[r][k], 0));
+    if (!threaded)   // (the issuing threads have enqueued their own waits)
+        for (uint32_t r = 1; r < n; r++)
+            if (g->dev[r]->tiles_local) HIP_TRY(c, hipStreamWaitEvent(X, g->done[r][k], 0));
+    const double waits_us = threaded ? 0.0 : us_since(t_tail);
     // shade / scatter the other devices' messages into the frame the root has just rendered its own tiles into
     vrt::Texel *frame = root->last_out;
     if (g->texels) {
@@ -269,6 +282,7 @@ static int grp_render_frame(vrt_ctx *c, const vrt_render_opts *opts, bool &issue
     g->prof.shard_max += shard_max;
     g->prof.join += join_us;
     g->prof.tail += us_since(t_tail);
+    g->prof.waits += waits_us;
     return VRT_OK;
 }
 
@@ -286,6 +300,7 @@ int grp_get_issue_profile(vrt_ctx *c, vrt_issue_profile *out) {
         out->shard_issue_us_max = g->prof.shard_max / f;
         out->join_wait_us = g->prof.join / f;
         out->tail_us = g->prof.tail / f;
+        out->message_waits_us = g->prof.waits / f;
     }
     g->prof = {};
     for (vrt_ctx *d : g->dev) { d->prof_render_us = 0.0; d->prof_frames = 0; }
