@@ -7,7 +7,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = sys.argv[1] if len(sys.argv) > 1 else "r05"
+R = sys.argv[1] if len(sys.argv) > 1 else "r06"
 
 
 def J(n):
@@ -23,10 +23,12 @@ rows = [
     ("... standing camera", f["value_fixed_camera"], f["ms_per_step_fixed_camera"], None, f"`{R}_final_bench.json`"),
     ("... one frame at a time, view at rest", f["value_1_in_flight"], f["ms_per_step_1_in_flight"], None, f"`{R}_final_bench.json`"),
     ("... one frame at a time, orbit", f["value_1_in_flight_orbit"], f["ms_per_step_1_in_flight_orbit"], None, f"`{R}_final_bench.json`"),
-    ("... the client's real frame: 30^3-chunk grid, untagged `chunk_roots` rewrite, render + blit", f["operating_point"]["2_in_flight"]["value"],
+    ("... the client's real frame: 30^3-chunk grid, untagged `chunk_roots` rewrite, render + present (declared: the frame's launch stores the window's image)", f["operating_point"]["2_in_flight"]["value"],
      f["operating_point"]["2_in_flight"]["ms_per_frame"], None, f"`{R}_final_bench.json` (`operating_point`)"),
     ("... the client's real frame, one frame at a time", f["operating_point"]["1_in_flight"]["value"],
      f["operating_point"]["1_in_flight"]["ms_per_frame"], None, f"`{R}_final_bench.json` (`operating_point`)"),
+    ("... the same with the blit as a launch of its own (undeclared), two in flight / one at a time: " + " / ".join("%.0f" % f["operating_point"][k]["value"] for k in ("2_in_flight_blit_launch", "1_in_flight_blit_launch")),
+     f["operating_point"]["2_in_flight_blit_launch"]["value"], f["operating_point"]["2_in_flight_blit_launch"]["ms_per_frame"], None, f"`{R}_final_bench.json` (`operating_point`)"),
     ("primary rays only", pr["value"], pr["ms_per_step"], fr(pr), f"`{R}_final_bench_primary.json`"),
     ("C3's shape on one GPU: 16^3 chunks", c3["value"], c3["ms_per_step"], fr(c3), f"`{R}_final_bench_c3shape.json`"),
     ("3840x2160 over C5's 32^3 world, primary + shadow", c5s["value"], c5s["ms_per_step"], fr(c5s), f"`{R}_final_bench_c5shape.json`"),
