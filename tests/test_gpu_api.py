@@ -245,6 +245,41 @@ def test_present_quantise_and_crosshair_blit(orc):
         gpu.present((0, 36))
 
 
+def test_issue_profile_counts_the_render_calls_and_their_parts(monkeypatch):
+    """vrt_get_issue_profile: what issuing frames cost the calling thread since the previous call — for one context the whole
+    vrt_render call, for a context over several devices also its parts, which add up to the call when one thread issues for
+    every device in turn (the default when the ordinals repeat) and overlap when issuing threads do it."""
+    sc = scenes.c2((256, 144))
+    gpu = gpu_for_scene(sc)
+    for _ in range(20):
+        gpu.render(MODE_PRIMARY_SHADOW)
+    p = gpu.issue_profile()
+    assert p["frames"] == 20 and p["devices"] == 1 and p["issuing_threads"] == 0 and 0.5 < p["render_us"] < 5000.0
+    assert p["root_issue_us"] == 0.0 and p["tail_us"] == 0.0
+    assert gpu.issue_profile()["frames"] == 0          # read and reset
+    gpu.close()
+    for threads in ("0", "1"):
+        monkeypatch.setenv("VRT_GROUP_THREADS", threads)
+        grp = Gpu(sc.world.max_nodes(), sc.world.size_in_chunks(), sc.size, devices=[0, 0, 0])
+        grp.upload_world(sc.world, sc.materials)
+        grp.write_cam_data(sc.cam)
+        grp.write_settings(sc.settings)
+        for _ in range(30):
+            grp.render(MODE_PRIMARY_SHADOW)
+        grp.issue_profile()
+        for _ in range(50):
+            grp.render(MODE_PRIMARY_SHADOW)
+        p = grp.issue_profile()
+        assert p["frames"] == 50 and p["devices"] == 3 and p["issuing_threads"] == (2 if threads == "1" else 0)
+        assert p["root_issue_us"] > 0 and p["shard_issue_us_mean"] > 0 and p["shard_issue_us_max"] >= p["shard_issue_us_mean"] and p["tail_us"] > 0
+        if threads == "0":   # one thread, in turn: the call is the sum of its parts; the caller makes the message waits
+            parts = p["root_issue_us"] + 2 * p["shard_issue_us_mean"] + p["tail_us"]
+            assert p["join_wait_us"] == 0.0 and 0 < p["message_waits_us"] < p["tail_us"] and abs(parts - p["render_us"]) < 0.15 * p["render_us"] + 3.0
+        else:                # every issuing thread makes its own message's wait
+            assert p["message_waits_us"] == 0.0
+        grp.close()
+
+
 def _poison_texels(gpu):
     """Overwrite the texel buffer of the last frame with 0xFF bytes (behind everything enqueued): a blit launched from here on
     would show it."""

@@ -1,10 +1,13 @@
-"""tools/soak_edits.py [seconds] [seed] [devices, e.g. 0,0,0] [texel|staged|poison ...] — a long random session against the oracle: edits (0-3 before a frame, now and then a cluster of 8-40 in one place), camera moves,
+"""tools/soak_edits.py [seconds] [seed] [devices, e.g. 0,0,0] [texel|staged|poison|present ...] — a long random session against the oracle: edits (0-3 before a frame, now and then a cluster of 8-40 in one place), camera moves,
 chunk_roots rewrites, the grid recentred by a chunk (center_chunks: the table shifts, world.min changes, the chunks that came
 into the grid arrive over the next frames), quiet stretches, changes of the number of frames in flight, whole-world rebuilds, the primary and the
 primary + shadow mode, variants 0 and 2 — and every few dozen frames the last frame is compared with the oracle's frame of
 the world as it is.  With a device list the context is ONE context over those devices (the same device several times
 rehearses it on one GPU): 8-byte records by default — then only the default march's frames — or texel messages.  Exercises the upload stream / per-frame-set table machinery for races that a short
-test would not meet.  Exit status 1 on the first mismatch."""
+test would not meet.  `present` (round 6): the session is the client's draw + present loop — the blit's uniforms declared before every frame
+(vrt_set_presentation: now the default crosshair, now another, now off), vrt_present_device behind every frame — and every check also holds
+the window's image at the texture's size to the oracle's blit of the frame: a frame that stored its own window pixels, or a blit launched
+behind it, whichever the declaration and the frame's kind made it.  Exit status 1 on the first mismatch."""
 import os
 import sys
 import time
@@ -38,6 +41,9 @@ import collections
 ops = collections.deque(maxlen=80)   # what was done lately, for the report of a mismatch
 t_end = time.time() + seconds
 next_report = time.time() + 20
+presenting = "present" in flags and not devices
+CROSSHAIRS = [dict(), dict(style=1, size=7.5, color=(1.0, 0.3, 0.2, 0.6)), dict(style=0), None]   # (None: undeclared)
+decl = CROSSHAIRS[0]
 while time.time() < t_end:
     burst = int(rng.integers(5, 60))
     for _ in range(burst):
@@ -103,7 +109,17 @@ while time.time() < t_end:
             variant = 2 if rng.random() < 0.2 and not records_only else 0
             ops.append(f"f{frames} mode {mode} variant {variant}")
         gpu.write_chunk_roots(sc.world.chunk_roots(), tag=sc.world.roots_generation())
+        if presenting:
+            if rng.random() < 0.05:
+                decl = CROSSHAIRS[int(rng.integers(0, len(CROSSHAIRS)))]
+                ops.append(f"f{frames} presentation {decl}")
+            if decl is None:
+                gpu.set_presentation(off=True)
+            else:
+                gpu.set_presentation((W, H), **decl)       # main.rs:429-432, every frame
         gpu.render(mode, variant=variant)
+        if presenting:
+            gpu.present_device((W, H), **(decl or {}))     # main.rs:454
         frames += 1
         r2 = rng.random()
         if r2 < 0.02:
@@ -123,7 +139,8 @@ while time.time() < t_end:
         gpu.stats()
     elif r3 < 0.15:
         gpu.accel_info()
-    shown = gpu.present((W + 32, H + 18)) if r3 > 0.9 and not devices else None
+    shown = gpu.present((W + 32, H + 18)) if r3 > 0.9 and not devices and not presenting else None
+    window = gpu.present((W, H), **(decl or {})) if presenting else None
     rgb, ids, _ = gpu.read_output()
     o = orc.from_package_scene(sc)
     o.set_cam(cam)
@@ -134,6 +151,10 @@ while time.time() < t_end:
         if not np.array_equal(shown, want):
             print(f"PRESENT MISMATCH at check {checks}: {int((shown != want).any(axis=2).sum())} pixels differ", flush=True)
             sys.exit(1)
+    if window is not None and not np.array_equal(window, orc.present(rgb, (W, H), **(decl or {}))):
+        print(f"WINDOW MISMATCH at check {checks}, frame {frames}: {int((window != orc.present(rgb, (W, H), **(decl or {}))).any(axis=2).sum())} pixels differ (declared {decl}, mode {mode}, variant {variant})", flush=True)
+        print("the last operations:\n  " + "\n  ".join(list(ops)[-12:]), flush=True)
+        sys.exit(1)
     if not np.array_equal(ids, r_ids) or float(np.nanmax(np.abs(rgb - r_rgb))) > 1e-4:
         print(f"MISMATCH at check {checks}, frame {frames}: {int((ids != r_ids).sum())} id words differ (mode {mode}, variant {variant})", flush=True)
         _, ids_again, _ = gpu.read_output()
