@@ -455,6 +455,23 @@ __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {
     return r;
 }
 
+// ... the same with a small constant mask (an inline operand: no register, no move): the low bits of a over the rest of b.  Chains
+// of these merge bit fields of several registers in one full-rate instruction each, where shift / and / or sequences end in the
+// half-rate three-operand forms (v_and_or_b32, v_or3_b32, v_lshl_or_b32)
+template <uint32_t MASK>
+__device__ __forceinline__ uint32_t low_bits_of(uint32_t a, uint32_t b) {
+    static_assert(MASK <= 64u, "an inline constant");
+    uint32_t r;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xca" : "=v"(r) : "n"(MASK), "v"(a), "v"(b));
+    return r;
+}
+// a | (b & c) in one instruction (truth table 0xF8: index = a << 2 | b << 1 | c)
+__device__ __forceinline__ uint32_t or_and(uint32_t a, uint32_t b, uint32_t c_mask_reg) {
+    uint32_t r;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xf8" : "=v"(r) : "v"(a), "v"(b), "v"(c_mask_reg));
+    return r;
+}
+
 // |a| * b: the absolute value is an operand modifier, not an instruction
 __device__ __forceinline__ float abs_mul(float a, float b) {
     float r;
