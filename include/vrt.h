@@ -277,7 +277,8 @@ int vrt_present(vrt_ctx *ctx, const vrt_crosshair *crosshair, uint32_t screen_w,
  * (the caller's after vrt_set_stream), so a host that draws and presents frame after frame (main.rs:452-454) keeps its
  * frames in flight — nothing is copied to the host and nothing waits.  *rgba8_device points at screen_w*screen_h*4 bytes of
  * the screen buffer of the frame's set: valid until the present of the frame vrt_set_frames_in_flight frames later (the
- * next one with one frame in flight) or vrt_destroy.  For a host that hands the image to its window system through GPU
+ * next one with one frame in flight) — with a declared presentation (vrt_set_presentation) until that frame is RENDERED: its own launch
+ * stores into the buffer — or vrt_destroy.  For a host that hands the image to its window system through GPU
  * interop (a 1080p frame is 8 MB of PCIe traffic otherwise).  vrt_synchronize before reading it from another stream. */
 int vrt_present_device(vrt_ctx *ctx, const vrt_crosshair *crosshair, uint32_t screen_w, uint32_t screen_h, void **rgba8_device,
                        uint64_t *bytes);
