@@ -105,10 +105,13 @@ def fake_render():
         off = (bg.bound[-1] - fgb.msgs[k].data_ptr()) // 4
         fgb.msgs[k][off:off + fgb.frame_words] = 1000 * frame_no[0] + rank
     frame_no[0] += 1
+fgb.reset_host_profile()
 fgb.submit(bg, fake_render, 3)
 fgb.submit(bg, fake_render, 2)
 fgb.drain(bg)
 assert frame_no[0] == 5 and len(bg.bound) == 5
+hp = fgb.host_profile()   # what the two collectives cost this rank's host thread (bench.py: expected_scaling's host term)
+assert hp["collectives"] == 2 and hp["frames_per_collective"] == 2.5 and hp["gather_call_us"] > 0 and hp["wait_us"] >= 0 and hp["assemble_us"] >= 0
 if rank == 0:
     fw = fgb.frame_words
     assert [a[0] for a in bg.assembled] == [fgb.recv[0].data_ptr() + j * fw * 4 for j in range(3)] + [fgb.recv[1].data_ptr() + j * fw * 4 for j in range(2)]
