@@ -4,7 +4,7 @@
 // (clientdesktop/src/graphics/ray_tracer.wgsl: update :173-180, create_ray_from_screen :159-171,
 // ray_world :182-316, find_node/find_chunk_node :76-125, ray_color :131-142, ray_sky :144-157).
 // How they compute it is not — see DESIGN.md §Kernels.  In short:
-//   * one wave64 per 8x8 screen tile (the reference's @workgroup_size(8,8,1) is exactly one CDNA wave);
+//   * one wave64 per 8x8 screen tile (the reference's @workgroup_size(8,8,1) is exactly one CDNA wave) and, since round 6, per workgroup;
 //   * the default march (variant 0, vrt_march.h march_grid) does not walk the octree: the leaf under a position comes from
 //     a cell grid + brick pool that vrt_accel.hip derives from the node pool on the device (at most two loads, no loop);
 //     variants 1 (the shader's text) and 2 (walk resumed below the deepest shared ancestor) read the octree itself;
@@ -25,7 +25,8 @@ namespace vrt {
 
 
 // ------------------------------------------------------------------------------------------------
-// Primary rays: one wave per 8x8 tile, 4 tiles per 256-thread workgroup.
+// Primary rays: one wave per 8x8 tile; with the hit buffer (the two-launch variants) 4 adjacent tiles per 256-thread workgroup,
+// without it one tile per workgroup.
 // ------------------------------------------------------------------------------------------------
 template <int MARCH, bool LDS_ROOTS, bool STATS, bool SHADOW>
 __global__ void __launch_bounds__(256) primary_tile_kernel(FrameParams P) {
@@ -38,7 +39,7 @@ __global__ void __launch_bounds__(256) primary_tile_kernel(FrameParams P) {
     stage_lds(P, s_roots, s_liquid, LDS_ROOTS);
 
     const uint32_t lane = threadIdx.x & 63u;
-    uint32_t t_local = blockIdx.x * 4u + (threadIdx.x >> 6);
+    uint32_t t_local = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // (four tiles a workgroup with the hit buffer, one without)
     const bool live = t_local < P.tiles_local;
     if (!SHADOW && P.tile_order && live) t_local = P.tile_order[t_local];   // longest tiles first (primary-only frames; below)
     MarchResult R;
@@ -660,7 +661,9 @@ static size_t lds_bytes(const FrameParams &P, bool lds_roots) { return (24u + (l
 
 template <int MARCH, bool LDS_ROOTS>
 static void launch_primary_t(const FrameParams &P, bool stats, bool shadow, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
-    const dim3 grid((P.tiles_local + 3u) / 4u), block(256);
+    // with the hit buffer a workgroup is four adjacent tiles (their records share its 256-record slice); primary rays alone: one tile =
+    // one wave = one workgroup, like the one-launch kernel (launch_fused_t)
+    const dim3 grid(shadow ? (P.tiles_local + 3u) / 4u : P.tiles_local), block(shadow ? 256 : 64);
     const size_t lds = lds_bytes(P, LDS_ROOTS);
     if (stats) {
         if (shadow) hipExtLaunchKernelGGL((primary_tile_kernel<MARCH, LDS_ROOTS, true, true>), grid, block, (uint32_t)lds, st, e0, e1, 0, P);
@@ -691,7 +694,14 @@ bool variant_supported(uint32_t variant) { return variant <= 3u; }
 
 template <int MARCH, bool LDS_ROOTS>
 static void launch_fused_t(const FrameParams &P, bool stats, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
-    constexpr int WAVES = 4;
+    // ONE tile = one wave = one workgroup (round 6; four until then).  The waves do not cooperate, and a workgroup of four holds its
+    // four wave slots until its slowest tile is done and is placed only where four slots are free at once: with single-wave workgroups
+    // the dispatcher fills every slot as it frees.  Same box, alternating runs (profiles/r06_waves_ab.txt): C2 43.9 -> 45.3 Grays/s,
+    // standing camera 43.0 -> 44.6, one frame at a time 40.3 -> 40.9 (orbit 35.9 -> 36.7), C3's shape 49.6 -> 50.6, the client's frame with
+    // two in flight 91.5 -> 87.1 us (one at a time 110.5 -> 111.7: its four neighbouring tiles no longer share a CU's L1); two waves a
+    // workgroup lie between, eight are worse than four (42.0).  (Every XCD taking whole tile rows — workgroup b runs on XCD b % 8 — on top
+    // of it: - 1 % on C2 and C3's shape, - 2 % of the client's frame: not kept.)
+    constexpr int WAVES = 1;
     const dim3 grid((P.tiles_local + WAVES - 1u) / WAVES), block(64 * WAVES);
     const uint32_t lds = (uint32_t)lds_bytes(P, LDS_ROOTS);
     if (P.clock && !stats) hipExtLaunchKernelGGL((primary_shadow_wave_kernel<MARCH, LDS_ROOTS, false, WAVES, true>), grid, block, lds, st, e0, e1, 0, P);
