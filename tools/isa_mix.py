@@ -2,7 +2,7 @@
 """tools/isa_mix.py [--out profiles/rNN_isa_mix] — instruction mix of the default march kernel, from its ISA.
 
 Compiles csrc/vrt_kernels.hip to gfx950 assembly with the Makefile's flags (hipcc -S, device only), takes the kernel the
-bench times (primary_shadow_wave_kernel<0, false, false, 4>: grid march, primary + shadow in one launch), finds its two
+bench times (primary_shadow_wave_kernel<0, false, false, 1>: grid march, primary + shadow in one launch), finds its two
 march loops (primary ray, shadow ray) and classifies every instruction of every basic block of each loop:
 
     valu_simple   full-rate VALU (add / sub / mul / fma / and / or / xor / shifts / mov, incl. the VOP3 forms with modifiers)
@@ -31,7 +31,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-KERNEL = "_ZN3vrt26primary_shadow_wave_kernelILi0ELb0ELb0ELi4ELb0EEEvNS_11FrameParamsE"
+KERNEL = "_ZN3vrt26primary_shadow_wave_kernelILi0ELb0ELb0ELi1ELb0EEEvNS_11FrameParamsE"
 HIPFLAGS = ("-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt "
             "-fno-gpu-flush-denormals-to-zero -Wno-unused-value").split()
 
@@ -128,7 +128,7 @@ def main():
     bl = blocks_of(kernel_text(asm))
     headers = [b[0] for b in bl if b[3]]
     assert len(headers) == 2, f"expected the inner march loop of the primary and of the shadow ray, found {headers}"
-    res = {"kernel": "primary_shadow_wave_kernel<0, false, false, 4>", "loops": {}}
+    res = {"kernel": "primary_shadow_wave_kernel<0, false, false, 1>", "loops": {}}
     listing = []
     total = {}
     for b in bl:

@@ -51,7 +51,7 @@ for lp in mix["loops"].values():
         fp[k] = fp.get(k, 0) + v
 n_v = sum(fp.get(k, 0) for k in ("valu_simple", "valu_half", "valu_pk", "valu_trans"))
 # bench.py's kernel names -> the kernels of the summary (the first that was dispatched); `mix`: the march loop's class mix applies
-pick = {"primary_shadow_march": (["primary_shadow_wave_kernel<0, false, false, 4, false>"], True),
+pick = {"primary_shadow_march": (["primary_shadow_wave_kernel<0, false, false, 1, false>"], True),
         "primary_march": (["primary_tile_kernel<0, false, false, true>", "primary_tile_kernel<0, false, false, false>"], True),
         "shadow_march": (["shadow_kernel<0, false, false>"], True),
         "path_primary_march": (["path_primary_kernel<0, false, false, false, false>", "path_primary_kernel<0, false, false, true, false>"], False),
