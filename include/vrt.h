@@ -353,7 +353,7 @@ typedef struct {
 int vrt_get_accel_info(vrt_ctx *ctx, vrt_accel_info *out);
 
 /* Copy the tables to host memory for inspection (synchronises): grid[cells] entries, x-major over the whole world
- * (lo = leaf size - 1; air leaf: lo; other leaf: voxel << 16 | lo; split depth-3 cell: 0x80000000 | brick * 64),
+ * (lo = leaf size - 1; air leaf: 0xFF800000 | lo; other leaf: voxel << 16 | lo; split depth-3 cell: 0x80000000 | brick * 64 < 0xFF800000),
  * bricks[bricks * 64] entries ((x&3) | (y&3) << 2 | (z&3) << 4 inside the cell; voxel << 1 | lo, lo = 1 for a size-2
  * leaf).  Either pointer may be NULL. */
 int vrt_read_accel(vrt_ctx *ctx, uint32_t *grid, uint16_t *bricks);

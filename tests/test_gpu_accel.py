@@ -34,15 +34,24 @@ def walk_octree(nodes: np.ndarray, roots: np.ndarray, S: int):
     return (node & 0x7FFF).astype(np.uint32), depth.astype(np.uint32)
 
 
+AIR_LEAF = 0xFF800000   # the cell grid's entry of an air leaf is AIR_LEAF | lo; the march cells keep lo alone
+
+
+def grid_entry(x: np.ndarray) -> np.ndarray:
+    """A march cell's first word as the cell grid holds it (vrt_device.h grid_entry)."""
+    return np.where((x >= 1) & (x <= 31), x | AIR_LEAF, x).astype(np.uint32)
+
+
 def lookup_tables(grid: np.ndarray, bricks: np.ndarray, S: int):
     """What the grid march reads for every voxel: (voxel, leaf size)."""
     n = S * 32
     z, y, x = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
     e = grid[z >> 2, y >> 2, x >> 2]
-    is_brick = (e & 0x80000000) != 0
+    is_air = e >= AIR_LEAF                   # an air leaf: lo under nine set bits (vrt_device.h kAirLeaf)
+    is_brick = ((e & 0x80000000) != 0) & ~is_air
     assert (e != 0).all()                    # 0 is the border's "outside the world"
-    voxel = (e >> 16) & 0x7FFF               # air leaves are their own lo: the voxel bits are zero
-    size = (e & 0xFFFF) + 1
+    voxel = np.where(is_air, 0, (e >> 16) & 0x7FFF).astype(e.dtype)
+    size = np.where(is_air, e & 31, e & 0xFFFF) + 1
     assert np.isin(size[~is_brick], (4, 8, 16, 32)).all()
     if is_brick.any():
         assert ((e[is_brick] & 0x3F) == 0).all()
@@ -79,7 +88,7 @@ def test_tables_equal_the_octree_walk_for_every_voxel():
     for chunk in range(8):
         cx, cy, cz = chunk % 2, (chunk // 2) % 2, chunk // 4
         sub = grid[cz * 8:(cz + 1) * 8, cy * 8:(cy + 1) * 8, cx * 8:(cx + 1) * 8].reshape(-1)
-        at = [int(e & 0x7FFFFFFF) // 64 for e in sub if e & 0x80000000]
+        at = [int(e & 0x7FFFFFFF) // 64 for e in sub if e & 0x80000000 and e < AIR_LEAF]
         if at:
             assert at == list(range(at[0], at[0] + len(at))) and at[0] >= end
             end = at[-1] + 1 + 8 + len(at) // 8          # brick_slack() of vrt_accel.hip
@@ -123,7 +132,7 @@ def test_tables_follow_edits_and_skip_identical_root_rewrites(orc):
     a = gpu.accel_info()
     assert (a.builds, a.chunk_builds) == (1, 3)
     grid, _ = gpu.read_accel()
-    assert (grid[:8, :8, :8] == 31).all()   # the dropped chunk is one 32^3 air leaf: lo = 31
+    assert (grid[:8, :8, :8] == (AIR_LEAF | 31)).all()   # the dropped chunk is one 32^3 air leaf: lo = 31
 
 
 def test_chunks_that_outgrow_their_brick_region_move_and_many_dirty_chunks_rebuild_the_world(orc):
@@ -335,7 +344,7 @@ def check_march_cells(gpu, world, liquids=(2, 3)):
     n = S * 32
     z, y, x = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
     c = cells[z >> 2, y >> 2, x >> 2]
-    assert np.array_equal(cells[..., 0], grid)             # .x is the cell grid's entry
+    assert np.array_equal(grid_entry(cells[..., 0]), grid)  # .x is the cell grid's entry (an air leaf's without the selector's set bits)
     u = (x & 3) | ((y & 3) << 2) | ((z & 3) << 4)
     word = np.where(u >= 32, c[..., 3], c[..., 2])
     passes = ((word >> (u & 31)) & 1).astype(bool)

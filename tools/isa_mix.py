@@ -17,7 +17,7 @@ march loops (primary ray, shadow ray) and classifies every instruction of every 
 
 (the classes and their issue costs are measured by tools/valu_rates.hip -> profiles/rNN_valu_issue_rates.txt).  The *fast
 path* is what a wave executes on a march step in which every lane is in a plain air leaf of the cell grid: since the march
-is two loops (DESIGN.md §3 m) that is exactly the inner loop.  Writes <out>.json (counts, code-object hash of the library
+is two loops (DESIGN.md §3 m) that is exactly the inner loop — since round 6 an asm statement of vrt_march.h, (r), found by its labels.  Writes <out>.json (counts, code-object hash of the library
 in the tree) and <out>.txt (the listing of both inner loops, block by block).
 """
 import argparse
@@ -112,6 +112,60 @@ def add(a, b):
     return {k: a.get(k, 0) + b.get(k, 0) for k in set(a) | set(b)}
 
 
+def write_out(res, listing, args):
+    try:
+        from voxelraytracing_amd import _ffi
+        res["code_object_sha256"] = _ffi.code_object_sha256()
+    except Exception as e:   # the library is not built: the mix still stands for the source
+        res["code_object_sha256"] = None
+        res["note"] = f"libvrt.so not hashed: {e}"
+    json.dump(res, open(args.out + ".json", "w"), indent=1, sort_keys=True)
+    with open(args.out + ".txt", "w") as f:
+        f.write(f"# {res['kernel']}: ISA of the two march loops, block by block (tools/isa_mix.py; hipcc -S, gfx950)\n")
+        for name in ("primary", "shadow"):
+            f.write(f"# {name} fast path per step: {json.dumps(res['loops'][name]['fast_path'], sort_keys=True)}\n")
+        f.write("\n".join(listing) + "\n")
+    for name in ("primary", "shadow"):
+        print(name, "fast path per step:", json.dumps(res["loops"][name]["fast_path"], sort_keys=True))
+
+
+def hand_written(text, args):
+    """Round 6: the inner loop is an asm statement of vrt_march.h (r) — labels .Lvrt_step_N (one trip per step: the lookup, the test,
+    the exit planes), .Lvrt_move_N (the move, the loop's branch), .Lvrt_zero_N (some lane's smallest distance is zero or NaN: rare,
+    out of line), .Lvrt_out_N.  What a fast step executes: `step` and `move` up to and including the loop's own branch."""
+    total = {}
+    for b in blocks_of(text):
+        total = add(total, count(b[1]))
+    res = {"kernel": "primary_shadow_wave_kernel<0, false, false, 1>", "loops": {}, "whole_kernel_static": total, "inner_loop": "hand-written (vrt_march.h (r))"}
+    starts = [i for i, l in enumerate(text) if re.match(r"^\s*\.Lvrt_step_\d+:", l)]
+    assert len(starts) == 2, f"expected the inner march loop of the primary and of the shadow ray, found {len(starts)}"
+    listing = []
+    for name, i0 in zip(("primary", "shadow"), starts):
+        n = re.match(r"^\s*\.Lvrt_step_(\d+):", text[i0]).group(1)
+        i1 = next(i for i in range(i0, len(text)) if text[i].strip().startswith(f".Lvrt_out_{n}:"))
+        blocks, lab = {}, None
+        for l in text[i0:i1]:
+            m = re.match(r"^\s*\.Lvrt_(\w+?)_\d+:", l)
+            if m:
+                lab = m.group(1)
+                blocks[lab] = []
+                continue
+            t = l.split(";")[0].strip()
+            if t and not t.startswith((".", ";")):
+                blocks[lab].append(t)
+        k = next(i for i, t in enumerate(blocks["move"]) if t.startswith("s_cbranch_scc")) + 1
+        blocks["exit"], blocks["move"] = blocks["move"][k:], blocks["move"][:k]   # behind the loop's branch: after kMaxSteps lookups only
+        per_block = {b: count(v) for b, v in blocks.items()}
+        fp = add(per_block["step"], per_block["move"])
+        res["loops"][name] = {"header": f".Lvrt_step_{n}", "fast_path_blocks": ["step", "move"], "fast_path": fp, "per_block": per_block,
+                              "rarely_executed_blocks": ["exit", "zero"]}
+        listing.append(f"==== {name} ray: inner march loop (.Lvrt_step_{n}) = the fast path, one trip per step ====")
+        for b in ("step", "move", "exit", "zero"):
+            listing.append(f"{b}:   {per_block[b]}" + ("" if b in ("step", "move") else "   (not in the fast path)"))
+            listing += ["    " + t for t in blocks[b]]
+    write_out(res, listing, args)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_isa_mix"))
@@ -125,7 +179,10 @@ def main():
             subprocess.check_call(["/opt/rocm/bin/hipcc", *HIPFLAGS, "-S", "--cuda-device-only", "-o", s,
                                    os.path.join(ROOT, "voxelraytracing_amd", "csrc", "vrt_kernels.hip")], stderr=subprocess.DEVNULL)
             asm = open(s).read()
-    bl = blocks_of(kernel_text(asm))
+    text = kernel_text(asm)
+    if any(re.match(r"^\s*\.Lvrt_step_\d+:", l) for l in text):
+        return hand_written(text, args)
+    bl = blocks_of(text)
     headers = [b[0] for b in bl if b[3]]
     assert len(headers) == 2, f"expected the inner march loop of the primary and of the shadow ray, found {headers}"
     res = {"kernel": "primary_shadow_wave_kernel<0, false, false, 1>", "loops": {}}
@@ -154,20 +211,7 @@ def main():
         for b in loop:
             listing.append(f"{b[0]}:   {per_block[b[0]]}" + ("   (not in the fast path: only when some lane's smallest distance is zero or NaN)" if b[0] in rare else ""))
             listing += ["    " + t for t in b[1]]
-    try:
-        from voxelraytracing_amd import _ffi
-        res["code_object_sha256"] = _ffi.code_object_sha256()
-    except Exception as e:   # the library is not built: the mix still stands for the source
-        res["code_object_sha256"] = None
-        res["note"] = f"libvrt.so not hashed: {e}"
-    json.dump(res, open(args.out + ".json", "w"), indent=1, sort_keys=True)
-    with open(args.out + ".txt", "w") as f:
-        f.write(f"# {res['kernel']}: ISA of the two march loops, block by block (tools/isa_mix.py; hipcc -S, gfx950)\n")
-        for name in ("primary", "shadow"):
-            f.write(f"# {name} fast path per step: {json.dumps(res['loops'][name]['fast_path'], sort_keys=True)}\n")
-        f.write("\n".join(listing) + "\n")
-    for name in ("primary", "shadow"):
-        print(name, "fast path per step:", json.dumps(res["loops"][name]["fast_path"], sort_keys=True))
+    write_out(res, listing, args)
 
 
 if __name__ == "__main__":

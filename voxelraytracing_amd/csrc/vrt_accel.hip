@@ -9,7 +9,9 @@
 //   cell grid   u32[8S][8S+1][8S+1] = [z][y][x]: one entry per depth-3 octree cell (4^3 voxels); the last row of
 //               every z slab and the last entry of every row are a border that stays 0.  The entry *is* the march's
 //               next decision (lo = leaf size - 1):
-//               air leaf at depth d <= 3     ->  lo                       (3, 7, 15 or 31: "step through, nothing to do")
+//               air leaf at depth d <= 3     ->  0xFF800000 | lo          (lo 3, 7, 15 or 31: "step through, nothing to do"; the
+//                                                                          set bits make the entry the march's bit selector as
+//                                                                          it is, vrt_device.h kAirLeaf)
 //               other leaf at depth d <= 3   ->  voxel << 16 | lo
 //               cell split at depth 3        ->  0x80000000 | brick * 64
 //               border / beyond the grid     ->  0                        (a raw buffer load past the end returns 0 too:
@@ -19,7 +21,8 @@
 //
 //   march cells (the path trace's bounce launches, vrt_path.hip): everything a march step has to know about a cell in ONE
 //               16-byte load, so that a split cell costs no second, dependent load —
-//               .x  the cell grid's entry (lo of a leaf in its low 5 bits, 0x80000000 | brick * 64 for a split cell)
+//               .x  the cell grid's entry — an air leaf's as lo alone — (lo of a leaf in its low 5 bits, 0x80000000 | brick * 64
+//                   for a split cell)
 //               .y  split cell: bit (u >> 1) & 31, u = (x&3) | (y&3) << 2 | (z&3) << 4, set <=> the voxel's 2^3 sub-block is
 //                   one depth-4 leaf (the index is what a shift of u gives: every sub-block owns four of the 32 bits)
 //               .z .w  64 bits, bit u set <=> a ray PASSES the voxel: it is air, or a liquid of the material table the tables
@@ -88,7 +91,8 @@ __device__ __forceinline__ size_t chunk_dir_index(uint32_t S, uint32_t chunk) {
 // does a chunk with this root node need a block of its own?  (one air leaf — a missing chunk is node 0 — shares block 1)
 __device__ __forceinline__ bool chunk_needs_block(uint32_t root_node) { return (root_node & 0x8000u) != 0u || (root_node & 0x7FFFu) != 0u; }
 
-// A leaf's grid entry: air -> lo, anything else -> voxel << 16 | lo  (lo = leaf size - 1).
+// A leaf's entry as the march cells hold it: air -> lo, anything else -> voxel << 16 | lo  (lo = leaf size - 1); the cell grid
+// holds grid_entry() of it.
 __device__ __forceinline__ uint32_t leaf_entry(uint32_t node, uint32_t lo) { return ((node & 0x7FFFu) << 16) | lo; }
 
 // voxel_mats[voxel].is_liquid == 1 with ids >= 256 clamped to material 255 (ray_tracer.wgsl:226), as a 256-bit mask
@@ -186,7 +190,7 @@ __global__ void __launch_bounds__(512) accel_cells_kernel(const uint16_t *nodes,
     uint32_t total;
     const uint32_t rank = rank_split_cells(split, s_wave, total);
     const size_t cell = cell_index(S, chunk, cx, cy, cz);
-    grid[cell] = split ? (0x80000000u | rank) : leaf_entry(node, (32u >> depth) - 1u);
+    grid[cell] = split ? (0x80000000u | rank) : grid_entry(leaf_entry(node, (32u >> depth) - 1u));
     if (t == 0) {
         chunk_bricks[chunk] = total;
         if (chunk_needs) chunk_needs[chunk] = chunk_needs_block(pool_node(nodes, n_nodes, root)) ? 1u : 0u;
@@ -268,7 +272,7 @@ __global__ void __launch_bounds__(512) accel_bricks_kernel(const uint16_t *nodes
         if (blk >= 2u && blk < mc.cap) mcell = mc.blocks + (size_t)blk * 512u + cell_in_block(cx, cy, cz);
     }
     const uint32_t root = roots[chunk];
-    if (!(e & 0x80000000u)) {
+    if (!is_split_entry(e)) {
         if (!mcell) return;
         uint32_t depth;
         const uint32_t node = descend3(nodes, n_nodes, root, cx, cy, cz, depth);
@@ -419,7 +423,7 @@ __global__ void __launch_bounds__(512) accel_chunks_kernel(const uint16_t *nodes
     };
     auto write_cell = [&](uint32_t ct, uint4 mcell_value) __attribute__((always_inline)) {
         const uint32_t x = ct & 7u, y = (ct >> 3) & 7u, z = ct >> 6;
-        grid[cell_index(S, chunk, x, y, z)] = mcell_value.x;
+        grid[cell_index(S, chunk, x, y, z)] = grid_entry(mcell_value.x);
         uint4 *mcell = nullptr;
         if (mc.blocks && mc.direct) mcell = mc.blocks + direct_cell_index(S, chunk, x, y, z);
         else if (own_block) mcell = mc.blocks + (size_t)s_blk * 512u + cell_in_block(x, y, z);

@@ -357,7 +357,7 @@ static constexpr uint32_t kMarchBlocksMax = 1u << 18;   // 2 GiB of march-cell b
 // load and a divergent branch less per change of chunk: 17.5 against 16.1 Grays/s on C4).  16^3 chunks: 35 MB; larger
 // worlds go through the directory (32^3: 23 MB instead of 273).
 static constexpr uint32_t kMarchDirectMaxS = 16;
-static constexpr uint32_t kAccelMaxBricks = (1u << 25) - 1u;
+static constexpr uint32_t kAccelMaxBricks = 0x1FE0000u - 1u;   // 0x80000000 | brick * 64 stays below vrt::kAirLeaf
 // Chunks that can be rebuilt alone between two whole-world builds: each may move, once, into a 512-brick region
 // (64 KiB) at the tail of the brick pool.
 static constexpr uint32_t kTailChunks = 128;

@@ -19,6 +19,16 @@ constexpr uint32_t kMaxSteps = 500u;    // ray_tracer.wgsl:220
 // compact records only: norm.y == -1 (the one thing face shading needs beyond the id word's norm flags, :298-306)
 constexpr uint32_t kIdNormYNeg = 1u << 23;
 
+// The cell grid's entry of an air leaf (vrt_accel.hip): lo = leaf size - 1 under nine set bits.  The march inserts a direction
+// mask into the position under the entry as the bit selector (vrt_march.h (h)): with the top nine bits set, the insert takes
+// them from the mask — which carries the exponent of 2^23 there — and the exit plane arrives as the float 2^23 + plane
+// without an instruction of its own ((q) of vrt_march.h).  The march cells' first word keeps the plain form (lo alone).
+constexpr uint32_t kAirLeaf = 0xFF800000u;
+// ... of a cell split at depth 3: 0x80000000 | brick * 64 — below the air leaves: the pool holds fewer than 0x1FE0000 bricks
+__host__ __device__ inline bool is_split_entry(uint32_t e) { return (int32_t)e < 0 && e < kAirLeaf; }
+// a march cell's first word (lo of an air leaf, voxel << 16 | lo, 0x80000000 | brick * 64) as the cell grid holds it
+__host__ __device__ inline uint32_t grid_entry(uint32_t x) { return x - 1u < 31u ? (kAirLeaf | x) : x; }
+
 // One output texel: {r, g, b as f32 bits, id word}. 16 B so that a wave stores 1 KiB contiguously.
 using Texel = uint4;
 

@@ -533,18 +533,22 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
     const V3 unit = unit_steps(dir);   // (:209-213)
     float ux = fabsf(unit.x), uy = fabsf(unit.y), uz = fabsf(unit.z);
     asm("" : "+v"(ux), "+v"(uy), "+v"(uz));   // (held in registers: the compiler would otherwise redo the three |.| on every step)
-    const uint32_t mxm = mx ? ~0u : 0u, mym = my ? ~0u : 0u, mzm = mz ? ~0u : 0u;
-    // (q) the exit plane as a float without a conversion: plane + 0x4B000000 is the bit pattern of 2^23 + plane for
-    // 0 <= plane < 2^23, and (2^23 + plane) - 2^23 is exact — two full-rate instructions for v_cvt_f32_i32's half-rate one
-    // (the bias rides on the subtraction of the direction mask that is there anyway)
-    // (the biased masks could serve as the insert's mask too — it reads their low five bits only — but with three registers
-    // fewer the allocator closes the primary loop with eight moves per trip: measured on the ISA, round 4)
+    // (q) the exit plane as a float without a conversion and without an instruction for the "+ 1": the bit selector of the insert
+    // below has its top nine bits set (an air leaf's entry of the cell grid has them as it is: vrt_device.h kAirLeaf), so the
+    // insert takes those bits from the direction mask — which carries the exponent of 2^23 there — and its result is the bit
+    // pattern of 2^23 + plane for 0 <= plane < 2^23; adding -2^23, or 1 - 2^23 when the exit plane is the high one ((v | lo) + 1),
+    // is exact (integers below 2^24).  Two full-rate instructions for v_cvt_f32_i32's half-rate one and the integer increment.
+    // (Until round 6 the "+ 1" and the exponent were an integer subtraction of their own: three instructions per step.)
     constexpr uint32_t kTwo23 = 0x4B000000u;
-    uint32_t mxb = mxm - kTwo23, myb = mym - kTwo23, mzb = mzm - kTwo23;
-    asm("" : "+v"(mxb), "+v"(myb), "+v"(mzb));   // (held in registers)
+    uint32_t mxm = kTwo23 | (mx ? 0x007FFFFFu : 0u), mym = kTwo23 | (my ? 0x007FFFFFu : 0u), mzm = kTwo23 | (mz ? 0x007FFFFFu : 0u);
+    float cx = mx ? -8388607.0f : -8388608.0f, cy = my ? -8388607.0f : -8388608.0f, cz = mz ? -8388607.0f : -8388608.0f;
+    asm("" : "+v"(mxm), "+v"(mym), "+v"(mzm));   // (held in registers)
 
     const uint32_t wsize = P.world.size;
     const TableBuf gb = table_buffer(P.grid, P.grid_bytes), bb = table_buffer(P.bricks, P.brick_bytes);
+    // (the grid's descriptor as its four words, for (r): base, base >> 32 with stride 0, bytes, the flags of table_buffer)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 gd = {(uint32_t)(uintptr_t)P.grid, (uint32_t)((uintptr_t)P.grid >> 32) & 0xFFFFu, P.grid_bytes, 0x00020000u};
     // rows and slabs carry one border entry / row: [8S][8S + 1][8S + 1]; both strides < 2^23 (grid_dim <= 800)
     const uint32_t row_bytes = (P.grid_dim + 1u) * 4u, slab_bytes = (P.grid_dim + 1u) * row_bytes;
 
@@ -559,20 +563,20 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
     // (l) lanes that have more to do than step through an air leaf carry a bit that pushes every entry out of the air-leaf
     // range, so the fast path asks one question only: lanes inside water (dew != -1: bookkeeping even in air), and every
     // lane of a `careful` wave (the shader's own bounds test, the lookup repeated at its i32(f32) coordinates)
-    // (as an addend: e - 1 for a plain lane; e + 0x7FFFFFFF for the others, which is >= 63 for every entry there is — 0, a
-    // leaf below 2^31, 0x80000000 | brick * 64 — so one add and one compare ask the question)
-    constexpr uint32_t kPlain = 0xFFFFFFFFu, kSlow = 0x7FFFFFFFu;
-    uint32_t slow_bias = careful ? kSlow : kPlain;
+    // (as a threshold: the air leaves are the highest entries there are — kAirLeaf | lo — so "not an air leaf" is e < kAirLeaf,
+    // and a lane that has more to do compares against a number above every entry: one compare asks the question)
+    constexpr uint32_t kPlain = kAirLeaf, kSlow = 0xFFFFFFFFu;
+    uint32_t slow_below = careful ? kSlow : kPlain;
     float total_len = 0.0f;
     uint32_t iter = 0u;      // wave-uniform trip count (loop control)
     uint32_t looked_up = 0u; // STATS: node lookups of this lane (:221) — one less than its trips if it left through the border
 
-    // ---- the step to the leaf's exit face (:243-283), for a leaf of size lo + 1 ----
-    auto take_step = [&](uint32_t lo) __attribute__((always_inline)) {
-        // (h) the exit plane: low = v & ~lo, high = (v | lo) + 1; the direction mask is 0 or ~0 = -1, so "+ 1" is "- mask"
-        const float tx = (__uint_as_float(bfi(lo, mxm, (uint32_t)vx) - mxb) - 8388608.0f) - pos.x;
-        const float ty = (__uint_as_float(bfi(lo, mym, (uint32_t)vy) - myb) - 8388608.0f) - pos.y;
-        const float tz = (__uint_as_float(bfi(lo, mzm, (uint32_t)vz) - mzb) - 8388608.0f) - pos.z;
+    // ---- the step to the leaf's exit face (:243-283), for a leaf of size lo + 1; `sel` = kAirLeaf | lo ----
+    auto take_step = [&](uint32_t sel) __attribute__((always_inline)) {
+        // (h) the exit plane: low = v & ~lo, high = (v | lo) + 1 — the insert gives v & ~lo or v | lo under the bits of 2^23
+        const float tx = (__uint_as_float(bfi(sel, mxm, (uint32_t)vx)) + cx) - pos.x;
+        const float ty = (__uint_as_float(bfi(sel, mym, (uint32_t)vy)) + cy) - pos.y;
+        const float tz = (__uint_as_float(bfi(sel, mzm, (uint32_t)vz)) + cz) - pos.z;
         // (b'') |t| * |unit| has the bits of (mask ? t : -t) * unit, except that a zero is always +0 (never observed)
         adx = abs_mul(tx, ux);
         ady = abs_mul(ty, uy);
@@ -609,21 +613,102 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
     // returns.  Same steps in the same order for every lane; `iter` counts them for the whole wave.
     for (;;) {
         uint32_t e;
-        bool exhausted = false;
-        for (;;) {
-            e = lookup();
-            if (__ballot(e + slow_bias >= 31u) != 0ull) break;
-            iter += 1u;
-            if (STATS) { looked_up += 1u; R.visits += (uint32_t)__clz((int)(e + 1u)) - 25u; }
-            take_step(e);   // an air leaf of the cell grid: the entry is lo
-            if (iter >= kMaxSteps) { exhausted = true; break; }
+#ifndef VRT_AB_COMPILED_LOOP
+        if constexpr (!STATS) {
+            // (r) The inner loop as the instructions themselves.  What the compiler makes of the C++ below is the same vector
+            // instructions, but it wraps every step in seven scalar instructions, four branches (three taken) and six s_nop /
+            // s_waitcnt: its loop exits become 64-bit flag registers that are set, selected, and-ed with exec and copied to vcc, and
+            // around the helpers above — one-instruction asm statements — it pads for hazards they do not have.  The scalar unit
+            // is shared by a CU's four SIMDs, and the step's scalar work showed as its price (profiles/r06_step_asm.txt).  Here:
+            // one scalar instruction (the trip count, as iter - kMaxSteps: its carry is the exit), three branches of which the
+            // loop's own is the only one taken, one s_waitcnt; 34 vector instructions.
+            // Same operations on the same operands in the same order of roundings as take_step() — which the general step below
+            // still uses; tests/test_gpu_parity.py holds both against the oracle bit for bit.
+            // Leaves with `e` = the entry some lane has to decide about (nothing of that step done), or after kMaxSteps lookups.
+            uint32_t t0, t1, t2;
+            uint32_t trips = __builtin_amdgcn_readfirstlane(iter) - kMaxSteps;   // (wave-uniform already: tells the compiler)
+            asm volatile(
+                ".Lvrt_step_%=:\n\t"
+                "v_ashrrev_i32_e32 %[t0], 2, %[vz]\n\t"
+                "v_ashrrev_i32_e32 %[t1], 2, %[vy]\n\t"
+                "v_and_b32_e32 %[t2], -4, %[vx]\n\t"
+                "v_mad_i32_i24 %[t1], %[t1], %[row], %[t2]\n\t"
+                "v_mad_i32_i24 %[t0], %[t0], %[slab], %[t1]\n\t"
+                "buffer_load_dword %[e], %[t0], %[desc], 0 offen\n\t"
+                "s_waitcnt vmcnt(0)\n\t"
+                "v_cmp_lt_u32_e32 vcc, %[e], %[below]\n\t"
+                "s_cbranch_vccnz .Lvrt_out_%=\n\t"                        // some lane is not in a plain air leaf
+                "v_bitop3_b32 %[ax], %[e], %[mx], %[vx] bitop3:0xca\n\t"     // (h), (q): the exit planes under the bits of 2^23
+                "v_bitop3_b32 %[ay], %[e], %[my], %[vy] bitop3:0xca\n\t"
+                "v_bitop3_b32 %[az], %[e], %[mz], %[vz] bitop3:0xca\n\t"
+                "v_add_f32_e32 %[ax], %[cx], %[ax]\n\t"
+                "v_add_f32_e32 %[ay], %[cy], %[ay]\n\t"
+                "v_add_f32_e32 %[az], %[cz], %[az]\n\t"
+                "v_sub_f32_e32 %[ax], %[ax], %[px]\n\t"
+                "v_sub_f32_e32 %[ay], %[ay], %[py]\n\t"
+                "v_sub_f32_e32 %[az], %[az], %[pz]\n\t"
+                "v_mul_f32_e64 %[ax], |%[ax]|, %[ux]\n\t"                    // (b'')
+                "v_mul_f32_e64 %[ay], |%[ay]|, %[uy]\n\t"
+                "v_mul_f32_e64 %[az], |%[az]|, %[uz]\n\t"
+                "v_min3_f32 %[st], %[ax], %[ay], %[az]\n\t"                  // (p)
+                "v_cmp_nlt_f32_e32 vcc, 0, %[st]\n\t"
+                "s_cbranch_vccnz .Lvrt_zero_%=\n"                            // some lane's smallest distance is zero or NaN: (c')
+                ".Lvrt_move_%=:\n\t"
+                "v_add_f32_e32 %[t0], 0x3a83126f, %[st]\n\t"                // step + 0.001
+                "v_cmp_eq_f32_e32 vcc, %[st], %[ax]\n\t"
+                "v_cndmask_b32_e32 %[t1], %[st], %[t0], vcc\n\t"
+                "v_cmp_eq_f32_e32 vcc, %[st], %[ay]\n\t"
+                "v_cndmask_b32_e32 %[t2], %[st], %[t0], vcc\n\t"
+                "v_cmp_eq_f32_e32 vcc, %[st], %[az]\n\t"
+                "v_cndmask_b32_e32 %[t0], %[st], %[t0], vcc\n\t"
+                "v_mul_f32_e32 %[t1], %[dx], %[t1]\n\t"
+                "v_mul_f32_e32 %[t2], %[dy], %[t2]\n\t"
+                "v_mul_f32_e32 %[t0], %[dz], %[t0]\n\t"
+                "v_add_f32_e32 %[px], %[px], %[t1]\n\t"
+                "v_add_f32_e32 %[py], %[py], %[t2]\n\t"
+                "v_add_f32_e32 %[pz], %[pz], %[t0]\n\t"
+                "v_add_f32_e32 %[tl], %[tl], %[st]\n\t"
+                "v_cvt_flr_i32_f32_e32 %[vx], %[px]\n\t"
+                "v_cvt_flr_i32_f32_e32 %[vy], %[py]\n\t"
+                "v_cvt_flr_i32_f32_e32 %[vz], %[pz]\n\t"
+                "s_add_u32 %[it], %[it], 1\n\t"                              // (carries when the count reaches kMaxSteps, :220)
+                "s_cbranch_scc0 .Lvrt_step_%=\n\t"
+                "s_branch .Lvrt_out_%=\n"
+                ".Lvrt_zero_%=:\n\t"
+                "v_add_u32_e32 %[t0], -1, %[ax]\n\t"
+                "v_add_u32_e32 %[t1], -1, %[ay]\n\t"
+                "v_add_u32_e32 %[t2], -1, %[az]\n\t"
+                "v_min3_u32 %[t0], %[t0], %[t1], %[t2]\n\t"
+                "v_add_u32_e32 %[st], 1, %[t0]\n\t"
+                "s_branch .Lvrt_move_%=\n"
+                ".Lvrt_out_%=:"
+                : [px] "+v"(pos.x), [py] "+v"(pos.y), [pz] "+v"(pos.z), [tl] "+v"(total_len), [vx] "+v"(vx), [vy] "+v"(vy), [vz] "+v"(vz),
+                  [st] "+v"(step), [ax] "+v"(adx), [ay] "+v"(ady), [az] "+v"(adz), [e] "=&v"(e), [it] "+s"(trips),
+                  [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)
+                : [mx] "v"(mxm), [my] "v"(mym), [mz] "v"(mzm), [cx] "v"(cx), [cy] "v"(cy), [cz] "v"(cz), [ux] "v"(ux), [uy] "v"(uy), [uz] "v"(uz),
+                  [dx] "v"(dir.x), [dy] "v"(dir.y), [dz] "v"(dir.z), [below] "v"(slow_below), [desc] "s"(gd), [row] "s"(row_bytes), [slab] "s"(slab_bytes)
+                : "vcc", "scc", "memory");
+            iter = trips + kMaxSteps;
+            if (iter >= kMaxSteps) break;   // (wave-uniform) at most kMaxSteps lookups (:220)
+        } else
+#endif
+        {
+            bool exhausted = false;
+            for (;;) {
+                e = lookup();
+                if (__ballot(e < slow_below) != 0ull) break;
+                iter += 1u;
+                if (STATS) { looked_up += 1u; R.visits += (uint32_t)__clz((int)((e & 31u) + 1u)) - 25u; }
+                take_step(e);   // an air leaf of the cell grid: the entry is the selector
+                if (iter >= kMaxSteps) { exhausted = true; break; }
+            }
+            if (exhausted) break;   // (wave-uniform) at most kMaxSteps lookups (:220)
         }
-        if (exhausted) break;   // (wave-uniform) at most kMaxSteps lookups (:220)
         // ---- the general step: find_node's answer may be a brick, a non-air leaf, the border ----
         iter += 1u;
         uint32_t lo = e;
         bool stop = false;
-        if (e + slow_bias >= 31u) {
+        if (e < slow_below) {
             if (careful) {  // wave-uniform: the shader's test (:285) on the shader's coordinates (i32(NaN) = 0), then its lookup
                 vx = trunc2i(pos.x);
                 vy = trunc2i(pos.y);
@@ -636,28 +721,28 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
             stop = e == 0u;  // border, or past either end of the grid: the position is outside the world
             if (!stop) {
                 voxel = 0u;
-                if ((int)e < 0) {
+                if (is_split_entry(e)) {
                     const uint32_t u = ((uint32_t)vx & 3u) | (((uint32_t)vy & 3u) << 2) | (((uint32_t)vz & 3u) << 4);
                     const uint32_t b = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(bb, (e + u) << 1, 0, 0);  // the shift drops bit 31
-                    lo = b & 1u;
+                    lo = kAirLeaf | (b & 1u);
                     voxel = b >> 1;
-                } else if (e > 31u) {
-                    lo = e & 31u;
+                } else if (e < kAirLeaf) {   // a leaf that is not air (an air leaf is its own selector)
+                    lo = kAirLeaf | (e & 31u);
                     voxel = e >> 16;
                 }
-                if (STATS) { looked_up += 1u; R.visits += (uint32_t)__clz((int)(lo + 1u)) - 25u; }
+                if (STATS) { looked_up += 1u; R.visits += (uint32_t)__clz((int)((lo & 31u) + 1u)) - 25u; }
                 if (voxel != 0u) {
                     if (!is_liquid_ranged(P, s_liquid, voxel)) stop = true;                // solid: the hit
-                    else if (dew == -1.0f) { dew = total_len; slow_bias = kSlow; }    // liquid: water bookkeeping (:231-242)
+                    else if (dew == -1.0f) { dew = total_len; slow_below = kSlow; }    // liquid: water bookkeeping (:231-242)
                 } else if (dew != -1.0f) {
                     R.water_dist += total_len - dew;
                     dew = -1.0f;
-                    if (!careful) slow_bias = kPlain;
+                    if (!careful) slow_below = kPlain;
                 }
             }
         } else if (STATS) {
             looked_up += 1u;
-            R.visits += (uint32_t)__clz((int)(lo + 1u)) - 25u;  // depth + 1 node words on the reference's walk
+            R.visits += (uint32_t)__clz((int)((lo & 31u) + 1u)) - 25u;  // depth + 1 node words on the reference's walk
         }
         if (stop) break;
         take_step(lo);
