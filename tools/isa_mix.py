@@ -130,9 +130,10 @@ def write_out(res, listing, args):
 
 
 def hand_written(text, args):
-    """Round 6: the inner loop is an asm statement of vrt_march.h (r) — labels .Lvrt_step_N (one trip per step: the lookup, the test,
-    the exit planes), .Lvrt_move_N (the move, the loop's branch), .Lvrt_zero_N (some lane's smallest distance is zero or NaN: rare,
-    out of line), .Lvrt_out_N.  What a fast step executes: `step` and `move` up to and including the loop's own branch."""
+    """Round 6: the inner loop is an asm statement of vrt_march.h (r) — labels .Lvrt_step_N (one trip per step: the lookup, the test),
+    .Lvrt_planes_N (the exit planes), .Lvrt_move_N (the move, the loop's branch), .Lvrt_zero_N (some lane's smallest distance is zero
+    or NaN: rare, out of line), .Lvrt_split_N / .Lvrt_leave_N ((s): lanes in split cells, the voxel of the brick), .Lvrt_out_N.
+    What a fast step executes: `step`, `planes` and `move` up to and including the loop's own branch."""
     total = {}
     for b in blocks_of(text):
         total = add(total, count(b[1]))
@@ -156,12 +157,17 @@ def hand_written(text, args):
         k = next(i for i, t in enumerate(blocks["move"]) if t.startswith("s_cbranch_scc")) + 1
         blocks["exit"], blocks["move"] = blocks["move"][k:], blocks["move"][:k]   # behind the loop's branch: after kMaxSteps lookups only
         per_block = {b: count(v) for b, v in blocks.items()}
-        fp = add(per_block["step"], per_block["move"])
-        res["loops"][name] = {"header": f".Lvrt_step_{n}", "fast_path_blocks": ["step", "move"], "fast_path": fp, "per_block": per_block,
-                              "rarely_executed_blocks": ["exit", "zero"]}
+        fast = [b for b in ("step", "planes", "move") if b in blocks]
+        fp = {}
+        for b in fast:
+            fp = add(fp, per_block[b])
+        others = [b for b in blocks if b not in fast]
+        res["loops"][name] = {"header": f".Lvrt_step_{n}", "fast_path_blocks": fast, "fast_path": fp, "per_block": per_block,
+                              "rarely_executed_blocks": [b for b in others if b in ("exit", "zero")],
+                              "split_cell_step_blocks": [b for b in others if b in ("split", "leave")]}
         listing.append(f"==== {name} ray: inner march loop (.Lvrt_step_{n}) = the fast path, one trip per step ====")
-        for b in ("step", "move", "exit", "zero"):
-            listing.append(f"{b}:   {per_block[b]}" + ("" if b in ("step", "move") else "   (not in the fast path)"))
+        for b in fast + others:
+            listing.append(f"{b}:   {per_block[b]}" + ("" if b in fast else "   (not in the fast path: a step through air voxels of split cells adds `split`)" if b == "split" else "   (not in the fast path)"))
             listing += ["    " + t for t in blocks[b]]
     write_out(res, listing, args)
 

@@ -546,9 +546,10 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
 
     const uint32_t wsize = P.world.size;
     const TableBuf gb = table_buffer(P.grid, P.grid_bytes), bb = table_buffer(P.bricks, P.brick_bytes);
-    // (the grid's descriptor as its four words, for (r): base, base >> 32 with stride 0, bytes, the flags of table_buffer)
+    // (the grid's and the bricks' descriptors as their four words, for (r): base, base >> 32 with stride 0, bytes, the flags of table_buffer)
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const u32x4 gd = {(uint32_t)(uintptr_t)P.grid, (uint32_t)((uintptr_t)P.grid >> 32) & 0xFFFFu, P.grid_bytes, 0x00020000u};
+    const u32x4 bd = {(uint32_t)(uintptr_t)P.bricks, (uint32_t)((uintptr_t)P.bricks >> 32) & 0xFFFFu, P.brick_bytes, 0x00020000u};
     // rows and slabs carry one border entry / row: [8S][8S + 1][8S + 1]; both strides < 2^23 (grid_dim <= 800)
     const uint32_t row_bytes = (P.grid_dim + 1u) * 4u, slab_bytes = (P.grid_dim + 1u) * row_bytes;
 
@@ -626,6 +627,7 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
             // still uses; tests/test_gpu_parity.py holds both against the oracle bit for bit.
             // Leaves with `e` = the entry some lane has to decide about (nothing of that step done), or after kMaxSteps lookups.
             uint32_t t0, t1, t2;
+            unsigned long long sa, sb, sx;
             uint32_t trips = __builtin_amdgcn_readfirstlane(iter) - kMaxSteps;   // (wave-uniform already: tells the compiler)
             asm volatile(
                 ".Lvrt_step_%=:\n\t"
@@ -637,7 +639,8 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
                 "buffer_load_dword %[e], %[t0], %[desc], 0 offen\n\t"
                 "s_waitcnt vmcnt(0)\n\t"
                 "v_cmp_lt_u32_e32 vcc, %[e], %[below]\n\t"
-                "s_cbranch_vccnz .Lvrt_out_%=\n\t"                        // some lane is not in a plain air leaf
+                "s_cbranch_vccnz .Lvrt_split_%=\n"                         // some lane is not in a plain air leaf
+                ".Lvrt_planes_%=:\n\t"
                 "v_bitop3_b32 %[ax], %[e], %[mx], %[vx] bitop3:0xca\n\t"     // (h), (q): the exit planes under the bits of 2^23
                 "v_bitop3_b32 %[ay], %[e], %[my], %[vy] bitop3:0xca\n\t"
                 "v_bitop3_b32 %[az], %[e], %[mz], %[vz] bitop3:0xca\n\t"
@@ -681,12 +684,40 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
                 "v_min3_u32 %[t0], %[t0], %[t1], %[t2]\n\t"
                 "v_add_u32_e32 %[st], 1, %[t0]\n\t"
                 "s_branch .Lvrt_move_%=\n"
+                // (s) Some lane is not in a plain air leaf (vcc).  Two steps in five of C2's are that for one reason only: plain lanes in
+                // split cells, on voxels of their bricks that are air (a ray close to a surface walks leaves of one and two voxels) —
+                // and for those the step is the one above with the brick's entry as the selector.  Anything else — a lane at the
+                // border (entry 0) or in a leaf that is not air ((int)e >= 0), a lane in water or a careful wave (its threshold is
+                // not kAirLeaf), a voxel of the brick that is not air — leaves for the general step with `e` as it was loaded.
+                ".Lvrt_split_%=:\n\t"
+                "v_cmp_le_i32_e64 %[sa], 0, %[e]\n\t"
+                "v_cmp_ne_u32_e64 %[sb], %[kair], %[below]\n\t"
+                "s_or_b64 %[sa], %[sa], %[sb]\n\t"
+                "s_cmp_lg_u64 %[sa], 0\n\t"
+                "s_cbranch_scc1 .Lvrt_out_%=\n\t"
+                "s_and_saveexec_b64 %[sx], vcc\n\t"                         // the lanes in split cells: u = (x&3) | (y&3) << 2 | (z&3) << 4
+                "v_lshlrev_b32_e32 %[t0], 2, %[vy]\n\t"
+                "v_lshlrev_b32_e32 %[t1], 4, %[vz]\n\t"
+                "v_bitop3_b32 %[t0], 3, %[vx], %[t0] bitop3:0xca\n\t"
+                "v_bitop3_b32 %[t0], 15, %[t0], %[t1] bitop3:0xca\n\t"
+                "v_and_b32_e32 %[t0], 63, %[t0]\n\t"
+                "v_add_lshl_u32 %[t0], %[e], %[t0], 1\n\t"                  // (the shift drops bit 31)
+                "buffer_load_ushort %[t1], %[t0], %[bdesc], 0 offen\n\t"
+                "s_waitcnt vmcnt(0)\n\t"
+                "v_cmp_lt_u32_e32 vcc, 1, %[t1]\n\t"                        // voxel << 1 | lo: a voxel that is not air
+                "s_cbranch_vccnz .Lvrt_leave_%=\n\t"
+                "v_and_or_b32 %[e], %[t1], 1, %[kair]\n\t"                  // the selector of the voxel's leaf (one voxel or two)
+                "s_mov_b64 exec, %[sx]\n\t"
+                "s_branch .Lvrt_planes_%=\n"
+                ".Lvrt_leave_%=:\n\t"
+                "s_mov_b64 exec, %[sx]\n"
                 ".Lvrt_out_%=:"
                 : [px] "+v"(pos.x), [py] "+v"(pos.y), [pz] "+v"(pos.z), [tl] "+v"(total_len), [vx] "+v"(vx), [vy] "+v"(vy), [vz] "+v"(vz),
                   [st] "+v"(step), [ax] "+v"(adx), [ay] "+v"(ady), [az] "+v"(adz), [e] "=&v"(e), [it] "+s"(trips),
-                  [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)
+                  [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [sa] "=&s"(sa), [sb] "=&s"(sb), [sx] "=&s"(sx)
                 : [mx] "v"(mxm), [my] "v"(mym), [mz] "v"(mzm), [cx] "v"(cx), [cy] "v"(cy), [cz] "v"(cz), [ux] "v"(ux), [uy] "v"(uy), [uz] "v"(uz),
-                  [dx] "v"(dir.x), [dy] "v"(dir.y), [dz] "v"(dir.z), [below] "v"(slow_below), [desc] "s"(gd), [row] "s"(row_bytes), [slab] "s"(slab_bytes)
+                  [dx] "v"(dir.x), [dy] "v"(dir.y), [dz] "v"(dir.z), [below] "v"(slow_below), [desc] "s"(gd), [row] "s"(row_bytes), [slab] "s"(slab_bytes),
+                  [bdesc] "s"(bd), [kair] "s"(kAirLeaf)
                 : "vcc", "scc", "memory");
             iter = trips + kMaxSteps;
             if (iter >= kMaxSteps) break;   // (wave-uniform) at most kMaxSteps lookups (:220)
