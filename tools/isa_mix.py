@@ -164,7 +164,8 @@ def hand_written(text, args):
         others = [b for b in blocks if b not in fast]
         res["loops"][name] = {"header": f".Lvrt_step_{n}", "fast_path_blocks": fast, "fast_path": fp, "per_block": per_block,
                               "rarely_executed_blocks": [b for b in others if b in ("exit", "zero")],
-                              "split_cell_step_blocks": [b for b in others if b in ("split", "leave")]}
+                              "split_cell_step_blocks": [b for b in others if b == "split"],
+                              "stop_and_leave_blocks": [b for b in others if b in ("decide", "leave")]}
         listing.append(f"==== {name} ray: inner march loop (.Lvrt_step_{n}) = the fast path, one trip per step ====")
         for b in fast + others:
             listing.append(f"{b}:   {per_block[b]}" + ("" if b in fast else "   (not in the fast path: a step through air voxels of split cells adds `split`)" if b == "split" else "   (not in the fast path)"))

@@ -549,6 +549,11 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
     // (the grid's and the bricks' descriptors as their four words, for (r): base, base >> 32 with stride 0, bytes, the flags of table_buffer)
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const u32x4 gd = {(uint32_t)(uintptr_t)P.grid, (uint32_t)((uintptr_t)P.grid >> 32) & 0xFFFFu, P.grid_bytes, 0x00020000u};
+    // (s): the liquids as the loop asks for them — voxel - liq_lo <= liq_span, never true of air (id 0).  A material table whose liquids
+    // are not one range makes every voxel a candidate: the general step asks the table
+    uint32_t liq_lo = P.liquid_lo, liq_span = P.liquid_span;
+    if (!P.liquid_is_range) { liq_lo = 1u; liq_span = 0xFFFFFFFEu; }
+    else if (liq_lo == 0u) { if (liq_span) { liq_lo = 1u; liq_span -= 1u; } else liq_lo = 0x80000000u; }
     const u32x4 bd = {(uint32_t)(uintptr_t)P.bricks, (uint32_t)((uintptr_t)P.bricks >> 32) & 0xFFFFu, P.brick_bytes, 0x00020000u};
     // rows and slabs carry one border entry / row: [8S][8S + 1][8S + 1]; both strides < 2^23 (grid_dim <= 800)
     const uint32_t row_bytes = (P.grid_dim + 1u) * 4u, slab_bytes = (P.grid_dim + 1u) * row_bytes;
@@ -627,9 +632,11 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
             // still uses; tests/test_gpu_parity.py holds both against the oracle bit for bit.
             // Leaves with `e` = the entry some lane has to decide about (nothing of that step done), or after kMaxSteps lookups.
             uint32_t t0, t1, t2;
-            unsigned long long sa, sb, sx;
+            unsigned long long sa, sb, sx, sd, sn;
+            uint32_t parked;
             uint32_t trips = __builtin_amdgcn_readfirstlane(iter) - kMaxSteps;   // (wave-uniform already: tells the compiler)
             asm volatile(
+                "s_mov_b64 %[sd], 0\n"
                 ".Lvrt_step_%=:\n\t"
                 "v_ashrrev_i32_e32 %[t0], 2, %[vz]\n\t"
                 "v_ashrrev_i32_e32 %[t1], 2, %[vy]\n\t"
@@ -686,17 +693,21 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
                 "s_branch .Lvrt_move_%=\n"
                 // (s) Some lane is not in a plain air leaf (vcc).  Two steps in five of C2's are that for one reason only: plain lanes in
                 // split cells, on voxels of their bricks that are air (a ray close to a surface walks leaves of one and two voxels) —
-                // and for those the step is the one above with the brick's entry as the selector.  Anything else — a lane at the
-                // border (entry 0) or in a leaf that is not air ((int)e >= 0), a lane in water or a careful wave (its threshold is
-                // not kAirLeaf), a voxel of the brick that is not air — leaves for the general step with `e` as it was loaded.
+                // and for those the step is the one above with the brick's entry as the selector.  One step in eleven has a lane that
+                // STOPS — at the border (entry 0), on a leaf or a brick's voxel that is solid: such a lane is parked (off the exec
+                // mask, its registers as they are, the voxel it stopped on recorded) and the others march on; `parked` tells the
+                // caller, which breaks out of its loop for it.  What is left for the general step: a lane in water or a careful wave
+                // (the threshold is not kAirLeaf) and a voxel that is a liquid — the loop leaves with `e` as it was loaded.
                 ".Lvrt_split_%=:\n\t"
-                "v_cmp_le_i32_e64 %[sa], 0, %[e]\n\t"
                 "v_cmp_ne_u32_e64 %[sb], %[kair], %[below]\n\t"
-                "s_or_b64 %[sa], %[sa], %[sb]\n\t"
-                "s_cmp_lg_u64 %[sa], 0\n\t"
+                "s_cmp_lg_u64 %[sb], 0\n\t"
                 "s_cbranch_scc1 .Lvrt_out_%=\n\t"
-                "s_and_saveexec_b64 %[sx], vcc\n\t"                         // the lanes in split cells: u = (x&3) | (y&3) << 2 | (z&3) << 4
-                "v_lshlrev_b32_e32 %[t0], 2, %[vy]\n\t"
+                "s_and_saveexec_b64 %[sx], vcc\n\t"                         // the lanes with something to decide: border, leaf, split cell
+                "v_cmp_gt_i32_e32 vcc, 0, %[e]\n\t"
+                "s_and_saveexec_b64 %[sa], vcc\n\t"                         // the lanes in split cells
+                "s_andn2_b64 %[sn], %[sa], exec\n\t"                        // the others: at the border, in a leaf that is not air
+                "s_cbranch_execz .Lvrt_decide_%=\n\t"
+                "v_lshlrev_b32_e32 %[t0], 2, %[vy]\n\t"                     // u = (x&3) | (y&3) << 2 | (z&3) << 4
                 "v_lshlrev_b32_e32 %[t1], 4, %[vz]\n\t"
                 "v_bitop3_b32 %[t0], 3, %[vx], %[t0] bitop3:0xca\n\t"
                 "v_bitop3_b32 %[t0], 15, %[t0], %[t1] bitop3:0xca\n\t"
@@ -705,21 +716,45 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
                 "buffer_load_ushort %[t1], %[t0], %[bdesc], 0 offen\n\t"
                 "s_waitcnt vmcnt(0)\n\t"
                 "v_cmp_lt_u32_e32 vcc, 1, %[t1]\n\t"                        // voxel << 1 | lo: a voxel that is not air
-                "s_cbranch_vccnz .Lvrt_leave_%=\n\t"
-                "v_and_or_b32 %[e], %[t1], 1, %[kair]\n\t"                  // the selector of the voxel's leaf (one voxel or two)
+                "s_or_b64 %[sb], %[sn], vcc\n\t"
+                "s_cbranch_scc1 .Lvrt_decide_%=\n\t"                        // someone stops, or meets a liquid
+                "v_and_or_b32 %[e], %[t1], 1, %[kair]\n\t"                  // all air: the selector of the voxel's leaf (one voxel or two)
                 "s_mov_b64 exec, %[sx]\n\t"
                 "s_branch .Lvrt_planes_%=\n"
+                ".Lvrt_decide_%=:\n\t"
+                "v_lshrrev_b32_e32 %[t2], 1, %[t1]\n\t"                     // the voxel of a brick's entry ...
+                "s_mov_b64 exec, %[sn]\n\t"
+                "v_lshrrev_b32_e32 %[t2], 16, %[e]\n\t"                     // ... of a leaf (the border: 0)
+                "s_mov_b64 exec, %[sa]\n\t"
+                "v_subrev_u32_e32 %[t0], %[liqlo], %[t2]\n\t"
+                "v_cmp_ge_u32_e32 vcc, %[liqspan], %[t0]\n\t"               // a liquid (air is none: liqlo >= 1): the general step's
+                "s_cbranch_vccnz .Lvrt_leave_%=\n\t"
+                "v_cmp_ne_u32_e32 vcc, 0, %[t2]\n\t"                        // solid
+                "v_cmp_eq_u32_e64 %[sb], 0, %[e]\n\t"                       // the border
+                "s_or_b64 %[sb], %[sb], vcc\n\t"                            // the lanes that stop here
+                "s_or_b64 %[sd], %[sd], %[sb]\n\t"
+                "s_andn2_b64 exec, %[sa], %[sb]\n\t"                        // split cells, air voxels:
+                "v_and_or_b32 %[e], %[t1], 1, %[kair]\n\t"                  // the selector of the voxel's leaf
+                "s_mov_b64 exec, %[sb]\n\t"
+                "v_mov_b32_e32 %[vox], %[t2]\n\t"                           // what a parked lane stopped on
+                "s_andn2_b64 exec, %[sx], %[sb]\n\t"                        // the lanes that march on
+                "s_cbranch_scc1 .Lvrt_planes_%=\n\t"
+                "s_branch .Lvrt_out_%=\n"                                   // none: every lane is parked
                 ".Lvrt_leave_%=:\n\t"
                 "s_mov_b64 exec, %[sx]\n"
-                ".Lvrt_out_%=:"
+                ".Lvrt_out_%=:\n\t"
+                "s_or_b64 exec, exec, %[sd]\n\t"
+                "v_cndmask_b32_e64 %[parked], 0, 1, %[sd]"
                 : [px] "+v"(pos.x), [py] "+v"(pos.y), [pz] "+v"(pos.z), [tl] "+v"(total_len), [vx] "+v"(vx), [vy] "+v"(vy), [vz] "+v"(vz),
                   [st] "+v"(step), [ax] "+v"(adx), [ay] "+v"(ady), [az] "+v"(adz), [e] "=&v"(e), [it] "+s"(trips),
-                  [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [sa] "=&s"(sa), [sb] "=&s"(sb), [sx] "=&s"(sx)
+                  [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [sa] "=&s"(sa), [sb] "=&s"(sb), [sx] "=&s"(sx), [sd] "=&s"(sd), [sn] "=&s"(sn),
+                  [vox] "+v"(voxel), [parked] "=&v"(parked)
                 : [mx] "v"(mxm), [my] "v"(mym), [mz] "v"(mzm), [cx] "v"(cx), [cy] "v"(cy), [cz] "v"(cz), [ux] "v"(ux), [uy] "v"(uy), [uz] "v"(uz),
                   [dx] "v"(dir.x), [dy] "v"(dir.y), [dz] "v"(dir.z), [below] "v"(slow_below), [desc] "s"(gd), [row] "s"(row_bytes), [slab] "s"(slab_bytes),
-                  [bdesc] "s"(bd), [kair] "s"(kAirLeaf)
+                  [bdesc] "s"(bd), [kair] "s"(kAirLeaf), [liqlo] "s"(liq_lo), [liqspan] "s"(liq_span)
                 : "vcc", "scc", "memory");
             iter = trips + kMaxSteps;
+            if (parked) break;              // stopped in the loop: border, or the solid voxel now in `voxel`
             if (iter >= kMaxSteps) break;   // (wave-uniform) at most kMaxSteps lookups (:220)
         } else
 #endif
