@@ -131,9 +131,9 @@ def write_out(res, listing, args):
 
 def hand_written(text, args):
     """Round 6: the inner loop is an asm statement of vrt_march.h (r) — labels .Lvrt_step_N (one trip per step: the lookup, the test),
-    .Lvrt_planes_N (the exit planes), .Lvrt_move_N (the move, the loop's branch), .Lvrt_zero_N (some lane's smallest distance is zero
-    or NaN: rare, out of line), .Lvrt_split_N / .Lvrt_leave_N ((s): lanes in split cells, the voxel of the brick), .Lvrt_out_N.
-    What a fast step executes: `step`, `planes` and `move` up to and including the loop's own branch."""
+    .Lvrt_planes_N (the exit planes), .Lvrt_move_N (which distances are the step), .Lvrt_advance_N (the move, the loop's branch),
+    .Lvrt_zero_N (some lane's smallest distance is zero or NaN: rare, out of line), .Lvrt_split_N / .Lvrt_leave_N ((s): lanes in split cells, the voxel of the brick), .Lvrt_out_N.
+    What a fast step executes: `step`, `planes`, `move` and `advance` up to and including the loop's own branch."""
     total = {}
     for b in blocks_of(text):
         total = add(total, count(b[1]))
@@ -154,10 +154,11 @@ def hand_written(text, args):
             t = l.split(";")[0].strip()
             if t and not t.startswith((".", ";")):
                 blocks[lab].append(t)
-        k = next(i for i, t in enumerate(blocks["move"]) if t.startswith("s_cbranch_scc")) + 1
-        blocks["exit"], blocks["move"] = blocks["move"][k:], blocks["move"][:k]   # behind the loop's branch: after kMaxSteps lookups only
+        last = "advance" if "advance" in blocks else "move"
+        k = next(i for i, t in enumerate(blocks[last]) if t.startswith("s_cbranch_scc")) + 1
+        blocks["exit"], blocks[last] = blocks[last][k:], blocks[last][:k]   # behind the loop's branch: after kMaxSteps lookups only
         per_block = {b: count(v) for b, v in blocks.items()}
-        fast = [b for b in ("step", "planes", "move") if b in blocks]
+        fast = [b for b in ("step", "planes", "move", "advance") if b in blocks]
         fp = {}
         for b in fast:
             fp = add(fp, per_block[b])

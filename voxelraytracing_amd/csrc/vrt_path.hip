@@ -173,15 +173,18 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
     {
         const TableBuf mb = table_buffer(P.mblk, P.mblk_bytes), db = table_buffer(P.cdir, P.cdir_bytes);
         const TableBuf bb = table_buffer(P.bricks, P.brick_bytes);
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // (the march cells' descriptor as its four words, for (r))
+        const u32x4 md = {(uint32_t)(uintptr_t)P.mblk, (uint32_t)((uintptr_t)P.mblk >> 32) & 0xFFFFu, P.mblk_bytes, 0x00020000u};
+        const u32x4 dd = {(uint32_t)(uintptr_t)P.cdir, (uint32_t)((uintptr_t)P.cdir >> 32) & 0xFFFFu, P.cdir_bytes, 0x00020000u};
         // the chunk directory: [S][S+1][S+1] with a zero border; a direct world: [4S][4S+1][4S+1] lines of 128 bytes
         const uint32_t drow = (P.grid_dim / 8u + 1u) * 4u, dslab = (P.grid_dim / 8u + 1u) * drow;
         const uint32_t row128 = (P.grid_dim / 2u + 1u) * 128u, slab128 = (P.grid_dim / 2u + 1u) * row128;   // < 2^23: S <= 16
         const uint32_t wsize = P.world.size;
         V3 pos{0.f, 0.f, 0.f}, dir{0.f, 0.f, 0.f};
         float ux = 0.f, uy = 0.f, uz = 0.f, step = -1.f, adx = 0.f, ady = 0.f, adz = 0.f;
-        // the direction masks with (q) of vrt_march.h riding on them: 0 or ~0, minus the bits of 2^23 — the bit-field insert
-        // looks at their low five bits only (lo <= 31), which are the plain mask's
+        // the direction masks and float constants of (q) of vrt_march.h: the bits of 2^23 over all ones or none; -2^23, + 1 towards +
         uint32_t mxm = 0u, mym = 0u, mzm = 0u, ref = 0u, iter = 0u, idx = 0u;
+        float cx = 0.f, cy = 0.f, cz = 0.f;
         int vx = 0, vy = 0, vz = 0;
         // the chunk the ray is in — its coordinates as one number — and where that chunk's block of march cells begins
         constexpr uint32_t kNoChunk = 0x7FFFFFFFu;
@@ -206,7 +209,8 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
             not_finite = !(finite3(origin) && finite3(dir));
             ux = pool[0u * E + idx]; uy = pool[1u * E + idx]; uz = pool[2u * E + idx];
             constexpr uint32_t kTwo23 = 0x4B000000u;
-            mxm = (dir.x >= 0.0f ? ~0u : 0u) - kTwo23; mym = (dir.y >= 0.0f ? ~0u : 0u) - kTwo23; mzm = (dir.z >= 0.0f ? ~0u : 0u) - kTwo23;
+            mxm = kTwo23 | (dir.x >= 0.0f ? 0x007FFFFFu : 0u); mym = kTwo23 | (dir.y >= 0.0f ? 0x007FFFFFu : 0u); mzm = kTwo23 | (dir.z >= 0.0f ? 0x007FFFFFu : 0u);
+            cx = dir.x >= 0.0f ? -8388607.0f : -8388608.0f; cy = dir.y >= 0.0f ? -8388607.0f : -8388608.0f; cz = dir.z >= 0.0f ? -8388607.0f : -8388608.0f;
             ref = 0u;
             ckey = kNoChunk;
             marching = true;
@@ -226,9 +230,10 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
         // the step to the leaf's exit face for a leaf of size lo + 1 (take_step of march_grid)
         auto take_step = [&](uint32_t lo) __attribute__((always_inline)) {
             // (h), (q) of vrt_march.h: the exit plane (v | lo) + 1 or v & ~lo, as a float without a conversion
-            const float tx = (__uint_as_float(bfi(lo, mxm, (uint32_t)vx) - mxm) - 8388608.0f) - pos.x;
-            const float ty = (__uint_as_float(bfi(lo, mym, (uint32_t)vy) - mym) - 8388608.0f) - pos.y;
-            const float tz = (__uint_as_float(bfi(lo, mzm, (uint32_t)vz) - mzm) - 8388608.0f) - pos.z;
+            const uint32_t sel = kAirLeaf | lo;
+            const float tx = (__uint_as_float(bfi(sel, mxm, (uint32_t)vx)) + cx) - pos.x;
+            const float ty = (__uint_as_float(bfi(sel, mym, (uint32_t)vy)) + cy) - pos.y;
+            const float tz = (__uint_as_float(bfi(sel, mzm, (uint32_t)vz)) + cz) - pos.z;
             adx = abs_mul(tx, ux);
             ady = abs_mul(ty, uy);
             adz = abs_mul(tz, uz);
@@ -307,6 +312,153 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
                 }
                 continue;
             }
+#ifndef VRT_AB_COMPILED_LOOP
+            {
+                // (r) of vrt_march.h, for this march: the steps of the lanes that march as the instructions themselves.  A lane whose
+                // voxel does not let it pass leaves the exec mask — its end state stays in its registers, `ref` = its cell's entry —
+                // and the others march on until few enough are left (the refill condition of the compiled loop below) or a lane runs out
+                // of lookups (:220; rare: the code behind the loop ends that ray).  v60..v63: the march cell (.x the entry, .y the
+                // size-2 bits, .z .w which voxels a ray passes).  What the compiler made of the loop below: 20 scalar instructions and
+                // four vector ones of control flow per step, its `marching` flag a register that is compared, counted and selected.
+                const unsigned long long live = __ballot(marching);
+                const uint32_t leave_at = next < n ? 64u - refill_at : 0u;   // leave when no more lanes than this still march
+                uint32_t t0, t1, t2, t3, u, sn;
+                unsigned long long sx, sa;
+// the lanes that march; the cell inside its line of 2 x 2 x 2 (bits 2 of x, y, z: [.. z2 y2 x2] in t0) ...
+#define VBM_HEAD \
+                    "s_mov_b64 %[sx], exec\n\t" \
+                    "s_and_b64 exec, exec, %[live]\n" \
+                    ".Lvbm_step_%=:\n\t" \
+                    "v_lshrrev_b32_e32 %[t0], 2, %[vx]\n\t" \
+                    "v_lshrrev_b32_e32 %[t1], 1, %[vy]\n\t" \
+                    "v_bitop3_b32 %[t0], 1, %[t0], %[t1] bitop3:0xca\n\t" \
+                    "v_bitop3_b32 %[t0], 3, %[t0], %[vz] bitop3:0xca\n\t" \
+                    "v_lshlrev_b32_e32 %[u], 2, %[vy]\n\t" \
+                    "v_lshlrev_b32_e32 %[t3], 4, %[vz]\n\t"
+// ... a direct world: the line among the lines of the whole world (bits 3 and up of the coordinates)
+#define VBM_ADDRESS_DIRECT \
+                    "v_ashrrev_i32_e32 %[t2], 3, %[vy]\n\t" \
+                    "v_ashrrev_i32_e32 %[t1], 3, %[vz]\n\t" \
+                    "v_bitop3_b32 %[t0], 7, %[t0], %[vx] bitop3:0xca\n\t" \
+                    "v_lshlrev_b32_e32 %[t0], 4, %[t0]\n\t" \
+                    "v_mad_i32_i24 %[t0], %[t2], %[row], %[t0]\n\t" \
+                    "v_mad_i32_i24 %[t0], %[t1], %[slab], %[t0]\n\t"
+// ... a world with a chunk directory: the chunk's block of cells — looked up when the ray has entered another chunk (its coordinates
+// as one number, base 128: -1 .. S <= 100 stay apart) —, the line inside the block (bits 3, 4: [z4 z3 | y4 y3 | x4 x3 | z2 y2 x2])
+#define VBM_ADDRESS_DIRECTORY \
+                    "v_lshlrev_b32_e32 %[t1], 9, %[vz]\n\t" \
+                    "v_ashrrev_i32_e32 %[t2], 5, %[vx]\n\t" \
+                    "v_bitop3_b32 %[t1], %[k3fff], %[u], %[t1] bitop3:0xca\n\t" \
+                    "v_bitop3_b32 %[t1], %[k7f], %[t2], %[t1] bitop3:0xca\n\t" \
+                    "v_cmp_ne_u32_e32 vcc, %[t1], %[ckey]\n\t" \
+                    "s_and_saveexec_b64 %[sa], vcc\n\t" \
+                    "s_cbranch_execz .Lvbm_same_%=\n\t" \
+                    "v_mov_b32_e32 %[ckey], %[t1]\n\t" \
+                    "v_ashrrev_i32_e32 %[t1], 5, %[vy]\n\t" \
+                    "v_lshlrev_b32_e32 %[t2], 2, %[t2]\n\t" \
+                    "v_mad_i32_i24 %[t1], %[t1], %[drow], %[t2]\n\t" \
+                    "v_ashrrev_i32_e32 %[t2], 5, %[vz]\n\t" \
+                    "v_mad_i32_i24 %[t1], %[t2], %[dslab], %[t1]\n\t" \
+                    "buffer_load_dword %[cblock], %[t1], %[ddesc], 0 offen\n\t" \
+                    "s_waitcnt vmcnt(0)\n\t" \
+                    "v_lshlrev_b32_e32 %[cblock], 13, %[cblock]\n" \
+                    ".Lvbm_same_%=:\n\t" \
+                    "s_mov_b64 exec, %[sa]\n\t" \
+                    "v_bitop3_b32 %[t1], %[k7f], %[u], %[t3] bitop3:0xca\n\t" \
+                    "v_bitop3_b32 %[t1], 31, %[vx], %[t1] bitop3:0xca\n\t" \
+                    "v_bitop3_b32 %[t0], 7, %[t0], %[t1] bitop3:0xca\n\t" \
+                    "v_and_b32_e32 %[t0], 0x1ff, %[t0]\n\t" \
+                    "v_lshl_add_u32 %[t0], %[t0], 4, %[cblock]\n\t"
+// one 16-byte load answers the step; u = (x&3) | (y&3) << 2 | (z&3) << 4 under z's upper bits; does a ray pass the voxel?  The lanes
+// that stop are off from here; the others: the selector (lo, or the size-2 bit of a split cell's voxel, under nine set bits), the step
+#define VBM_BODY \
+                    "v_bitop3_b32 %[u], 3, %[vx], %[u] bitop3:0xca\n\t" \
+                    "buffer_load_dwordx4 v[60:63], %[t0], %[mdesc], 0 offen\n\t" \
+                    "v_bitop3_b32 %[u], 15, %[u], %[t3] bitop3:0xca\n\t" \
+                    "v_add_u32_e32 %[it], 1, %[it]\n\t" \
+                    "s_waitcnt vmcnt(0)\n\t" \
+                    "v_lshrrev_b64 v[62:63], %[u], v[62:63]\n\t" \
+                    "v_mov_b32_e32 %[ref], v60\n\t" \
+                    "v_and_b32_e32 %[t0], 1, v62\n\t" \
+                    "v_cmp_eq_u32_e32 vcc, 1, %[t0]\n\t" \
+                    "s_and_b64 exec, exec, vcc\n\t" \
+                    "s_cbranch_scc0 .Lvbm_out_%=\n\t" \
+                    "v_bfe_u32 %[t0], %[u], 1, 5\n\t" \
+                    "v_bfe_u32 %[t0], v61, %[t0], 1\n\t" \
+                    "v_and_b32_e32 %[t1], 31, v60\n\t" \
+                    "v_or3_b32 %[t0], %[t1], %[t0], %[kair]\n\t" \
+                    "v_bitop3_b32 %[ax], %[t0], %[mx], %[vx] bitop3:0xca\n\t" \
+                    "v_bitop3_b32 %[ay], %[t0], %[my], %[vy] bitop3:0xca\n\t" \
+                    "v_bitop3_b32 %[az], %[t0], %[mz], %[vz] bitop3:0xca\n\t" \
+                    "v_add_f32_e32 %[ax], %[cx], %[ax]\n\t" \
+                    "v_add_f32_e32 %[ay], %[cy], %[ay]\n\t" \
+                    "v_add_f32_e32 %[az], %[cz], %[az]\n\t" \
+                    "v_sub_f32_e32 %[ax], %[ax], %[px]\n\t" \
+                    "v_sub_f32_e32 %[ay], %[ay], %[py]\n\t" \
+                    "v_sub_f32_e32 %[az], %[az], %[pz]\n\t" \
+                    "v_mul_f32_e64 %[ax], |%[ax]|, %[ux]\n\t" \
+                    "v_mul_f32_e64 %[ay], |%[ay]|, %[uy]\n\t" \
+                    "v_mul_f32_e64 %[az], |%[az]|, %[uz]\n\t" \
+                    "v_min3_f32 %[st], %[ax], %[ay], %[az]\n\t" \
+                    "v_cmp_nlt_f32_e32 vcc, 0, %[st]\n\t" \
+                    "s_cbranch_vccnz .Lvbm_zero_%=\n" \
+                    ".Lvbm_move_%=:\n\t" \
+                    "v_add_f32_e32 %[t0], 0x3a83126f, %[st]\n\t" \
+                    "v_cmp_eq_f32_e32 vcc, %[st], %[ax]\n\t" \
+                    "v_cndmask_b32_e32 %[t1], %[st], %[t0], vcc\n\t" \
+                    "v_cmp_eq_f32_e32 vcc, %[st], %[ay]\n\t" \
+                    "v_cndmask_b32_e32 %[t2], %[st], %[t0], vcc\n\t" \
+                    "v_cmp_eq_f32_e32 vcc, %[st], %[az]\n\t" \
+                    "v_cndmask_b32_e32 %[t0], %[st], %[t0], vcc\n\t" \
+                    "v_mul_f32_e32 %[t1], %[dx], %[t1]\n\t" \
+                    "v_mul_f32_e32 %[t2], %[dy], %[t2]\n\t" \
+                    "v_mul_f32_e32 %[t0], %[dz], %[t0]\n\t" \
+                    "v_add_f32_e32 %[px], %[px], %[t1]\n\t" \
+                    "v_add_f32_e32 %[py], %[py], %[t2]\n\t" \
+                    "v_add_f32_e32 %[pz], %[pz], %[t0]\n\t" \
+                    "v_cvt_flr_i32_f32_e32 %[vx], %[px]\n\t" \
+                    "v_cvt_flr_i32_f32_e32 %[vy], %[py]\n\t" \
+                    "v_cvt_flr_i32_f32_e32 %[vz], %[pz]\n\t" \
+                    "v_cmp_lt_u32_e32 vcc, 0x1f3, %[it]\n\t" \
+                    "s_cbranch_vccnz .Lvbm_out_%=\n\t" \
+                    "s_bcnt1_i32_b64 %[sn], exec\n\t" \
+                    "s_cmp_gt_u32 %[sn], %[leave]\n\t" \
+                    "s_cbranch_scc1 .Lvbm_step_%=\n\t" \
+                    "s_branch .Lvbm_out_%=\n" \
+                    ".Lvbm_zero_%=:\n\t" \
+                    "v_add_u32_e32 %[t0], -1, %[ax]\n\t" \
+                    "v_add_u32_e32 %[t1], -1, %[ay]\n\t" \
+                    "v_add_u32_e32 %[t2], -1, %[az]\n\t" \
+                    "v_min3_u32 %[t0], %[t0], %[t1], %[t2]\n\t" \
+                    "v_add_u32_e32 %[st], 1, %[t0]\n\t" \
+                    "s_branch .Lvbm_move_%=\n" \
+                    ".Lvbm_out_%=:\n\t" \
+                    "s_mov_b64 %[sa], exec\n\t" \
+                    "s_mov_b64 exec, %[sx]\n\t" \
+                    "v_cndmask_b32_e64 %[t3], 0, 1, %[sa]"
+#define VBM_OUTPUTS \
+                    [px] "+v"(pos.x), [py] "+v"(pos.y), [pz] "+v"(pos.z), [vx] "+v"(vx), [vy] "+v"(vy), [vz] "+v"(vz), [st] "+v"(step), [ax] "+v"(adx), \
+                    [ay] "+v"(ady), [az] "+v"(adz), [ref] "+v"(ref), [it] "+v"(iter), [t0] "=&v"(t0), \
+                    [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [u] "=&v"(u), [sn] "=&s"(sn), [sx] "=&s"(sx), [sa] "=&s"(sa)
+#define VBM_OUTPUTS_DIRECTORY , [ckey] "+v"(ckey), [cblock] "+v"(cblock)
+#define VBM_INPUTS \
+                    [mx] "v"(mxm), [my] "v"(mym), [mz] "v"(mzm), [cx] "v"(cx), [cy] "v"(cy), [cz] "v"(cz), [ux] "v"(ux), [uy] "v"(uy), [uz] "v"(uz), \
+                    [dx] "v"(dir.x), [dy] "v"(dir.y), [dz] "v"(dir.z), [mdesc] "s"(md), [row] "s"(row128), [slab] "s"(slab128), [kair] "s"(kAirLeaf), \
+                    [live] "s"(live), [leave] "s"(leave_at)
+#define VBM_INPUTS_DIRECTORY , [ddesc] "s"(dd), [drow] "s"(drow), [dslab] "s"(dslab), [k7f] "s"(0x7Fu), [k3fff] "s"(0x3FFFu)
+#define VBM_CLOBBERS "vcc", "scc", "memory", "v60", "v61", "v62", "v63"
+                if constexpr (DIRECT) asm volatile(VBM_HEAD VBM_ADDRESS_DIRECT VBM_BODY : VBM_OUTPUTS : VBM_INPUTS : VBM_CLOBBERS);
+                else asm volatile(VBM_HEAD VBM_ADDRESS_DIRECTORY VBM_BODY : VBM_OUTPUTS VBM_OUTPUTS_DIRECTORY : VBM_INPUTS VBM_INPUTS_DIRECTORY : VBM_CLOBBERS);
+                marching = t3 != 0u;   // (the loop's last word: which lanes still march)
+                if (marching && iter >= kMaxSteps) {
+                    // out of lookups in air or in a liquid (:220, :293): the segment ends as a hit on the voxel of the last lookup — which
+                    // for a split cell is in its brick, at the position that was looked up
+                    marching = false;
+                    ref = (int)ref < 0 ? ((uint32_t)__builtin_amdgcn_raw_buffer_load_b16(bb, ((ref & 0x7FFFFFFFu) + (u & 63u)) << 1, 0, 0) >> 1) << 16 : ref;
+                }
+                continue;
+            }
+#endif
             for (;;) {
                 if (marching) {
                     // the chunk's block of march cells: looked up in the chunk directory when the ray has entered another chunk
