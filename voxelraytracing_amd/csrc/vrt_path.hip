@@ -332,9 +332,7 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
                     "v_lshrrev_b32_e32 %[t0], 2, %[vx]\n\t" \
                     "v_lshrrev_b32_e32 %[t1], 1, %[vy]\n\t" \
                     "v_bitop3_b32 %[t0], 1, %[t0], %[t1] bitop3:0xca\n\t" \
-                    "v_bitop3_b32 %[t0], 3, %[t0], %[vz] bitop3:0xca\n\t" \
-                    "v_lshlrev_b32_e32 %[u], 2, %[vy]\n\t" \
-                    "v_lshlrev_b32_e32 %[t3], 4, %[vz]\n\t"
+                    "v_bitop3_b32 %[t0], 3, %[t0], %[vz] bitop3:0xca\n\t"
 // ... a direct world: the line among the lines of the whole world (bits 3 and up of the coordinates)
 #define VBM_ADDRESS_DIRECT \
                     "v_ashrrev_i32_e32 %[t2], 3, %[vy]\n\t" \
@@ -342,10 +340,15 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
                     "v_bitop3_b32 %[t0], 7, %[t0], %[vx] bitop3:0xca\n\t" \
                     "v_lshlrev_b32_e32 %[t0], 4, %[t0]\n\t" \
                     "v_mad_i32_i24 %[t0], %[t2], %[row], %[t0]\n\t" \
-                    "v_mad_i32_i24 %[t0], %[t1], %[slab], %[t0]\n\t"
+                    "v_mad_i32_i24 %[t0], %[t1], %[slab], %[t0]\n\t" \
+                    "buffer_load_dwordx4 v[60:63], %[t0], %[mdesc], 0 offen\n\t" \
+                    "v_lshlrev_b32_e32 %[u], 2, %[vy]\n\t" \
+                    "v_lshlrev_b32_e32 %[t3], 4, %[vz]\n\t"
 // ... a world with a chunk directory: the chunk's block of cells — looked up when the ray has entered another chunk (its coordinates
 // as one number, base 128: -1 .. S <= 100 stay apart) —, the line inside the block (bits 3, 4: [z4 z3 | y4 y3 | x4 x3 | z2 y2 x2])
 #define VBM_ADDRESS_DIRECTORY \
+                    "v_lshlrev_b32_e32 %[u], 2, %[vy]\n\t" \
+                    "v_lshlrev_b32_e32 %[t3], 4, %[vz]\n\t" \
                     "v_lshlrev_b32_e32 %[t1], 9, %[vz]\n\t" \
                     "v_ashrrev_i32_e32 %[t2], 5, %[vx]\n\t" \
                     "v_bitop3_b32 %[t1], %[k3fff], %[u], %[t1] bitop3:0xca\n\t" \
@@ -368,23 +371,24 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
                     "v_bitop3_b32 %[t1], 31, %[vx], %[t1] bitop3:0xca\n\t" \
                     "v_bitop3_b32 %[t0], 7, %[t0], %[t1] bitop3:0xca\n\t" \
                     "v_and_b32_e32 %[t0], 0x1ff, %[t0]\n\t" \
-                    "v_lshl_add_u32 %[t0], %[t0], 4, %[cblock]\n\t"
-// one 16-byte load answers the step; u = (x&3) | (y&3) << 2 | (z&3) << 4 under z's upper bits; does a ray pass the voxel?  The lanes
-// that stop are off from here; the others: the selector (lo, or the size-2 bit of a split cell's voxel, under nine set bits), the step
+                    "v_lshl_add_u32 %[t0], %[t0], 4, %[cblock]\n\t" \
+                    "buffer_load_dwordx4 v[60:63], %[t0], %[mdesc], 0 offen\n\t"
+// one 16-byte load answers the step — behind it, while it is in flight: u = (x&3) | (y&3) << 2 | (z&3) << 4 under z's upper bits, the
+// shift that brings u's bit of .z .w to the top (does a ray pass the voxel?  the sign says), the position of the size-2 bit.  The lanes
+// that stop are off from there; the others: the selector (lo, or the size-2 bit of a split cell's voxel, under nine set bits), the step
 #define VBM_BODY \
                     "v_bitop3_b32 %[u], 3, %[vx], %[u] bitop3:0xca\n\t" \
-                    "buffer_load_dwordx4 v[60:63], %[t0], %[mdesc], 0 offen\n\t" \
                     "v_bitop3_b32 %[u], 15, %[u], %[t3] bitop3:0xca\n\t" \
                     "v_add_u32_e32 %[it], 1, %[it]\n\t" \
+                    "v_sub_u32_e32 %[t3], 63, %[u]\n\t" \
+                    "v_bfe_u32 %[t2], %[u], 1, 5\n\t" \
                     "s_waitcnt vmcnt(0)\n\t" \
-                    "v_lshrrev_b64 v[62:63], %[u], v[62:63]\n\t" \
+                    "v_lshlrev_b64 v[62:63], %[t3], v[62:63]\n\t" \
                     "v_mov_b32_e32 %[ref], v60\n\t" \
-                    "v_and_b32_e32 %[t0], 1, v62\n\t" \
-                    "v_cmp_eq_u32_e32 vcc, 1, %[t0]\n\t" \
+                    "v_cmp_gt_i32_e32 vcc, 0, v63\n\t" \
                     "s_and_b64 exec, exec, vcc\n\t" \
                     "s_cbranch_scc0 .Lvbm_out_%=\n\t" \
-                    "v_bfe_u32 %[t0], %[u], 1, 5\n\t" \
-                    "v_bfe_u32 %[t0], v61, %[t0], 1\n\t" \
+                    "v_bfe_u32 %[t0], v61, %[t2], 1\n\t" \
                     "v_and_b32_e32 %[t1], 31, v60\n\t" \
                     "v_or3_b32 %[t0], %[t1], %[t0], %[kair]\n\t" \
                     "v_bitop3_b32 %[ax], %[t0], %[mx], %[vx] bitop3:0xca\n\t" \
