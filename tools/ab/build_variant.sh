@@ -6,7 +6,7 @@ NAME=$1; FLAGS=$2
 SRC=$(cd "$(dirname "$0")/../../voxelraytracing_amd/csrc" && pwd)
 OUT=$(cd "$(dirname "$0")" && pwd)
 T=/tmp/vrt_ab_$NAME; mkdir -p $T
-HIPFLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero -Wno-unused-value $FLAGS"
+HIPFLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero -fno-slp-vectorize -Wno-unused-value $FLAGS"
 FILES="vrt_kernels vrt_path vrt_accel vrt_frames vrt_order vrt_uploads vrt_present vrt_group"
 EXP="vrt_exp_register vrt_path_window"   # (csrc/experiments/: every variant is an experiments build)
 for f in $FILES; do /opt/rocm/bin/hipcc $HIPFLAGS -c -o $T/$f.o $SRC/$f.hip & done

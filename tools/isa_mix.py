@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 
 KERNEL = "_ZN3vrt26primary_shadow_wave_kernelILi0ELb0ELb0ELi1ELb0EEEvNS_11FrameParamsE"
 HIPFLAGS = ("-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt "
-            "-fno-gpu-flush-denormals-to-zero -Wno-unused-value").split()
+            "-fno-gpu-flush-denormals-to-zero -fno-slp-vectorize -Wno-unused-value").split()
 
 TRANS = ("v_rcp", "v_sqrt", "v_rsq", "v_exp", "v_log", "v_sin", "v_cos")
 HALF = ("v_cmp", "v_cmpx", "v_cndmask", "v_cvt", "v_floor", "v_ceil", "v_trunc", "v_rndne", "v_fract", "v_min", "v_max", "v_med3", "v_bfi",

@@ -546,15 +546,11 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
 
     const uint32_t wsize = P.world.size;
     const TableBuf gb = table_buffer(P.grid, P.grid_bytes), bb = table_buffer(P.bricks, P.brick_bytes);
-    // (the grid's and the bricks' descriptors as their four words, for (r): base, base >> 32 with stride 0, bytes, the flags of table_buffer)
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 gd = {(uint32_t)(uintptr_t)P.grid, (uint32_t)((uintptr_t)P.grid >> 32) & 0xFFFFu, P.grid_bytes, 0x00020000u};
     // (s): the liquids as the loop asks for them — voxel - liq_lo <= liq_span, never true of air (id 0).  A material table whose liquids
     // are not one range makes every voxel a candidate: the general step asks the table
     uint32_t liq_lo = P.liquid_lo, liq_span = P.liquid_span;
     if (!P.liquid_is_range) { liq_lo = 1u; liq_span = 0xFFFFFFFEu; }
     else if (liq_lo == 0u) { if (liq_span) { liq_lo = 1u; liq_span -= 1u; } else liq_lo = 0x80000000u; }
-    const u32x4 bd = {(uint32_t)(uintptr_t)P.bricks, (uint32_t)((uintptr_t)P.bricks >> 32) & 0xFFFFu, P.brick_bytes, 0x00020000u};
     // rows and slabs carry one border entry / row: [8S][8S + 1][8S + 1]; both strides < 2^23 (grid_dim <= 800)
     const uint32_t row_bytes = (P.grid_dim + 1u) * 4u, slab_bytes = (P.grid_dim + 1u) * row_bytes;
 
@@ -750,8 +746,8 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
                   [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [sa] "=&s"(sa), [sb] "=&s"(sb), [sx] "=&s"(sx), [sd] "=&s"(sd), [sn] "=&s"(sn),
                   [vox] "+v"(voxel), [parked] "=&v"(parked)
                 : [mx] "v"(mxm), [my] "v"(mym), [mz] "v"(mzm), [cx] "v"(cx), [cy] "v"(cy), [cz] "v"(cz), [ux] "v"(ux), [uy] "v"(uy), [uz] "v"(uz),
-                  [dx] "v"(dir.x), [dy] "v"(dir.y), [dz] "v"(dir.z), [below] "v"(slow_below), [desc] "s"(gd), [row] "s"(row_bytes), [slab] "s"(slab_bytes),
-                  [bdesc] "s"(bd), [kair] "s"(kAirLeaf), [liqlo] "s"(liq_lo), [liqspan] "s"(liq_span)
+                  [dx] "v"(dir.x), [dy] "v"(dir.y), [dz] "v"(dir.z), [below] "v"(slow_below), [desc] "s"(gb), [row] "s"(row_bytes), [slab] "s"(slab_bytes),
+                  [bdesc] "s"(bb), [kair] "s"(kAirLeaf), [liqlo] "s"(liq_lo), [liqspan] "s"(liq_span)
                 : "vcc", "scc", "memory");
             iter = trips + kMaxSteps;
             if (parked) break;              // stopped in the loop: border, or the solid voxel now in `voxel`

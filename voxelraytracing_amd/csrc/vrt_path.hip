@@ -173,9 +173,6 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
     {
         const TableBuf mb = table_buffer(P.mblk, P.mblk_bytes), db = table_buffer(P.cdir, P.cdir_bytes);
         const TableBuf bb = table_buffer(P.bricks, P.brick_bytes);
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // (the march cells' descriptor as its four words, for (r))
-        const u32x4 md = {(uint32_t)(uintptr_t)P.mblk, (uint32_t)((uintptr_t)P.mblk >> 32) & 0xFFFFu, P.mblk_bytes, 0x00020000u};
-        const u32x4 dd = {(uint32_t)(uintptr_t)P.cdir, (uint32_t)((uintptr_t)P.cdir >> 32) & 0xFFFFu, P.cdir_bytes, 0x00020000u};
         // the chunk directory: [S][S+1][S+1] with a zero border; a direct world: [4S][4S+1][4S+1] lines of 128 bytes
         const uint32_t drow = (P.grid_dim / 8u + 1u) * 4u, dslab = (P.grid_dim / 8u + 1u) * drow;
         const uint32_t row128 = (P.grid_dim / 2u + 1u) * 128u, slab128 = (P.grid_dim / 2u + 1u) * row128;   // < 2^23: S <= 16
@@ -320,14 +317,12 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
                 // of lookups (:220; rare: the code behind the loop ends that ray).  v60..v63: the march cell (.x the entry, .y the
                 // size-2 bits, .z .w which voxels a ray passes).  What the compiler made of the loop below: 20 scalar instructions and
                 // four vector ones of control flow per step, its `marching` flag a register that is compared, counted and selected.
-                const unsigned long long live = __ballot(marching);
                 const uint32_t leave_at = next < n ? 64u - refill_at : 0u;   // leave when no more lanes than this still march
-                uint32_t t0, t1, t2, t3, u, sn;
-                unsigned long long sx, sa;
-// the lanes that march; the cell inside its line of 2 x 2 x 2 (bits 2 of x, y, z: [.. z2 y2 x2] in t0) ...
+                uint32_t t0, t1, t2, t3, u;
+                unsigned long long sx = __ballot(marching), sa;   // sx: the lanes that march, then — inside — the lanes the loop was entered with
+// the lanes that march (exec is saved in the register that named them); the cell inside its line of 2 x 2 x 2 (bits 2 of x, y, z: [.. z2 y2 x2] in t0) ...
 #define VBM_HEAD \
-                    "s_mov_b64 %[sx], exec\n\t" \
-                    "s_and_b64 exec, exec, %[live]\n" \
+                    "s_and_saveexec_b64 %[sx], %[sx]\n" \
                     ".Lvbm_step_%=:\n\t" \
                     "v_lshrrev_b32_e32 %[t0], 2, %[vx]\n\t" \
                     "v_lshrrev_b32_e32 %[t1], 1, %[vy]\n\t" \
@@ -345,14 +340,16 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
                     "v_lshlrev_b32_e32 %[u], 2, %[vy]\n\t" \
                     "v_lshlrev_b32_e32 %[t3], 4, %[vz]\n\t"
 // ... a world with a chunk directory: the chunk's block of cells — looked up when the ray has entered another chunk (its coordinates
-// as one number, base 128: -1 .. S <= 100 stay apart) —, the line inside the block (bits 3, 4: [z4 z3 | y4 y3 | x4 x3 | z2 y2 x2])
+// as one number, base 128: -1 .. S <= 100 stay apart: z's upper bits | y's bits 5..11 | x's bits 5..11) —, the line inside the block (bits 3, 4: [z4 z3 | y4 y3 | x4 x3 | z2 y2 x2])
 #define VBM_ADDRESS_DIRECTORY \
                     "v_lshlrev_b32_e32 %[u], 2, %[vy]\n\t" \
                     "v_lshlrev_b32_e32 %[t3], 4, %[vz]\n\t" \
-                    "v_lshlrev_b32_e32 %[t1], 9, %[vz]\n\t" \
+                    "v_ashrrev_i32_e32 %[t1], 5, %[vz]\n\t" \
+                    "v_bfe_u32 %[t2], %[vy], 5, 7\n\t" \
+                    "v_lshl_or_b32 %[t1], %[t1], 7, %[t2]\n\t" \
+                    "v_bfe_u32 %[t2], %[vx], 5, 7\n\t" \
+                    "v_lshl_or_b32 %[t1], %[t1], 7, %[t2]\n\t" \
                     "v_ashrrev_i32_e32 %[t2], 5, %[vx]\n\t" \
-                    "v_bitop3_b32 %[t1], %[k3fff], %[u], %[t1] bitop3:0xca\n\t" \
-                    "v_bitop3_b32 %[t1], %[k7f], %[t2], %[t1] bitop3:0xca\n\t" \
                     "v_cmp_ne_u32_e32 vcc, %[t1], %[ckey]\n\t" \
                     "s_and_saveexec_b64 %[sa], vcc\n\t" \
                     "s_cbranch_execz .Lvbm_same_%=\n\t" \
@@ -367,10 +364,11 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
                     "v_lshlrev_b32_e32 %[cblock], 13, %[cblock]\n" \
                     ".Lvbm_same_%=:\n\t" \
                     "s_mov_b64 exec, %[sa]\n\t" \
-                    "v_bitop3_b32 %[t1], %[k7f], %[u], %[t3] bitop3:0xca\n\t" \
-                    "v_bitop3_b32 %[t1], 31, %[vx], %[t1] bitop3:0xca\n\t" \
+                    "v_bitop3_b32 %[t1], 31, %[vx], %[u] bitop3:0xca\n\t" \
+                    "v_and_b32_e32 %[t2], 0x180, %[t3]\n\t" \
+                    "v_and_b32_e32 %[t1], 0x7f, %[t1]\n\t" \
                     "v_bitop3_b32 %[t0], 7, %[t0], %[t1] bitop3:0xca\n\t" \
-                    "v_and_b32_e32 %[t0], 0x1ff, %[t0]\n\t" \
+                    "v_or_b32_e32 %[t0], %[t0], %[t2]\n\t" \
                     "v_lshl_add_u32 %[t0], %[t0], 4, %[cblock]\n\t" \
                     "buffer_load_dwordx4 v[60:63], %[t0], %[mdesc], 0 offen\n\t"
 // one 16-byte load answers the step — behind it, while it is in flight: u = (x&3) | (y&3) << 2 | (z&3) << 4 under z's upper bits, the
@@ -389,8 +387,8 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
                     "s_and_b64 exec, exec, vcc\n\t" \
                     "s_cbranch_scc0 .Lvbm_out_%=\n\t" \
                     "v_bfe_u32 %[t0], v61, %[t2], 1\n\t" \
-                    "v_and_b32_e32 %[t1], 31, v60\n\t" \
-                    "v_or3_b32 %[t0], %[t1], %[t0], %[kair]\n\t" \
+                    "v_and_or_b32 %[t0], v60, 31, %[t0]\n\t" \
+                    "v_or_b32_e32 %[t0], 0xff800000, %[t0]\n\t" \
                     "v_bitop3_b32 %[ax], %[t0], %[mx], %[vx] bitop3:0xca\n\t" \
                     "v_bitop3_b32 %[ay], %[t0], %[my], %[vy] bitop3:0xca\n\t" \
                     "v_bitop3_b32 %[az], %[t0], %[mz], %[vz] bitop3:0xca\n\t" \
@@ -425,8 +423,8 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
                     "v_cvt_flr_i32_f32_e32 %[vz], %[pz]\n\t" \
                     "v_cmp_lt_u32_e32 vcc, 0x1f3, %[it]\n\t" \
                     "s_cbranch_vccnz .Lvbm_out_%=\n\t" \
-                    "s_bcnt1_i32_b64 %[sn], exec\n\t" \
-                    "s_cmp_gt_u32 %[sn], %[leave]\n\t" \
+                    "s_bcnt1_i32_b64 vcc_lo, exec\n\t" \
+                    "s_cmp_gt_u32 vcc_lo, %[leave]\n\t" \
                     "s_cbranch_scc1 .Lvbm_step_%=\n\t" \
                     "s_branch .Lvbm_out_%=\n" \
                     ".Lvbm_zero_%=:\n\t" \
@@ -437,21 +435,21 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
                     "v_add_u32_e32 %[st], 1, %[t0]\n\t" \
                     "s_branch .Lvbm_move_%=\n" \
                     ".Lvbm_out_%=:\n\t" \
-                    "s_mov_b64 %[sa], exec\n\t" \
+                    "s_mov_b64 vcc, exec\n\t" \
                     "s_mov_b64 exec, %[sx]\n\t" \
-                    "v_cndmask_b32_e64 %[t3], 0, 1, %[sa]"
+                    "v_cndmask_b32_e64 %[t3], 0, 1, vcc"
 #define VBM_OUTPUTS \
                     [px] "+v"(pos.x), [py] "+v"(pos.y), [pz] "+v"(pos.z), [vx] "+v"(vx), [vy] "+v"(vy), [vz] "+v"(vz), [st] "+v"(step), [ax] "+v"(adx), \
                     [ay] "+v"(ady), [az] "+v"(adz), [ref] "+v"(ref), [it] "+v"(iter), [t0] "=&v"(t0), \
-                    [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [u] "=&v"(u), [sn] "=&s"(sn), [sx] "=&s"(sx), [sa] "=&s"(sa)
-#define VBM_OUTPUTS_DIRECTORY , [ckey] "+v"(ckey), [cblock] "+v"(cblock)
+                    [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [u] "=&v"(u), [sx] "+s"(sx)
+#define VBM_OUTPUTS_DIRECTORY , [ckey] "+v"(ckey), [cblock] "+v"(cblock), [sa] "=&s"(sa)
 #define VBM_INPUTS \
                     [mx] "v"(mxm), [my] "v"(mym), [mz] "v"(mzm), [cx] "v"(cx), [cy] "v"(cy), [cz] "v"(cz), [ux] "v"(ux), [uy] "v"(uy), [uz] "v"(uz), \
-                    [dx] "v"(dir.x), [dy] "v"(dir.y), [dz] "v"(dir.z), [mdesc] "s"(md), [row] "s"(row128), [slab] "s"(slab128), [kair] "s"(kAirLeaf), \
-                    [live] "s"(live), [leave] "s"(leave_at)
-#define VBM_INPUTS_DIRECTORY , [ddesc] "s"(dd), [drow] "s"(drow), [dslab] "s"(dslab), [k7f] "s"(0x7Fu), [k3fff] "s"(0x3FFFu)
+                    [dx] "v"(dir.x), [dy] "v"(dir.y), [dz] "v"(dir.z), [mdesc] "s"(mb), [leave] "s"(leave_at)
+#define VBM_INPUTS_DIRECT , [row] "s"(row128), [slab] "s"(slab128)
+#define VBM_INPUTS_DIRECTORY , [ddesc] "s"(db), [drow] "s"(drow), [dslab] "s"(dslab)
 #define VBM_CLOBBERS "vcc", "scc", "memory", "v60", "v61", "v62", "v63"
-                if constexpr (DIRECT) asm volatile(VBM_HEAD VBM_ADDRESS_DIRECT VBM_BODY : VBM_OUTPUTS : VBM_INPUTS : VBM_CLOBBERS);
+                if constexpr (DIRECT) asm volatile(VBM_HEAD VBM_ADDRESS_DIRECT VBM_BODY : VBM_OUTPUTS : VBM_INPUTS VBM_INPUTS_DIRECT : VBM_CLOBBERS);
                 else asm volatile(VBM_HEAD VBM_ADDRESS_DIRECTORY VBM_BODY : VBM_OUTPUTS VBM_OUTPUTS_DIRECTORY : VBM_INPUTS VBM_INPUTS_DIRECTORY : VBM_CLOBBERS);
                 marching = t3 != 0u;   // (the loop's last word: which lanes still march)
                 if (marching && iter >= kMaxSteps) {
