@@ -723,7 +723,10 @@ def main():
                 # the same at the costs tools/valu_rates.hip measured (upper bounds: they carry the microbenchmark's own loop)
                 "valu_issue_cycles_per_launch_at_measured_costs": valu_measured, "frac_at_measured_costs": valu_measured / avail,
                 "salu_unit_cycles_per_launch_at_measured_cost": cls.get("salu"),
-                "note": "the scalar unit is shared by a CU's four SIMDs and issues beside the VALU; its cycles are not additive"}
+                "note": "the scalar unit is shared by a CU's four SIMDs and issues beside the VALU; its cycles are not additive.  A frac above 1 "
+                        "says the classes' architectural issue times (2 / 4 / 8 cycles) overestimate this mix — beside plain instructions a "
+                        "'half-rate' one cost ~ 3.3 cycles in the same-box A/Bs of profiles/r06_step_asm.txt, a plain one ~ 2.5 — i.e. the "
+                        "VALU has no issue slots left: `roofline.frac` (2 cycles for every wave-instruction) is the conservative figure"}
     elif pmc and world == 1 and not sharded and not devices:
         # The path trace: a frame is the primary launch(es) + the bounce launch(es) (a chain per 8 samples).  `achieved` is the
         # dominant kernel's VALU wave-instructions of a frame over the time its launches take ALONE on the GPU — the one-frame-
