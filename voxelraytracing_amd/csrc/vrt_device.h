@@ -80,6 +80,7 @@ struct FrameParams {
     uint32_t n_nodes, n_roots;
     uint32_t width, height;
     uint32_t tiles_x, tiles_total;
+    uint32_t tiles_x_magic;  // ceil(2^32 / tiles_x) when tile / tiles_x = umulhi(tile, magic) for every tile of the frame, else 0 (tile_pixel)
     // this context's t_local-th tile is screen tile (t_local / shard_run) * shard_period + shard_first + t_local % shard_run
     uint32_t shard_first, shard_run, shard_period, tiles_local;
     uint32_t hit_seg_cap;    // capacity of one hit-buffer segment, a multiple of 256
@@ -130,6 +131,16 @@ enum Counter : int {
 };
 
 // screen tile of the context's t_local-th tile (vrt_config: shard_rank / shard_count / shard_root_weight)
+// A lane's pixel of its wave's tile.  The tile is the WAVE's: its row and column are three instructions of the scalar unit (a multiply-high
+// by the host's magic number, a multiply, a subtraction) — as a per-lane division by a run-time value they were 27 vector instructions
+// of every tile, five of them 32 x 32 multiplies.
+__device__ __forceinline__ void tile_pixel(const FrameParams &P, uint32_t tile, uint32_t lane, uint32_t &px, uint32_t &py) {
+    const uint32_t t = __builtin_amdgcn_readfirstlane(tile);
+    const uint32_t row = P.tiles_x_magic ? __umulhi(t, P.tiles_x_magic) : t / P.tiles_x;
+    px = (t - row * P.tiles_x) * 8u + (lane & 7u);
+    py = row * 8u + (lane >> 3);
+}
+
 __host__ __device__ __forceinline__ uint32_t shard_tile(uint32_t t_local, uint32_t first, uint32_t run, uint32_t period) {
     return run == 1u ? t_local * period + first : (t_local / run) * period + first + t_local % run;
 }

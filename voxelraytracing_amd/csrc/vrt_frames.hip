@@ -194,6 +194,8 @@ void fill_uniforms(const vrt_ctx *c, vrt::FrameParams &P) {
     P.width = c->width;
     P.height = c->height;
     P.tiles_x = c->tiles_x;
+    // tile / tiles_x as a multiply-high: exact while tile * tiles_x < 2^32 (error of the rounded-up reciprocal x tile < 1)
+    P.tiles_x_magic = (c->tiles_x > 1u && (uint64_t)c->tiles_total * c->tiles_x < (1ull << 32)) ? (uint32_t)(((1ull << 32) + c->tiles_x - 1u) / c->tiles_x) : 0u;
     P.tiles_total = c->tiles_total;
     P.shard_first = c->shard_first;
     P.shard_run = c->shard_run;

@@ -46,8 +46,8 @@ __global__ void __launch_bounds__(256) primary_tile_kernel(FrameParams P) {
     R.iters = 0; R.visits = 0; R.hit = false; R.trips = 0;
     if (live) {
         const uint32_t tile = shard_tile(t_local, P.shard_first, P.shard_run, P.shard_period);
-        const uint32_t px = (tile % P.tiles_x) * 8u + (lane & 7u);
-        const uint32_t py = (tile / P.tiles_x) * 8u + (lane >> 3);
+        uint32_t px, py;
+        tile_pixel(P, tile, lane, px, py);
         const uint32_t slot = P.tile_major ? t_local * 64u + lane : py * P.width + px;
 
         V3 origin, dir;

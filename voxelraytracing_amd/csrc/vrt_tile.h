@@ -123,8 +123,8 @@ template <int MARCH, bool LDS_ROOTS, bool STATS>
 __device__ __forceinline__ void trace_tile(const FrameParams &P, const uint32_t *s_roots, const uint32_t *s_liquid, uint32_t t_local,
                                            uint32_t lane, MarchResult &R, MarchResult &S) {
     const uint32_t tile = shard_tile(t_local, P.shard_first, P.shard_run, P.shard_period);
-    const uint32_t px = (tile % P.tiles_x) * 8u + (lane & 7u);
-    const uint32_t py = (tile / P.tiles_x) * 8u + (lane >> 3);
+    uint32_t px, py;
+    tile_pixel(P, tile, lane, px, py);
     const uint32_t slot = P.tile_major ? t_local * 64u + lane : py * P.width + px;
 
     V3 origin, dir;
