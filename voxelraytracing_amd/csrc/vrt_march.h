@@ -546,6 +546,8 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
 
     const uint32_t wsize = P.world.size;
     const TableBuf gb = table_buffer(P.grid, P.grid_bytes), bb = table_buffer(P.bricks, P.brick_bytes);
+    // (the bricks as an array of 16-bit entries — stride 2, indexed — for (s): the index is a merge, not an addition and a shift)
+    const TableBuf bb16 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(P.bricks), 2, P.brick_bytes / 2u, 0x00020000);
     // (s): the liquids as the loop asks for them — voxel - liq_lo <= liq_span, never true of air (id 0).  A material table whose liquids
     // are not one range makes every voxel a candidate: the general step asks the table
     uint32_t liq_lo = P.liquid_lo, liq_span = P.liquid_span;
@@ -628,11 +630,12 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
             // still uses; tests/test_gpu_parity.py holds both against the oracle bit for bit.
             // Leaves with `e` = the entry some lane has to decide about (nothing of that step done), or after kMaxSteps lookups.
             uint32_t t0, t1, t2;
-            unsigned long long sa, sb, sx, sd, sn;
+            unsigned long long sa, sb, sx, sd, sn, sw;
             uint32_t parked;
             uint32_t trips = __builtin_amdgcn_readfirstlane(iter) - kMaxSteps;   // (wave-uniform already: tells the compiler)
             asm volatile(
-                "s_mov_b64 %[sd], 0\n"
+                "s_mov_b64 %[sd], 0\n\t"
+                "v_cmp_ne_u32_e64 %[sw], %[kair], %[below]\n"                // lanes in water, a careful wave: the general step's
                 ".Lvrt_step_%=:\n\t"
                 "v_ashrrev_i32_e32 %[t0], 2, %[vz]\n\t"
                 "v_ashrrev_i32_e32 %[t1], 2, %[vy]\n\t"
@@ -695,8 +698,7 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
                 // caller, which breaks out of its loop for it.  What is left for the general step: a lane in water or a careful wave
                 // (the threshold is not kAirLeaf) and a voxel that is a liquid — the loop leaves with `e` as it was loaded.
                 ".Lvrt_split_%=:\n\t"
-                "v_cmp_ne_u32_e64 %[sb], %[kair], %[below]\n\t"
-                "s_cmp_lg_u64 %[sb], 0\n\t"
+                "s_cmp_lg_u64 %[sw], 0\n\t"                                 // (a lane in water, a careful wave: asked once, at the loop's entry)
                 "s_cbranch_scc1 .Lvrt_out_%=\n\t"
                 "s_and_saveexec_b64 %[sx], vcc\n\t"                         // the lanes with something to decide: border, leaf, split cell
                 "v_cmp_gt_i32_e32 vcc, 0, %[e]\n\t"
@@ -706,10 +708,9 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
                 "v_lshlrev_b32_e32 %[t0], 2, %[vy]\n\t"                     // u = (x&3) | (y&3) << 2 | (z&3) << 4
                 "v_lshlrev_b32_e32 %[t1], 4, %[vz]\n\t"
                 "v_bitop3_b32 %[t0], 3, %[vx], %[t0] bitop3:0xca\n\t"
-                "v_bitop3_b32 %[t0], 15, %[t0], %[t1] bitop3:0xca\n\t"
-                "v_and_b32_e32 %[t0], 63, %[t0]\n\t"
-                "v_add_lshl_u32 %[t0], %[e], %[t0], 1\n\t"                  // (the shift drops bit 31)
-                "buffer_load_ushort %[t1], %[t0], %[bdesc], 0 offen\n\t"
+                "v_bitop3_b32 %[t0], 15, %[t0], %[t1] bitop3:0xca\n\t"      // (z's upper bits on top)
+                "v_bitop3_b32 %[t0], %[kbrick], %[e], %[t0] bitop3:0xca\n\t"  // brick * 64 from the entry (bits 6..30), u below: the 16-bit entry's index
+                "buffer_load_ushort %[t1], %[t0], %[bdesc], 0 idxen\n\t"
                 "s_waitcnt vmcnt(0)\n\t"
                 "v_cmp_lt_u32_e32 vcc, 1, %[t1]\n\t"                        // voxel << 1 | lo: a voxel that is not air
                 "s_or_b64 %[sb], %[sn], vcc\n\t"
@@ -743,11 +744,11 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
                 "v_cndmask_b32_e64 %[parked], 0, 1, %[sd]"
                 : [px] "+v"(pos.x), [py] "+v"(pos.y), [pz] "+v"(pos.z), [tl] "+v"(total_len), [vx] "+v"(vx), [vy] "+v"(vy), [vz] "+v"(vz),
                   [st] "+v"(step), [ax] "+v"(adx), [ay] "+v"(ady), [az] "+v"(adz), [e] "=&v"(e), [it] "+s"(trips),
-                  [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [sa] "=&s"(sa), [sb] "=&s"(sb), [sx] "=&s"(sx), [sd] "=&s"(sd), [sn] "=&s"(sn),
+                  [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [sa] "=&s"(sa), [sb] "=&s"(sb), [sx] "=&s"(sx), [sd] "=&s"(sd), [sn] "=&s"(sn), [sw] "=&s"(sw),
                   [vox] "+v"(voxel), [parked] "=&v"(parked)
                 : [mx] "v"(mxm), [my] "v"(mym), [mz] "v"(mzm), [cx] "v"(cx), [cy] "v"(cy), [cz] "v"(cz), [ux] "v"(ux), [uy] "v"(uy), [uz] "v"(uz),
                   [dx] "v"(dir.x), [dy] "v"(dir.y), [dz] "v"(dir.z), [below] "v"(slow_below), [desc] "s"(gb), [row] "s"(row_bytes), [slab] "s"(slab_bytes),
-                  [bdesc] "s"(bb), [kair] "s"(kAirLeaf), [liqlo] "s"(liq_lo), [liqspan] "s"(liq_span)
+                  [bdesc] "s"(bb16), [kair] "s"(kAirLeaf), [kbrick] "s"(0x7FFFFFC0u), [liqlo] "s"(liq_lo), [liqspan] "s"(liq_span)
                 : "vcc", "scc", "memory");
             iter = trips + kMaxSteps;
             if (parked) break;              // stopped in the loop: border, or the solid voxel now in `voxel`
