@@ -635,6 +635,7 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
             uint32_t trips = __builtin_amdgcn_readfirstlane(iter) - kMaxSteps;   // (wave-uniform already: tells the compiler)
             asm volatile(
                 "s_mov_b64 %[sd], 0\n\t"
+                "s_setprio 1\n\t"                                           // (the waves in the loop before the ones that set up or shade: + 1 %)
                 "v_cmp_ne_u32_e64 %[sw], %[kair], %[below]\n"                // lanes in water, a careful wave: the general step's
                 ".Lvrt_step_%=:\n\t"
                 "v_ashrrev_i32_e32 %[t0], 2, %[vz]\n\t"
@@ -740,6 +741,7 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
                 ".Lvrt_leave_%=:\n\t"
                 "s_mov_b64 exec, %[sx]\n"
                 ".Lvrt_out_%=:\n\t"
+                "s_setprio 0\n\t"
                 "s_or_b64 exec, exec, %[sd]\n\t"
                 "v_cndmask_b32_e64 %[parked], 0, 1, %[sd]"
                 : [px] "+v"(pos.x), [py] "+v"(pos.y), [pz] "+v"(pos.z), [tl] "+v"(total_len), [vx] "+v"(vx), [vy] "+v"(vy), [vz] "+v"(vz),
