@@ -617,7 +617,6 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
     // returns.  Same steps in the same order for every lane; `iter` counts them for the whole wave.
     for (;;) {
         uint32_t e;
-#ifndef VRT_AB_COMPILED_LOOP
         if constexpr (!STATS) {
             // (r) The inner loop as the instructions themselves.  What the compiler makes of the C++ below is the same vector
             // instructions, but it wraps every step in seven scalar instructions, four branches (three taken) and six s_nop /
@@ -755,9 +754,7 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
             iter = trips + kMaxSteps;
             if (parked) break;              // stopped in the loop: border, or the solid voxel now in `voxel`
             if (iter >= kMaxSteps) break;   // (wave-uniform) at most kMaxSteps lookups (:220)
-        } else
-#endif
-        {
+        } else {   // (the kernels that count: the same loop as the compiler lays it out, with the per-lane counters)
             bool exhausted = false;
             for (;;) {
                 e = lookup();

@@ -309,13 +309,12 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
                 }
                 continue;
             }
-#ifndef VRT_AB_COMPILED_LOOP
             {
                 // (r) of vrt_march.h, for this march: the steps of the lanes that march as the instructions themselves.  A lane whose
                 // voxel does not let it pass leaves the exec mask — its end state stays in its registers, `ref` = its cell's entry —
-                // and the others march on until few enough are left (the refill condition of the compiled loop below) or a lane runs out
+                // and the others march on until few enough are left (the refill condition: the loop above has its C++ form) or a lane runs out
                 // of lookups (:220; rare: the code behind the loop ends that ray).  v60..v63: the march cell (.x the entry, .y the
-                // size-2 bits, .z .w which voxels a ray passes).  What the compiler made of the loop below: 20 scalar instructions and
+                // size-2 bits, .z .w which voxels a ray passes).  What the compiler had made of this loop in C++: 20 scalar instructions and
                 // four vector ones of control flow per step, its `marching` flag a register that is compared, counted and selected.
                 const uint32_t leave_at = next < n ? 64u - refill_at : 0u;   // leave when no more lanes than this still march
                 uint32_t t0, t1, t2, t3, u;
@@ -459,60 +458,6 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
                     ref = (int)ref < 0 ? ((uint32_t)__builtin_amdgcn_raw_buffer_load_b16(bb, ((ref & 0x7FFFFFFFu) + (u & 63u)) << 1, 0, 0) >> 1) << 16 : ref;
                 }
                 continue;
-            }
-#endif
-            for (;;) {
-                if (marching) {
-                    // the chunk's block of march cells: looked up in the chunk directory when the ray has entered another chunk
-                    // (coordinates -1 .. S: one voxel beyond the world at most; they make one number, base 128).  Outside the
-                    // world the directory's border — or a load past either end of it — says block 0, whose cells are all zeros
-                    // The cell inside its line of 2 x 2 x 2 (bits 2 of the coordinates), the line inside the chunk's block (bits 3, 4) —
-                    // or, in a direct world, among the lines of the whole world (bits 3 and up; the border lines stay zero)
-                    // (round 6: the bit fields are merged by v_bitop3_b32 with constant masks — "the low k bits of a over the rest of b",
-                    // full rate — instead of shift / and / or chains that end in half-rate three-operand forms: the same offsets from
-                    // 10 instructions instead of 13 in a direct world, 15 instead of 21 through the directory.)
-                    // bits 2 of x, y, z side by side below whatever lies above them: [.. z2 y2 x2]
-                    const uint32_t sub = low_bits_of<3u>(low_bits_of<1u>((uint32_t)vx >> 2, (uint32_t)vy >> 1), (uint32_t)vz);
-                    uint32_t off;
-                    if (DIRECT) {
-                        // ((x >> 3) << 3 | sub) << 4 = (x >> 3) << 7 + sub << 4: x's bits 3 and up stay where they are
-                        off = mad_i24(vz >> 3, slab128, mad_i24(vy >> 3, row128, low_bits_of<7u>(sub, (uint32_t)vx) << 4));
-                    } else {
-                        // the chunk's number: bits 5.. of x | of y << 7 | of z << 14 (seven bits each: -1 .. S <= 100 stay apart)
-                        const uint32_t ysh = (uint32_t)vy << 2, zsh = (uint32_t)vz << 9;
-                        const uint32_t key = bfi(0x7Fu, (uint32_t)(vx >> 5), bfi(0x3FFFu, ysh, zsh));
-                        if (key != ckey) {   // (looking it up on every step instead: 1 % slower — the load is an L1 hit, but a dependent one)
-                            ckey = key;
-                            cblock = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(db, mad_i24(vz >> 5, dslab, mad_i24(vy >> 5, drow, (uint32_t)(vx >> 5) << 2)), 0, 0) << 13;
-                        }
-                        // [z4 z3 | y4 y3 | x4 x3 | z2 y2 x2]: x's bits 3, 4 are in place, y's come from y << 2, z's from z << 4
-                        const uint32_t cell = low_bits_of<7u>(sub, low_bits_of<31u>((uint32_t)vx, bfi(0x7Fu, ysh, (uint32_t)vz << 4)));
-                        off = cblock + ((cell & 0x1FFu) << 4);
-                    }
-                    // one 16-byte load answers the step: c.x the cell's entry, c.y the size-2 mask of a split cell, c.z / c.w
-                    // the voxels a ray passes (zero stops it)
-                    const uint4 c = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(mb, off, 0, 0));
-                    iter += 1u;
-                    // u = (x&3) | (y&3) << 2 | (z&3) << 4, with z's upper bits left on top: the shifts below use the low bits only
-                    // (two merges: x's low two bits over y << 2, those four over z << 4)
-                    const uint32_t u = low_bits_of<15u>(low_bits_of<3u>((uint32_t)vx, (uint32_t)vy << 2), (uint32_t)vz << 4);
-                    const uint32_t passes = (uint32_t)((((unsigned long long)c.w << 32) | c.z) >> (u & 63u)) & 1u;
-                    const uint32_t lo = (c.x & 31u) | __builtin_amdgcn_ubfe(c.y, (u >> 1) & 31u, 1u);
-                    bool stop = passes == 0u;
-                    ref = c.x;
-                    if (!stop) {
-                        take_step(lo);
-                        if (iter >= kMaxSteps) {
-                            // out of lookups in air or in a liquid (:220, :293): the segment ends as a hit on the voxel of the last
-                            // lookup — which for a split cell is in its brick, at the position that was looked up
-                            stop = true;
-                            ref = (int)c.x < 0 ? ((uint32_t)__builtin_amdgcn_raw_buffer_load_b16(bb, ((c.x & 0x7FFFFFFFu) + (u & 63u)) << 1, 0, 0) >> 1) << 16 : c.x;
-                        }
-                    }
-                    marching = !stop;
-                }
-                const uint32_t n_march = (uint32_t)__popcll(__ballot(marching));
-                if (n_march == 0u || (next < n && 64u - n_march >= refill_at)) break;
             }
         }
     }
