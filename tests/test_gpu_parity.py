@@ -521,7 +521,7 @@ def test_fuzz_all_marches_agree_on_many_cameras():
     """400 seeded cameras — random, axis-aligned, on integer coordinates and chunk faces, inside terrain, under water,
     outside the world, extreme fov — rendered by the default march and by the literal restatement of the shader (which
     the oracle tests pin): id words, radiance and per-pixel step counts identical, frame by frame; every tenth camera also
-    by the other two variants."""
+    by the other two variants; every camera also by the default kernel without its counters (the hand-written march loop)."""
     from voxelraytracing_amd.world import gen_height
     sc = scenes.c2((96, 64))
     gpu = gpu_for_scene(sc)
@@ -559,8 +559,55 @@ def test_fuzz_all_marches_agree_on_many_cameras():
             assert np.array_equal(ids, frames[1][1]), what
             assert np.array_equal(steps, frames[1][2]) and visits == frames[1][3], what
             assert np.array_equal(rgb, frames[1][0], equal_nan=True), what
+        # ... and by the kernel that does not count: its march loop is the hand-written one (vrt_march.h (r), (s): the zero-distance path, the
+        # split cells' air voxels, parked lanes, the exits for water and non-finite rays), the counting kernels' is the compiler's
+        gpu.render(MODE_PRIMARY_SHADOW, variant=0)
+        rgb, ids, _ = gpu.read_output()
+        what = f"camera {i} kind {kind} eye {eye} rot {rot} fov {fov} the frame without counters"
+        assert np.array_equal(ids, frames[1][1]), what
+        assert np.array_equal(rgb, frames[1][0], equal_nan=True), what
         n_checked += 1
     assert n_checked == 400
+
+
+def test_fuzz_path_trace_kernels_agree_on_many_cameras():
+    """96 seeded cameras of the kinds above, path-traced (3 bounces) by the counting kernels — a launch per bounce, the compiler's march
+    loop, pinned to the oracle by test_path_trace_matches_oracle — and by the default ones, whose bounce segments are one launch with the
+    hand-written march loop (vrt_path.hip): identical id words and radiance, frame by frame."""
+    from voxelraytracing_amd.world import gen_height
+    sc = scenes.c4((96, 64), bounces=3)
+    gpu = gpu_for_scene(sc)
+    rng = np.random.default_rng(20261005)
+    for i in range(96):
+        kind = i % 8
+        eye = [float(v) for v in rng.uniform(0.5, 255.5, 3)]
+        rot = [float(rng.uniform(-89, 89)), float(rng.uniform(0, 360)), 0.0]
+        fov = float(rng.uniform(30, 120))
+        if kind == 1:
+            rot = [float(rng.choice([0.0, 90.0, -90.0])), float(rng.choice([0.0, 90.0, 180.0, 270.0])), 0.0]
+        elif kind == 2:
+            eye = [float(int(v)) for v in eye]
+        elif kind == 3:
+            eye = [float(32 * int(rng.integers(1, 8))), eye[1], float(32 * int(rng.integers(1, 8)))]
+        elif kind == 4:
+            eye[1] = float(gen_height(1, int(eye[0]), int(eye[2]))) + float(rng.choice([-2.5, -0.5, 0.0, 0.001, 0.5, 3.0]))
+        elif kind == 5:
+            eye[1] = float(rng.uniform(41.0, 70.0))
+            rot[0] = float(rng.uniform(-89, -10))
+        elif kind == 6:
+            eye[int(rng.integers(0, 3))] = float(rng.choice([-3.0, 0.0, 256.0, 300.0]))
+        elif kind == 7:
+            fov = float(rng.choice([1.0, 5.0, 150.0, 175.0]))
+            rot[2] = float(rng.uniform(-180, 180))
+        gpu.write_cam_data(g.cam_data_create(tuple(rot), tuple(eye), fov, (96.0, 64.0)))
+        gpu.render(MODE_PATH, stats=True, seed=i)
+        rgb, ids, _ = gpu.read_output()
+        gpu.render(MODE_PATH, seed=i)
+        rgb2, ids2, _ = gpu.read_output()
+        what = f"camera {i} kind {kind} eye {eye} rot {rot} fov {fov}"
+        assert np.array_equal(ids2, ids), what
+        assert np.array_equal(rgb2, rgb, equal_nan=True), what
+    gpu.close()
 
 
 def test_c5_world_32_cubed_matches_oracle(orc):
