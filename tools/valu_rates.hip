@@ -81,6 +81,12 @@ KERNEL(k_mul_u24, "v_mul_u32_u24 %8, %8, %9\n v_mul_u32_u24 %9, %9, %10\n v_mul_
 KERNEL(k_div_scale, "v_div_scale_f32 %0, vcc, %0, %1, %2\n v_div_scale_f32 %2, vcc, %2, %1, %3\n v_div_scale_f32 %3, vcc, %3, %1, %4\n v_div_scale_f32 %4, vcc, %4, %1, %5\n v_div_scale_f32 %5, vcc, %5, %1, %6\n v_div_scale_f32 %6, vcc, %6, %1, %7\n v_div_scale_f32 %7, vcc, %7, %1, %0\n v_div_scale_f32 %0, vcc, %0, %2, %3\n")
 KERNEL(k_div_fmas, "v_div_fmas_f32 %0, %0, %1, %2\n v_div_fmas_f32 %2, %2, %1, %3\n v_div_fmas_f32 %3, %3, %1, %4\n v_div_fmas_f32 %4, %4, %1, %5\n v_div_fmas_f32 %5, %5, %1, %6\n v_div_fmas_f32 %6, %6, %1, %7\n v_div_fmas_f32 %7, %7, %1, %0\n v_div_fmas_f32 %0, %0, %2, %3\n")
 KERNEL(k_pk_fma_f32, "v_pk_fma_f32 v[20:21], v[20:21], v[22:23], v[24:25]\n v_pk_fma_f32 v[24:25], v[24:25], v[22:23], v[26:27]\n v_pk_fma_f32 v[26:27], v[26:27], v[22:23], v[28:29]\n v_pk_fma_f32 v[28:29], v[28:29], v[22:23], v[20:21]\n v_pk_fma_f32 v[20:21], v[20:21], v[24:25], v[26:27]\n v_pk_fma_f32 v[24:25], v[24:25], v[26:27], v[28:29]\n v_pk_fma_f32 v[26:27], v[26:27], v[28:29], v[20:21]\n v_pk_fma_f32 v[28:29], v[28:29], v[20:21], v[24:25]\n")
+// Mixes (round 6, second half): the same 8-instruction bodies with two classes interleaved — a packed f32 or a half-rate instruction between
+// plain ones — to be read against the classes' own rows: is a mix the sum of its parts?  (profiles/r06_step_asm.txt: in the march kernel it is not)
+KERNEL(k_mix_pk_plain, "v_pk_add_f32 v[20:21], v[20:21], v[22:23]\n v_add_f32 %0, %0, %1\n v_pk_mul_f32 v[24:25], v[24:25], v[22:23]\n v_mul_f32 %2, %2, %1\n v_pk_add_f32 v[26:27], v[26:27], v[22:23]\n v_add_f32 %3, %3, %1\n v_pk_mul_f32 v[28:29], v[28:29], v[22:23]\n v_mul_f32 %4, %4, %1\n")
+KERNEL(k_mix_pk_dependent, "v_pk_add_f32 v[20:21], v[20:21], v[22:23]\n v_add_f32 %0, %0, v20\n v_pk_mul_f32 v[24:25], v[24:25], v[22:23]\n v_mul_f32 %2, %2, v25\n v_pk_add_f32 v[26:27], v[26:27], v[22:23]\n v_add_f32 %3, %3, v26\n v_pk_mul_f32 v[28:29], v[28:29], v[22:23]\n v_mul_f32 %4, %4, v29\n")
+KERNEL(k_mix_half_plain, "v_min3_f32 %0, %0, %1, %2\n v_add_f32 %3, %3, %1\n v_cvt_flr_i32_f32 %8, %4\n v_mul_f32 %5, %5, %1\n v_cmp_eq_f32 vcc, %6, %1\n v_add_f32 %7, %7, %1\n v_cndmask_b32 %2, %2, %3, vcc\n v_mul_f32 %4, %4, %1\n")
+KERNEL(k_mix_step_like, "v_bitop3_b32 %8, %9, %10, %11 bitop3:0xca\n v_add_f32 %0, %1, %0\n v_sub_f32 %2, %2, %3\n v_mul_f32 %4, |%4|, %5\n v_min3_f32 %6, %0, %2, %4\n v_cmp_eq_f32 vcc, %6, %0\n v_cndmask_b32 %7, %6, %1, vcc\n v_cvt_flr_i32_f32 %9, %7\n")
 KERNEL(k_cvt_f32_u32, "v_cvt_f32_u32 %0, %8\n v_cvt_f32_u32 %2, %9\n v_cvt_f32_u32 %3, %10\n v_cvt_f32_u32 %4, %11\n v_cvt_f32_u32 %5, %8\n v_cvt_f32_u32 %6, %9\n v_cvt_f32_u32 %7, %10\n v_cvt_f32_u32 %1, %11\n")
 KERNEL(k_bpermute, "ds_bpermute_b32 %0, %8, %0\n ds_bpermute_b32 %2, %8, %2\n ds_bpermute_b32 %3, %8, %3\n ds_bpermute_b32 %4, %8, %4\n s_waitcnt lgkmcnt(0)\n ds_bpermute_b32 %5, %8, %5\n ds_bpermute_b32 %6, %8, %6\n ds_bpermute_b32 %7, %8, %7\n")
 // scalar instructions: alone, and interleaved one to one with simple VALU (does the scalar stream ride along for free?)
@@ -164,7 +170,7 @@ int main() {
     RUN(k_bfi_b32); RUN(k_mad_u24); RUN(k_mad_i24); RUN(k_max3_u32); RUN(k_div_fixup); RUN(k_pk_add_f32);
     RUN(k_sqrt_f32); RUN(k_rcp_f32);
     RUN(k_bitop3); RUN(k_bitop3_2src); RUN(k_setreg_add); RUN(k_bfe_u32); RUN(k_lshl_add); RUN(k_fmac_f32); RUN(k_pk_mul_f32); RUN(k_sub_f32_lit); RUN(k_cndmask_lit); RUN(k_cmp_sgpr_f32);
-    RUN(k_mul_lo_u32); RUN(k_mul_hi_u32); RUN(k_mad_u64_u32); RUN(k_mul_u24); RUN(k_div_scale); RUN(k_div_fmas); RUN(k_pk_fma_f32); RUN(k_cvt_f32_u32); RUN(k_bpermute);
+    RUN(k_mul_lo_u32); RUN(k_mul_hi_u32); RUN(k_mad_u64_u32); RUN(k_mul_u24); RUN(k_div_scale); RUN(k_div_fmas); RUN(k_pk_fma_f32); RUN(k_mix_pk_plain); RUN(k_mix_pk_dependent); RUN(k_mix_half_plain); RUN(k_mix_step_like); RUN(k_cvt_f32_u32); RUN(k_bpermute);
     RUN(k_salu); RUN(k_salu_valu); RUN(k_nop);
     RUN(k_fma_lanes_0_15); RUN(k_fma_lanes_0_31); RUN(k_fma_every_4th); RUN(k_fma_one_in_16); RUN(k_min3_lanes_0_15); RUN(k_min3_lanes_0_31); RUN(k_min3_every_4th);
     return 0;

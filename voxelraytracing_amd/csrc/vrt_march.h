@@ -637,10 +637,10 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
                 "s_setprio 1\n\t"                                           // (the waves in the loop before the ones that set up or shade: + 1 %)
                 "v_cmp_ne_u32_e64 %[sw], %[kair], %[below]\n"                // lanes in water, a careful wave: the general step's
                 ".Lvrt_step_%=:\n\t"
-                "v_ashrrev_i32_e32 %[t0], 2, %[vz]\n\t"
                 "v_ashrrev_i32_e32 %[t1], 2, %[vy]\n\t"
                 "v_and_b32_e32 %[t2], -4, %[vx]\n\t"
                 "v_mad_i32_i24 %[t1], %[t1], %[row], %[t2]\n\t"
+                "v_ashrrev_i32_e32 %[t0], 2, %[vz]\n\t"
                 "v_mad_i32_i24 %[t0], %[t0], %[slab], %[t1]\n\t"
                 "buffer_load_dword %[e], %[t0], %[desc], 0 offen\n\t"
                 "s_waitcnt vmcnt(0)\n\t"
@@ -663,21 +663,23 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
                 "v_cmp_nlt_f32_e32 vcc, 0, %[st]\n\t"
                 "s_cbranch_vccnz .Lvrt_zero_%=\n"                            // some lane's smallest distance is zero or NaN: (c')
                 ".Lvrt_move_%=:\n\t"
+                // (the half-rate instructions — compares, selects, conversions — each between two plain ones: next to a plain instruction
+                // a half-rate one issues in a plain one's time, next to another half-rate one it takes its own: tools/valu_rates.hip k_mix_*)
                 "v_add_f32_e32 %[t0], 0x3a83126f, %[st]\n\t"                // step + 0.001
                 "v_cmp_eq_f32_e32 vcc, %[st], %[ax]\n\t"
-                "v_cndmask_b32_e32 %[t1], %[st], %[t0], vcc\n\t"
-                "v_cmp_eq_f32_e32 vcc, %[st], %[ay]\n\t"
-                "v_cndmask_b32_e32 %[t2], %[st], %[t0], vcc\n\t"
-                "v_cmp_eq_f32_e32 vcc, %[st], %[az]\n\t"
-                "v_cndmask_b32_e32 %[t0], %[st], %[t0], vcc\n\t"
-                "v_mul_f32_e32 %[t1], %[dx], %[t1]\n\t"
-                "v_mul_f32_e32 %[t2], %[dy], %[t2]\n\t"
-                "v_mul_f32_e32 %[t0], %[dz], %[t0]\n\t"
-                "v_add_f32_e32 %[px], %[px], %[t1]\n\t"
-                "v_add_f32_e32 %[py], %[py], %[t2]\n\t"
-                "v_add_f32_e32 %[pz], %[pz], %[t0]\n\t"
                 "v_add_f32_e32 %[tl], %[tl], %[st]\n\t"
+                "v_cndmask_b32_e32 %[t1], %[st], %[t0], vcc\n\t"
+                "v_mul_f32_e32 %[t1], %[dx], %[t1]\n\t"
+                "v_cmp_eq_f32_e32 vcc, %[st], %[ay]\n\t"
+                "v_add_f32_e32 %[px], %[px], %[t1]\n\t"
+                "v_cndmask_b32_e32 %[t2], %[st], %[t0], vcc\n\t"
+                "v_mul_f32_e32 %[t2], %[dy], %[t2]\n\t"
+                "v_cmp_eq_f32_e32 vcc, %[st], %[az]\n\t"
+                "v_add_f32_e32 %[py], %[py], %[t2]\n\t"
+                "v_cndmask_b32_e32 %[t0], %[st], %[t0], vcc\n\t"
+                "v_mul_f32_e32 %[t0], %[dz], %[t0]\n\t"
                 "v_cvt_flr_i32_f32_e32 %[vx], %[px]\n\t"
+                "v_add_f32_e32 %[pz], %[pz], %[t0]\n\t"
                 "v_cvt_flr_i32_f32_e32 %[vy], %[py]\n\t"
                 "v_cvt_flr_i32_f32_e32 %[vz], %[pz]\n\t"
                 "s_add_u32 %[it], %[it], 1\n\t"                              // (carries when the count reaches kMaxSteps, :220)
