@@ -640,7 +640,7 @@ def main():
     # PMC tool stamps with the code object and the workload it measured; they are printed only for that very build and workload
     code = _ffi.code_object_sha256()
     workload_key = f"{args.mode}:{args.chunks}:{args.width}x{args.height}:v{args.variant}" + (f":{args.spp}spp:{args.bounces}b" if args.mode == "path" else "")
-    pmc, pmc_all, pmc_note = None, {}, None
+    pmc, pmc_all, pmc_note, issue_cost = None, {}, None, {}
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
         if tj.get("code_object_sha256") != code:
@@ -650,6 +650,7 @@ def main():
         else:
             pmc_all = tj["workloads"][workload_key].get("kernels", {})
             pmc = pmc_all.get(dom_name)
+            issue_cost = tj.get("issue_cost_cycles", {})
     except Exception as e:
         pmc_note = f"profiles/traffic_latest.json unreadable: {e}"
     clock_ghz = extras.get("shader_clock_ghz")
@@ -690,6 +691,15 @@ def main():
         roof["frac"] = roof["achieved"] / roof["peak"]
         roof["achieved_headline_period"] = n_valu / period_s / 1e9
         roof["frac_headline_period"] = roof["achieved_headline_period"] / roof["peak"]
+        if issue_cost.get("valu_simple"):
+            # the same at what a plain instruction really takes to issue (tools/valu_rates.hip; profiles/rNN_valu_issue_rates.txt) — which is
+            # also what a half-rate instruction takes between plain ones (k_mix_half_plain): the count at this price is the VALU's time
+            roof["measured_issue_cycles_per_plain_instruction"] = issue_cost["valu_simple"]
+            roof["frac_at_measured_issue_time"] = roof["frac"] * issue_cost["valu_simple"] / 2.0
+            if issue_cost.get("mix_half_plain"):
+                roof["measured_issue_cycles_per_instruction_half_rate_and_plain_alternating"] = issue_cost["mix_half_plain"]
+            if issue_cost.get("mix_pk_plain"):
+                roof["measured_issue_cycles_per_instruction_packed_and_plain_alternating"] = issue_cost["mix_pk_plain"]
         roof["frac_note"] = ("instructions per second over the peak at 2 cycles per wave-instruction, on the period of the frame the counters "
                              "are of (standing camera); removing instructions lowers it; class_weighted.frac (each class at its issue time) "
                              "says how full the VALU pipes are")

@@ -84,6 +84,9 @@ if os.path.exists(out):
             res = old
     except Exception:
         pass
+for k_, n_ in (("mix_half_plain", "k_mix_half_plain"), ("mix_pk_plain", "k_mix_pk_plain"), ("mix_step_like", "k_mix_step_like")):
+    if n_ in rates:
+        cost[k_] = rates[n_]   # (per instruction of the alternating body: tools/valu_rates.hip k_mix_*)
 res["issue_cost_cycles"] = cost
 res["fast_path_mix"] = fp
 res["workloads"][workload] = {"kernels": kernels, "_source": f"{summary} (tools/pmc.sh: separate --pmc passes), {mix_path}, {rates_path}"}
