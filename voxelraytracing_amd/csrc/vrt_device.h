@@ -23,6 +23,8 @@ constexpr uint32_t kIdNormYNeg = 1u << 23;
 // mask into the position under the entry as the bit selector (vrt_march.h (h)): with the top nine bits set, the insert takes
 // them from the mask — which carries the exponent of 2^23 there — and the exit plane arrives as the float 2^23 + plane
 // without an instruction of its own ((q) of vrt_march.h).  The march cells' first word keeps the plain form (lo alone).
+constexpr uint32_t kCamNotFinite = 1u, kCamOnPlane = 2u, kCamOutside = 4u;   // FrameParams.cam_origin_facts
+
 constexpr uint32_t kAirLeaf = 0xFF800000u;
 // ... of a cell split at depth 3: 0x80000000 | brick * 64 — below the air leaves: the pool holds fewer than 0x1FE0000 bricks
 __host__ __device__ inline bool is_split_entry(uint32_t e) { return (int32_t)e < 0 && e < kAirLeaf; }
@@ -109,6 +111,12 @@ struct FrameParams {
     const float *ndc_x;      // [width]  ((float)px * 2) / proj_size.x - 1        (create_ray_from_screen :160)
     const float *ndc_y;      // [height] ((float)py * 2) / proj_size.y - 1        (:161)
     float cam_sun_dir[3];    // normalize(sun_pos - world.min - (cam.pos - world.min)): ray_sky's sun_dir for primary rays (:149)
+    // A primary ray's origin is the camera — the same for every pixel — and so is what the march asks of it before its first step: the
+    // host evaluates both once per frame, in the kernels' own binary32 operations (march_grid<.., CAMERA>)
+    float cam_origin[3];     // cam.pos - f32(world.min) (:169)
+    float sun_local[3];      // settings.sun_pos - f32(world.min): the sun as the shadow ray's and the sky's direction subtract from it
+    float world_max;         // 0.0 + f32(world.size) (:285)
+    uint32_t cam_origin_facts;   // kCamNotFinite | kCamOnPlane (the start nudge :188-190 applies) | kCamOutside (:285, asked of the origin as it is)
 };
 
 // The path-trace buffers are compacted per segment, not globally: one device-scope counter saturates at ~88

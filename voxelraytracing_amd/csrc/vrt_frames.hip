@@ -136,6 +136,30 @@ int ensure_ndc(vrt_ctx *c) {
     return VRT_OK;
 }
 
+// A primary ray's origin (:169) and what ray_world asks of it before the first step — finite? on a voxel plane (the nudge, :188-190)? outside
+// the world (:285)? — in the operations of create_ray / march_grid (vrt_march.h), once per frame instead of once per lane.
+static void cam_origin_facts(const vrt_ctx *c, float origin[3], uint32_t *facts) {
+    volatile float o[3];
+    for (int k = 0; k < 3; k++) {
+        volatile float wm = (float)c->world.min[k];
+        o[k] = c->cam.pos[k] - wm;
+        origin[k] = o[k];
+    }
+    uint32_t f = 0u;
+    if (!(std::isfinite(o[0]) && std::isfinite(o[1]) && std::isfinite(o[2]))) f |= vrt::kCamNotFinite;
+    bool on_plane = false, outside = false;
+    volatile float world_max = 0.0f + (float)c->world.size;
+    for (int k = 0; k < 3; k++) {
+        volatile float fl = floorf(o[k]);
+        volatile float frac = o[k] - fl;
+        if (frac < 0.001f) on_plane = true;
+        if (o[k] <= 0.0f || o[k] >= world_max) outside = true;
+    }
+    if (on_plane) f |= vrt::kCamOnPlane;
+    if (outside) f |= vrt::kCamOutside;
+    *facts = f;
+}
+
 // ray_sky's sun_dir for a ray starting at the camera (ray_tracer.wgsl:149, origin = cam.pos - world.min :169).
 static void cam_sun_dir(const vrt_ctx *c, float out[3]) {
     volatile float d[3];
@@ -218,6 +242,16 @@ void fill_uniforms(const vrt_ctx *c, vrt::FrameParams &P) {
     P.ndc_x = c->d_ndc;
     P.ndc_y = c->d_ndc + c->width;
     cam_sun_dir(c, P.cam_sun_dir);
+    cam_origin_facts(c, P.cam_origin, &P.cam_origin_facts);
+    for (int k = 0; k < 3; k++) {
+        volatile float wm = (float)c->world.min[k];
+        volatile float a = c->settings.sun_pos[k] - wm;
+        P.sun_local[k] = a;
+    }
+    {
+        volatile float wmax = 0.0f + (float)c->world.size;
+        P.world_max = wmax;
+    }
 
 }
 

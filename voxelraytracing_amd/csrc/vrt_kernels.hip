@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(256) primary_tile_kernel(FrameParams P) {
 
         V3 origin, dir;
         create_ray(P, (int)px, (int)py, origin, dir);
-        R = march<MARCH, LDS_ROOTS, STATS>(P, s_roots, s_liquid, origin, dir);
+        R = march<MARCH, LDS_ROOTS, STATS, true>(P, s_roots, s_liquid, origin, dir);
         V3 color;
         uint32_t id = shade<MARCH == 1>(P, R, origin, dir, color);
 
@@ -135,9 +135,7 @@ __global__ void __launch_bounds__(256) shadow_kernel(FrameParams P) {
         const uint4 rec = P.hits[blockIdx.x * 256u + threadIdx.x];
         slot = rec.x;
         const V3 so{__uint_as_float(rec.y), __uint_as_float(rec.z), __uint_as_float(rec.w)};
-        const V3 sd = normalize_wave(V3{P.settings.sun_pos[0] - (float)P.world.min[0] - so.x,
-                                    P.settings.sun_pos[1] - (float)P.world.min[1] - so.y,
-                                    P.settings.sun_pos[2] - (float)P.world.min[2] - so.z});
+        const V3 sd = normalize_wave(V3{P.sun_local[0] - so.x, P.sun_local[1] - so.y, P.sun_local[2] - so.z});   // (sun_pos - f32(world.min), the host's)
         R = march<MARCH, LDS_ROOTS, STATS>(P, s_roots, s_liquid, so, sd);
         if (R.hit) {
             uint4 t = P.out[slot];

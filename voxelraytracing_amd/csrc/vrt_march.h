@@ -294,7 +294,7 @@ __device__ __forceinline__ MarchResult march_fast(const FrameParams &P, const ui
         pos.y += 0.001f * dir.y;
         pos.z += 0.001f * dir.z;
     }
-    const float world_max = 0.0f + (float)P.world.size;
+    const float world_max = P.world_max;   // 0.0 + f32(world.size), the host's
     if ((pos.x <= 0.0f || pos.y <= 0.0f || pos.z <= 0.0f) || (pos.x >= world_max || pos.y >= world_max || pos.z >= world_max))
         return R;
 
@@ -504,7 +504,8 @@ __device__ __forceinline__ bool finite3(V3 v) {
            ((__float_as_uint(v.z) & 0x7F800000u) != 0x7F800000u);
 }
 
-template <bool STATS>
+// CAMERA: `origin` is the camera's (a primary ray): what the march asks of the origin alone is FrameParams.cam_origin_facts, the host's.
+template <bool STATS, bool CAMERA = false>
 __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const uint32_t *s_liquid, V3 origin, V3 dir) {
     MarchResult R;
     R.hit = false;
@@ -518,16 +519,21 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
 
     const bool mx = dir.x >= 0.0f, my = dir.y >= 0.0f, mz = dir.z >= 0.0f;
     // (l): is any ray of this wave not finite?  (Wave-uniform; evaluated before lanes leave.)
-    const bool careful = __ballot(!(finite3(origin) && finite3(dir))) != 0ull;
+    const bool careful = CAMERA ? ((P.cam_origin_facts & kCamNotFinite) != 0u || __ballot(!finite3(dir)) != 0ull)
+                                : __ballot(!(finite3(origin) && finite3(dir))) != 0ull;
 
     V3 pos = origin;
-    if (pos.x - floorf(pos.x) < 0.001f || pos.y - floorf(pos.y) < 0.001f || pos.z - floorf(pos.z) < 0.001f) {
+    const bool nudge = CAMERA ? (P.cam_origin_facts & kCamOnPlane) != 0u
+                              : (pos.x - floorf(pos.x) < 0.001f || pos.y - floorf(pos.y) < 0.001f || pos.z - floorf(pos.z) < 0.001f);
+    if (nudge) {
         pos.x += 0.001f * dir.x;
         pos.y += 0.001f * dir.y;
         pos.z += 0.001f * dir.z;
     }
-    const float world_max = 0.0f + (float)P.world.size;
-    if ((pos.x <= 0.0f || pos.y <= 0.0f || pos.z <= 0.0f) || (pos.x >= world_max || pos.y >= world_max || pos.z >= world_max))
+    const float world_max = P.world_max;   // 0.0 + f32(world.size), the host's
+    if (CAMERA && !(P.cam_origin_facts & kCamOnPlane)) {   // (wave-uniform: the origin as it is)
+        if (P.cam_origin_facts & kCamOutside) return R;
+    } else if ((pos.x <= 0.0f || pos.y <= 0.0f || pos.z <= 0.0f) || (pos.x >= world_max || pos.y >= world_max || pos.z >= world_max))
         return R;
 
     const V3 unit = unit_steps(dir);   // (:209-213)
@@ -832,12 +838,12 @@ __device__ __forceinline__ MarchResult march_grid(const FrameParams &P, const ui
     return R;
 }
 
-template <int MARCH, bool LDS_ROOTS, bool STATS = false>
+template <int MARCH, bool LDS_ROOTS, bool STATS = false, bool CAMERA = false>
 __device__ __forceinline__ MarchResult march(const FrameParams &P, const uint32_t *s_roots, const uint32_t *s_liquid,
                                              V3 origin, V3 dir) {
     if (MARCH == 1) return march_literal<LDS_ROOTS>(P, s_roots, s_liquid, origin, dir);
     if (MARCH == 2) return march_fast<LDS_ROOTS>(P, s_roots, s_liquid, origin, dir);
-    return march_grid<STATS>(P, s_liquid, origin, dir);
+    return march_grid<STATS, CAMERA>(P, s_liquid, origin, dir);
 }
 
 // ray_sky, ray_tracer.wgsl:144-157
@@ -851,9 +857,7 @@ __device__ __forceinline__ V3 ray_sky(const FrameParams &P, V3 origin, V3 dir) {
     const V3 grad{vmix(1.0f, P.settings.sky_color[0], sky_gradient_t), vmix(0.3f, P.settings.sky_color[1], sky_gradient_t),
                   vmix(0.0f, P.settings.sky_color[2], sky_gradient_t)};
     const V3 sun_dir = CAM_ORIGIN ? V3{P.cam_sun_dir[0], P.cam_sun_dir[1], P.cam_sun_dir[2]}
-                                  : normalize_wave(V3{P.settings.sun_pos[0] - (float)P.world.min[0] - origin.x,
-                                                  P.settings.sun_pos[1] - (float)P.world.min[1] - origin.y,
-                                                  P.settings.sun_pos[2] - (float)P.world.min[2] - origin.z});
+                                  : normalize_wave(V3{P.sun_local[0] - origin.x, P.sun_local[1] - origin.y, P.sun_local[2] - origin.z});
     const float sun = (vdot(dir, sun_dir) > (1.0f - 0.01f) && ground_to_sky_t >= 1.0f) ? 1.0f : 0.0f;
     const float add = sun * P.settings.sun_intensity;
     return V3{vmix(0.03f, grad.x, ground_to_sky_t) + add, vmix(0.03f, grad.y, ground_to_sky_t) + add,
@@ -873,8 +877,7 @@ __device__ __forceinline__ void create_ray(const FrameParams &P, int sx, int sy,
     const V3 w{e0 * iv[0] + e1 * iv[1] + e2 * iv[2] + e3 * iv[3], e0 * iv[4] + e1 * iv[5] + e2 * iv[6] + e3 * iv[7],
                e0 * iv[8] + e1 * iv[9] + e2 * iv[10] + e3 * iv[11]};
     dir = normalize_wave(w);
-    origin = V3{P.cam.pos[0] - (float)P.world.min[0], P.cam.pos[1] - (float)P.world.min[1],
-                P.cam.pos[2] - (float)P.world.min[2]};
+    origin = V3{P.cam_origin[0], P.cam_origin[1], P.cam_origin[2]};   // cam.pos - f32(world.min), the host's (vrt_frames.hip: cam_origin_facts)
 }
 
 // Face shading + ray_color + overlay, ray_tracer.wgsl:127-142, 296-314. Returns the id word.

@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(256) path_bounce_cells_kernel(CellsLaunch L) {
     const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, none));
     float *pool = reinterpret_cast<float *>(smem + 8) + (wave + none) * kWords;
     uint16_t *order = reinterpret_cast<uint16_t *>(smem + 8 + 4u * kWords) + (wave + none) * E;
-    const float world_max = 0.0f + (float)P.world.size;
+    const float world_max = P.world_max;   // 0.0 + f32(world.size), the host's
     const bool last_bounce = left == 1u;   // (the launch's last segment is the paths' last)
 
     // ---- A: the unit steps of every ray (nine divides, three square roots), full width ----

@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(256) path_primary_kernel(FrameParams P) {
         create_ray(P, (int)px, (int)py, origin, dir);
         // every sample of a pixel starts with the same ray (the samples differ from their first bounce on: the RNG is not
         // asked before a hit), so the primary segment is marched once for all the samples of this launch chain
-        R = march<MARCH, LDS_ROOTS, STATS>(P, s_roots, s_liquid, origin, dir);
+        R = march<MARCH, LDS_ROOTS, STATS, true>(P, s_roots, s_liquid, origin, dir);
         uint32_t id0 = R.voxel & VRT_ID_VOXEL_MASK;   // the id word of the primary segment, composed as shade() does
         if (R.hit) id0 |= VRT_ID_HIT;
         if (R.norm.x != 0.0f) id0 |= VRT_ID_NX;

@@ -129,7 +129,7 @@ __device__ __forceinline__ void trace_tile(const FrameParams &P, const uint32_t 
 
     V3 origin, dir;
     create_ray(P, (int)px, (int)py, origin, dir);
-    R = march<MARCH, LDS_ROOTS, STATS>(P, s_roots, s_liquid, origin, dir);
+    R = march<MARCH, LDS_ROOTS, STATS, true>(P, s_roots, s_liquid, origin, dir);
     V3 color;
     uint32_t id = shade<MARCH == 1>(P, R, origin, dir, color);
 
@@ -137,9 +137,7 @@ __device__ __forceinline__ void trace_tile(const FrameParams &P, const uint32_t 
     if (launch) {
         id |= VRT_ID_SHADOW_RAY;
         const V3 so{R.pos.x + R.norm.x * kShadowBias, R.pos.y + R.norm.y * kShadowBias, R.pos.z + R.norm.z * kShadowBias};
-        const V3 sd = normalize_wave(V3{P.settings.sun_pos[0] - (float)P.world.min[0] - so.x,
-                                    P.settings.sun_pos[1] - (float)P.world.min[1] - so.y,
-                                    P.settings.sun_pos[2] - (float)P.world.min[2] - so.z});
+        const V3 sd = normalize_wave(V3{P.sun_local[0] - so.x, P.sun_local[1] - so.y, P.sun_local[2] - so.z});   // (sun_pos - f32(world.min), the host's)
         S = march<MARCH, LDS_ROOTS, STATS>(P, s_roots, s_liquid, so, sd);
         if (S.hit) {
             color.x *= kShadowFactor;
